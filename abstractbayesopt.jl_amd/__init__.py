@@ -1,0 +1,32 @@
+"""abstractbayesopt.jl_amd — MI355X-native GP surrogate backend behind AbstractBayesOpt.jl's
+AbstractSurrogate / AbstractAcquisition interface (hot path only: update → posterior → EI/UCB →
+top-k).  Import as ``import abstractbayesopt.jl_amd as abo``."""
+from . import _lib, acquisition, distributed, synth
+from ._lib import AboError, DimensionMismatch, PosDefException
+from .acquisition import (AbstractAcquisition, ExpectedImprovement, ProbabilityImprovement, UpperConfidenceBound,
+                          evaluate, latin_hypercube, optimize_acquisition)
+from .domains import ContinuousDomain
+from .kernels import (ApproxMatern52Kernel, ApproxMatern72Kernel, ConstMean, Kernel, Matern32Kernel, Matern52Kernel,
+                      ScaledKernel, SqExponentialKernel, ZeroMean, with_lengthscale)
+from . import surrogate as _s
+from .surrogate import (AbstractSurrogate, HipStandardGP, _get_minimum, _update_model_parameters,
+                        get_factor, get_kernel_constructor, get_lengthscale, get_mean_std, get_scale, mean_and_var,
+                        nlml, nlml_fitted, nlml_ls, posterior_mean, posterior_var, prep_input, prep_output,
+                        rescale_model, std_y, unstandardized_mean_and_var)
+
+StandardGP = HipStandardGP   # drop-in alias
+
+
+def update(obj, a, b):
+    """`update` is one generic function in the reference, dispatched on its first argument:
+    update(model, xs, ys) (StandardGP.jl:79) / update(acq, ys, surrogate) (ExpectedImprovement.jl:81)."""
+    if isinstance(obj, AbstractAcquisition):
+        return acquisition.update(obj, a, b)
+    return _s.update(obj, a, b)
+
+
+def copy(obj):
+    """Base.copy for surrogates (StandardGP.jl:26) and acquisition functions."""
+    if isinstance(obj, AbstractAcquisition):
+        return acquisition.copy(obj)
+    return _s.copy(obj)

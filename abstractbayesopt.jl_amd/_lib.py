@@ -1,0 +1,99 @@
+"""ctypes binding of libabo_hip.so (include/abo_hip.h).  There is no CPU fallback: if the HIP
+library is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libabo_hip.so")
+
+ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
+HOST, DEVICE = 0, 1
+
+EXPORTS = ["abo_create", "abo_retain", "abo_destroy", "abo_fit", "abo_predict", "abo_acq", "abo_nlml",
+           "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version",
+           "abo_test_gemm_nt"]
+
+
+class AboParams(C.Structure):
+    _fields_ = [("family", C.c_int32), ("device", C.c_int32), ("ell", C.c_double), ("sigma_f2", C.c_double),
+                ("noise_var", C.c_double), ("mean_c", C.c_double), ("jitter", C.c_double),
+                ("n_max", C.c_int64), ("chunk", C.c_int64)]
+
+
+class AboTimings(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fit_kernel_matrix_ms", "fit_cholesky_ms", "fit_inverse_ms",
+                                          "fit_alpha_ms", "fit_total_ms", "acq_kxz_ms", "acq_var_gemm_ms",
+                                          "acq_finalize_ms", "acq_topk_ms", "acq_total_ms")] + \
+               [("var_gemm_launches", C.c_int64), ("var_gemm_flop", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PosDefException(Exception):
+    """Mirror of LinearAlgebra.PosDefException(info) — the exception the BO driver's rollback
+    catches (src/bayesian_opt.jl:126-141)."""
+
+    def __init__(self, info, msg=""):
+        super().__init__(msg or f"matrix is not positive definite; Cholesky factorization failed at {info}")
+        self.info = int(info)
+
+
+class DimensionMismatch(Exception):
+    """Mirror of Julia's DimensionMismatch (test/test_bayesian_opt.jl:788-817)."""
+
+
+class AboError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AboError(f"{LIB_PATH} not found: the HIP library has not been built "
+                       "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.abo_create.argtypes = [C.POINTER(AboParams), C.POINTER(vp)]
+    L.abo_retain.argtypes = [vp]
+    L.abo_destroy.argtypes = [vp]
+    L.abo_fit.argtypes = [vp, vp, i64, i32, vp, i32, C.POINTER(i64)]
+    L.abo_predict.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
+    L.abo_acq.argtypes = [vp, vp, i64, i32, i32, i32, f64, f64, i64, vp, i32, vp, vp, i32]
+    L.abo_nlml.argtypes = [vp, C.POINTER(f64)]
+    L.abo_get_factor.argtypes = [vp, vp, vp, vp]
+    L.abo_get_n.argtypes = [vp, C.POINTER(i64), C.POINTER(i32)]
+    L.abo_get_timings.argtypes = [vp, C.POINTER(AboTimings)]
+    L.abo_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    L.abo_abi_version.argtypes = []
+    L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
+    for name in EXPORTS:
+        getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().abo_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status: int, info: int = 0):
+    if status == ABO_OK:
+        return
+    msg = last_error()
+    if status == ABO_ENOTPD:
+        raise PosDefException(info, msg)
+    if status == ABO_EDIM:
+        raise DimensionMismatch(msg)
+    if status == ABO_EINVAL:
+        raise ValueError(msg)
+    if status == ABO_ENOMEM:
+        raise MemoryError(msg)
+    raise AboError(msg)

@@ -1,0 +1,36 @@
+"""Builds libabo_hip.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib", "libabo_hip.so")
+SOURCES = ["gemm.hip", "kgen.hip", "chol.hip", "misc.hip", "api.hip"]
+# -amdgpu-mfma-vgpr-form: keep fp64 MFMA accumulators in VGPRs; the AGPR form makes hipcc shuttle
+# every accumulator through v_accvgpr_read/write each k-step (2.2x slower, profiles/r01_mfma_f64_probe.txt)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "abo_hip.h")]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

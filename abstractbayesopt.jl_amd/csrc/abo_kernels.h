@@ -1,0 +1,99 @@
+// Internal launcher interface between the C-ABI (api.hip) and the kernel translation units.
+// Everything here is device-pointer based; no torch types, no host math.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace abo {
+
+constexpr int TB = 128;  // block (tile) edge used by every blocked stage; all padded sizes are multiples of it
+
+inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
+
+// ---- fp64 MFMA GEMM family (gemm.hip) -------------------------------------------------------
+enum KMode { K_FULL = 0, K_A_LOWER = 1, K_A_UPPER = 2 };
+
+struct GemmArgs {
+    const double* A;      // [M][lda]   row-major, k contiguous
+    const double* B;      // [N][ldb]   row-major, k contiguous  (C = A·Bᵀ)
+    double* C;            // [M][ldc]
+    double* Ct;           // optional transposed copy  Ct[j][i] = C[i][j]
+    int64_t lda, ldb, ldc, ldct;
+    int64_t sA, sB, sC, sCt;   // batch strides (elements)
+    int M, N, K;          // M, N multiples of 128; K multiple of 16
+    int kmode;            // K_FULL; K_A_LOWER: k < (ti+1)·128; K_A_UPPER: k ≥ ti·128
+    int lower_only;       // 1: skip tiles with tj > ti (SYRK on the lower triangle)
+    int batch;
+    double alpha, beta;
+    const int64_t* info;  // optional: if *info != 0 the kernel exits at once (failed factorisation)
+};
+hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s);
+
+// V = W·K_XZ restricted to k ≤ i (W lower-triangular), reduced on the fly to per-row-block column
+// sums of squares: partial[ti][j] = Σ_{i in block ti} (Σ_k W[i][k]·Kxz[j][k])²
+struct VarGemmArgs {
+    const double* W;      // [Np][ldw]
+    const double* Kxz;    // [Mc][ldk]   candidate-major chunk, k contiguous
+    double* partial;      // [Np/128][ldp]
+    int64_t ldw, ldk, ldp;
+    int Np, Mc;           // multiples of 128
+};
+hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s);
+
+// ---- kernel-matrix generation (kgen.hip) ----------------------------------------------------
+struct KgenArgs {
+    const double* Xs;     // [Np][dp]   training points, pre-scaled by 1/ell, zero padded
+    const double* Z;      // [M][d]     raw candidate points (caller layout), scaled on load
+    const double* alpha;  // [Np] zero padded, or nullptr (no mean)
+    double* Kout;         // [Mc][ldk]  Kout[j][k] = sigma_f2·kappa(||Xs_k − s·z_j||²), 0 for k ≥ N
+    double* mu;           // [Mc] mean_c + Σ_k Kout[j][k]·alpha[k], or nullptr
+    int64_t ldk;
+    int64_t M;            // number of valid candidates overall
+    int64_t j0;           // first candidate of this chunk
+    int Mc;               // padded chunk rows (multiple of 16)
+    int N, Np, d, dp, family;
+    double s, sigma_f2, mean_c;
+};
+hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
+// K[i][i] += noise for i < N; K[i][i] = 1 for N ≤ i < Np (identity padding keeps the factor PD)
+hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s);
+// Xs[i][c] = X[i][c]·s (zero padded to [Np][dp])
+hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st);
+
+// ---- factorisation pieces (chol.hip) --------------------------------------------------------
+// factor the 128×128 diagonal block at (r0,r0) of K in place (lower), write its inverse into the
+// matching diagonal block of W (lower) and WT (upper = transposed); on a non-positive pivot set
+// *info = r0 + j + 1 (if still 0) and leave.
+hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
+// out[i] = Σ_{k ≤ i} Wm[i][k]·v[k]   (lower == 1)   or   Σ_{k ≥ i} Wm[i][k]·v[k]   (lower == 0)
+hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* out, int Np, int lower, hipStream_t s);
+// out[0] = 2·Σ_{i<N} log L[i][i];  out[1] = Σ_{i<N} delta[i]·alpha[i]
+hipError_t launch_nlml_terms(const double* L, int64_t ld, const double* delta, const double* alpha, int N, double* out, hipStream_t s);
+// delta[i] = y[i] − c (i < N), 0 for padding
+hipError_t launch_center(const double* y, double* delta, int N, int Np, double c, hipStream_t s);
+
+// ---- posterior epilogue + selection (misc.hip) ----------------------------------------------
+struct FinalizeArgs {
+    const double* partial;   // [T][ldp]
+    const double* mu_in;     // [Mc]
+    double* mu_out;          // [M] or nullptr (global arrays, indexed j0 + j)
+    double* var_out;         // [M] or nullptr
+    double* score_out;       // [M] or nullptr
+    int64_t ldp, j0, M;
+    int T, Mc;
+    int kind;                // ABO_ACQ_*, or −1 for none
+    double sigma_f2, p0, best_y;
+};
+hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+struct TopkWork {            // scratch sized by topk_workspace_entries()
+    uint64_t* keys[2];
+    int64_t* idx[2];
+};
+int64_t topk_workspace_entries(int64_t M, int k);
+// top-k of scores[0..M) in Julia's `sortperm(scores; rev=true)` order; writes k (val, idx) pairs
+// (idx + idx_base; tail (NaN, −1) when M < k) to device arrays top_val/top_idx.
+hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base, TopkWork w,
+                       double* top_val, int64_t* top_idx, hipStream_t s);
+
+}  // namespace abo

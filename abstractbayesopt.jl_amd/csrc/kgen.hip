@@ -1,0 +1,173 @@
+// Kernel-matrix generation: K[j][k] = sigma_f2 · kappa(||s·x_k − s·z_j||²), s = 1/ell.
+//
+// Reference arithmetic being replaced: [upstream KernelFunctions] kernelmatrix of
+// ScaledKernel(inner ∘ ScaleTransform(1/ell), sigma_f2) (normal form built at
+// src/surrogates/StandardGP.jl:41-64), evaluated for K_XX in update() (:79-83) and for K_XZ in
+// posterior_mean / posterior_var (:361-379).  Inputs are multiplied by s first, then the squared
+// differences are summed directly (no ||x||²+||z||²−2x·z expansion: it loses digits and buys
+// nothing at d ≤ 64).
+//
+// Layout / mapping (HBM-write-bound for SE, VALU-bound for Matérn):
+//  * output is candidate-major, k contiguous — exactly the "NT" B-operand the fp64 MFMA tile core
+//    reads, so the contraction kernel needs no transpose;
+//  * a workgroup owns 16 candidates and sweeps all k; lane ↔ k (two consecutive k per lane, one
+//    16-byte coalesced store per candidate row), the lane's two training points live in registers,
+//    the 16 scaled candidates sit in LDS and are read as wave-wide broadcasts;
+//  * the posterior mean falls out of the same pass: mu_j = mean_c + Σ_k K[j][k]·alpha[k]
+//    (per-lane partials in registers, fixed-order block reduction — deterministic).
+#include "abo_kernels.h"
+#include "../../include/abo_hip.h"
+
+namespace abo {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+constexpr int JT = 16;        // candidates per workgroup
+constexpr int KSTEP = 512;    // k per sweep step (256 threads × 2)
+
+template <int FAM>
+__device__ __forceinline__ double kappa_eval(double d2) {
+    if constexpr (FAM == ABO_KERNEL_SE) {
+        return exp(-0.5 * d2);
+    } else if constexpr (FAM == ABO_KERNEL_MATERN52) {
+        // (1 + √5 d + 5 d²/3) e^{−√5 d}; closed form also covers the reference's Taylor branch
+        // (src/surrogates/GradientGP.jl:94-101) to 1e-16
+        const double s5 = 2.23606797749978969640917366873128;
+        const double d = sqrt(d2);
+        return (1.0 + s5 * d + 5.0 * d2 / 3.0) * exp(-s5 * d);
+    } else if constexpr (FAM == ABO_KERNEL_MATERN72) {
+        // src/surrogates/GradientGP.jl:320-327
+        const double s7 = 2.64575131106459059050161575363926;
+        const double d = sqrt(d2);
+        return (1.0 + s7 * d + 14.0 / 5.0 * d2 + 7.0 * s7 / 15.0 * d2 * d) * exp(-s7 * d);
+    } else {
+        const double s3 = 1.73205080756887729352744634150587;
+        const double d = sqrt(d2);
+        return (1.0 + s3 * d) * exp(-s3 * d);
+    }
+}
+
+template <int FAM, int DP>
+__global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
+    __shared__ double zs[JT][DP];
+    __shared__ double red[4][JT];
+    const int t = threadIdx.x;
+    const int jb = blockIdx.x * JT;
+    for (int idx = t; idx < JT * DP; idx += 256) {
+        const int jj = idx / DP, c = idx % DP;
+        const int64_t gj = p.j0 + jb + jj;
+        zs[jj][c] = (c < p.d && gj < p.M) ? p.Z[gj * p.d + c] * p.s : 0.0;
+    }
+    __syncthreads();
+
+    double mu[JT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) mu[jj] = 0.0;
+
+    for (int k0 = 0; k0 < p.Np; k0 += KSTEP) {
+        const int k = k0 + 2 * t;
+        if (k < p.Np) {
+            double x0[DP], x1[DP];
+            const double* xp = p.Xs + (int64_t)k * DP;
+            if constexpr (DP >= 2) {
+#pragma unroll
+                for (int c = 0; c < DP; c += 2) {
+                    const d2_t v0 = *reinterpret_cast<const d2_t*>(xp + c);
+                    const d2_t v1 = *reinterpret_cast<const d2_t*>(xp + DP + c);
+                    x0[c] = v0[0]; x0[c + 1] = v0[1];
+                    x1[c] = v1[0]; x1[c + 1] = v1[1];
+                }
+            } else {
+                x0[0] = xp[0]; x1[0] = xp[1];
+            }
+            const bool ok0 = k < p.N, ok1 = (k + 1) < p.N;
+            double a0 = 0.0, a1 = 0.0;
+            if (p.alpha) { a0 = p.alpha[k]; a1 = p.alpha[k + 1]; }
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) {
+                // rows past the last candidate are written as zeros (K_XX relies on it for its
+                // identity padding; for K_XZ they are padding candidates nobody reads)
+                const bool okj = (p.j0 + jb + jj) < p.M;
+                // keep the candidate coordinates in LDS: without this hipcc hoists all JT·DP
+                // broadcast reads out of the k sweep and pins them in (up to 512) registers
+                asm volatile("" ::: "memory");
+                double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < DP; ++c) {
+                    const double z = zs[jj][c];
+                    const double e0 = x0[c] - z, e1 = x1[c] - z;
+                    r0 = fma(e0, e0, r0);
+                    r1 = fma(e1, e1, r1);
+                }
+                const double v0 = (ok0 && okj) ? p.sigma_f2 * kappa_eval<FAM>(r0) : 0.0;
+                const double v1 = (ok1 && okj) ? p.sigma_f2 * kappa_eval<FAM>(r1) : 0.0;
+                *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
+                mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
+            }
+        }
+    }
+    if (p.mu == nullptr) return;
+    // fixed-order reduction: lanes (xor tree) → 4 waves (serial)
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        double v = mu[jj];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][jj] = v;
+    }
+    __syncthreads();
+    if (t < JT) p.mu[jb + t] = p.mean_c + (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]);
+}
+
+template <int FAM>
+static hipError_t launch_fam(const KgenArgs& a, hipStream_t s) {
+    dim3 grid(a.Mc / JT), block(256);
+    switch (a.dp) {
+        case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((kgen_kernel<FAM, 4>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((kgen_kernel<FAM, 8>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((kgen_kernel<FAM, 16>), grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((kgen_kernel<FAM, 32>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_kgen(const KgenArgs& a, hipStream_t s) {
+    if (a.Mc <= 0) return hipSuccess;
+    switch (a.family) {
+        case ABO_KERNEL_SE: return launch_fam<ABO_KERNEL_SE>(a, s);
+        case ABO_KERNEL_MATERN52: return launch_fam<ABO_KERNEL_MATERN52>(a, s);
+        case ABO_KERNEL_MATERN72: return launch_fam<ABO_KERNEL_MATERN72>(a, s);
+        case ABO_KERNEL_MATERN32: return launch_fam<ABO_KERNEL_MATERN32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+__global__ void diag_fix_kernel(double* K, int64_t ld, int N, int Np, double noise) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Np) return;
+    if (i < N) K[(int64_t)i * ld + i] += noise;
+    else K[(int64_t)i * ld + i] = 1.0;
+}
+
+hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s) {
+    hipLaunchKernelGGL(diag_fix_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, K, ld, N, Np, noise);
+    return hipGetLastError();
+}
+
+__global__ void scale_points_kernel(const double* X, double* Xs, int N, int Np, int d, int dp, double s) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)Np * dp) return;
+    const int i = (int)(idx / dp), c = (int)(idx % dp);
+    Xs[idx] = (i < N && c < d) ? X[(int64_t)i * d + c] * s : 0.0;
+}
+
+hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st) {
+    const int64_t n = (int64_t)Np * dp;
+    hipLaunchKernelGGL(scale_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, Xs, N, Np, d, dp, s);
+    return hipGetLastError();
+}
+
+}  // namespace abo

@@ -1,0 +1,156 @@
+// Posterior epilogue (variance assembly + EI / UCB / PI) and the top-k selection.
+//
+// Reference arithmetic being replaced:
+//   var = k(z,z) − colsum((L⁻¹K_XZ)²) + 1e-18   [upstream AbstractGPs var(::FiniteGP) with the default
+//         1e-18 jitter] via src/surrogates/StandardGP.jl:377-379
+//   EI   src/acquisition_functions/ExpectedImprovement.jl:40-66   (Normal cdf = erfc(−z/√2)/2)
+//   UCB  src/acquisition_functions/UpperConfidenceBound.jl:38-45
+//   PI   src/acquisition_functions/ProbabilityImprovement.jl:38-63 (incl. the σ²≤1e-12 → max(Δ,0) quirk)
+//   top-k  sortperm(scores; rev=true)[1:k]   src/acquisition_functions/acq_utils.jl:51-52
+// All of it is O(M) byte-moving work: one coalesced pass, no atomics, fixed summation order.
+#include "abo_kernels.h"
+#include "../../include/abo_hip.h"
+
+namespace abo {
+
+__device__ __forceinline__ double norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440084436210485); }
+__device__ __forceinline__ double norm_pdf(double z) { return exp(-0.5 * z * z) * 0.39894228040143267793994605993438; }
+
+__device__ __forceinline__ double acq_score(int kind, double mu, double var, double p0, double best_y) {
+    if (kind == ABO_ACQ_UCB) return -mu + p0 * sqrt(fmax(var, 0.0));
+    if (kind == ABO_ACQ_MEAN) return -mu;
+    const double delta = (best_y - p0) - mu;
+    if (var <= 1e-12) return fmax(delta, 0.0);
+    const double sg = sqrt(var);
+    const double z = delta / sg;
+    if (kind == ABO_ACQ_EI) return delta * norm_cdf(z) + sg * norm_pdf(z);
+    return norm_cdf(z);
+}
+
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs p) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.Mc) return;
+    const int64_t gj = p.j0 + j;
+    if (gj >= p.M) return;
+    double q = 0.0;
+    for (int t = 0; t < p.T; ++t) q += p.partial[(int64_t)t * p.ldp + j];   // row blocks in order
+    const double var = p.sigma_f2 - q + 1e-18;
+    const double mu = p.mu_in[j];
+    if (p.mu_out) p.mu_out[gj] = mu;
+    if (p.var_out) p.var_out[gj] = var;
+    if (p.score_out) p.score_out[gj] = acq_score(p.kind, mu, var, p.p0, p.best_y);
+}
+
+hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s) {
+    if (a.Mc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_kernel, dim3((a.Mc + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---- top-k ------------------------------------------------------------------------------------
+// Total order of Julia's stable `sortperm(scores; rev=true)`: isless-descending (NaN first, then
+// +Inf … −Inf, with 0.0 before −0.0), equal scores by ascending index.  Scores are mapped to
+// order-preserving u64 keys; each workgroup bitonic-sorts 2048 (key, idx) pairs in LDS and keeps its
+// first KP; passes repeat until one block is left.  No atomics: bit-reproducible.
+constexpr int TK_E = 2048;   // entries per workgroup
+constexpr uint64_t KEY_PAD = 0ull;
+constexpr int64_t IDX_PAD = 0x7fffffffffffffffll;
+
+__device__ __forceinline__ uint64_t score_key(double s) {
+    if (s != s) return 0xffffffffffffffffull;
+    const uint64_t b = (uint64_t)__double_as_longlong(s);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// true if entry (ka, ia) must come before (kb, ib)
+__device__ __forceinline__ bool before(uint64_t ka, int64_t ia, uint64_t kb, int64_t ib) {
+    return (ka > kb) || (ka == kb && ia < ib);
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(256) topk_pass_kernel(const double* __restrict__ scores, const uint64_t* __restrict__ kin,
+                                                        const int64_t* __restrict__ iin, int64_t n, int kp,
+                                                        uint64_t* __restrict__ kout, int64_t* __restrict__ iout) {
+    __shared__ uint64_t sk[TK_E];
+    __shared__ int64_t si[TK_E];
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * TK_E;
+    for (int e = t; e < TK_E; e += 256) {
+        const int64_t g = base + e;
+        uint64_t k = KEY_PAD;
+        int64_t i = IDX_PAD;
+        if (g < n) {
+            if (FIRST) { k = score_key(scores[g]); i = g; }
+            else { k = kin[g]; i = iin[g]; }
+        }
+        sk[e] = k;
+        si[e] = i;
+    }
+    __syncthreads();
+    for (int size = 2; size <= TK_E; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int e = t; e < TK_E / 2; e += 256) {
+                const int lo = 2 * e - (e & (stride - 1));   // index with the `stride` bit clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;            // this run sorts "before-first"
+                const uint64_t k0 = sk[lo], k1 = sk[hi];
+                const int64_t i0 = si[lo], i1 = si[hi];
+                const bool swap = up ? before(k1, i1, k0, i0) : before(k0, i0, k1, i1);
+                if (swap) { sk[lo] = k1; si[lo] = i1; sk[hi] = k0; si[hi] = i0; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = t; e < kp; e += 256) {
+        kout[(int64_t)blockIdx.x * kp + e] = sk[e];
+        iout[(int64_t)blockIdx.x * kp + e] = si[e];
+    }
+}
+
+__global__ void topk_emit_kernel(const double* scores, const int64_t* idx, int64_t M, int k, int64_t idx_base,
+                                 double* top_val, int64_t* top_idx) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k) return;
+    const int64_t i = idx[e];
+    if (i == IDX_PAD || i >= M) {
+        top_val[e] = __longlong_as_double(0x7ff8000000000000ll);
+        top_idx[e] = -1;
+    } else {
+        top_val[e] = scores[i];
+        top_idx[e] = i + idx_base;
+    }
+}
+
+static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
+
+int64_t topk_workspace_entries(int64_t M, int k) {
+    const int kp = pow2_at_least(k < 1 ? 1 : k);
+    const int64_t blocks = (M + TK_E - 1) / TK_E;
+    return (blocks < 1 ? 1 : blocks) * (int64_t)kp;
+}
+
+hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base, TopkWork w, double* top_val,
+                       int64_t* top_idx, hipStream_t s) {
+    if (k <= 0) return hipSuccess;
+    if (k > TK_E / 2) return hipErrorInvalidValue;
+    const int kp = pow2_at_least(k);
+    int64_t n = M;
+    int cur = 0;
+    int64_t blocks = (n + TK_E - 1) / TK_E;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((topk_pass_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, scores, nullptr, nullptr, n, kp,
+                       w.keys[0], w.idx[0]);
+    n = blocks * kp;
+    while (blocks > 1) {
+        blocks = (n + TK_E - 1) / TK_E;
+        hipLaunchKernelGGL((topk_pass_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, nullptr, w.keys[cur],
+                           w.idx[cur], n, kp, w.keys[cur ^ 1], w.idx[cur ^ 1]);
+        cur ^= 1;
+        n = blocks * kp;
+    }
+    hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, scores, w.idx[cur], M, k, idx_base,
+                       top_val, top_idx);
+    return hipGetLastError();
+}
+
+}  // namespace abo

@@ -1,0 +1,146 @@
+/*
+ * abo_hip.h — C-ABI of libabo_hip.so, the MI355X (gfx950) GP-surrogate backend that drops in behind
+ * AbstractBayesOpt.jl's AbstractSurrogate / AbstractAcquisition interface.
+ *
+ * The reference has no FFI of its own (it is pure Julia); each entry point below states the
+ * reference function whose arithmetic it replaces (file:line relative to the reference repo) —
+ * i.e. what a `HipStandardGP <: AbstractSurrogate` shim would `ccall` from that method
+ * (binding shown in INTEGRATION.md).
+ *
+ * Conventions
+ *  - every function returns an int32 status (ABO_OK == 0); on failure abo_last_error() holds text
+ *  - points are POINT-MAJOR contiguous fp64: X[i*d + c]  (== a Julia d×N column-major Matrix)
+ *  - `*_space` says where a caller buffer lives: ABO_HOST (pageable/pinned host memory) or
+ *    ABO_DEVICE (memory of the handle's GPU, e.g. a torch tensor's data_ptr or a hipMalloc)
+ *  - calls are synchronous: results are complete (host copies done, device buffers written and
+ *    the internal stream idle) when the call returns
+ *  - a handle is not re-entrant; different handles may be used from different threads
+ *  - indices are 0-based (the Julia shim adds 1)
+ */
+#ifndef ABO_HIP_H
+#define ABO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABO_ABI_VERSION 1
+
+/* status codes */
+enum {
+    ABO_OK = 0,
+    ABO_ENOTPD = 1,   /* K + noise·I not positive definite → LinearAlgebra.PosDefException(info)
+                         (caught at src/bayesian_opt.jl:126-141) */
+    ABO_EDIM = 2,     /* dimension mismatch → DimensionMismatch (test/test_bayesian_opt.jl:788-817) */
+    ABO_EINVAL = 3,   /* bad argument / not fitted */
+    ABO_EHIP = 4,     /* HIP runtime error */
+    ABO_ENOMEM = 5    /* device allocation failed */
+};
+
+/* kernel families: k(x,z) = sigma_f2 · kappa(||x−z|| / ell)  (StandardGP normal form,
+ * src/surrogates/StandardGP.jl:41-64; kappas: [upstream KernelFunctions] SqExponentialKernel /
+ * Matern52Kernel / Matern32Kernel and src/surrogates/GradientGP.jl:94-101, :320-327) */
+enum { ABO_KERNEL_SE = 0, ABO_KERNEL_MATERN52 = 1, ABO_KERNEL_MATERN72 = 2, ABO_KERNEL_MATERN32 = 3 };
+
+/* acquisition epilogues */
+enum {
+    ABO_ACQ_EI = 0,   /* src/acquisition_functions/ExpectedImprovement.jl:40-66   p0 = xi   */
+    ABO_ACQ_UCB = 1,  /* src/acquisition_functions/UpperConfidenceBound.jl:38-45  p0 = beta */
+    ABO_ACQ_PI = 2,   /* src/acquisition_functions/ProbabilityImprovement.jl:38-63 p0 = xi  */
+    ABO_ACQ_MEAN = 3  /* score = −mu (exploitation only; no reference counterpart) */
+};
+
+enum { ABO_HOST = 0, ABO_DEVICE = 1 };
+
+typedef struct abo_gp abo_gp; /* opaque, reference-counted */
+
+typedef struct abo_params {
+    int32_t family;     /* ABO_KERNEL_* */
+    int32_t device;     /* HIP device ordinal this handle lives on */
+    double ell;         /* lengthscale  (get_lengthscale, src/surrogates/StandardGP.jl:261) */
+    double sigma_f2;    /* kernel scale (get_scale, :274) */
+    double noise_var;   /* observation noise variance (StandardGP.noise_var, :13) */
+    double mean_c;      /* prior mean: 0 = ZeroMean, c = ConstMean(c) (:42-44, :223-229) */
+    double jitter;      /* 0 = reference behaviour (never add jitter); >0 = opt-in retry with
+                           noise_var + jitter·10^r, r = 0..3, when the factorisation fails */
+    int64_t n_max;      /* capacity hint for appends (0 = size to the fit) */
+    int64_t chunk;      /* candidate chunk size for the posterior (0 = auto) */
+} abo_params;
+
+/* phase timings of the last fit / acq call, milliseconds, measured with HIP events on the
+ * handle's own stream (see abo_get_timings) */
+typedef struct abo_timings {
+    double fit_kernel_matrix_ms, fit_cholesky_ms, fit_inverse_ms, fit_alpha_ms, fit_total_ms;
+    double acq_kxz_ms, acq_var_gemm_ms, acq_finalize_ms, acq_topk_ms, acq_total_ms;
+    int64_t var_gemm_launches;   /* number of launches of the dominant kernel in the last acq */
+    double var_gemm_flop;        /* algorithmic flop (N²·M, triangular) those launches performed */
+} abo_timings;
+
+/* --- lifetime -------------------------------------------------------------------------------
+ * StandardGP(kernel, noise_var; mean) (src/surrogates/StandardGP.jl:41-64).  The handle starts
+ * un-conditioned (gpx === nothing). */
+int32_t abo_create(const abo_params* params, abo_gp** out);
+/* Base.copy(::StandardGP) (src/surrogates/StandardGP.jl:26, surrogates_utils.jl:12-14): device
+ * state is immutable after fit, so a copy is a shared reference. */
+int32_t abo_retain(abo_gp* gp);
+/* finaliser; frees device state when the last reference goes */
+int32_t abo_destroy(abo_gp* gp);
+
+/* --- update ---------------------------------------------------------------------------------
+ * update(model::StandardGP, xs, ys) (src/surrogates/StandardGP.jl:79-83): full refit,
+ * K = k(X,X) + noise·I, L = chol(K), delta = y − mean_c, alpha = K⁻¹ delta, W = L⁻¹.
+ * *info = 0 on success, k>0 (1-based LAPACK potrf convention) with status ABO_ENOTPD when the
+ * leading minor of order k is not positive definite; the handle then stays un-conditioned. */
+int32_t abo_fit(abo_gp* gp, const double* X, int64_t N, int32_t d, const double* y, int32_t space,
+                int64_t* info);
+
+/* --- posterior ------------------------------------------------------------------------------
+ * posterior_mean / posterior_var (src/surrogates/StandardGP.jl:361-363, :377-379), fused as in
+ * unstandardized_mean_and_var's mean_and_var (:395-404):
+ *   mu = mean_c + K_ZX·alpha,   var = sigma_f2 − colsum((L⁻¹K_XZ)²) + 1e-18  (latent variance).
+ * mu / var may each be NULL. */
+int32_t abo_predict(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, double* mu,
+                    double* var, int32_t out_space);
+
+/* --- acquisition over a candidate batch -------------------------------------------------------
+ * scores = acqf(surrogate, grid_points); sortperm(scores; rev=true)[1:k]
+ * (src/acquisition_functions/acq_utils.jl:50-52) with the EI/UCB/PI epilogue fused behind the
+ * posterior.  scores (length M) is optional; top_val/top_idx (length k) are optional when k == 0.
+ * Ordering is Julia's stable reverse sort: descending score, ties → lowest index, NaN first.
+ * top_idx are global indices idx_base + j (idx_base = this rank's shard offset).  When M < k the
+ * tail is filled with (NaN, −1).  scores/top_* live in out_space. */
+int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind,
+                double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
+                double* top_val, int64_t* top_idx, int32_t out_space);
+
+/* --- scalars ----------------------------------------------------------------------------------
+ * nlml (src/surrogates/StandardGP.jl:99-114) of the fitted state:
+ * ½(N log 2π + logdet(K+noise I) + deltaᵀ alpha). */
+int32_t abo_nlml(abo_gp* gp, double* out);
+
+/* --- introspection (tests) ----------------------------------------------------------------------
+ * L (N×N row-major, strictly-upper part zero), alpha (N), Linv = L⁻¹ (N×N row-major); any may be
+ * NULL.  Host buffers. */
+int32_t abo_get_factor(abo_gp* gp, double* L, double* alpha, double* Linv);
+int32_t abo_get_n(abo_gp* gp, int64_t* N, int32_t* d);
+int32_t abo_get_timings(abo_gp* gp, abo_timings* out);
+
+/* --- errors / version ---------------------------------------------------------------------------*/
+/* copies the calling thread's last error text (NUL-terminated, truncated to cap) */
+int32_t abo_last_error(char* buf, size_t cap);
+int32_t abo_abi_version(void);
+
+/* --- building blocks exposed for tests and profiling (all buffers DEVICE memory) ------------------
+ * C[i][j] = alpha·Σ_k A[i][k]·B[j][k] + beta·C[i][j]; M, N multiples of 128, K multiple of 16,
+ * leading dimensions even.  Exercises the fp64 MFMA tile core every solver stage is built on. */
+int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M,
+                         int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, double alpha,
+                         double beta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABO_HIP_H */
