@@ -57,6 +57,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise AboError(f"{LIB_PATH} not found: the HIP library has not been built "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.  If this
+    # library were loaded first it would pull in /opt/rocm's copy, torch would then bind to a mix of the
+    # two and no device would be visible.  Loading torch first makes the dynamic linker resolve our
+    # libamdhip64.so.7 dependency to the copy already in the process.  (A Julia host has no torch and
+    # simply uses the system runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.abo_create.argtypes = [C.POINTER(AboParams), C.POINTER(vp)]
