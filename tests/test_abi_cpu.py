@@ -1,0 +1,63 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol
+include/abo_hip.h declares, and the product path fails loudly (no CPU fallback) when no device exists."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import abstractbayesopt.jl_amd as abo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "abo_hip.h")).read()
+    declared = sorted(set(re.findall(r"^int32_t\s+(abo_\w+)\s*\(", hdr, flags=re.M)))
+    assert declared, "no declarations parsed"
+    assert sorted(abo._lib.EXPORTS) == declared
+    lib = abo._lib.lib()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.abo_abi_version() == int(re.search(r"#define ABO_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_struct_layout_matches_header():
+    # abo_params: 2×int32, 5×double, 2×int64 ; abo_timings: 10×double, int64, double
+    assert C.sizeof(abo._lib.AboParams) == 8 + 5 * 8 + 2 * 8
+    assert C.sizeof(abo._lib.AboTimings) == 12 * 8
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = abo._lib.lib()
+    assert lib.abo_create(None, None) == abo._lib.ABO_EINVAL
+    assert "null" in abo._lib.last_error()
+    bad = abo._lib.AboParams(family=9, device=0, ell=1.0, sigma_f2=1.0, noise_var=0.0, mean_c=0.0, jitter=0.0)
+    hp = C.c_void_p()
+    assert lib.abo_create(C.byref(bad), C.byref(hp)) == abo._lib.ABO_EINVAL
+    bad = abo._lib.AboParams(family=0, device=0, ell=-1.0, sigma_f2=1.0, noise_var=0.0, mean_c=0.0, jitter=0.0)
+    assert lib.abo_create(C.byref(bad), C.byref(hp)) == abo._lib.ABO_EINVAL
+    assert lib.abo_destroy(None) == abo._lib.ABO_OK
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a box without a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    gp = abo.HipStandardGP(abo.SqExponentialKernel(), 0.1)
+    with pytest.raises((abo.AboError, ValueError)):
+        abo.update(gp, [0.0, 0.5, 1.0], [0.0, 0.25, 1.0])
+    with pytest.raises(ValueError):
+        abo.posterior_mean(gp, [0.25])        # gpx === nothing
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "abstractbayesopt.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "gp_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f

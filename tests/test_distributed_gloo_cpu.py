@@ -1,0 +1,72 @@
+"""world_size-2 gloo test of the only exchange step of the multi-GPU path: every rank contributes
+its shard's local top-k, all_gather, identical merge — must equal the single-process selection over
+the whole candidate batch (stable reverse sortperm, acq_utils.jl:51-52).  The local scores here are
+synthetic (seeded) numbers standing in for what the HIP path returns per shard."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from abstractbayesopt.jl_amd import distributed as D
+from oracle import gp_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, M, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)
+    scores = np.round(rng.normal(size=M), 2)        # ties across shards
+    scores[M // 2] = np.nan
+    lo, hi = D.shard_range(M, rank, world)
+    v, i = O.top_k(scores[lo:hi], k)
+    v = np.concatenate([v, np.full(k - len(v), np.nan)])
+    i = np.concatenate([i + lo, np.full(k - len(i), -1, dtype=np.int64)])
+    mv, mi = D.all_gather_topk(torch.from_numpy(v), torch.from_numpy(i), k)
+    q.put((rank, mv.numpy().copy(), mi.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, M, k):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, M, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_topk_merge_matches_global():
+    M, k = 10001, 100
+    res = _run(2, M, k)
+    rng = np.random.default_rng(11)
+    scores = np.round(rng.normal(size=M), 2)
+    scores[M // 2] = np.nan
+    ov, oi = O.top_k(scores, k)
+    for rank, mv, mi in res:
+        np.testing.assert_array_equal(mi, oi)
+        np.testing.assert_array_equal(mv, ov)
+
+
+def test_two_rank_short_shards():
+    # fewer candidates than k on each rank: padding entries (NaN, −1) must vanish in the merge
+    res = _run(2, 7, 16)
+    for rank, mv, mi in res:
+        assert len(mi) == 7 and sorted(mi.tolist()) == list(range(7))

@@ -1,0 +1,124 @@
+"""CPU tests of the host-side mirror of the reference interface (no device work)."""
+import numpy as np
+import pytest
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import distributed as D
+from abstractbayesopt.jl_amd import synth
+from oracle import gp_oracle as O
+
+
+def test_kernel_normal_form():
+    # test/test_surrogates.jl:10-57: any kernel is reduced to ScaledKernel(inner ∘ ScaleTransform(1/ℓ), σ²)
+    gp = abo.HipStandardGP(abo.SqExponentialKernel(), 0.1)
+    assert abo.get_lengthscale(gp) == [1.0] and abo.get_scale(gp) == [1.0]
+    gp = abo.HipStandardGP(abo.with_lengthscale(abo.SqExponentialKernel(), 2.0), 0.1)
+    assert abo.get_lengthscale(gp) == [2.0] and abo.get_scale(gp) == [1.0]
+    gp = abo.HipStandardGP(4.0 * abo.with_lengthscale(abo.Matern52Kernel(), 2.0), 0.1)
+    assert abo.get_lengthscale(gp) == [2.0] and abo.get_scale(gp) == [4.0]
+    gp = abo.HipStandardGP(3.0 * abo.Matern52Kernel(), 0.1, mean=abo.ConstMean(1.5))
+    assert abo.get_lengthscale(gp) == [1.0] and abo.get_scale(gp) == [3.0] and gp.mean.c == 1.5
+    assert gp.gpx is None and gp.noise_var == 0.1
+    assert abo.get_kernel_constructor(gp) == abo.Matern52Kernel()
+    assert abo.prep_input(gp, [1.0]) == [1.0] and abo.prep_output(gp, [2.0]) == [2.0]
+
+
+def test_rescale_model_and_mean_std():
+    # StandardGP.jl:164-232
+    gp = abo.HipStandardGP(2.0 * abo.with_lengthscale(abo.SqExponentialKernel(), 0.5), 0.4, mean=abo.ConstMean(3.0))
+    r = abo.rescale_model(gp, 2.0)
+    assert abo.get_scale(r) == [0.5] and abo.get_lengthscale(r) == [0.5] and r.noise_var == 0.1 and r.mean.c == 1.5
+    y = [1.0, 2.0, 4.0]
+    m, s = abo.get_mean_std(gp, y, "mean_scale")
+    assert abs(m - 7 / 3) < 1e-15 and abs(s - np.std(y, ddof=1)) < 1e-15
+    assert abo.get_mean_std(gp, y, "scale_only")[0] == 0.0 and abo.get_mean_std(gp, y, "mean_only")[1] == 1.0
+    np.testing.assert_allclose(abo.std_y(gp, y, m, s), (np.array(y) - m) / s)
+    assert abo._get_minimum(gp, y) == 1.0
+
+
+def test_acquisition_update_semantics():
+    # test/test_acquisition.jl:45-63,:97-113: EI/PI take best_y = min(ys); UCB unchanged
+    gp = abo.HipStandardGP(abo.SqExponentialKernel(), 0.1)
+    ei = abo.update(abo.ExpectedImprovement(0.01, 10.0), [2.0, 1.0, 0.5], gp)
+    assert ei.best_y == 0.5 and ei.xi == 0.01
+    pi = abo.update(abo.ProbabilityImprovement(0.02, 10.0), [2.0, 1.0, 0.5], gp)
+    assert pi.best_y == 0.5 and pi.xi == 0.02
+    ucb = abo.UpperConfidenceBound(2.0)
+    assert abo.update(ucb, [1.0], gp) == ucb
+    assert abo.copy(ei) == ei and abo.copy(ei) is not ei
+
+
+def test_continuous_domain_validation():
+    # test/test_domains.jl:6-54
+    d = abo.ContinuousDomain([0.0, -1.0], [1.0, 1.0])
+    assert d.bounds == [(0.0, 1.0), (-1.0, 1.0)]
+    with pytest.raises(ValueError):
+        abo.ContinuousDomain([0.0], [1.0, 2.0])
+    with pytest.raises(ValueError):
+        abo.ContinuousDomain([2.0], [1.0])
+    abo.ContinuousDomain([1.0], [1.0])          # degenerate box is allowed
+
+
+def test_latin_hypercube_one_point_per_stratum():
+    rng = np.random.default_rng(0)
+    g = abo.latin_hypercube(1000, [0.0, -2.0, 5.0], [1.0, 2.0, 6.0], rng)
+    assert g.shape == (1000, 3)
+    for c, (lo, hi) in enumerate([(0.0, 1.0), (-2.0, 2.0), (5.0, 6.0)]):
+        strata = np.floor((g[:, c] - lo) / (hi - lo) * 1000).astype(int)
+        assert sorted(strata.tolist()) == list(range(1000))
+
+
+def test_synth_is_counter_based():
+    a = synth.points(2, 1000, 8)
+    b = synth.points(2, 300, 8, first=200)
+    np.testing.assert_array_equal(a[200:500], b)
+    assert 0.0 <= a.min() and a.max() < 1.0 and abs(a.mean() - 0.5) < 0.02
+    X, y = synth.standardized_problem(512, 4, 0.05)
+    assert abs(y.mean()) < 1e-12 and abs(y.std(ddof=1) - 1.0) < 1e-12
+    n = synth.normal(3, 0, 20000)
+    assert abs(n.mean()) < 0.03 and abs(n.std() - 1.0) < 0.03
+
+
+def test_shard_ranges_cover_exactly():
+    for M in (0, 1, 7, 8, 1000, 8388608):
+        for w in (1, 2, 3, 8):
+            r = [D.shard_range(M, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == M
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_topk_equals_global_stable_order():
+    rng = np.random.default_rng(5)
+    s = np.round(rng.normal(size=5000), 1)          # many ties
+    s[[10, 4000]] = np.nan
+    s[77] = np.inf
+    k = 100
+    vals, idx = [], []
+    for r in range(4):
+        lo, hi = D.shard_range(len(s), r, 4)
+        v, i = O.top_k(s[lo:hi], k)
+        vals.append(v); idx.append(i + lo)
+    mv, mi = D.merge_topk(np.stack(vals), np.stack(idx), k)
+    ov, oi = O.top_k(s, k)
+    np.testing.assert_array_equal(mi, oi)
+    np.testing.assert_array_equal(mv, ov)
+    # short shards padded with (NaN, −1) are dropped
+    mv, mi = D.merge_topk(np.array([[1.0, np.nan], [3.0, 2.0]]), np.array([[5, -1], [9, 7]]), 4)
+    assert mi.tolist() == [9, 7, 5] and mv.tolist() == [3.0, 2.0, 1.0]
+
+
+def test_input_containers():
+    from abstractbayesopt.jl_amd.surrogate import as_points
+    _, m, d, space, _ = as_points([0.0, 0.5, 1.0])
+    assert (m, d, space) == (3, 1, 0)
+    _, m, d, _, _ = as_points([[0.0, 1.0], [2.0, 3.0]])
+    assert (m, d) == (2, 2)
+    with pytest.raises(abo.DimensionMismatch):
+        as_points([[0.0, 1.0], [2.0]])
+    import torch
+    _, m, d, space, _ = as_points(torch.zeros(4, 3, dtype=torch.float64))
+    assert (m, d, space) == (4, 3, 0)
+    with pytest.raises(TypeError):
+        as_points(torch.zeros(4, 3, dtype=torch.float32))
