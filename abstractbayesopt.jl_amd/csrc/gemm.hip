@@ -14,11 +14,18 @@
 //    one 16-byte LDS read per lane feeds two MFMA k-steps: lane l reads [row l&15][k = 2(l>>4), +1].
 //    The k-permutation this implies is identical for A and B, so the products pair up correctly.
 //  * LDS rows are padded 16 → 20 doubles (160 B): with that stride the four 16-lane groups of a
-//    ds_read_b128 each touch 16 distinct 16-byte slots (conflict-free), and rows stay 16-B aligned
-//    for ds_write_b128.
-//  * global → register prefetch of stage t+1 is issued before the MFMAs of stage t; registers are
-//    written to LDS after the barrier (issue-early / write-late).  Two workgroups per CU (40 KB LDS,
-//    ≤256 VGPRs) keep the matrix pipe busy across each other's barriers.
+//    ds_read_b128 each touch 16 distinct 16-byte slots (conflict-free, SQ_LDS_BANK_CONFLICT = 0),
+//    and rows stay 16-B aligned for ds_write_b128.
+//  * Software pipeline with ONE barrier per stage: LDS holds two stages (80 KB per workgroup, two
+//    workgroups per CU), registers hold two half-stage fragment sets and the staging registers of the
+//    global loads that run two stages ahead.
+//  * Every LDS/VMEM instruction is issued directly behind one of the wave's own MFMAs
+//    (sched_group_barrier, steady-state iteration = one basic block).  Measured
+//    (profiles/r01_var_gemm_ablation.txt): the same instructions issued as a burst cost 6 % of the
+//    kernel — a wave that is not issuing MFMAs advances about one instruction per MFMA slot of its
+//    SIMD partner — while dealt out one per MFMA they cost nothing; a strict ping-pong of MFMA and
+//    memory roles between the two waves of a SIMD is slower still (the memory phase becomes as long
+//    as the MFMA phase).  Static s_setprio between the co-resident workgroups changes nothing.
 #include "abo_kernels.h"
 
 namespace abo {
@@ -45,58 +52,131 @@ __device__ __forceinline__ void tile_lstore(double* s, const d2_t (&r)[4]) {
     for (int q = 0; q < 4; ++q) *reinterpret_cast<d2_t*>(s + (row + 32 * q) * LDT + kk) = r[q];
 }
 
-// one BK=16 stage: 2 × (8 ds_read_b128 + 32 MFMA) per wave
-__device__ __forceinline__ void tile_mma(const double* As, const double* Bs, d4_t (&acc)[4][4], int wm, int wn,
-                                         int lane) {
-    const int r16 = lane & 15, g = lane >> 4;
-    const double* ap = As + (wm * 64 + r16) * LDT + g * 2;
-    const double* bp = Bs + (wn * 64 + r16) * LDT + g * 2;
+// fragments of one half stage (8 of the 16 k): 4 A rows-of-16 and 4 B rows-of-16, two k each
+struct Frag {
+    d2_t a[4], b[4];
+};
+
+__device__ __forceinline__ void frag_read(const double* ap, const double* bp, int half, Frag& f) {
 #pragma unroll
-    for (int k8 = 0; k8 < 2; ++k8) {
-        d2_t a[4], b[4];
+    for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const d2_t*>(ap + i * 16 * LDT + half * 8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const d2_t*>(ap + i * 16 * LDT + k8 * 8);
+    for (int i = 0; i < 4; ++i) f.b[i] = *reinterpret_cast<const d2_t*>(bp + i * 16 * LDT + half * 8);
+}
+
+// 16 MFMAs: one k-step (kk = 0 or 1 of the fragment pair) × 4×4 tiles
+template <int KK>
+__device__ __forceinline__ void frag_mma(const Frag& f, d4_t (&acc)[4][4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const d2_t*>(bp + i * 16 * LDT + k8 * 8);
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
-    }
+        for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[mi][KK], f.b[ni][KK], acc[mi][ni], 0, 0, 0);
 }
 
 // acc += A[0:128][kbeg:kend] · B[0:128][kbeg:kend]ᵀ ; Ag/Bg point at the tile's first row.
+//
+// iteration t (stage = 16 k):
+//     32 MFMA on F0 = fragments(t, half 0), and behind one MFMA each:
+//         8 ds_write   S(stage t+1) → LDS[(t+1)&1]
+//         8 ds_read    fragments(t, half 1) → F1
+//         8 global_load stage t+2 → S
+//     barrier          (stage t+1 complete in LDS; nobody still reads stage t)
+//     32 MFMA on F1, and behind the first eight: 8 ds_read fragments(t+1, half 0) → F0
+// The last two stages of a tile (nothing left to prefetch) run a plain version of the same steps.
 __device__ __forceinline__ void tile_loop(const double* __restrict__ Ag, int64_t lda, const double* __restrict__ Bg,
                                           int64_t ldb, int kbeg, int kend, double* smem, d4_t (&acc)[4][4]) {
-    double* As = smem;
-    double* Bs = smem + TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    d2_t ra[4], rb[4];
-    if (kbeg < kend) {
-        tile_gload(Ag, lda, kbeg, ra);
-        tile_gload(Bg, ldb, kbeg, rb);
-        tile_lstore(As, ra);
-        tile_lstore(Bs, rb);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int aoff = (wm * 64 + r16) * LDT + g * 2;
+    const int boff = TILE + (wn * 64 + r16) * LDT + g * 2;
+    const int nk = (kend - kbeg) / BK;
+    if (nk <= 0) return;
+    d2_t sa[4], sb[4];
+    Frag f0, f1;
+    tile_gload(Ag, lda, kbeg, sa);
+    tile_gload(Bg, ldb, kbeg, sb);
+    tile_lstore(smem, sa);
+    tile_lstore(smem + TILE, sb);
+    if (nk > 1) {
+        tile_gload(Ag, lda, kbeg + BK, sa);
+        tile_gload(Bg, ldb, kbeg + BK, sb);
     }
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = (k0 + BK) < kend;
-        if (more) {
-            tile_gload(Ag, lda, k0 + BK, ra);
-            tile_gload(Bg, ldb, k0 + BK, rb);
+    frag_read(smem + aoff, smem + boff, 0, f0);
+    int t = 0;
+    {
+        // steady state (stages t+1 and t+2 exist): one basic block per iteration
+        for (; t + 2 < nk; ++t) {
+            double* cur = smem + (t & 1) * (2 * TILE);
+            double* nxt = smem + ((t + 1) & 1) * (2 * TILE);
+            tile_lstore(nxt, sa);
+            tile_lstore(nxt + TILE, sb);
+            frag_read(cur + aoff, cur + boff, 1, f1);
+            tile_gload(Ag, lda, kbeg + (t + 2) * BK, sa);
+            tile_gload(Bg, ldb, kbeg + (t + 2) * BK, sb);
+            frag_mma<0>(f0, acc);
+            frag_mma<1>(f0, acc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            frag_read(nxt + aoff, nxt + boff, 0, f0);
+            frag_mma<0>(f1, acc);
+            frag_mma<1>(f1, acc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        tile_mma(As, Bs, acc, wm, wn, lane);
-        __syncthreads();
-        if (more) {
-            tile_lstore(As, ra);
-            tile_lstore(Bs, rb);
-        }
-        __syncthreads();
     }
+    for (; t < nk; ++t) {
+        double* cur = smem + (t & 1) * (2 * TILE);
+        double* nxt = smem + ((t + 1) & 1) * (2 * TILE);
+        frag_mma<0>(f0, acc);                                      // (c) first 16
+        // The sched_barriers pin what hipcc otherwise undoes: every LDS/global operation of the
+        // iteration is issued behind 16 MFMAs (issued at the top they put an lgkmcnt wait on
+        // themselves in front of the first MFMA: the counter is in-order and 4 bits wide), and the
+        // barrier stays behind all 32 MFMAs of F0 (hoisted, every wave sits out the LDS round trip
+        // with an empty matrix pipe).
+        __builtin_amdgcn_sched_barrier(0);
+        frag_read(cur + aoff, cur + boff, 1, f1);                  // (a)
+        if (t + 1 < nk) {                          // (b) stage t+1 → LDS, stage t+2 → S
+            tile_lstore(nxt, sa);
+            tile_lstore(nxt + TILE, sb);
+            if (t + 2 < nk) {
+                tile_gload(Ag, lda, kbeg + (t + 2) * BK, sa);
+                tile_gload(Bg, ldb, kbeg + (t + 2) * BK, sb);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mma<1>(f0, acc);                                      // (c) second 16
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                           // (d)
+        if (t + 1 < nk) frag_read(nxt + aoff, nxt + boff, 0, f0);  // (e)
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mma<0>(f1, acc);                                      // (f)
+        frag_mma<1>(f1, acc);
+    }
+    __syncthreads();   // callers reuse the LDS
 }
 
 __device__ __forceinline__ void acc_zero(d4_t (&acc)[4][4]) {
@@ -108,7 +188,7 @@ __device__ __forceinline__ void acc_zero(d4_t (&acc)[4][4]) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * TILE];
+    __shared__ __attribute__((aligned(16))) double smem[4 * TILE];
     if (p.info != nullptr && *p.info != 0) return;
     const int tj = blockIdx.x, ti = blockIdx.y, bz = blockIdx.z;
     if (p.lower_only && tj > ti) return;
@@ -154,7 +234,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
 // the tail of the launch.  blockIdx.x → (ti, tj) with tj fastest: consecutive workgroups share the
 // same W row panel and stream different candidate panels.
 __global__ void __launch_bounds__(256, 2) var_gemm_kernel(VarGemmArgs p) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * TILE];
+    __shared__ __attribute__((aligned(16))) double smem[4 * TILE];
     const int Tj = p.Mc / BN;
     const int Ti = p.Np / BM;
     const int b = blockIdx.x;
