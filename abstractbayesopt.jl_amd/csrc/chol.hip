@@ -10,82 +10,177 @@
 
 namespace abo {
 
-constexpr int NB = 128;
-constexpr int LDA = NB + 1;   // odd stride: column walks are conflict-free
+typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// One workgroup (256 threads), block resident in LDS (129 KB of the CU's 160 KB).
-//   phase 1: unblocked right-looking Cholesky on the lower triangle (pivot check per column)
-//   phase 2: Linv by forward substitution, one column per thread; column c of Linv is written
-//            into ROW c of the (now free) strict upper triangle, so no second LDS image is needed
-//   phase 3: write L (lower, zeros above) back to K, Linv to W (lower) and Linvᵀ to WT (upper)
+constexpr int NB = 128;
+constexpr int LDA = NB + 1;   // odd stride: column walks spread over the banks
+constexpr int SB = 16;        // sub-block edge = MFMA tile edge
+constexpr int NSB = NB / SB;  // 8
+
+// in-wave ordering point for LDS traffic between lanes of ONE wave: the LDS queue of a wave is
+// in-order, so a drained counter plus a compiler fence is all that is needed (no s_barrier)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One workgroup (4 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
+// as an 8×8 grid of 16×16 sub-blocks so that everything but the 16×16 diagonal factorisations runs
+// on the fp64 MFMA (v_mfma_f64_16x16x4_f64) with 24 + 8 workgroup barriers in total:
+//   phase 1  right-looking Cholesky over sub-block columns p = 0..7:
+//            (1) wave 0 factors the 16×16 diagonal sub-block in place (16 in-wave steps, pivot check)
+//            (2) one thread per row below solves x·L_ppᵀ = a (16-term forward substitution in registers)
+//            (3) trailing sub-blocks C_ij −= L_ip·L_jpᵀ, one MFMA chain per sub-block, spread over the waves
+//   phase 2  X = L⁻¹ in place: column n of X_cc is written into ROW n of the (free) strict upper triangle,
+//            i.e. the upper triangle ends up holding Xᵀ, reciprocals of the diagonal in dinv[]:
+//            (a) 16×16 diagonal inverses, one thread per column;
+//            (b) off-diagonal sub-blocks by distance δ = i−c: X_ic = −X_ii·(Σ_{c≤k<i} L_ik·X_kc); the inner sum
+//                comes out of the MFMA in C/D layout, which is exactly the B-operand layout of the next
+//                MFMA when its k-steps are taken as {g, g+4, g+8, g+12} — no data movement in between
+//   phase 3  write L back to K (lower, zeros above), X to W (lower) and Xᵀ to WT (upper).
+#define AA(r, c) a[(r) * LDA + (c)]
 __global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, double* WT, int64_t ld, int r0,
                                                         int64_t* info) {
     __shared__ double a[NB * LDA];
-    __shared__ double col[NB];
     __shared__ double dinv[NB];
     __shared__ int fail;
     const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
     if (*info != 0) return;
     if (t == 0) fail = 0;
     double* Kb = K + (int64_t)r0 * ld + r0;
     for (int idx = t; idx < NB * NB; idx += 256) {
         const int i = idx >> 7, j = idx & 127;
-        a[i * LDA + j] = Kb[(int64_t)i * ld + j];
+        AA(i, j) = Kb[(int64_t)i * ld + j];
     }
     __syncthreads();
 
-    for (int j = 0; j < NB; ++j) {
-        const double d = a[j * LDA + j];
-        if (!(d > 0.0)) {          // also catches NaN; uniform across the block
-            if (t == 0) { fail = 1; *info = (int64_t)r0 + j + 1; }
-            break;
-        }
-        const double piv = sqrt(d);
-        __syncthreads();           // everyone has read a[j][j] before it is overwritten
-        if (t == 0) { a[j * LDA + j] = piv; dinv[j] = 1.0 / piv; }
-        for (int i = j + 1 + t; i < NB; i += 256) {
-            const double l = a[i * LDA + j] / piv;
-            a[i * LDA + j] = l;
-            col[i] = l;
+    // ---------------- phase 1: Cholesky ----------------
+    for (int p = 0; p < NSB; ++p) {
+        const int o = SB * p;
+        if (wave == 0) {                                   // (1) 16×16 diagonal sub-block, in-wave
+            for (int j = 0; j < SB; ++j) {
+                const double d = AA(o + j, o + j);
+                if (!(d > 0.0)) {                          // also catches NaN; wave-uniform
+                    if (lane == 0) { fail = 1; *info = (int64_t)r0 + o + j + 1; }
+                    break;
+                }
+                const double piv = sqrt(d);
+                const double rp = 1.0 / piv;
+                wave_lds_sync();                           // everyone holds d before a[j][j] changes
+                if (lane < SB && lane > j) AA(o + lane, o + j) *= rp;
+                if (lane == j) { AA(o + j, o + j) = piv; dinv[o + j] = rp; }
+                wave_lds_sync();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = g + 4 * q;
+                    if (k > j && k <= r16) AA(o + r16, o + k) = fma(-AA(o + r16, o + j), AA(o + k, o + j), AA(o + r16, o + k));
+                }
+                wave_lds_sync();
+            }
         }
         __syncthreads();
-        // trailing update of the lower triangle: two threads per row, interleaved columns
-        {
-            const int i = j + 1 + (t >> 1);
-            if (i < NB) {
-                const double li = col[i];
-                for (int k = j + 1 + (t & 1); k <= i; k += 2) a[i * LDA + k] = fma(-li, col[k], a[i * LDA + k]);
+        if (fail) return;                                  // uniform (LDS flag after the barrier)
+        const int below = NB - o - SB;                     // rows under the diagonal sub-block
+        if (t < below) {                                   // (2) panel solve, one row per thread
+            const int i = o + SB + t;
+            double x[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                double v = AA(i, o + j);
+#pragma unroll
+                for (int k = 0; k < j; ++k) v = fma(-x[k], AA(o + j, o + k), v);
+                x[j] = v * dinv[o + j];
+            }
+#pragma unroll
+            for (int j = 0; j < SB; ++j) AA(i, o + j) = x[j];
+        }
+        __syncthreads();
+        {                                                  // (3) trailing update on the lower sub-blocks
+            const int nb = NSB - 1 - p;                    // sub-block rows/cols left
+            const int total = nb * (nb + 1) / 2;
+            for (int e = wave; e < total; e += 4) {
+                int bi = 0, rem = e;                       // e -> (bi ≥ bj) in row-major lower order
+                while (rem > bi) { rem -= bi + 1; ++bi; }
+                const int bj = rem;
+                const int ri = SB * (p + 1 + bi), rj = SB * (p + 1 + bj);
+                d4_t c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = AA(ri + g + 4 * r, rj + r16);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-AA(ri + r16, o + g + 4 * s4), AA(rj + r16, o + g + 4 * s4), c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) AA(ri + g + 4 * r, rj + r16) = c[r];
             }
         }
         __syncthreads();
     }
-    __syncthreads();
-    if (fail) return;
 
-    // Linv[:, c] for c = t: x_c = 1/L_cc ; x_i = −(Σ_{k=c}^{i−1} L[i][k]·x_k)/L_ii  stored at a[c][i]
-    if (t < NB) {
-        const int c = t;
-        for (int i = c + 1; i < NB; ++i) {
-            double s = a[i * LDA + c] * dinv[c];
-            for (int k = c + 1; k < i; ++k) s = fma(a[i * LDA + k], a[c * LDA + k], s);
-            a[c * LDA + i] = -s * dinv[i];
+    // ---------------- phase 2: X = L⁻¹, Xᵀ into the strict upper triangle ----------------
+    if (t < NB) {                                          // (a) diagonal sub-block inverses
+        const int o = SB * (t >> 4), n = t & 15;
+        double x[SB];
+#pragma unroll
+        for (int m = 0; m < SB; ++m) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < m; ++k) sacc = fma(AA(o + m, o + k), x[k], sacc);
+            x[m] = (m < n) ? 0.0 : (m == n ? dinv[o + m] : -sacc * dinv[o + m]);
         }
+#pragma unroll
+        for (int m = 0; m < SB; ++m)
+            if (m > n) AA(o + n, o + m) = x[m];
     }
     __syncthreads();
+    for (int dl = 1; dl < NSB; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
+        for (int c = wave; c + dl < NSB; c += 4) {
+            const int i = c + dl;
+            const int oc = SB * c, oi = SB * i;
+            d4_t tt = {0.0, 0.0, 0.0, 0.0};
+            for (int k = c; k < i; ++k) {
+                const int ok = SB * k;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int kk = g + 4 * s4;
+                    const double av = AA(oi + r16, ok + kk);                       // L_ik[m = r16][kk]
+                    double bv = AA(oc + r16, ok + kk);                             // X_kc[kk][n = r16] (stored transposed)
+                    if (k == c) bv = (kk > r16) ? bv : (kk == r16 ? dinv[oc + r16] : 0.0);
+                    tt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, tt, 0, 0, 0);
+                }
+            }
+            d4_t xr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int kk = g + 4 * s4;
+                const double up = AA(oi + kk, oi + r16);                           // X_ii[m = r16][kk], m > kk
+                const double av = (r16 > kk) ? up : (r16 == kk ? dinv[oi + r16] : 0.0);
+                xr = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tt[s4], xr, 0, 0, 0);   // B[kk = g+4·s4][n] = tt[s4]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) AA(oc + r16, oi + g + 4 * r) = -xr[r];   // X_ic[m][n] → a[c·16+n][i·16+m]
+        }
+        __syncthreads();
+    }
 
+    // ---------------- phase 3: write back ----------------
     double* Wb = W + (int64_t)r0 * ld + r0;
     double* WTb = WT + (int64_t)r0 * ld + r0;
     for (int idx = t; idx < NB * NB; idx += 256) {
         const int i = idx >> 7, j = idx & 127;
         double l, w, wt;
-        if (i > j) { l = a[i * LDA + j]; w = a[j * LDA + i]; wt = 0.0; }
-        else if (i == j) { l = a[i * LDA + i]; w = dinv[i]; wt = dinv[i]; }
-        else { l = 0.0; w = 0.0; wt = a[i * LDA + j]; }
+        if (i > j) { l = AA(i, j); w = AA(j, i); wt = 0.0; }
+        else if (i == j) { l = AA(i, i); w = dinv[i]; wt = dinv[i]; }
+        else { l = 0.0; w = 0.0; wt = AA(i, j); }
         Kb[(int64_t)i * ld + j] = l;
         Wb[(int64_t)i * ld + j] = w;
         WTb[(int64_t)i * ld + j] = wt;
     }
 }
+#undef AA
 
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, K, W, WT, ld, r0, info);
