@@ -10,7 +10,7 @@ ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
 HOST, DEVICE = 0, 1
 
 EXPORTS = ["abo_create", "abo_retain", "abo_destroy", "abo_fit", "abo_predict", "abo_acq", "abo_nlml",
-           "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version",
+           "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
            "abo_test_gemm_nt"]
 
 
@@ -80,6 +80,7 @@ def lib():
     L.abo_get_timings.argtypes = [vp, C.POINTER(AboTimings)]
     L.abo_last_error.argtypes = [C.c_char_p, C.c_size_t]
     L.abo_abi_version.argtypes = []
+    L.abo_pool_trim.argtypes = [i32]
     L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
     for name in EXPORTS:
         getattr(L, name).restype = i32

@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -45,19 +47,103 @@ int32_t fail(int32_t code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                    \
     } while (0)
 
+// Device-memory pool.  `update` returns a NEW model every BO step (src/surrogates/StandardGP.jl:82)
+// and the previous one dies right after, so without a pool every step pays hipMalloc/hipFree for
+// ~4 GB of factor + workspace (and the implicit device synchronisations of hipFree).  Freed blocks
+// are kept per device (up to ABO_POOL_LIMIT_MB, default 32 GiB) and handed back to the next handle.
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void*> blocks;
+    size_t held = 0;
+};
+Pool g_pool[16];
+
+size_t pool_limit() {
+    static size_t lim = [] {
+        const char* e = getenv("ABO_POOL_LIMIT_MB");
+        return (e ? (size_t)atoll(e) : (size_t)32768) << 20;
+    }();
+    return lim;
+}
+
+size_t round_size(size_t bytes) {
+    const size_t g = bytes < ((size_t)1 << 20) ? 4096 : ((size_t)2 << 20);
+    return (bytes + g - 1) / g * g;
+}
+
+hipError_t pool_alloc(int dev, size_t bytes, void** p, size_t* cap) {
+    const size_t want = round_size(bytes);
+    Pool& pl = g_pool[dev & 15];
+    {
+        std::lock_guard<std::mutex> lk(pl.mu);
+        auto it = pl.blocks.lower_bound(want);
+        if (it != pl.blocks.end() && it->first <= want + want / 4 + ((size_t)1 << 20)) {
+            *p = it->second; *cap = it->first;
+            pl.held -= it->first;
+            pl.blocks.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {           // out of memory: give the pool back to the driver and retry once
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> lk(pl.mu);
+            for (auto& kv : pl.blocks) drop.push_back(kv.second);
+            pl.blocks.clear(); pl.held = 0;
+        }
+        for (void* q : drop) (void)hipFree(q);
+        (void)hipGetLastError();
+        e = hipMalloc(p, want);
+    }
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+void pool_free(int dev, void* p, size_t cap) {
+    Pool& pl = g_pool[dev & 15];
+    {
+        std::lock_guard<std::mutex> lk(pl.mu);
+        if (pl.held + cap <= pool_limit()) {
+            pl.blocks.emplace(cap, p);
+            pl.held += cap;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void pool_trim(int dev) {
+    Pool& pl = g_pool[dev & 15];
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(pl.mu);
+        for (auto& kv : pl.blocks) drop.push_back(kv.second);
+        pl.blocks.clear(); pl.held = 0;
+    }
+    for (void* q : drop) (void)hipFree(q);
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    int dev = 0;
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
-        return e;
+        release();
+        return pool_alloc(dev, bytes, &p, &cap);
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) pool_free(dev, p, cap); p = nullptr; cap = 0; }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
+
+// stream + events of a handle, recycled the same way (hipStreamCreate / ~400 hipEventCreate per step otherwise)
+struct ExecCtx {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;
+};
+std::mutex g_ctx_mu;
+std::vector<ExecCtx*> g_ctx_free[16];
 
 int dp_for(int d) {
     int p = 1;
@@ -70,7 +156,8 @@ int dp_for(int d) {
 struct abo_gp {
     std::atomic<int> refs{1};
     abo_params prm{};
-    hipStream_t stream = nullptr;
+    ExecCtx* ctx = nullptr;
+    hipStream_t stream = nullptr;      // == ctx->stream
     bool fitted = false;
     int64_t N = 0, Np = 0;
     int d = 0, dp = 0;
@@ -79,24 +166,34 @@ struct abo_gp {
     DevBuf Xraw, Xs, ybuf, delta, alpha, tvec, K, W, WT, T, info, scal;
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
-    std::vector<hipEvent_t> ev;
     abo_timings tm{};
+
+    std::vector<hipEvent_t>& evs() { return ctx->ev; }
+
+    void set_device(int dev) {
+        DevBuf* all[] = {&Xraw, &Xs, &ybuf, &delta, &alpha, &tvec, &K, &W, &WT, &T, &info, &scal, &Zdev, &Kxz,
+                         &partial, &mu_c, &mu_all, &var_all, &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1,
+                         &top_val, &top_idx};
+        for (DevBuf* b : all) b->dev = dev;
+    }
 
     void free_all() {
         DevBuf* all[] = {&Xraw, &Xs, &ybuf, &delta, &alpha, &tvec, &K, &W, &WT, &T, &info, &scal, &Zdev, &Kxz,
                          &partial, &mu_c, &mu_all, &var_all, &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1,
                          &top_val, &top_idx};
         for (DevBuf* b : all) b->release();
-        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-        ev.clear();
-        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (ctx) {
+            std::lock_guard<std::mutex> lk(g_ctx_mu);
+            g_ctx_free[prm.device & 15].push_back(ctx);
+            ctx = nullptr; stream = nullptr;
+        }
     }
     hipError_t events(size_t n) {
-        while (ev.size() < n) {
+        while (ctx->ev.size() < n) {
             hipEvent_t e;
             hipError_t r = hipEventCreate(&e);
             if (r != hipSuccess) return r;
-            ev.push_back(e);
+            ctx->ev.push_back(e);
         }
         return hipSuccess;
     }
@@ -132,7 +229,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     double* WT = g->WT.as<double>();
     int64_t* info = g->info.as<int64_t>();
 
-    HIPCHK(hipEventRecord(g->ev[0], s));
+    HIPCHK(hipEventRecord(g->evs()[0], s));
     HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
     KgenArgs ka{};
     ka.Xs = g->Xs.as<double>(); ka.Z = g->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = K; ka.mu = nullptr;
@@ -142,7 +239,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     HIPCHK(launch_diag_fix(K, ld, N, Np, noise, s));
     HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
     HIPCHK(hipMemsetAsync(WT, 0, sizeof(double) * ld * ld, s));
-    HIPCHK(hipEventRecord(g->ev[1], s));
+    HIPCHK(hipEventRecord(g->evs()[1], s));
 
     const int T = Np / TB;
     for (int p = 0; p < T; ++p) {
@@ -167,7 +264,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
         u.alpha = -1.0; u.beta = 1.0; u.info = info;
         HIPCHK(launch_gemm_nt(u, s));
     }
-    HIPCHK(hipEventRecord(g->ev[2], s));
+    HIPCHK(hipEventRecord(g->evs()[2], s));
     HIPCHK(hipMemcpyAsync(info_host, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (*info_host != 0) return ABO_OK;   // caller decides (retry with jitter or ENOTPD)
@@ -205,22 +302,22 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             HIPCHK(launch_gemm_nt(b, s));
         }
     }
-    HIPCHK(hipEventRecord(g->ev[3], s));
+    HIPCHK(hipEventRecord(g->evs()[3], s));
     // alpha = Wᵀ(W·delta)
     HIPCHK(launch_trmv(W, ld, g->delta.as<double>(), g->tvec.as<double>(), Np, 1, s));
     HIPCHK(launch_trmv(WT, ld, g->tvec.as<double>(), g->alpha.as<double>(), Np, 0, s));
     HIPCHK(launch_nlml_terms(K, ld, g->delta.as<double>(), g->alpha.as<double>(), N, g->scal.as<double>(), s));
-    HIPCHK(hipEventRecord(g->ev[4], s));
+    HIPCHK(hipEventRecord(g->evs()[4], s));
     double sc[2];
     HIPCHK(hipMemcpyAsync(sc, g->scal.as<double>(), sizeof sc, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     g->logdet = sc[0];
     g->quad = sc[1];
-    g->tm.fit_kernel_matrix_ms = ev_ms(g->ev[0], g->ev[1]);
-    g->tm.fit_cholesky_ms = ev_ms(g->ev[1], g->ev[2]);
-    g->tm.fit_inverse_ms = ev_ms(g->ev[2], g->ev[3]);
-    g->tm.fit_alpha_ms = ev_ms(g->ev[3], g->ev[4]);
-    g->tm.fit_total_ms = ev_ms(g->ev[0], g->ev[4]);
+    g->tm.fit_kernel_matrix_ms = ev_ms(g->evs()[0], g->evs()[1]);
+    g->tm.fit_cholesky_ms = ev_ms(g->evs()[1], g->evs()[2]);
+    g->tm.fit_inverse_ms = ev_ms(g->evs()[2], g->evs()[3]);
+    g->tm.fit_alpha_ms = ev_ms(g->evs()[3], g->evs()[4]);
+    g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
     return ABO_OK;
 }
 
@@ -254,7 +351,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t M, int kind, double p0, d
         const int64_t j0 = c * Mc;
         const int64_t m = (M - j0) < Mc ? (M - j0) : Mc;
         const int mcp = (int)pad_up(m, TB);
-        hipEvent_t* e = &g->ev[8 + 6 * c];
+        hipEvent_t* e = &g->evs()[8 + 6 * c];
         KgenArgs ka{};
         ka.Xs = g->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
         ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->N;
@@ -289,7 +386,7 @@ void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
     const int64_t nchunk = (M + Mc - 1) / Mc;
     double kx = 0, vg = 0, fi = 0;
     for (int64_t c = 0; c < nchunk; ++c) {
-        hipEvent_t* e = &g->ev[8 + 6 * c];
+        hipEvent_t* e = &g->evs()[8 + 6 * c];
         kx += ev_ms(e[0], e[1]);
         if (with_var) vg += ev_ms(e[2], e[3]);
         fi += ev_ms(e[4], e[5]);
@@ -344,8 +441,20 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
     abo_gp* g = new (std::nothrow) abo_gp();
     if (!g) return fail(ABO_ENOMEM, "abo_create: host allocation failed");
     g->prm = *params;
-    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete g; return fail(ABO_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    g->set_device(params->device);
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        auto& fl = g_ctx_free[params->device & 15];
+        if (!fl.empty()) { g->ctx = fl.back(); fl.pop_back(); }
+    }
+    hipError_t e = hipSuccess;
+    if (!g->ctx) {
+        g->ctx = new (std::nothrow) ExecCtx();
+        if (!g->ctx) { delete g; return fail(ABO_ENOMEM, "abo_create: host allocation failed"); }
+        e = hipStreamCreateWithFlags(&g->ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete g->ctx; delete g; return fail(ABO_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    }
+    g->stream = g->ctx->stream;
     e = g->events(8);
     if (e != hipSuccess) { g->free_all(); delete g; return fail(ABO_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     *out = g;
@@ -441,16 +550,16 @@ int32_t abo_predict(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
         if (out_space == ABO_DEVICE) var_d = var;
         else { HIPCHK(g->var_all.ensure(sizeof(double) * M)); var_d = g->var_all.as<double>(); }
     }
-    HIPCHK(hipEventRecord(g->ev[5], s));
+    HIPCHK(hipEventRecord(g->evs()[5], s));
     rc = posterior(g, Zd, M, -1, 0.0, 0.0, mu_d, var_d, nullptr);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(g->ev[6], s));
+    HIPCHK(hipEventRecord(g->evs()[6], s));
     if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
     if (var && out_space == ABO_HOST) { rc = copy_out(var, var_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(s));
     collect_posterior_timings(g, M, var != nullptr);
     g->tm.acq_topk_ms = 0.0;
-    g->tm.acq_total_ms = ev_ms(g->ev[5], g->ev[6]);
+    g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[6]);
     return ABO_OK;
 }
 
@@ -472,7 +581,7 @@ int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_spac
         if (rc) return rc;
         if (scores && out_space == ABO_DEVICE) sc_d = scores;
         else { HIPCHK(g->score_all.ensure(sizeof(double) * M)); sc_d = g->score_all.as<double>(); }
-        HIPCHK(hipEventRecord(g->ev[5], s));
+        HIPCHK(hipEventRecord(g->evs()[5], s));
         const bool need_var = kind != ABO_ACQ_MEAN;
         if (need_var) {
             rc = posterior(g, Zd, M, kind, p0, best_y, nullptr, nullptr, sc_d);
@@ -487,10 +596,10 @@ int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_spac
             HIPCHK(launch_finalize(fa, s));
         }
         if (rc) return rc;
-        HIPCHK(hipEventRecord(g->ev[6], s));
+        HIPCHK(hipEventRecord(g->evs()[6], s));
     } else {
-        HIPCHK(hipEventRecord(g->ev[5], s));
-        HIPCHK(hipEventRecord(g->ev[6], s));
+        HIPCHK(hipEventRecord(g->evs()[5], s));
+        HIPCHK(hipEventRecord(g->evs()[6], s));
     }
     if (k > 0) {
         const int64_t we = topk_workspace_entries(M, k);
@@ -513,15 +622,15 @@ int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_spac
             rc = copy_out(top_idx, ti, sizeof(int64_t) * k, ABO_HOST, s); if (rc) return rc;
         }
     }
-    HIPCHK(hipEventRecord(g->ev[7], s));
+    HIPCHK(hipEventRecord(g->evs()[7], s));
     if (scores && out_space == ABO_HOST && M > 0) {
         rc = copy_out(scores, sc_d, sizeof(double) * M, ABO_HOST, s);
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     if (M > 0) collect_posterior_timings(g, M, kind != ABO_ACQ_MEAN);
-    g->tm.acq_topk_ms = ev_ms(g->ev[6], g->ev[7]);
-    g->tm.acq_total_ms = ev_ms(g->ev[5], g->ev[7]);
+    g->tm.acq_topk_ms = ev_ms(g->evs()[6], g->evs()[7]);
+    g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[7]);
     return ABO_OK;
 }
 
@@ -564,6 +673,14 @@ int32_t abo_get_factor(abo_gp* g, double* L, double* alpha, double* Linv) {
     if (L)   // off-diagonal upper blocks of the in-place factor still hold K: present a clean L
         for (int64_t i = 0; i < N; ++i)
             for (int64_t j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
+    return ABO_OK;
+}
+
+int32_t abo_pool_trim(int32_t device) {
+    if (device < 0 || device > 15) return fail(ABO_EINVAL, "abo_pool_trim: bad device %d", device);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    pool_trim(device);
     return ABO_OK;
 }
 

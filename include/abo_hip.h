@@ -128,6 +128,13 @@ int32_t abo_get_factor(abo_gp* gp, double* L, double* alpha, double* Linv);
 int32_t abo_get_n(abo_gp* gp, int64_t* N, int32_t* d);
 int32_t abo_get_timings(abo_gp* gp, abo_timings* out);
 
+/* --- memory -----------------------------------------------------------------------------------
+ * Device buffers of destroyed handles are cached per device (update() makes a new model every BO
+ * step and drops the old one, src/surrogates/StandardGP.jl:82 / src/bayesian_opt.jl:116-125) and
+ * reused by the next handle; this returns the cached blocks of one device to the driver.  The cache
+ * is bounded by the environment variable ABO_POOL_LIMIT_MB (default 32768). */
+int32_t abo_pool_trim(int32_t device);
+
 /* --- errors / version ---------------------------------------------------------------------------*/
 /* copies the calling thread's last error text (NUL-terminated, truncated to cap) */
 int32_t abo_last_error(char* buf, size_t cap);
