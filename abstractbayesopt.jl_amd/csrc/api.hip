@@ -324,8 +324,10 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
 int64_t pick_chunk(const abo_gp* g, int64_t M) {
     int64_t mc = g->prm.chunk;
     if (mc <= 0) {
-        // ~1 GiB of K_XZ per chunk, at least 2048 and at most 65536 candidates
-        mc = ((int64_t)1 << 30) / (g->Np * (int64_t)sizeof(double));
+        // ~512 MiB of K_XZ per chunk (measured optimum at N = 8192: tools/chunk_sweep.sh — larger
+        // chunks lose L2/MALL reuse of the candidate panels, smaller ones pay launch tails), at least
+        // 2048 and at most 65536 candidates
+        mc = ((int64_t)1 << 29) / (g->Np * (int64_t)sizeof(double));
         if (mc < 2048) mc = 2048;
         if (mc > 65536) mc = 65536;
     }

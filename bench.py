@@ -80,6 +80,19 @@ def cpu_baseline(cfg, sample_m=8192):
     }
 
 
+def pmc_traffic(config, mc_per_launch):
+    """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC pass
+    (FETCH_SIZE/WRITE_SIZE collected in their own runs by tools/run_pmc.sh, gfx950 ×2 correction on
+    FETCH_SIZE) — PMC counters cannot be read from inside this process, so the figure is the per-candidate
+    traffic of that pass scaled to this run's candidates per launch."""
+    path = os.path.join(ROOT, "profiles", f"r01_{config}_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        d = json.load(f)
+    return d["traffic_bytes_per_candidate"] * mc_per_launch, d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +101,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-m", type=int, default=8192)
+    ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -117,7 +131,7 @@ def main():
     X, y = synth.standardized_problem(N, d, 0.03)
     Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
     Zd = torch.from_numpy(synth.points(2, hi - lo, d, first=lo)).to(dev)
-    gp = abo.HipStandardGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, device=local_rank)
+    gp = abo.HipStandardGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, device=local_rank, chunk=args.chunk)
     best_y = float(y.min())
     acq = abo.ExpectedImprovement(p0, best_y) if acq_name == "ei" else abo.UpperConfidenceBound(p0)
     K_TOP = 100
@@ -154,6 +168,7 @@ def main():
         flop = med["var_gemm_flop"]                       # N²·M_per (triangular credit), all launches of one step
         t_kernel_ms = med["acq_var_gemm_ms"]
         achieved = flop / (t_kernel_ms * 1e-3) / 1e12 if t_kernel_ms > 0 else 0.0
+        traffic, pmc = pmc_traffic(args.config, M_per / max(launches, 1))
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +183,9 @@ def main():
             "roofline": {
                 "kernel": "var_gemm_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
+                "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + (M_per / max(launches, 1)) * N + (N / 128) * (M_per / max(launches, 1))),
                 "flop_per_launch": flop / max(launches, 1), "launches_per_step": launches,
                 "avg_launch_ms": t_kernel_ms / max(launches, 1),
                 "note": "algorithmic flop = N^2*M (triangular credit, SURVEY 8(d)); duration = HIP events on the "
