@@ -1,11 +1,12 @@
 """abstractbayesopt.jl_amd — MI355X-native GP surrogate backend behind AbstractBayesOpt.jl's
 AbstractSurrogate / AbstractAcquisition interface (hot path only: update → posterior → EI/UCB →
 top-k).  Import as ``import abstractbayesopt.jl_amd as abo``."""
-from . import _lib, acquisition, distributed, synth
+from . import _lib, acquisition, distributed, incremental, synth
 from ._lib import AboError, DimensionMismatch, PosDefException
 from .acquisition import (AbstractAcquisition, ExpectedImprovement, ProbabilityImprovement, UpperConfidenceBound,
                           evaluate, latin_hypercube, optimize_acquisition)
 from .domains import ContinuousDomain
+from .incremental import ResidentCandidates, append, greedy_qei
 from .kernels import (ApproxMatern52Kernel, ApproxMatern72Kernel, ConstMean, Kernel, Matern32Kernel, Matern52Kernel,
                       ScaledKernel, SqExponentialKernel, ZeroMean, with_lengthscale)
 from . import surrogate as _s

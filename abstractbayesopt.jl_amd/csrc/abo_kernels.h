@@ -37,6 +37,7 @@ struct VarGemmArgs {
     double* partial;      // [Np/128][ldp]
     int64_t ldw, ldk, ldp;
     int Np, Mc;           // multiples of 128
+    int nvalid;           // rows ≥ nvalid (the view's N) are excluded from the norm
 };
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s);
 
@@ -57,6 +58,8 @@ struct KgenArgs {
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
 // K[i][i] += noise for i < N; K[i][i] = 1 for N ≤ i < Np (identity padding keeps the factor PD)
 hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s);
+// A[i][i] = v for lo ≤ i < hi
+hipError_t launch_set_diag(double* A, int64_t ld, int lo, int hi, double v, hipStream_t s);
 // Xs[i][c] = X[i][c]·s (zero padded to [Np][dp])
 hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st);
 
@@ -72,6 +75,21 @@ hipError_t launch_nlml_terms(const double* L, int64_t ld, const double* delta, c
 // delta[i] = y[i] − c (i < N), 0 for padding
 hipError_t launch_center(const double* y, double* delta, int N, int Np, double c, hipStream_t s);
 
+// bordered append (chol.hip): given k = k(X,x*), l = W·k, v = Wᵀ·l, write row N of L and W, column N of WT,
+// the new alpha and the down-date vector vext = [−v ; 1]; scal = {l_nn², β, l_nn, kᵀα}; *info = N+1 if l_nn² ≤ 0
+struct AppendArgs {
+    double* L; double* W; double* WT;
+    int64_t ld;
+    const double* krow; const double* lvec; const double* vvec;
+    const double* alpha_old; double* alpha_new; double* vext;
+    const double* delta;
+    int N, cap;
+    double kss;              // k(x*,x*) + noise
+    double* scal;
+    int64_t* info;
+};
+hipError_t launch_append(const AppendArgs& a, hipStream_t s);
+
 // ---- posterior epilogue + selection (misc.hip) ----------------------------------------------
 struct FinalizeArgs {
     const double* partial;   // [T][ldp]
@@ -85,6 +103,13 @@ struct FinalizeArgs {
     double sigma_f2, p0, best_y;
 };
 hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+// resident-candidate kernels (C5)
+// mu[j] += c[j]·beta ; var[j] −= c[j]²/s2        (posterior down-date after a bordered append)
+hipError_t launch_downdate(double* mu, double* var, const double* c, int64_t M, double beta, double s2, hipStream_t s);
+// score[j] = acq(mu[j], var[j])
+hipError_t launch_score(const double* mu, const double* var, double* score, int64_t M, int kind, double p0, double best_y,
+                        hipStream_t s);
 
 struct TopkWork {            // scratch sized by topk_workspace_entries()
     uint64_t* keys[2];

@@ -153,35 +153,65 @@ int dp_for(int d) {
 
 }  // namespace
 
+// Heavy device state, shared by every view (copy / appended model) that descends from one fit.
+// Rows < frontier of Xs / delta / L / W / WT are immutable; an append only writes row `frontier`
+// (identity padding until then), so older views stay valid and rollback is free.
+struct Storage {
+    std::atomic<int> refs{1};
+    int dev = 0;
+    int d = 0, dp = 0;
+    int64_t cap = 0;        // padded capacity = leading dimension of K/W/WT (multiple of 128)
+    int64_t frontier = 0;   // number of training points whose rows are written
+    double noise_used = 0.0;
+    DevBuf Xraw, Xs, ybuf, delta, K, W, WT;
+    void set_device(int dv) {
+        dev = dv;
+        DevBuf* all[] = {&Xraw, &Xs, &ybuf, &delta, &K, &W, &WT};
+        for (DevBuf* b : all) b->dev = dv;
+    }
+    void release_all() {
+        DevBuf* all[] = {&Xraw, &Xs, &ybuf, &delta, &K, &W, &WT};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+void storage_unref(Storage* st) {
+    if (st && st->refs.fetch_sub(1) == 1) { st->release_all(); delete st; }
+}
+
 struct abo_gp {
     std::atomic<int> refs{1};
     abo_params prm{};
     ExecCtx* ctx = nullptr;
     hipStream_t stream = nullptr;      // == ctx->stream
+    Storage* st = nullptr;             // null until conditioned on data
     bool fitted = false;
-    int64_t N = 0, Np = 0;
+    int64_t N = 0, Np = 0;             // this view's training size and its 128-padded size
     int d = 0, dp = 0;
-    double noise_used = 0.0;
     double logdet = 0.0, quad = 0.0;
-    DevBuf Xraw, Xs, ybuf, delta, alpha, tvec, K, W, WT, T, info, scal;
+    // bordered-append bookkeeping (valid when this view was produced by abo_append)
+    bool from_append = false;
+    double ap_s2 = 0.0, ap_beta = 0.0; // Schur complement l_nn² and (y* − μ(x*))/l_nn²
+    DevBuf alpha, vext, tvec, T, info, scal;
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
     abo_timings tm{};
 
     std::vector<hipEvent_t>& evs() { return ctx->ev; }
+    int64_t ld() const { return st->cap; }
 
     void set_device(int dev) {
-        DevBuf* all[] = {&Xraw, &Xs, &ybuf, &delta, &alpha, &tvec, &K, &W, &WT, &T, &info, &scal, &Zdev, &Kxz,
-                         &partial, &mu_c, &mu_all, &var_all, &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1,
-                         &top_val, &top_idx};
+        DevBuf* all[] = {&alpha, &vext, &tvec, &T, &info, &scal, &Zdev, &Kxz, &partial, &mu_c, &mu_all, &var_all,
+                         &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx};
         for (DevBuf* b : all) b->dev = dev;
     }
 
     void free_all() {
-        DevBuf* all[] = {&Xraw, &Xs, &ybuf, &delta, &alpha, &tvec, &K, &W, &WT, &T, &info, &scal, &Zdev, &Kxz,
-                         &partial, &mu_c, &mu_all, &var_all, &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1,
-                         &top_val, &top_idx};
+        DevBuf* all[] = {&alpha, &vext, &tvec, &T, &info, &scal, &Zdev, &Kxz, &partial, &mu_c, &mu_all, &var_all,
+                         &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx};
         for (DevBuf* b : all) b->release();
+        storage_unref(st);
+        st = nullptr;
         if (ctx) {
             std::lock_guard<std::mutex> lk(g_ctx_mu);
             g_ctx_free[prm.device & 15].push_back(ctx);
@@ -199,6 +229,24 @@ struct abo_gp {
     }
 };
 
+// candidate set resident in HBM with its posterior (C5: O(N·M) down-dates instead of re-evaluation)
+struct abo_cand {
+    int device = 0, d = 0;
+    int64_t M = 0;
+    const Storage* synced_st = nullptr;   // identity of the factor the mu/var belong to
+    int64_t synced_N = -1;
+    DevBuf Z, mu, var, score, cdot, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx, pt;
+    void set_device(int dev) {
+        device = dev;
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &pt};
+        for (DevBuf* b : all) b->dev = dev;
+    }
+    void free_all() {
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &pt};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
 namespace {
 
 int32_t copy_in(void* dst, const void* src, size_t bytes, int32_t space, hipStream_t s) {
@@ -213,6 +261,8 @@ int32_t copy_out(void* dst, const void* src, size_t bytes, int32_t space, hipStr
     return ABO_OK;
 }
 
+int32_t factorise(abo_gp* g, double noise, int64_t* info_host);
+
 float ev_ms(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, a, b);
@@ -222,23 +272,30 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 // Right-looking blocked Cholesky, 128-wide panels, then L⁻¹ by recursive doubling.
 int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     hipStream_t s = g->stream;
+    Storage* st = g->st;
     const int Np = (int)g->Np, N = (int)g->N;
-    const int64_t ld = g->Np;
-    double* K = g->K.as<double>();
-    double* W = g->W.as<double>();
-    double* WT = g->WT.as<double>();
+    const int64_t ld = st->cap;
+    double* K = st->K.as<double>();
+    double* W = st->W.as<double>();
+    double* WT = st->WT.as<double>();
     int64_t* info = g->info.as<int64_t>();
 
     HIPCHK(hipEventRecord(g->evs()[0], s));
     HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
+    // whole capacity region: zeros, identity on the padded diagonal (rows ≥ N), K on the active part
+    if (ld > Np) HIPCHK(hipMemsetAsync(K, 0, sizeof(double) * ld * ld, s));
+    HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
+    HIPCHK(hipMemsetAsync(WT, 0, sizeof(double) * ld * ld, s));
     KgenArgs ka{};
-    ka.Xs = g->Xs.as<double>(); ka.Z = g->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = K; ka.mu = nullptr;
+    ka.Xs = st->Xs.as<double>(); ka.Z = st->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = K; ka.mu = nullptr;
     ka.ldk = ld; ka.M = N; ka.j0 = 0; ka.Mc = Np; ka.N = N; ka.Np = Np; ka.d = g->d; ka.dp = g->dp;
     ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
     HIPCHK(launch_kgen(ka, s));
-    HIPCHK(launch_diag_fix(K, ld, N, Np, noise, s));
-    HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
-    HIPCHK(hipMemsetAsync(WT, 0, sizeof(double) * ld * ld, s));
+    HIPCHK(launch_diag_fix(K, ld, N, (int)ld, noise, s));
+    if (ld > Np) {
+        HIPCHK(launch_set_diag(W, ld, Np, (int)ld, 1.0, s));
+        HIPCHK(launch_set_diag(WT, ld, Np, (int)ld, 1.0, s));
+    }
     HIPCHK(hipEventRecord(g->evs()[1], s));
 
     const int T = Np / TB;
@@ -304,9 +361,9 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     }
     HIPCHK(hipEventRecord(g->evs()[3], s));
     // alpha = Wᵀ(W·delta)
-    HIPCHK(launch_trmv(W, ld, g->delta.as<double>(), g->tvec.as<double>(), Np, 1, s));
+    HIPCHK(launch_trmv(W, ld, st->delta.as<double>(), g->tvec.as<double>(), Np, 1, s));
     HIPCHK(launch_trmv(WT, ld, g->tvec.as<double>(), g->alpha.as<double>(), Np, 0, s));
-    HIPCHK(launch_nlml_terms(K, ld, g->delta.as<double>(), g->alpha.as<double>(), N, g->scal.as<double>(), s));
+    HIPCHK(launch_nlml_terms(K, ld, st->delta.as<double>(), g->alpha.as<double>(), N, g->scal.as<double>(), s));
     HIPCHK(hipEventRecord(g->evs()[4], s));
     double sc[2];
     HIPCHK(hipMemcpyAsync(sc, g->scal.as<double>(), sizeof sc, hipMemcpyDeviceToHost, s));
@@ -355,7 +412,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t M, int kind, double p0, d
         const int mcp = (int)pad_up(m, TB);
         hipEvent_t* e = &g->evs()[8 + 6 * c];
         KgenArgs ka{};
-        ka.Xs = g->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
+        ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
         ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->N;
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
         ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = g->prm.mean_c;
@@ -364,8 +421,8 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t M, int kind, double p0, d
         HIPCHK(hipEventRecord(e[1], s));
         if (var_out || score_out) {
             VarGemmArgs va{};
-            va.W = g->W.as<double>(); va.Kxz = g->Kxz.as<double>(); va.partial = g->partial.as<double>();
-            va.ldw = Np; va.ldk = Np; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp;
+            va.W = g->st->W.as<double>(); va.Kxz = g->Kxz.as<double>(); va.partial = g->partial.as<double>();
+            va.ldw = g->st->cap; va.ldk = Np; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
             HIPCHK(hipEventRecord(e[2], s));
             HIPCHK(launch_var_gemm(va, s));
             HIPCHK(hipEventRecord(e[3], s));
@@ -412,6 +469,149 @@ int32_t stage_candidates(abo_gp* g, const double* Z, int64_t M, int32_t z_space,
     HIPCHK(g->Zdev.ensure(sizeof(double) * M * g->d));
     HIPCHK(hipMemcpyAsync(g->Zdev.p, Z, sizeof(double) * M * g->d, hipMemcpyHostToDevice, g->stream));
     *Zd = g->Zdev.as<double>();
+    return ABO_OK;
+}
+
+// Full refit into a fresh Storage of capacity max(N, n_max).  X/y: caller buffers (host or device).
+int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, int32_t space, int64_t* info) {
+    hipStream_t s = g->stream;
+    g->fitted = false;
+    g->from_append = false;
+    Storage* st = new (std::nothrow) Storage();
+    if (!st) return fail(ABO_ENOMEM, "abo_fit: host allocation failed");
+    st->set_device(g->prm.device);
+    st->d = d; st->dp = dp_for(d);
+    const int64_t want = g->prm.n_max > N ? g->prm.n_max : N;
+    st->cap = pad_up(want, TB);
+    const int64_t cap = st->cap;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = st->Xraw.ensure(sizeof(double) * cap * d);
+    if (e == hipSuccess) e = st->Xs.ensure(sizeof(double) * cap * st->dp);
+    if (e == hipSuccess) e = st->ybuf.ensure(sizeof(double) * cap);
+    if (e == hipSuccess) e = st->delta.ensure(sizeof(double) * cap);
+    if (e == hipSuccess) e = st->K.ensure(sizeof(double) * cap * cap);
+    if (e == hipSuccess) e = st->W.ensure(sizeof(double) * cap * cap);
+    if (e == hipSuccess) e = st->WT.ensure(sizeof(double) * cap * cap);
+    if (e != hipSuccess) {
+        storage_unref(st);
+        return fail(e == hipErrorOutOfMemory ? ABO_ENOMEM : ABO_EHIP, "abo_fit: device allocation failed: %s", hipGetErrorString(e));
+    }
+    // stage the inputs BEFORE dropping the previous storage: X / y may alias it (refit after append)
+    int32_t rc = copy_in(st->Xraw.p, X, sizeof(double) * N * d, space, s);
+    if (!rc) rc = copy_in(st->ybuf.p, y, sizeof(double) * N, space, s);
+    if (rc) { storage_unref(st); return rc; }
+    HIPCHK(hipStreamSynchronize(s));
+    storage_unref(g->st);
+    g->st = st;
+    g->N = N; g->d = d; g->dp = st->dp; g->Np = pad_up(N, TB);
+    const int64_t Np = g->Np;
+    HIPCHK(g->alpha.ensure(sizeof(double) * cap));
+    HIPCHK(g->tvec.ensure(sizeof(double) * cap));
+    HIPCHK(g->T.ensure(sizeof(double) * Np * Np));
+    HIPCHK(g->info.ensure(sizeof(int64_t)));
+    HIPCHK(g->scal.ensure(sizeof(double) * 8));
+    HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
+    HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
+    HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
+
+    int64_t inf = 0;
+    double noise = g->prm.noise_var;
+    for (int attempt = 0;; ++attempt) {
+        rc = factorise(g, noise, &inf);
+        if (rc) return rc;
+        if (inf == 0) break;
+        if (!(g->prm.jitter > 0.0) || attempt >= 4) {
+            if (info) *info = inf;
+            return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
+                        (long long)inf);
+        }
+        noise = g->prm.noise_var + g->prm.jitter * std::pow(10.0, attempt);
+    }
+    st->noise_used = noise;
+    st->frontier = N;
+    g->fitted = true;
+    return ABO_OK;
+}
+
+// Bordered ("rank-1 append") update: view `g` (N points) → new view `n` (N+1 points) sharing g's storage.
+//   k = k(X, x*),  l = W·k,  l_nn² = k** + noise − ‖l‖²,  v = Wᵀ·l = K⁻¹k
+//   L[N] = [lᵀ, l_nn]      W[N] = [−vᵀ/l_nn, 1/l_nn]      β = (δ* − kᵀα)/l_nn²      α' = [α − βv ; β]
+// Falls back to a full refit (new storage, doubled capacity) when the capacity is used up or when
+// another view already appended to the shared storage (copy-on-write for diverging histories).
+int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* info) {
+    Storage* st = g->st;
+    const int d = g->d;
+    const int64_t N = g->N;
+    hipStream_t s = n->stream;
+    if (N + 1 > st->cap || st->frontier != N) {
+        // gather this view's data on the device and refit with room to grow
+        DevBuf xb, yb;
+        xb.dev = yb.dev = g->prm.device;
+        HIPCHK(xb.ensure(sizeof(double) * (N + 1) * d));
+        HIPCHK(yb.ensure(sizeof(double) * (N + 1)));
+        HIPCHK(hipMemcpyAsync(xb.p, st->Xraw.p, sizeof(double) * N * d, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(yb.p, st->ybuf.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(xb.as<double>() + N * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(yb.as<double>() + N, &y, sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (n->prm.n_max < 2 * (N + 1)) n->prm.n_max = 2 * (N + 1);
+        int32_t rc = fit_impl(n, xb.as<double>(), N + 1, d, yb.as<double>(), ABO_DEVICE, info);
+        xb.release(); yb.release();
+        return rc;
+    }
+    const int64_t ld = st->cap;
+    const int64_t Np = g->Np;                       // padded size of the OLD view
+    const int64_t Np1 = pad_up(N + 1, TB);
+    HIPCHK(n->alpha.ensure(sizeof(double) * ld));
+    HIPCHK(n->vext.ensure(sizeof(double) * ld));
+    HIPCHK(n->tvec.ensure(sizeof(double) * ld * 2));
+    HIPCHK(n->Kxz.ensure(sizeof(double) * 16 * Np));
+    HIPCHK(n->info.ensure(sizeof(int64_t)));
+    HIPCHK(n->scal.ensure(sizeof(double) * 8));
+    double* Xraw = st->Xraw.as<double>();
+    // new point: raw coordinates, scaled coordinates, centred target (rows N — beyond every older view)
+    HIPCHK(hipMemcpyAsync(Xraw + N * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->ybuf.as<double>() + N, &y, sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_scale_points(Xraw + N * d, st->Xs.as<double>() + N * st->dp, 1, 1, d, st->dp, 1.0 / g->prm.ell, s));
+    HIPCHK(launch_center(st->ybuf.as<double>() + N, st->delta.as<double>() + N, 1, 1, g->prm.mean_c, s));
+    HIPCHK(hipMemsetAsync(n->info.p, 0, sizeof(int64_t), s));
+    // k = k(X, x*) into row 0 of a 16-row scratch
+    KgenArgs ka{};
+    ka.Xs = st->Xs.as<double>(); ka.Z = Xraw + N * d; ka.alpha = nullptr; ka.Kout = n->Kxz.as<double>(); ka.mu = nullptr;
+    ka.ldk = Np; ka.M = 1; ka.j0 = 0; ka.Mc = 16; ka.N = (int)N; ka.Np = (int)Np; ka.d = d; ka.dp = st->dp;
+    ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
+    HIPCHK(launch_kgen(ka, s));
+    double* krow = n->Kxz.as<double>();
+    double* lvec = n->tvec.as<double>();
+    double* vvec = n->tvec.as<double>() + ld;
+    HIPCHK(launch_trmv(st->W.as<double>(), ld, krow, lvec, (int)Np, 1, s));
+    HIPCHK(launch_trmv(st->WT.as<double>(), ld, lvec, vvec, (int)Np, 0, s));
+    AppendArgs aa{};
+    aa.L = st->K.as<double>(); aa.W = st->W.as<double>(); aa.WT = st->WT.as<double>(); aa.ld = ld;
+    aa.krow = krow; aa.lvec = lvec; aa.vvec = vvec; aa.alpha_old = g->alpha.as<double>(); aa.alpha_new = n->alpha.as<double>();
+    aa.vext = n->vext.as<double>(); aa.delta = st->delta.as<double>(); aa.N = (int)N; aa.cap = (int)ld;
+    aa.kss = g->prm.sigma_f2 + st->noise_used; aa.scal = n->scal.as<double>(); aa.info = n->info.as<int64_t>();
+    HIPCHK(launch_append(aa, s));
+    double sc[4];
+    int64_t inf = 0;
+    HIPCHK(hipMemcpyAsync(sc, n->scal.p, sizeof sc, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&inf, n->info.p, sizeof inf, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (inf != 0) {
+        if (info) *info = inf;
+        return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
+                    (long long)inf);
+    }
+    storage_unref(n->st);
+    st->refs.fetch_add(1);
+    n->st = st;
+    st->frontier = N + 1;
+    n->N = N + 1; n->Np = Np1; n->d = d; n->dp = st->dp;
+    n->from_append = true;
+    n->ap_s2 = sc[0]; n->ap_beta = sc[1];
+    n->logdet = g->logdet + 2.0 * std::log(sc[2]);
+    n->quad = g->quad + sc[1] * sc[1] * sc[0];
+    n->fitted = true;
     return ABO_OK;
 }
 
@@ -487,47 +687,21 @@ int32_t abo_fit(abo_gp* g, const double* X, int64_t N, int32_t d, const double* 
     if (d < 1 || d > 32) return fail(ABO_EINVAL, "abo_fit: input dimension %d outside the supported 1..32", d);
     if (N > (int64_t)1 << 20) return fail(ABO_EINVAL, "abo_fit: N = %lld too large", (long long)N);
     HIPCHK(hipSetDevice(g->prm.device));
-    hipStream_t s = g->stream;
-    g->fitted = false;
-    g->N = N; g->d = d; g->dp = dp_for(d);
-    int64_t cap = g->prm.n_max > N ? g->prm.n_max : N;
-    (void)cap;
-    g->Np = pad_up(N, TB);
-    const int64_t Np = g->Np;
-    HIPCHK(g->Xraw.ensure(sizeof(double) * N * d));
-    HIPCHK(g->Xs.ensure(sizeof(double) * Np * g->dp));
-    HIPCHK(g->ybuf.ensure(sizeof(double) * N));
-    HIPCHK(g->delta.ensure(sizeof(double) * Np));
-    HIPCHK(g->alpha.ensure(sizeof(double) * Np));
-    HIPCHK(g->tvec.ensure(sizeof(double) * Np));
-    HIPCHK(g->K.ensure(sizeof(double) * Np * Np));
-    HIPCHK(g->W.ensure(sizeof(double) * Np * Np));
-    HIPCHK(g->WT.ensure(sizeof(double) * Np * Np));
-    HIPCHK(g->T.ensure(sizeof(double) * Np * Np));
-    HIPCHK(g->info.ensure(sizeof(int64_t)));
-    HIPCHK(g->scal.ensure(sizeof(double) * 2));
-    int32_t rc = copy_in(g->Xraw.p, X, sizeof(double) * N * d, space, s);
-    if (rc) return rc;
-    rc = copy_in(g->ybuf.p, y, sizeof(double) * N, space, s);
-    if (rc) return rc;
-    HIPCHK(launch_scale_points(g->Xraw.as<double>(), g->Xs.as<double>(), (int)N, (int)Np, d, g->dp, 1.0 / g->prm.ell, s));
-    HIPCHK(launch_center(g->ybuf.as<double>(), g->delta.as<double>(), (int)N, (int)Np, g->prm.mean_c, s));
+    return fit_impl(g, X, N, d, y, space, info);
+}
 
-    int64_t inf = 0;
-    double noise = g->prm.noise_var;
-    for (int attempt = 0;; ++attempt) {
-        rc = factorise(g, noise, &inf);
-        if (rc) return rc;
-        if (inf == 0) break;
-        if (!(g->prm.jitter > 0.0) || attempt >= 4) {
-            if (info) *info = inf;
-            return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
-                        (long long)inf);
-        }
-        noise = g->prm.noise_var + g->prm.jitter * std::pow(10.0, attempt);
-    }
-    g->noise_used = noise;
-    g->fitted = true;
+int32_t abo_append(abo_gp* g, const double* x, int32_t d, double y, int64_t* info, abo_gp** out) {
+    if (info) *info = 0;
+    if (!g || !x || !out) return fail(ABO_EINVAL, "abo_append: null argument");
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g->prm.device));
+    abo_gp* n = nullptr;
+    rc = abo_create(&g->prm, &n);
+    if (rc) return rc;
+    rc = append_impl(g, n, x, y, info);
+    if (rc) { abo_destroy(n); return rc; }
+    *out = n;
     return ABO_OK;
 }
 
@@ -660,14 +834,14 @@ int32_t abo_get_factor(abo_gp* g, double* L, double* alpha, double* Linv) {
     if (!g) return fail(ABO_EINVAL, "null handle");
     if (!g->fitted) return fail(ABO_EINVAL, "surrogate is not conditioned on data yet (call abo_fit first)");
     HIPCHK(hipSetDevice(g->prm.device));
-    const int64_t N = g->N, Np = g->Np;
+    const int64_t N = g->N;
     hipStream_t s = g->stream;
     if (L) {
-        HIPCHK(hipMemcpy2DAsync(L, sizeof(double) * N, g->K.p, sizeof(double) * Np, sizeof(double) * N, N,
+        HIPCHK(hipMemcpy2DAsync(L, sizeof(double) * N, g->st->K.p, sizeof(double) * g->st->cap, sizeof(double) * N, N,
                                 hipMemcpyDeviceToHost, s));
     }
     if (Linv) {
-        HIPCHK(hipMemcpy2DAsync(Linv, sizeof(double) * N, g->W.p, sizeof(double) * Np, sizeof(double) * N, N,
+        HIPCHK(hipMemcpy2DAsync(Linv, sizeof(double) * N, g->st->W.p, sizeof(double) * g->st->cap, sizeof(double) * N, N,
                                 hipMemcpyDeviceToHost, s));
     }
     if (alpha) HIPCHK(hipMemcpyAsync(alpha, g->alpha.p, sizeof(double) * N, hipMemcpyDeviceToHost, s));
@@ -675,6 +849,153 @@ int32_t abo_get_factor(abo_gp* g, double* L, double* alpha, double* Linv) {
     if (L)   // off-diagonal upper blocks of the in-place factor still hold K: present a clean L
         for (int64_t i = 0; i < N; ++i)
             for (int64_t j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
+    return ABO_OK;
+}
+
+// ---- resident candidate sets (C5: greedy q-EI on a fixed grid with O(N·M) down-dates) ------------
+static int32_t cand_topk(abo_gp* g, abo_cand* c, const double* sc_d, int32_t k, int64_t idx_base, double* top_val,
+                         int64_t* top_idx, int32_t out_space) {
+    hipStream_t s = g->stream;
+    const int64_t we = topk_workspace_entries(c->M, k);
+    HIPCHK(c->tk_keys0.ensure(sizeof(uint64_t) * we));
+    HIPCHK(c->tk_keys1.ensure(sizeof(uint64_t) * we));
+    HIPCHK(c->tk_idx0.ensure(sizeof(int64_t) * we));
+    HIPCHK(c->tk_idx1.ensure(sizeof(int64_t) * we));
+    TopkWork w{{c->tk_keys0.as<uint64_t>(), c->tk_keys1.as<uint64_t>()}, {c->tk_idx0.as<int64_t>(), c->tk_idx1.as<int64_t>()}};
+    double* tv = top_val;
+    int64_t* ti = top_idx;
+    if (out_space == ABO_HOST) {
+        HIPCHK(c->top_val.ensure(sizeof(double) * k));
+        HIPCHK(c->top_idx.ensure(sizeof(int64_t) * k));
+        tv = c->top_val.as<double>();
+        ti = c->top_idx.as<int64_t>();
+    }
+    HIPCHK(launch_topk(sc_d, c->M, k, idx_base, w, tv, ti, s));
+    if (out_space == ABO_HOST) {
+        int32_t rc = copy_out(top_val, tv, sizeof(double) * k, ABO_HOST, s); if (rc) return rc;
+        rc = copy_out(top_idx, ti, sizeof(int64_t) * k, ABO_HOST, s); if (rc) return rc;
+    }
+    return ABO_OK;
+}
+
+int32_t abo_cand_refresh(abo_gp* g, abo_cand* c) {
+    if (!c) return fail(ABO_EINVAL, "abo_cand_refresh: null candidate set");
+    int32_t rc = check_fitted(g, c->d);
+    if (rc) return rc;
+    if (g->prm.device != c->device) return fail(ABO_EINVAL, "candidate set lives on device %d, model on %d", c->device, g->prm.device);
+    HIPCHK(hipSetDevice(g->prm.device));
+    if (c->M > 0) {
+        HIPCHK(hipEventRecord(g->evs()[5], g->stream));
+        rc = posterior(g, c->Z.as<double>(), c->M, -1, 0.0, 0.0, c->mu.as<double>(), c->var.as<double>(), nullptr);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(g->evs()[6], g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        collect_posterior_timings(g, c->M, true);
+        g->tm.acq_topk_ms = 0.0;
+        g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[6]);
+    }
+    c->synced_st = g->st;
+    c->synced_N = g->N;
+    return ABO_OK;
+}
+
+int32_t abo_cand_create(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, abo_cand** out) {
+    if (!out) return fail(ABO_EINVAL, "abo_cand_create: null argument");
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_cand_create: bad candidate buffer");
+    HIPCHK(hipSetDevice(g->prm.device));
+    abo_cand* c = new (std::nothrow) abo_cand();
+    if (!c) return fail(ABO_ENOMEM, "abo_cand_create: host allocation failed");
+    c->set_device(g->prm.device);
+    c->d = d; c->M = M;
+    hipError_t e = c->Z.ensure(sizeof(double) * (M > 0 ? M : 1) * d);
+    if (e == hipSuccess) e = c->mu.ensure(sizeof(double) * (M > 0 ? M : 1));
+    if (e == hipSuccess) e = c->var.ensure(sizeof(double) * (M > 0 ? M : 1));
+    if (e != hipSuccess) { c->free_all(); delete c; return fail(ABO_ENOMEM, "abo_cand_create: %s", hipGetErrorString(e)); }
+    rc = copy_in(c->Z.p, Z, sizeof(double) * M * d, z_space, g->stream);
+    if (!rc) rc = abo_cand_refresh(g, c);
+    if (rc) { (void)hipStreamSynchronize(g->stream); c->free_all(); delete c; return rc; }
+    *out = c;
+    return ABO_OK;
+}
+
+int32_t abo_cand_destroy(abo_cand* c) {
+    if (!c) return ABO_OK;
+    (void)hipSetDevice(c->device);
+    c->free_all();
+    delete c;
+    return ABO_OK;
+}
+
+int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
+    if (!c) return fail(ABO_EINVAL, "abo_cand_downdate: null candidate set");
+    int32_t rc = check_fitted(g, c->d);
+    if (rc) return rc;
+    if (!g->from_append || g->st != c->synced_st || g->N != c->synced_N + 1)
+        return fail(ABO_EINVAL, "abo_cand_downdate: the model is not the one-point append of the model this candidate set "
+                                "was last evaluated with (call abo_cand_refresh)");
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    if (c->M > 0) {
+        // c(z) = k(z,x*) − k_zᵀ K⁻¹ k_* = Σ_{k ≤ N} k(z, x_k)·vext[k]: one kernel-evaluation pass, nothing stored
+        HIPCHK(c->cdot.ensure(sizeof(double) * pad_up(c->M, 16)));
+        const int64_t step = 65536;
+        for (int64_t j0 = 0; j0 < c->M; j0 += step) {
+            const int64_t m = (c->M - j0) < step ? (c->M - j0) : step;
+            KgenArgs ka{};
+            ka.Xs = g->st->Xs.as<double>(); ka.Z = c->Z.as<double>(); ka.alpha = g->vext.as<double>(); ka.Kout = nullptr;
+            ka.mu = c->cdot.as<double>() + j0; ka.ldk = 0; ka.M = c->M; ka.j0 = j0; ka.Mc = (int)pad_up(m, 16);
+            ka.N = (int)g->N; ka.Np = (int)g->Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family;
+            ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
+            HIPCHK(launch_kgen(ka, s));
+        }
+        HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->cdot.as<double>(), c->M, g->ap_beta, g->ap_s2, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    c->synced_N = g->N;
+    return ABO_OK;
+}
+
+int32_t abo_cand_acq(abo_gp* g, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores,
+                     int32_t k, double* top_val, int64_t* top_idx, int32_t out_space) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_acq: null argument");
+    if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_cand_acq: unknown acquisition kind %d", kind);
+    if (k < 0 || k > 1024) return fail(ABO_EINVAL, "abo_cand_acq: k = %d outside 0..1024", k);
+    if (k > 0 && (!top_val || !top_idx)) return fail(ABO_EINVAL, "abo_cand_acq: k > 0 needs top_val and top_idx");
+    if (g->prm.device != c->device) return fail(ABO_EINVAL, "candidate set lives on device %d, model on %d", c->device, g->prm.device);
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    double* sc_d = (scores && out_space == ABO_DEVICE) ? scores : nullptr;
+    if (!sc_d) { HIPCHK(c->score.ensure(sizeof(double) * (c->M > 0 ? c->M : 1))); sc_d = c->score.as<double>(); }
+    HIPCHK(launch_score(c->mu.as<double>(), c->var.as<double>(), sc_d, c->M, kind, p0, best_y, s));
+    if (k > 0) { int32_t rc = cand_topk(g, c, sc_d, k, idx_base, top_val, top_idx, out_space); if (rc) return rc; }
+    if (scores && out_space == ABO_HOST && c->M > 0) {
+        int32_t rc = copy_out(scores, sc_d, sizeof(double) * c->M, ABO_HOST, s);
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return ABO_OK;
+}
+
+int32_t abo_cand_get(abo_gp* g, abo_cand* c, double* mu, double* var, int32_t out_space) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_get: null argument");
+    HIPCHK(hipSetDevice(g->prm.device));
+    if (mu) { int32_t rc = copy_out(mu, c->mu.p, sizeof(double) * c->M, out_space, g->stream); if (rc) return rc; }
+    if (var) { int32_t rc = copy_out(var, c->var.p, sizeof(double) * c->M, out_space, g->stream); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return ABO_OK;
+}
+
+int32_t abo_cand_point(abo_gp* g, abo_cand* c, int64_t idx, double* x, double* mu, double* var) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_point: null argument");
+    if (idx < 0 || idx >= c->M) return fail(ABO_EINVAL, "abo_cand_point: index %lld outside 0..%lld", (long long)idx, (long long)c->M - 1);
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    if (x) HIPCHK(hipMemcpyAsync(x, c->Z.as<double>() + idx * c->d, sizeof(double) * c->d, hipMemcpyDeviceToHost, s));
+    if (mu) HIPCHK(hipMemcpyAsync(mu, c->mu.as<double>() + idx, sizeof(double), hipMemcpyDeviceToHost, s));
+    if (var) HIPCHK(hipMemcpyAsync(var, c->var.as<double>() + idx, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return ABO_OK;
 }
 

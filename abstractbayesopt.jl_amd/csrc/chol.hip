@@ -235,6 +235,64 @@ hipError_t launch_nlml_terms(const double* L, int64_t ld, const double* delta, c
     return hipGetLastError();
 }
 
+// Bordered append, stage 1 (one workgroup): s2 = kss − ‖l‖², kα = kᵀα_old, pivot check.
+__global__ void __launch_bounds__(1024) append_reduce_kernel(AppendArgs p) {
+    __shared__ double r0[1024], r1[1024];
+    double a0 = 0.0, a1 = 0.0;
+    for (int i = threadIdx.x; i < p.N; i += 1024) {
+        a0 = fma(p.lvec[i], p.lvec[i], a0);
+        a1 = fma(p.krow[i], p.alpha_old[i], a1);
+    }
+    r0[threadIdx.x] = a0;
+    r1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double s2 = p.kss - r0[0];
+        if (!(s2 > 0.0)) { *p.info = (int64_t)p.N + 1; p.scal[0] = s2; return; }
+        const double lnn = sqrt(s2);
+        const double beta = (p.delta[p.N] - r1[0]) / s2;
+        p.scal[0] = s2; p.scal[1] = beta; p.scal[2] = lnn; p.scal[3] = r1[0];
+    }
+}
+
+// stage 2: rows/columns N of the factors, new alpha, down-date vector
+__global__ void __launch_bounds__(256) append_write_kernel(AppendArgs p) {
+    if (*p.info != 0) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= p.cap) return;
+    const double lnn = p.scal[2], beta = p.scal[1];
+    const double rl = 1.0 / lnn;
+    const int64_t N = p.N;
+    if (j < N) {
+        const double v = p.vvec[j];
+        const double w = -v * rl;
+        p.L[N * p.ld + j] = p.lvec[j];
+        p.W[N * p.ld + j] = w;
+        p.WT[(int64_t)j * p.ld + N] = w;
+        p.alpha_new[j] = fma(-beta, v, p.alpha_old[j]);
+        p.vext[j] = -v;
+    } else if (j == N) {
+        p.L[N * p.ld + N] = lnn;
+        p.W[N * p.ld + N] = rl;
+        p.WT[N * p.ld + N] = rl;
+        p.alpha_new[N] = beta;
+        p.vext[N] = 1.0;
+    } else {
+        p.alpha_new[j] = 0.0;
+        p.vext[j] = 0.0;
+    }
+}
+
+hipError_t launch_append(const AppendArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(append_reduce_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(append_write_kernel, dim3((a.cap + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 __global__ void center_kernel(const double* y, double* delta, int N, int Np, double c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Np) delta[i] = (i < N) ? y[i] - c : 0.0;

@@ -251,13 +251,21 @@ __global__ void __launch_bounds__(256, 2) var_gemm_kernel(VarGemmArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     double* red = smem;  // [2][128]; the tile loop ended with a barrier, LDS is free
+    // rows ≥ nvalid of the last row block are padding *for this view*: a later bordered append may
+    // have written real factor rows there (shared storage), so they must not enter the norm
+    const int row0 = ti * BM + wm * 64 + (lane >> 4);
+    const bool edge = (ti + 1) * BM > p.nvalid;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
         double s = 0.0;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s = fma(acc[mi][ni][r], acc[mi][ni][r], s);
+            for (int r = 0; r < 4; ++r) {
+                double v = acc[mi][ni][r];
+                if (edge && row0 + mi * 16 + 4 * r >= p.nvalid) v = 0.0;
+                s = fma(v, v, s);
+            }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (lane < 16) red[wm * 128 + wn * 64 + ni * 16 + lane] = s;

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
                 }
                 const double v0 = (ok0 && okj) ? p.sigma_f2 * kappa_eval<FAM>(r0) : 0.0;
                 const double v1 = (ok1 && okj) ? p.sigma_f2 * kappa_eval<FAM>(r1) : 0.0;
-                *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
+                if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
                 mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
             }
         }
@@ -154,6 +154,17 @@ __global__ void diag_fix_kernel(double* K, int64_t ld, int N, int Np, double noi
 
 hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s) {
     hipLaunchKernelGGL(diag_fix_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, K, ld, N, Np, noise);
+    return hipGetLastError();
+}
+
+__global__ void set_diag_kernel(double* A, int64_t ld, int lo, int hi, double v) {
+    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hi) A[(int64_t)i * ld + i] = v;
+}
+
+hipError_t launch_set_diag(double* A, int64_t ld, int lo, int hi, double v, hipStream_t s) {
+    if (hi <= lo) return hipSuccess;
+    hipLaunchKernelGGL(set_diag_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, s, A, ld, lo, hi, v);
     return hipGetLastError();
 }
 

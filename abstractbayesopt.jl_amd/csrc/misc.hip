@@ -47,6 +47,34 @@ hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) downdate_kernel(double* mu, double* var, const double* c, int64_t M, double beta,
+                                                        double s2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double cj = c[j];
+    mu[j] = fma(cj, beta, mu[j]);
+    var[j] = var[j] - cj * cj / s2;
+}
+
+hipError_t launch_downdate(double* mu, double* var, const double* c, int64_t M, double beta, double s2, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(downdate_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, mu, var, c, M, beta, s2);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) score_kernel(const double* mu, const double* var, double* score, int64_t M, int kind,
+                                                     double p0, double best_y) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < M) score[j] = acq_score(kind, mu[j], var[j], p0, best_y);
+}
+
+hipError_t launch_score(const double* mu, const double* var, double* score, int64_t M, int kind, double p0, double best_y,
+                        hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, mu, var, score, M, kind, p0, best_y);
+    return hipGetLastError();
+}
+
 // ---- top-k ------------------------------------------------------------------------------------
 // Total order of Julia's stable `sortperm(scores; rev=true)`: isless-descending (NaN first, then
 // +Inf … −Inf, with 0.0 before −0.0), equal scores by ascending index.  Scores are mapped to

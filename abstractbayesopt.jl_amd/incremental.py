@@ -1,0 +1,154 @@
+"""Incremental path of BASELINE config 5: bordered ("rank-1") Cholesky append, candidate sets resident
+in HBM with O(N·M) posterior down-dates, and greedy (Kriging-believer) q-EI on top of them.
+
+The reference has no counterpart — its `update` always refits (src/surrogates/StandardGP.jl:79-83) and
+its EI is single-point (src/acquisition_functions/ExpectedImprovement.jl:40-66).  Every sub-step here
+has exactly the semantics of those two (condition on one more point; EI over the grid), so parity is
+checked against the from-scratch path on the N+j points."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DEVICE, HOST
+from .acquisition import AbstractAcquisition, ExpectedImprovement
+from .surrogate import HipStandardGP, _Handle, as_points
+
+
+def append(model: HipStandardGP, x, y: float) -> HipStandardGP:
+    """Condition on one more observation (x, y) in O(N²): returns a new model sharing the factor storage;
+    `model` stays valid (free rollback).  Raises PosDefException(N+1) if the bordered pivot is ≤ 0.
+    Give the model capacity with HipStandardGP(..., n_max=N_max) to avoid refit fallbacks."""
+    L = _lib.lib()
+    xa = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    hp = C.c_void_p()
+    info = C.c_int64(0)
+    st = L.abo_append(model._require(), xa.ctypes.data, xa.shape[0], float(y), C.byref(info), C.byref(hp))
+    _lib.check(st, info.value)
+    return model._clone(_Handle(hp.value))
+
+
+class _CandHandle:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().abo_cand_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class ResidentCandidates:
+    """M candidates kept on the GPU together with their posterior μ, σ² under `model`."""
+
+    def __init__(self, model: HipStandardGP, Z):
+        L = _lib.lib()
+        zp, m, d, space, keep = as_points(Z)
+        hp = C.c_void_p()
+        _lib.check(L.abo_cand_create(model._require(), zp, m, d, space, C.byref(hp)))
+        self._h = _CandHandle(hp.value)
+        self.M, self.d = m, d
+        self.model = model
+
+    def refresh(self, model: HipStandardGP):
+        """Full re-evaluation (after a refit or a hyper-parameter change)."""
+        _lib.check(_lib.lib().abo_cand_refresh(model._require(), self._h.ptr))
+        self.model = model
+
+    def downdate(self, model: HipStandardGP):
+        """`model` must be `append(self.model, x, y)`: O(N·M) update of the stored μ, σ²."""
+        _lib.check(_lib.lib().abo_cand_downdate(model._require(), self._h.ptr))
+        self.model = model
+
+    def mean_and_var(self):
+        mu, var = np.empty(self.M), np.empty(self.M)
+        _lib.check(_lib.lib().abo_cand_get(self.model._require(), self._h.ptr, mu.ctypes.data, var.ctypes.data, HOST))
+        return mu, var
+
+    def point(self, idx: int):
+        x = np.empty(self.d)
+        mu, var = C.c_double(), C.c_double()
+        _lib.check(_lib.lib().abo_cand_point(self.model._require(), self._h.ptr, int(idx), x.ctypes.data,
+                                             C.byref(mu), C.byref(var)))
+        return x, mu.value, var.value
+
+    def evaluate(self, acq: AbstractAcquisition, k: int = 0, idx_base: int = 0, return_scores: bool = False,
+                 device_out: bool = False):
+        """Acquisition epilogue + top-k on the stored posterior (no kernel evaluations)."""
+        L = _lib.lib()
+        if device_out:
+            import torch
+            dev = torch.device("cuda", self.model.device)
+            scores = torch.empty(self.M, dtype=torch.float64, device=dev) if return_scores else None
+            tv = torch.empty(k, dtype=torch.float64, device=dev) if k > 0 else None
+            ti = torch.empty(k, dtype=torch.int64, device=dev) if k > 0 else None
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            space = DEVICE
+        else:
+            scores = np.empty(self.M) if return_scores else None
+            tv = np.empty(k) if k > 0 else None
+            ti = np.empty(k, dtype=np.int64) if k > 0 else None
+            ptr = lambda a: a.ctypes.data if a is not None else None
+            space = HOST
+        _lib.check(L.abo_cand_acq(self.model._require(), self._h.ptr, acq.kind, acq._p0(), acq._best(), idx_base,
+                                  ptr(scores), k, ptr(tv), ptr(ti), space))
+        return scores, tv, ti
+
+
+def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: float, best_y: float, idx_base: int = 0,
+               group=None):
+    """Greedy q-EI (Kriging believer): for j = 1..q  pick argmax EI over the resident grid, condition on the
+    fantasy (z_j, μ(z_j)) with a bordered append, down-date the grid's posterior, repeat.
+    With torch.distributed initialised (`group`), every rank holds a shard of the grid: the arg-max is the
+    only exchange (one all_gather of (score, global index, μ, x[d]) per pick) and every rank applies the
+    same append.  Returns (batch points (q, d), their global indices, their EI values, the final model).
+    `cands` must be in sync with `model`; on return it is in sync with the returned model."""
+    acq = ExpectedImprovement(xi, best_y)
+    picks, idxs, vals = [], [], []
+    dist = None
+    if group is not None or _dist_ready():
+        import torch.distributed as dist
+    for _ in range(q):
+        _, tv, ti = cands.evaluate(acq, k=1, idx_base=idx_base)
+        if ti[0] >= 0:
+            x, mu, _ = cands.point(int(ti[0]) - idx_base)
+            rec = np.concatenate([[tv[0], float(ti[0]), mu], x])
+        else:                                  # empty shard
+            rec = np.concatenate([[np.nan, -1.0, 0.0], np.zeros(cands.d)])
+        if dist is not None and dist.get_world_size(group) > 1:
+            rec = _allgather_best(rec, dist, group)
+        score, gidx, mu, x = rec[0], int(rec[1]), rec[2], rec[3:]
+        model = append(model, x, mu)           # fantasy observation y = μ(x): β = 0, only σ² changes
+        cands.downdate(model)
+        picks.append(x.copy()); idxs.append(gidx); vals.append(score)
+    return np.array(picks), np.array(idxs, dtype=np.int64), np.array(vals), model
+
+
+def _dist_ready():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized()
+    except Exception:
+        return False
+
+
+def _allgather_best(rec: np.ndarray, dist, group):
+    """all_gather one record per rank, keep the winner in the reference's order (score desc, ties → lowest
+    global index, NaN scores of empty shards ignored)."""
+    import torch
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(rec.copy())
+    use_cuda = dist.get_backend(group) == "nccl"
+    if use_cuda:
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    recs = torch.stack(out).cpu().numpy()
+    valid = recs[recs[:, 1] >= 0]
+    order = np.lexsort((valid[:, 1], -valid[:, 0]))
+    return valid[order[0]]

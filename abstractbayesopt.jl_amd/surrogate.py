@@ -76,7 +76,7 @@ class HipStandardGP(AbstractSurrogate):
     """StandardGP(kernel, noise_var; mean=nothing) (src/surrogates/StandardGP.jl:41-64)."""
 
     def __init__(self, kernel: Kernel, noise_var: float, mean=None, device: int | None = None, jitter: float = 0.0,
-                 chunk: int = 0):
+                 chunk: int = 0, n_max: int = 0):
         if mean is None:
             mean = ZeroMean()
         inner, scale, ell = extract_scale_and_lengthscale(kernel)
@@ -86,6 +86,7 @@ class HipStandardGP(AbstractSurrogate):
         self.mean = mean
         self.jitter = float(jitter)
         self.chunk = int(chunk)
+        self.n_max = int(n_max)          # capacity for incremental appends (0 = size to the fit)
         if device is None:
             device = _current_device()
         self.device = int(device)
@@ -103,12 +104,12 @@ class HipStandardGP(AbstractSurrogate):
     def _params(self) -> AboParams:
         return AboParams(family=self.kernel.family, device=self.device, ell=float(self.kernel.lengthscale),
                          sigma_f2=float(self.kernel.scale), noise_var=float(self.noise_var),
-                         mean_c=float(getattr(self.mean, "c", 0.0)), jitter=self.jitter, n_max=0, chunk=self.chunk)
+                         mean_c=float(getattr(self.mean, "c", 0.0)), jitter=self.jitter, n_max=self.n_max, chunk=self.chunk)
 
     def _clone(self, handle):
         m = object.__new__(HipStandardGP)
-        m.kernel, m.noise_var, m.mean, m.jitter, m.chunk, m.device = (self.kernel, self.noise_var, self.mean,
-                                                                     self.jitter, self.chunk, self.device)
+        m.kernel, m.noise_var, m.mean, m.jitter, m.chunk, m.device, m.n_max = (self.kernel, self.noise_var, self.mean,
+                                                                              self.jitter, self.chunk, self.device, self.n_max)
         m._h = handle
         return m
 
@@ -270,12 +271,12 @@ def rescale_model(model: HipStandardGP, sigma):
     if not isinstance(mean, ZeroMean):
         mean = ConstMean(mean.c / sigma)
     return HipStandardGP(new_kernel, model.noise_var / sigma ** 2, mean=mean, device=model.device,
-                         jitter=model.jitter, chunk=model.chunk)
+                         jitter=model.jitter, chunk=model.chunk, n_max=model.n_max)
 
 
 def _update_model_parameters(model: HipStandardGP, kernel: Kernel):
     return HipStandardGP(kernel, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter,
-                         chunk=model.chunk)
+                         chunk=model.chunk, n_max=model.n_max)
 
 
 def get_lengthscale(model: HipStandardGP):

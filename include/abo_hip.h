@@ -55,7 +55,8 @@ enum {
 
 enum { ABO_HOST = 0, ABO_DEVICE = 1 };
 
-typedef struct abo_gp abo_gp; /* opaque, reference-counted */
+typedef struct abo_gp abo_gp;     /* opaque, reference-counted: one (immutable) conditioned model */
+typedef struct abo_cand abo_cand; /* opaque: a candidate set resident in HBM together with its posterior */
 
 typedef struct abo_params {
     int32_t family;     /* ABO_KERNEL_* */
@@ -97,6 +98,18 @@ int32_t abo_destroy(abo_gp* gp);
 int32_t abo_fit(abo_gp* gp, const double* X, int64_t N, int32_t d, const double* y, int32_t space,
                 int64_t* info);
 
+/* --- incremental update (BASELINE config 5; no counterpart in the reference, which always refits —
+ * nearest code: update(), src/surrogates/StandardGP.jl:79-83) -------------------------------------
+ * Bordered ("rank-1 append") Cholesky update: returns in *out a NEW model conditioned on the N+1
+ * points that shares the factor storage of `gp`; `gp` itself stays valid and unchanged (rows ≤ N of
+ * the factor are never touched), which is what the driver's rollback needs (src/bayesian_opt.jl:116-141).
+ *   k = k(X,x), l = L⁻¹k, l_nn² = k(x,x) + noise − ‖l‖² (ABO_ENOTPD, *info = N+1 if ≤ 0),
+ *   L' = [[L,0],[lᵀ,l_nn]], α' = [α − βv ; β] with v = K⁻¹k, β = (y − m − kᵀα)/l_nn².
+ * O(N²) flops, two passes over L⁻¹.  Falls back to a full refit (with doubled capacity) when the
+ * storage is full (abo_params.n_max) or when another model already appended to the shared storage.
+ * x: d host doubles. */
+int32_t abo_append(abo_gp* gp, const double* x, int32_t d, double y, int64_t* info, abo_gp** out);
+
 /* --- posterior ------------------------------------------------------------------------------
  * posterior_mean / posterior_var (src/surrogates/StandardGP.jl:361-363, :377-379), fused as in
  * unstandardized_mean_and_var's mean_and_var (:395-404):
@@ -115,6 +128,24 @@ int32_t abo_predict(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z
 int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind,
                 double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
                 double* top_val, int64_t* top_idx, int32_t out_space);
+
+/* --- resident candidate sets (BASELINE config 5: greedy q-EI over a fixed grid) --------------------
+ * abo_cand_create copies M candidates to the device and evaluates their posterior with `gp`
+ * (same arithmetic as abo_predict).  After `gp2 = abo_append(gp, x*, y*)`, abo_cand_downdate(gp2, c)
+ * updates the stored posterior in O(N·M) instead of O(N²·M):
+ *   c(z) = k(z,x*) − k_zᵀK⁻¹k_*,   σ²(z) −= c(z)²/l_nn²,   μ(z) += c(z)·(y* − μ(x*))/l_nn²
+ * (ABO_EINVAL if gp2 is not the one-point append of the model the set was last synced with).
+ * abo_cand_acq runs the EI/UCB/PI epilogue + top-k of abo_acq on the stored posterior;
+ * abo_cand_point returns one candidate's coordinates and posterior (host outputs, any may be NULL);
+ * abo_cand_refresh re-evaluates from scratch (after a refit or a hyper-parameter change). */
+int32_t abo_cand_create(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, abo_cand** out);
+int32_t abo_cand_destroy(abo_cand* c);
+int32_t abo_cand_refresh(abo_gp* gp, abo_cand* c);
+int32_t abo_cand_downdate(abo_gp* gp, abo_cand* c);
+int32_t abo_cand_acq(abo_gp* gp, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base,
+                     double* scores, int32_t k, double* top_val, int64_t* top_idx, int32_t out_space);
+int32_t abo_cand_get(abo_gp* gp, abo_cand* c, double* mu, double* var, int32_t out_space);
+int32_t abo_cand_point(abo_gp* gp, abo_cand* c, int64_t idx, double* x, double* mu, double* var);
 
 /* --- scalars ----------------------------------------------------------------------------------
  * nlml (src/surrogates/StandardGP.jl:99-114) of the fitted state:

@@ -1,0 +1,137 @@
+"""GPU parity tests (-m gpu) of the incremental path (BASELINE config 5): bordered
+append, O(N·M) posterior down-date on a resident candidate set, greedy q-EI.  The reference has no
+counterpart (it always refits), so parity is defined against the from-scratch path on the N+j points —
+both this library's own full refit and the CPU oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import synth
+from oracle import gp_oracle as O
+
+from tests.test_gpu_parity import make_model
+
+
+@pytest.mark.parametrize("family,d,N0,n_app,ell,noise,mean_c,n_max", [
+    (O.SE, 2, 5, 6, 0.7, 1e-4, 0.0, 64),
+    (O.MATERN52, 4, 120, 20, 1.0, 1e-3, 0.5, 256),     # crosses the 128 padding boundary
+    (O.MATERN52, 16, 500, 13, 2.0, 1e-2, 0.0, 640),    # C5 dimension
+    (O.MATERN72, 3, 250, 10, 0.8, 1e-3, 0.0, 0),       # no spare capacity: first append refits with room to grow
+])
+def test_append_matches_full_refit(family, d, N0, n_app, ell, noise, mean_c, n_max):
+    X = synth.points(1, N0 + n_app, d)
+    y = synth.objective(X, 0.05) + mean_c
+    Z = synth.points(2, 777, d)
+    m = abo.update(make_model(family, ell, 1.3, noise, mean_c, n_max=n_max), X[:N0], y[:N0])
+    models = [m]
+    for j in range(n_app):
+        m = abo.append(m, X[N0 + j], y[N0 + j])
+        models.append(m)
+    ref = abo.update(make_model(family, ell, 1.3, noise, mean_c), X, y)
+    L, al, Li = abo.get_factor(m)
+    Lr, alr, Lir = abo.get_factor(ref)
+    st = O.fit(family, ell, 1.3, noise, mean_c, X, y)
+    tol = max(1e-11, 4e-16 * (1 + (N0 + n_app) * 1.3 / noise))
+    assert np.max(np.abs(L - st.L)) <= tol * 2 and np.max(np.abs(L - Lr)) <= tol * 2
+    assert np.max(np.abs(Li @ st.L - np.eye(N0 + n_app))) <= tol * 20
+    assert np.max(np.abs(al - st.alpha)) <= tol * 1e3 * max(1.0, np.max(np.abs(st.alpha)))
+    mu, var = abo.mean_and_var(m, Z)
+    mu_o, var_o = O.predict(st, Z)
+    assert np.max(np.abs(mu - mu_o)) <= tol * 1e2 * max(1.0, np.max(np.abs(mu_o)))
+    assert np.max(np.abs(var - var_o)) <= tol * 1e2 * 1.3
+    assert abs(abo.nlml_fitted(m) - O.nlml(st)) <= tol * 1e2 * max(1.0, abs(O.nlml(st)))
+    # every intermediate model is still valid and unchanged (free rollback, bayesian_opt.jl:116-141)
+    k = n_app // 2
+    st_k = O.fit(family, ell, 1.3, noise, mean_c, X[:N0 + k], y[:N0 + k])
+    mu_k, var_k = abo.mean_and_var(models[k], Z[:100])
+    mu_ko, var_ko = O.predict(st_k, Z[:100])
+    assert np.max(np.abs(mu_k - mu_ko)) <= tol * 1e2 * max(1.0, np.max(np.abs(mu_ko)))
+    assert np.max(np.abs(var_k - var_ko)) <= tol * 1e2 * 1.3
+
+
+def test_append_posdef_failure_leaves_model_intact():
+    # test/test_bayesian_opt.jl:749-786 through the incremental path: duplicate point, zero noise
+    X = np.array([[-1.0, -1.0], [5.0, -5.0]])
+    m = abo.update(make_model(O.SE, 1.0, 1.0, 0.0, n_max=16), X, [1.0, 2.0])
+    with pytest.raises(abo.PosDefException) as e:
+        abo.append(m, [-1.0 + 1e-12, -1.0 + 1e-12], 1.0)
+    assert e.value.info == 3
+    ok = abo.append(m, [2.0, 2.0], 0.5)          # the shared storage is still appendable
+    mu = abo.posterior_mean(ok, [[2.0, 2.0]])
+    assert abs(mu[0] - 0.5) < 1e-9
+    assert np.isfinite(abo.posterior_mean(m, [[0.0, 0.0]])[0])
+    with pytest.raises(abo.DimensionMismatch):
+        abo.append(m, [1.0, 2.0, 3.0], 0.0)
+
+
+def test_diverging_appends_copy_on_write():
+    X = synth.points(1, 40, 3)
+    y = synth.objective(X)
+    base = abo.update(make_model(O.MATERN52, 0.9, 1.0, 1e-3, n_max=64), X[:38], y[:38])
+    a = abo.append(base, X[38], y[38])
+    b = abo.append(base, X[39], y[39])            # second branch from the same parent → private storage
+    Z = synth.points(2, 50, 3)
+    for mdl, idx in ((a, list(range(38)) + [38]), (b, list(range(38)) + [39])):
+        st = O.fit(O.MATERN52, 0.9, 1.0, 1e-3, 0.0, X[idx], y[idx])
+        mu_o, var_o = O.predict(st, Z)
+        mu, var = abo.mean_and_var(mdl, Z)
+        assert np.max(np.abs(mu - mu_o)) < 1e-9 and np.max(np.abs(var - var_o)) < 1e-9
+
+
+def test_resident_candidates_downdate_matches_full_evaluation():
+    d, N0 = 8, 300
+    X = synth.points(1, N0 + 5, d)
+    y = synth.objective(X, 0.02)
+    Z = synth.points(2, 5000, d)
+    m = abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3, n_max=N0 + 64), X[:N0], y[:N0])
+    cands = abo.ResidentCandidates(m, Z)
+    mu0, var0 = cands.mean_and_var()
+    mu_f, var_f = abo.mean_and_var(m, Z)
+    np.testing.assert_array_equal(mu0, mu_f)
+    np.testing.assert_array_equal(var0, var_f)
+    for j in range(5):
+        m = abo.append(m, X[N0 + j], y[N0 + j])
+        cands.downdate(m)
+    mu1, var1 = cands.mean_and_var()
+    st = O.fit(O.MATERN52, 1.0, 1.0, 1e-3, 0.0, X, y)
+    mu_o, var_o = O.predict(st, Z)
+    assert np.max(np.abs(mu1 - mu_o)) < 1e-9
+    assert np.max(np.abs(var1 - var_o)) < 1e-9
+    # acquisition epilogue on the stored posterior == fused path on the same model
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    s_r, tv_r, ti_r = cands.evaluate(acq, k=10, return_scores=True)
+    s_f, tv_f, ti_f = abo.evaluate(acq, m, Z, k=10)
+    np.testing.assert_allclose(s_r, s_f, rtol=0, atol=1e-10)
+    # a model that is not the one-point append of the synced one is refused
+    with pytest.raises(ValueError):
+        cands.downdate(abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y))
+    cands.refresh(m)
+    np.testing.assert_allclose(cands.mean_and_var()[1], var_o, atol=1e-9)
+
+
+def test_greedy_qei_matches_from_scratch_loop():
+    """Each greedy sub-step has exactly the semantics of update() + EI over the grid: replay it with the
+    CPU oracle from scratch and compare picks and EI values."""
+    d, N0, M, q = 4, 200, 3000, 6
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    best = float(y.min())
+    fam, ell, sf2, noise = O.MATERN52, 0.6, 1.0, 1e-6     # near-noiseless: σ² collapses at a picked point
+    m = abo.update(make_model(fam, ell, sf2, noise, n_max=N0 + 16), X, y)
+    cands = abo.ResidentCandidates(m, Z)
+    pts, idxs, vals, m_q = abo.greedy_qei(m, cands, q, 0.01, best)
+    Xo, yo = X.copy(), y.copy()
+    for j in range(q):
+        st = O.fit(fam, ell, sf2, noise, 0.0, Xo, yo)
+        mu, var = O.predict(st, Z)
+        ei = O.expected_improvement(mu, var, best, 0.01)
+        v, i = O.top_k(ei, 1)
+        assert i[0] == idxs[j], (j, i[0], idxs[j])
+        assert abs(v[0] - vals[j]) <= 1e-9 * max(1.0, abs(v[0]))
+        np.testing.assert_array_equal(pts[j], Z[i[0]])
+        Xo = np.vstack([Xo, Z[i[0]]])
+        yo = np.append(yo, mu[i[0]])              # Kriging believer
+    L, al, _ = abo.get_factor(m_q)
+    assert L.shape == (N0 + q, N0 + q)
