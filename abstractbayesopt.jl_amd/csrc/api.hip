@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <new>
 #include <vector>
 
@@ -154,15 +155,22 @@ int dp_for(int d) {
 }  // namespace
 
 // Heavy device state, shared by every view (copy / appended model) that descends from one fit.
-// Rows < frontier of Xs / delta / L / W / WT are immutable; an append only writes row `frontier`
-// (identity padding until then), so older views stay valid and rollback is free.
+// Rows < N of Xs / delta / L / W / WT are immutable for every live view of size N; an append only
+// writes row N of the largest live view, so older views stay valid and rollback is free.
 struct Storage {
     std::atomic<int> refs{1};
     int dev = 0;
     int d = 0, dp = 0;
     int64_t cap = 0;        // padded capacity = leading dimension of K/W/WT (multiple of 128)
-    int64_t frontier = 0;   // number of training points whose rows are written
     double noise_used = 0.0;
+    // sizes N of the live views on this storage.  A view may append in place only if no live view
+    // is larger (rows ≥ its N are then dead: stale rows of discarded fantasy branches are masked
+    // everywhere by the view's own N, and the append overwrites row N).
+    std::mutex mu;
+    std::multiset<int64_t> live;
+    void add_view(int64_t n) { std::lock_guard<std::mutex> lk(mu); live.insert(n); }
+    void drop_view(int64_t n) { std::lock_guard<std::mutex> lk(mu); auto it = live.find(n); if (it != live.end()) live.erase(it); }
+    int64_t max_live() { std::lock_guard<std::mutex> lk(mu); return live.empty() ? 0 : *live.rbegin(); }
     DevBuf Xraw, Xs, ybuf, delta, K, W, WT;
     void set_device(int dv) {
         dev = dv;
@@ -210,6 +218,7 @@ struct abo_gp {
         DevBuf* all[] = {&alpha, &vext, &tvec, &T, &info, &scal, &Zdev, &Kxz, &partial, &mu_c, &mu_all, &var_all,
                          &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx};
         for (DevBuf* b : all) b->release();
+        if (st && fitted) st->drop_view(N);
         storage_unref(st);
         st = nullptr;
         if (ctx) {
@@ -235,14 +244,16 @@ struct abo_cand {
     int64_t M = 0;
     const Storage* synced_st = nullptr;   // identity of the factor the mu/var belong to
     int64_t synced_N = -1;
-    DevBuf Z, mu, var, score, cdot, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx, pt;
+    const Storage* bak_st = nullptr;      // abo_cand_save snapshot
+    int64_t bak_N = -1;
+    DevBuf Z, mu, var, score, cdot, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx, mu_bak, var_bak;
     void set_device(int dev) {
         device = dev;
-        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &pt};
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak};
         for (DevBuf* b : all) b->dev = dev;
     }
     void free_all() {
-        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &pt};
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -475,7 +486,6 @@ int32_t stage_candidates(abo_gp* g, const double* Z, int64_t M, int32_t z_space,
 // Full refit into a fresh Storage of capacity max(N, n_max).  X/y: caller buffers (host or device).
 int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, int32_t space, int64_t* info) {
     hipStream_t s = g->stream;
-    g->fitted = false;
     g->from_append = false;
     Storage* st = new (std::nothrow) Storage();
     if (!st) return fail(ABO_ENOMEM, "abo_fit: host allocation failed");
@@ -501,6 +511,8 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     if (!rc) rc = copy_in(st->ybuf.p, y, sizeof(double) * N, space, s);
     if (rc) { storage_unref(st); return rc; }
     HIPCHK(hipStreamSynchronize(s));
+    if (g->st && g->fitted) g->st->drop_view(g->N);
+    g->fitted = false;
     storage_unref(g->st);
     g->st = st;
     g->N = N; g->d = d; g->dp = st->dp; g->Np = pad_up(N, TB);
@@ -528,7 +540,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
         noise = g->prm.noise_var + g->prm.jitter * std::pow(10.0, attempt);
     }
     st->noise_used = noise;
-    st->frontier = N;
+    st->add_view(N);
     g->fitted = true;
     return ABO_OK;
 }
@@ -543,7 +555,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     const int d = g->d;
     const int64_t N = g->N;
     hipStream_t s = n->stream;
-    if (N + 1 > st->cap || st->frontier != N) {
+    if (N + 1 > st->cap || st->max_live() > N) {
         // gather this view's data on the device and refit with room to grow
         DevBuf xb, yb;
         xb.dev = yb.dev = g->prm.device;
@@ -584,8 +596,9 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     double* krow = n->Kxz.as<double>();
     double* lvec = n->tvec.as<double>();
     double* vvec = n->tvec.as<double>() + ld;
-    HIPCHK(launch_trmv(st->W.as<double>(), ld, krow, lvec, (int)Np, 1, s));
-    HIPCHK(launch_trmv(st->WT.as<double>(), ld, lvec, vvec, (int)Np, 0, s));
+    // only rows/columns < N: anything beyond may be the stale remains of a discarded branch
+    HIPCHK(launch_trmv(st->W.as<double>(), ld, krow, lvec, (int)N, 1, s));
+    HIPCHK(launch_trmv(st->WT.as<double>(), ld, lvec, vvec, (int)N, 0, s));
     AppendArgs aa{};
     aa.L = st->K.as<double>(); aa.W = st->W.as<double>(); aa.WT = st->WT.as<double>(); aa.ld = ld;
     aa.krow = krow; aa.lvec = lvec; aa.vvec = vvec; aa.alpha_old = g->alpha.as<double>(); aa.alpha_new = n->alpha.as<double>();
@@ -605,7 +618,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     storage_unref(n->st);
     st->refs.fetch_add(1);
     n->st = st;
-    st->frontier = N + 1;
+    st->add_view(N + 1);
     n->N = N + 1; n->Np = Np1; n->d = d; n->dp = st->dp;
     n->from_append = true;
     n->ap_s2 = sc[0]; n->ap_beta = sc[1];
@@ -975,6 +988,30 @@ int32_t abo_cand_acq(abo_gp* g, abo_cand* c, int32_t kind, double p0, double bes
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
+    return ABO_OK;
+}
+
+int32_t abo_cand_save(abo_gp* g, abo_cand* c) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_save: null argument");
+    HIPCHK(hipSetDevice(g->prm.device));
+    const size_t bytes = sizeof(double) * (c->M > 0 ? c->M : 1);
+    HIPCHK(c->mu_bak.ensure(bytes));
+    HIPCHK(c->var_bak.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(c->mu_bak.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(c->var_bak.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    c->bak_st = c->synced_st; c->bak_N = c->synced_N;
+    return ABO_OK;
+}
+
+int32_t abo_cand_restore(abo_gp* g, abo_cand* c) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_restore: null argument");
+    if (c->bak_N < 0) return fail(ABO_EINVAL, "abo_cand_restore: nothing saved");
+    HIPCHK(hipSetDevice(g->prm.device));
+    HIPCHK(hipMemcpyAsync(c->mu.p, c->mu_bak.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(c->var.p, c->var_bak.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    c->synced_st = c->bak_st; c->synced_N = c->bak_N;
     return ABO_OK;
 }
 

@@ -65,6 +65,16 @@ class ResidentCandidates:
         _lib.check(_lib.lib().abo_cand_downdate(model._require(), self._h.ptr))
         self.model = model
 
+    def save(self):
+        """Snapshot the stored posterior (before exploring fantasy appends)."""
+        _lib.check(_lib.lib().abo_cand_save(self.model._require(), self._h.ptr))
+        self._saved_model = self.model
+
+    def restore(self):
+        """Roll back to the last snapshot."""
+        _lib.check(_lib.lib().abo_cand_restore(self._saved_model._require(), self._h.ptr))
+        self.model = self._saved_model
+
     def mean_and_var(self):
         mu, var = np.empty(self.M), np.empty(self.M)
         _lib.check(_lib.lib().abo_cand_get(self.model._require(), self._h.ptr, mu.ctypes.data, var.ctypes.data, HOST))

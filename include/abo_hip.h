@@ -106,7 +106,8 @@ int32_t abo_fit(abo_gp* gp, const double* X, int64_t N, int32_t d, const double*
  *   k = k(X,x), l = L⁻¹k, l_nn² = k(x,x) + noise − ‖l‖² (ABO_ENOTPD, *info = N+1 if ≤ 0),
  *   L' = [[L,0],[lᵀ,l_nn]], α' = [α − βv ; β] with v = K⁻¹k, β = (y − m − kᵀα)/l_nn².
  * O(N²) flops, two passes over L⁻¹.  Falls back to a full refit (with doubled capacity) when the
- * storage is full (abo_params.n_max) or when another model already appended to the shared storage.
+ * storage is full (abo_params.n_max) or while a LARGER model on the same storage is still alive
+ * (destroying the fantasy models of a q-EI exploration makes their parent appendable in place again).
  * x: d host doubles. */
 int32_t abo_append(abo_gp* gp, const double* x, int32_t d, double y, int64_t* info, abo_gp** out);
 
@@ -137,11 +138,15 @@ int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_spa
  * (ABO_EINVAL if gp2 is not the one-point append of the model the set was last synced with).
  * abo_cand_acq runs the EI/UCB/PI epilogue + top-k of abo_acq on the stored posterior;
  * abo_cand_point returns one candidate's coordinates and posterior (host outputs, any may be NULL);
- * abo_cand_refresh re-evaluates from scratch (after a refit or a hyper-parameter change). */
+ * abo_cand_refresh re-evaluates from scratch (after a refit or a hyper-parameter change);
+ * abo_cand_save / abo_cand_restore snapshot and roll back the stored posterior (greedy q-EI explores
+ * fantasy appends, then the real observation is appended to the un-fantasised model). */
 int32_t abo_cand_create(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, abo_cand** out);
 int32_t abo_cand_destroy(abo_cand* c);
 int32_t abo_cand_refresh(abo_gp* gp, abo_cand* c);
 int32_t abo_cand_downdate(abo_gp* gp, abo_cand* c);
+int32_t abo_cand_save(abo_gp* gp, abo_cand* c);
+int32_t abo_cand_restore(abo_gp* gp, abo_cand* c);
 int32_t abo_cand_acq(abo_gp* gp, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base,
                      double* scores, int32_t k, double* top_val, int64_t* top_idx, int32_t out_space);
 int32_t abo_cand_get(abo_gp* gp, abo_cand* c, double* mu, double* var, int32_t out_space);

@@ -135,3 +135,38 @@ def test_greedy_qei_matches_from_scratch_loop():
         yo = np.append(yo, mu[i[0]])              # Kriging believer
     L, al, _ = abo.get_factor(m_q)
     assert L.shape == (N0 + q, N0 + q)
+
+
+def test_qei_exploration_then_real_append_on_the_parent():
+    """C5 step shape: explore q fantasy appends, drop them, roll the candidate posterior back, then append
+    the real observation to the (still valid) parent — in place again once the fantasy models are gone,
+    with their stale factor rows masked everywhere."""
+    d, N0, M = 5, 130, 2000          # 130: the fantasies spill into a second 128-row block
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    fam, ell, sf2, noise = O.MATERN52, 0.8, 1.0, 1e-4
+    base = abo.update(make_model(fam, ell, sf2, noise, n_max=N0 + 32), X, y)
+    cands = abo.ResidentCandidates(base, Z)
+    cands.save()
+    for rounds in range(3):
+        pts, idxs, vals, m_q = abo.greedy_qei(base, cands, 5, 0.01, float(y.min()))
+        del m_q
+        cands.restore()
+        mu_b, var_b = cands.mean_and_var()
+        mu_f, var_f = abo.mean_and_var(base, Z)       # parent unaffected by the dead fantasy rows
+        np.testing.assert_allclose(mu_b, mu_f, rtol=0, atol=1e-10)   # (down-dated vs re-evaluated: rounding only)
+        np.testing.assert_allclose(var_b, var_f, rtol=0, atol=1e-10)
+        y_real = float(np.sin(pts[0]).sum())
+        new = abo.append(base, pts[0], y_real)
+        cands.downdate(new)
+        X = np.vstack([X, pts[0]]); y = np.append(y, y_real)
+        st = O.fit(fam, ell, sf2, noise, 0.0, X, y)
+        mu_o, var_o = O.predict(st, Z)
+        mu_c, var_c = cands.mean_and_var()
+        assert np.max(np.abs(mu_c - mu_o)) < 1e-8 and np.max(np.abs(var_c - var_o)) < 1e-8
+        mu_n, var_n = abo.mean_and_var(new, Z)
+        assert np.max(np.abs(mu_n - mu_o)) < 1e-8 and np.max(np.abs(var_n - var_o)) < 1e-8
+        L, al, Li = abo.get_factor(new)
+        assert np.max(np.abs(L - st.L)) < 1e-9
+        base = new
+        cands.save()
