@@ -12,7 +12,7 @@ HOST, DEVICE = 0, 1
 EXPORTS = ["abo_create", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_predict", "abo_acq", "abo_nlml",
            "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
-           "abo_test_gemm_nt"]
+           "abo_test_gemm_nt", "abo_test_kappa"]
 
 
 class AboParams(C.Structure):
@@ -92,6 +92,7 @@ def lib():
     L.abo_last_error.argtypes = [C.c_char_p, C.c_size_t]
     L.abo_abi_version.argtypes = []
     L.abo_pool_trim.argtypes = [i32]
+    L.abo_test_kappa.argtypes = [i32, i32, vp, vp, i64]
     L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
     for name in EXPORTS:
         getattr(L, name).restype = i32

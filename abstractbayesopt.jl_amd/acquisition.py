@@ -129,17 +129,122 @@ def latin_hypercube(n: int, lower, upper, rng) -> np.ndarray:
     return lower + u * (upper - lower)
 
 
+def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, lower, upper, max_iter: int = 100,
+                  g_tol: float = 1e-5, f_abstol: float = 2.2e-9, x_abstol: float = 1e-4, history: int = 10):
+    """Local refinement stage of optimize_acquisition (acq_utils.jl:55-71), batched for the GPU.
+
+    The reference runs one box-constrained L-BFGS per start (Fminbox(LBFGS(HagerZhang)), central finite
+    differences, g_tol=1e-5, f_abstol=2.2e-9, x_abstol=1e-4), i.e. thousands of sequential M = 1 posterior
+    calls.  Here all S starts advance in lockstep: one fused acquisition call evaluates the whole
+    central-difference stencil (2d·S points), one more per line-search trial (S points) — a projected
+    L-BFGS with Armijo backtracking, the same stopping rules, every posterior/acquisition value from the
+    HIP path.  Returns (points (S, d), values (S,))."""
+    lower = np.asarray(lower, dtype=np.float64)
+    upper = np.asarray(upper, dtype=np.float64)
+    x = np.clip(np.asarray(starts, dtype=np.float64).copy(), lower, upper)
+    S, d = x.shape
+    f = acqf(surrogate, x)
+    active = np.isfinite(f)
+    eps3 = np.finfo(np.float64).eps ** (1.0 / 3.0)
+    Sh, Yh = [], []                                   # L-BFGS history (lists of (S, d) arrays)
+
+    def gradient(xa):
+        """central differences, one-sided where the stencil would leave the box"""
+        n = xa.shape[0]
+        h = eps3 * np.maximum(np.abs(xa), 1.0)                      # (n, d)
+        xp = np.minimum(xa + h, upper)
+        xm = np.maximum(xa - h, lower)
+        pts = np.empty((n, 2 * d, d))
+        pts[:] = xa[:, None, :]
+        for c in range(d):
+            pts[:, 2 * c, c] = xp[:, c]
+            pts[:, 2 * c + 1, c] = xm[:, c]
+        vals = acqf(surrogate, pts.reshape(n * 2 * d, d)).reshape(n, 2 * d)
+        span = xp - xm
+        g = (vals[:, 0::2] - vals[:, 1::2]) / np.where(span > 0, span, 1.0)
+        return np.where(span > 0, g, 0.0)
+
+    def project(xa, ga):
+        """projected gradient: drop components that push against an active bound"""
+        return np.where(((xa <= lower) & (ga < 0)) | ((xa >= upper) & (ga > 0)), 0.0, ga)
+
+    x_prev = pg_prev = None
+    for _ in range(max_iter):
+        idx = np.flatnonzero(active)
+        if idx.size == 0:
+            break
+        pg = np.zeros((S, d))
+        pg[idx] = project(x[idx], gradient(x[idx]))
+        if x_prev is not None:                                 # curvature pair of the last accepted step
+            s_k = np.where(active[:, None], x - x_prev, 0.0)   # (maximisation: y = g_old − g_new)
+            y_k = np.where(active[:, None], pg_prev - pg, 0.0)
+            Sh.append(s_k); Yh.append(y_k)
+            if len(Sh) > history:
+                Sh.pop(0); Yh.pop(0)
+        active &= ~(np.max(np.abs(pg), axis=1) <= g_tol)
+        if not active.any():
+            break
+        # two-loop recursion (ascent direction), batched over starts; pairs with s·y ≤ 0 are skipped per start
+        q = pg.copy()
+        stack = []
+        for s_k, y_k in zip(reversed(Sh), reversed(Yh)):
+            sy = np.sum(s_k * y_k, axis=1)
+            rho = np.where(sy > 1e-300, 1.0 / np.where(sy > 1e-300, sy, 1.0), 0.0)
+            a = rho * np.sum(s_k * q, axis=1)
+            stack.append((a, rho, s_k, y_k))
+            q = q - a[:, None] * y_k
+        if Sh:
+            sy = np.sum(Sh[-1] * Yh[-1], axis=1)
+            yy = np.sum(Yh[-1] * Yh[-1], axis=1)
+            q = q * np.where((sy > 1e-300) & (yy > 0), sy / np.where(yy > 0, yy, 1.0), 1.0)[:, None]
+        for a, rho, s_k, y_k in reversed(stack):
+            b = rho * np.sum(y_k * q, axis=1)
+            q = q + (a - b)[:, None] * s_k
+        p = q
+        bad = ~(np.sum(p * pg, axis=1) > 0)                    # not an ascent direction → steepest ascent
+        p[bad] = pg[bad]
+        # Armijo backtracking on the projected step, all unfinished starts per trial in one fused call
+        t = np.ones(S)
+        if not Sh:                                             # first step: a tenth of the box at most
+            t = np.minimum(1.0, 0.1 * np.min(upper - lower) / np.maximum(np.max(np.abs(p), axis=1), 1e-300))
+        x_new, f_new = x.copy(), f.copy()
+        todo = active.copy()
+        for _ls in range(20):                                  # HagerZhang(linesearchmax = 20) in the reference
+            j = np.flatnonzero(todo)
+            if j.size == 0:
+                break
+            cand = np.clip(x[j] + t[j, None] * p[j], lower, upper)
+            fc = acqf(surrogate, cand)
+            ok = np.isfinite(fc) & (fc >= f[j] + 1e-4 * np.sum(pg[j] * (cand - x[j]), axis=1))
+            acc = j[ok]
+            x_new[acc], f_new[acc] = cand[ok], fc[ok]
+            todo[acc] = False
+            t[j[~ok]] *= 0.5
+        done = todo | (np.max(np.abs(x_new - x), axis=1) <= x_abstol) | (np.abs(f_new - f) <= f_abstol)
+        x_prev, pg_prev = x, pg
+        x, f = x_new, f_new
+        active &= ~done
+    return x, f
+
+
 def optimize_acquisition(acqf: AbstractAcquisition, surrogate: HipStandardGP, domain, n_grid: int = 10_000,
-                         n_local: int = 100, rng=None, return_starts: bool = False):
-    """Grid stage of optimize_acquisition (acq_utils.jl:33-52): LHS grid → fused scores → top
-    `n_local` starts.  Returns the best grid point (the start the reference's refinement loop would
-    visit first); with return_starts=True also the (n_local, d) start points and their scores.
-    The per-start box-L-BFGS refinement (acq_utils.jl:55-71) is the next row of the scope table."""
+                         n_local: int = 100, rng=None, return_starts: bool = False, refine: bool = True):
+    """optimize_acquisition (acq_utils.jl:33-73): LHS grid → fused scores → top `n_local` starts
+    (:44-52) → local refinement of every start, best refined point returned (:55-73).  `refine=False`
+    stops after the grid stage and returns the best grid point.  With return_starts=True also returns
+    the (n_local, d) start points and their grid scores."""
     rng = np.random.default_rng() if rng is None else rng
     grid = latin_hypercube(n_grid, domain.lower, domain.upper, rng)
     k = min(n_local, n_grid)
     _, vals, idx = evaluate(acqf, surrogate, grid, k=k, return_scores=False)
     starts = grid[idx]
+    best = starts[0].copy()
+    if refine:
+        xr, fr = refine_starts(acqf, surrogate, starts, domain.lower, domain.upper)
+        fr = np.where(np.isfinite(fr), fr, -np.inf)
+        j = int(np.argmax(fr))                                 # first maximum, as the reference's strict `>` keeps
+        if fr[j] >= vals[0]:
+            best = xr[j].copy()
     if return_starts:
-        return starts[0].copy(), starts, vals
-    return starts[0].copy()
+        return best, starts, vals
+    return best

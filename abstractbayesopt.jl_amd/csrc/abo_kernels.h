@@ -56,6 +56,8 @@ struct KgenArgs {
     double s, sigma_f2, mean_c;
 };
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
+// test hook: out[i] = kappa(family, d2[i]) with the device math the generator uses
+hipError_t launch_kappa_test(int family, const double* d2, double* out, int64_t n, hipStream_t s);
 // K[i][i] += noise for i < N; K[i][i] = 1 for N ≤ i < Np (identity padding keeps the factor PD)
 hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s);
 // A[i][i] = v for lo ≤ i < hi

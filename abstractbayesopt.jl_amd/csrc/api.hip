@@ -1044,6 +1044,15 @@ int32_t abo_pool_trim(int32_t device) {
     return ABO_OK;
 }
 
+int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n) {
+    if (!d2 || !out || n < 0) return fail(ABO_EINVAL, "abo_test_kappa: bad argument");
+    if (family < ABO_KERNEL_SE || family > ABO_KERNEL_MATERN32) return fail(ABO_EINVAL, "abo_test_kappa: unknown family");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(launch_kappa_test(family, d2, out, n, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ABO_OK;
+}
+
 int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M, int32_t N, int32_t K,
                          int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta) {
     if (!A || !B || !C) return fail(ABO_EINVAL, "abo_test_gemm_nt: null argument");

@@ -179,6 +179,8 @@ int32_t abo_abi_version(void);
 /* --- building blocks exposed for tests and profiling (all buffers DEVICE memory) ------------------
  * C[i][j] = alpha·Σ_k A[i][k]·B[j][k] + beta·C[i][j]; M, N multiples of 128, K multiple of 16,
  * leading dimensions even.  Exercises the fp64 MFMA tile core every solver stage is built on. */
+/* out[i] = kappa(family, d2[i]) evaluated with the device math of the kernel-matrix generator */
+int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n);
 int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, double alpha,
                          double beta);

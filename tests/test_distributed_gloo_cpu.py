@@ -70,3 +70,33 @@ def test_two_rank_short_shards():
     res = _run(2, 7, 16)
     for rank, mv, mi in res:
         assert len(mi) == 7 and sorted(mi.tolist()) == list(range(7))
+
+
+def _worker_best(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abstractbayesopt.jl_amd.incremental import _allgather_best
+    # per-rank best record of a greedy q-EI pick: (score, global index, mu, x[3]); rank 1 ties rank 0's score
+    # with a higher index, rank 2 (if any) has an empty shard
+    recs = {0: [0.7, 41.0, -0.3, 0.1, 0.2, 0.3], 1: [0.7, 99.0, 0.5, 0.4, 0.5, 0.6], 2: [float("nan"), -1.0, 0.0, 0, 0, 0]}
+    out = _allgather_best(np.array(recs[rank]), dist, None)
+    q.put((rank, out.copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_qei_pick_exchange_prefers_lowest_index_on_ties():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_worker_best, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rec in res:
+        assert rec[1] == 41.0 and rec[0] == 0.7 and rec[2] == -0.3 and rec[3:].tolist() == [0.1, 0.2, 0.3]

@@ -321,3 +321,78 @@ def test_full_size_properties_c3():
     mu2, var2 = abo.mean_and_var(m, Z)
     np.testing.assert_array_equal(mu, mu2)
     np.testing.assert_array_equal(var, var2)
+
+
+@pytest.mark.parametrize("family", [O.SE, O.MATERN52, O.MATERN72, O.MATERN32])
+def test_kappa_device_math(family):
+    """The kernel-matrix generator uses its own exp / sqrt sequences (no libm calls): check them against
+    60-digit mpmath over the whole useful range, including the κ(0) = 1 neighbourhood the reference
+    special-cases (GradientGP.jl:94-101) and the underflow tail."""
+    import mpmath as mp
+    import torch
+    mp.mp.dps = 60
+    rng = np.random.default_rng(family)
+    d2 = np.concatenate([[0.0, 1e-300, 1e-200, 1e-30, 1e-12, 1e-10, 9.9e-11, 1e-6, 0.5, 1.0, 2.0, 100.0, 1e3, 1e5, 2e5, 1e6],
+                         10.0 ** rng.uniform(-8, 3, 3000), rng.uniform(0, 50, 3000)])
+    x = torch.from_numpy(d2).cuda()
+    out = torch.empty_like(x)
+    torch.cuda.synchronize()
+    abo._lib.check(abo._lib.lib().abo_test_kappa(0, family, x.data_ptr(), out.data_ptr(), x.numel()))
+    got = out.cpu().numpy()
+
+    def exact(v):
+        v = mp.mpf(float(v))
+        if family == O.SE:
+            return mp.exp(-v / 2)
+        d = mp.sqrt(v)
+        if family == O.MATERN52:
+            return (1 + mp.sqrt(5) * d + 5 * v / 3) * mp.exp(-mp.sqrt(5) * d)
+        if family == O.MATERN72:
+            return (1 + mp.sqrt(7) * d + mp.mpf(14) / 5 * v + 7 * mp.sqrt(7) / 15 * v * d) * mp.exp(-mp.sqrt(7) * d)
+        return (1 + mp.sqrt(3) * d) * mp.exp(-mp.sqrt(3) * d)
+
+    ref = np.array([float(exact(v)) for v in d2])
+    big = ref > 1e-300
+    rel = np.abs(got[big] - ref[big]) / ref[big]
+    # the exponent's argument −c·d is itself rounded to fp64, so the attainable accuracy is ~ε·|argument|
+    arg = {O.SE: 0.5 * d2, O.MATERN52: np.sqrt(5 * d2), O.MATERN72: np.sqrt(7 * d2), O.MATERN32: np.sqrt(3 * d2)}[family]
+    allowed = 1.5e-15 + 2.5e-16 * arg[big]
+    assert np.all(rel <= allowed), (np.max(rel / allowed), d2[big][np.argmax(rel / allowed)])
+    assert np.all(np.abs(got[~big] - ref[~big]) < 1e-300)
+    assert got[0] == 1.0 and np.all(np.isfinite(got))
+
+
+def test_optimize_acquisition_refinement_stage():
+    """acq_utils.jl:55-71: every start is refined inside the box and the best refined point is returned.
+    The batched projected L-BFGS must (i) never lose against its start, (ii) stay in the box, (iii) reach
+    the optimum SciPy's L-BFGS-B finds on the CPU oracle's acquisition from the same start."""
+    from scipy.optimize import minimize
+    from abstractbayesopt.jl_amd.acquisition import refine_starts
+    d = 3
+    X, y = synth.standardized_problem(60, d, 0.02)
+    fam, ell, sf2, noise = O.MATERN52, 0.5, 1.0, 1e-3
+    m = abo.update(make_model(fam, ell, sf2, noise), X, y)
+    st = O.fit(fam, ell, sf2, noise, 0.0, X, y)
+    lower, upper = np.zeros(d), np.ones(d)
+    for acq, oracle in ((abo.UpperConfidenceBound(2.0), lambda z: O.upper_confidence_bound(*O.predict(st, z), 2.0)),
+                        (abo.ExpectedImprovement(0.01, float(y.min())),
+                         lambda z: O.expected_improvement(*O.predict(st, z), float(y.min()), 0.01))):
+        starts = synth.points(7, 12, d)
+        f0 = acq(m, starts)
+        xr, fr = refine_starts(acq, m, starts, lower, upper)
+        assert np.all(fr >= f0 - 1e-15)
+        assert np.all(xr >= lower) and np.all(xr <= upper)
+        np.testing.assert_allclose(acq(m, xr), fr, rtol=0, atol=1e-12)
+        for i in range(4):
+            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B",
+                           bounds=list(zip(lower, upper)), options={"ftol": 1e-14, "gtol": 1e-8})
+            # same basin is not guaranteed for every start; require ≥ SciPy's value up to the stopping tolerances
+            assert fr[i] >= -res.fun - 1e-5 * max(1.0, abs(res.fun)) or fr[i] >= f0[i], (i, fr[i], -res.fun)
+    dom = abo.ContinuousDomain(lower, upper)
+    rng = np.random.default_rng(1)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    best, starts, vals = abo.optimize_acquisition(acq, m, dom, n_grid=2000, n_local=20, rng=rng, return_starts=True)
+    assert acq(m, [best])[0] >= vals[0] - 1e-15 and np.all(best >= lower) and np.all(best <= upper)
+    rng = np.random.default_rng(1)
+    grid_only = abo.optimize_acquisition(acq, m, dom, n_grid=2000, n_local=20, rng=rng, refine=False)
+    np.testing.assert_array_equal(grid_only, starts[0])
