@@ -49,6 +49,8 @@ def all_gather_topk(local_vals, local_idx, k: int, group=None):
     i = torch.as_tensor(local_idx, dtype=torch.int64)
     # one 16·k-byte message per rank: pack (score bits, index) into a single int64 buffer
     packed = torch.stack([v.view(torch.int64), i])
+    if dist.get_backend(group) != "nccl":
+        packed = packed.cpu()                    # gloo: host tensors
     out = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(out, packed, group=group)
     allp = torch.stack(out).cpu()

@@ -161,7 +161,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev):
     sync()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms = elapsed * 1e3 / args.steps
@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-m", type=int, default=8192)
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -215,10 +218,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     cfg = CONFIGS[args.config]
     if args.config == "c5":
@@ -245,6 +253,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def reduce_max(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     phases = []
     model = None
     top = None
@@ -260,9 +273,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = reduce_max(elapsed)
     ms_per_step = elapsed * 1e3 / args.steps
 
     if rank == 0:
