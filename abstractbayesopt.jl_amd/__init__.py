@@ -6,6 +6,7 @@ from ._lib import AboError, DimensionMismatch, PosDefException
 from .acquisition import (AbstractAcquisition, ExpectedImprovement, ProbabilityImprovement, UpperConfidenceBound,
                           evaluate, latin_hypercube, optimize_acquisition)
 from .domains import ContinuousDomain
+from .hyperparams import lengthscale_bounds, monte_carlo_fill_distance, nlml_and_grad, optimize_hyperparameters
 from .incremental import ResidentCandidates, append, greedy_qei
 from .kernels import (ApproxMatern52Kernel, ApproxMatern72Kernel, ConstMean, Kernel, Matern32Kernel, Matern52Kernel,
                       ScaledKernel, SqExponentialKernel, ZeroMean, with_lengthscale)

@@ -56,6 +56,19 @@ struct KgenArgs {
     double s, sigma_f2, mean_c;
 };
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
+// NLML gradient reduction: Σ_ij (Kinv − ααᵀ)_ij ∂K_ij/∂log ℓ over the lower tiles, plus tr(Kinv), αᵀα, αᵀδ
+struct NlmlGradArgs {
+    const double* Xs;      // [Np][dp]
+    const double* Kinv;    // [Np][ld]  lower 128-tiles valid
+    const double* alpha;   // [Np]
+    const double* delta;   // [Np]
+    double* partial;       // [Np/16]
+    double* out;           // [4]
+    int64_t ld;
+    int N, Np, dp, family;
+    double sigma_f2;
+};
+hipError_t launch_nlml_grad(const NlmlGradArgs& a, hipStream_t s);
 // test hook: out[i] = kappa(family, d2[i]) with the device math the generator uses
 hipError_t launch_kappa_test(int family, const double* d2, double* out, int64_t n, hipStream_t s);
 // K[i][i] += noise for i < N; K[i][i] = 1 for N ≤ i < Np (identity padding keeps the factor PD)

@@ -830,6 +830,40 @@ int32_t abo_nlml(abo_gp* g, double* out) {
     return ABO_OK;
 }
 
+int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_sigma_f2) {
+    if (!g) return fail(ABO_EINVAL, "abo_nlml_grad: null handle");
+    if (!g->fitted) return fail(ABO_EINVAL, "surrogate is not conditioned on data yet (call abo_fit first)");
+    if (g->from_append || g->st->max_live() != g->N)
+        return fail(ABO_EINVAL, "abo_nlml_grad needs a freshly fitted model (hyper-parameter search refits anyway)");
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const int64_t Np = g->Np, ld = g->st->cap;
+    const int N = (int)g->N;
+    HIPCHK(g->T.ensure(sizeof(double) * Np * Np));
+    HIPCHK(g->partial.ensure(sizeof(double) * (Np / 16 + 8)));
+    HIPCHK(g->scal.ensure(sizeof(double) * 8));
+    // K⁻¹ = WᵀW on the lower 128-tiles: Kinv[i][j] = Σ_{k ≥ i} WT[i][k]·WT[j][k]
+    GemmArgs a{};
+    a.A = g->st->WT.as<double>(); a.lda = ld; a.B = g->st->WT.as<double>(); a.ldb = ld;
+    a.C = g->T.as<double>(); a.ldc = Np; a.M = (int)Np; a.N = (int)Np; a.K = (int)Np;
+    a.kmode = K_A_UPPER; a.lower_only = 1; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
+    HIPCHK(launch_gemm_nt(a, s));
+    NlmlGradArgs ga{};
+    ga.Xs = g->st->Xs.as<double>(); ga.Kinv = g->T.as<double>(); ga.alpha = g->alpha.as<double>();
+    ga.delta = g->st->delta.as<double>(); ga.partial = g->partial.as<double>(); ga.out = g->scal.as<double>() + 4;
+    ga.ld = Np; ga.N = N; ga.Np = (int)Np; ga.dp = g->dp; ga.family = g->prm.family; ga.sigma_f2 = g->prm.sigma_f2;
+    HIPCHK(launch_nlml_grad(ga, s));
+    double o[4];
+    HIPCHK(hipMemcpyAsync(o, g->scal.as<double>() + 4, sizeof o, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // ∂NLML/∂θ = ½ tr((K⁻¹ − ααᵀ) ∂K/∂θ);  ∂K/∂log σ_f² = K − noise·I  and  K α = δ
+    const double noise = g->st->noise_used;
+    if (nlml) *nlml = 0.5 * ((double)g->N * std::log(2.0 * M_PI) + g->logdet + g->quad);
+    if (d_log_ell) *d_log_ell = 0.5 * o[0];
+    if (d_log_sigma_f2) *d_log_sigma_f2 = 0.5 * ((double)N - noise * o[1] - o[3] + noise * o[2]);
+    return ABO_OK;
+}
+
 int32_t abo_get_n(abo_gp* g, int64_t* N, int32_t* d) {
     if (!g) return fail(ABO_EINVAL, "null handle");
     if (N) *N = g->fitted ? g->N : 0;

@@ -87,6 +87,129 @@ __device__ __forceinline__ double kappa_eval(double d2) {
     }
 }
 
+// ∂k/∂log ℓ on the squared scaled distance d2 (∂r/∂log ℓ = −r, so dK = −σ_f²·r·κ'(r)):
+//   SE   σ_f² d2 e^{−d2/2}            M32  σ_f² 3 d2 e^{−√3 d}
+//   M52  σ_f² (5/3) d2 (1+√5 d) e^{−√5 d}     M72  σ_f² d2 (7/5 + (7√7/5) d + (49/15) d2) e^{−√7 d}
+template <int FAM>
+__device__ __forceinline__ double dkappa_dlogell(double d2) {
+    if constexpr (FAM == ABO_KERNEL_SE) {
+        return d2 * exp_nonpos(-0.5 * d2);
+    } else if constexpr (FAM == ABO_KERNEL_MATERN52) {
+        const double s5 = 2.23606797749978969640917366873128;
+        const double d = sqrt_pos(d2);
+        return (5.0 / 3.0) * d2 * fma(s5, d, 1.0) * exp_nonpos(-s5 * d);
+    } else if constexpr (FAM == ABO_KERNEL_MATERN72) {
+        const double s7 = 2.64575131106459059050161575363926;
+        const double d = sqrt_pos(d2);
+        return d2 * fma(d2, 49.0 / 15.0, fma(d, 7.0 * s7 / 5.0, 7.0 / 5.0)) * exp_nonpos(-s7 * d);
+    } else {
+        const double s3 = 1.73205080756887729352744634150587;
+        return 3.0 * d2 * exp_nonpos(-s3 * sqrt_pos(d2));
+    }
+}
+
+// partial[block] = Σ over the block's pairs of w_ij·(Kinv[i][j] − α_i α_j)·∂K_ij/∂log ℓ, lower 128×128 tiles
+// of the training set only (w = 2 for strictly-lower tiles, 1 inside diagonal tiles, which are complete).
+// Same lane ↔ column mapping as kgen_kernel: 16 rows per workgroup, lanes sweep two columns each.
+template <int FAM, int DP>
+__global__ void __launch_bounds__(256) nlml_grad_kernel(NlmlGradArgs p) {
+    __shared__ double zs[JT][DP];
+    __shared__ double ai[JT];
+    __shared__ double red[4];
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * JT;                    // first row of this workgroup
+    for (int idx = t; idx < JT * DP; idx += 256) zs[idx / DP][idx % DP] = p.Xs[(int64_t)(ib + idx / DP) * DP + idx % DP];
+    if (t < JT) ai[t] = p.alpha[ib + t];
+    __syncthreads();
+    const int kend = (ib / 128 + 1) * 128;             // columns up to the end of the row's diagonal tile
+    const int diag0 = (ib / 128) * 128;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < kend; k0 += KSTEP) {
+        const int k = k0 + 2 * t;
+        if (k < kend) {
+            double x0[DP], x1[DP];
+            const double* xp = p.Xs + (int64_t)k * DP;
+#pragma unroll
+            for (int c = 0; c < DP; ++c) { x0[c] = xp[c]; x1[c] = xp[DP + c]; }
+            const double a0 = p.alpha[k], a1 = p.alpha[k + 1];
+            const double w = (k >= diag0) ? 1.0 : 2.0;
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) {
+                asm volatile("" ::: "memory");
+                const int i = ib + jj;
+                double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < DP; ++c) {
+                    const double z = zs[jj][c];
+                    const double e0 = x0[c] - z, e1 = x1[c] - z;
+                    r0 = fma(e0, e0, r0);
+                    r1 = fma(e1, e1, r1);
+                }
+                const double* kr = p.Kinv + (int64_t)i * p.ld + k;
+                const double m0 = kr[0] - ai[jj] * a0, m1 = kr[1] - ai[jj] * a1;
+                const double g0 = (i < p.N && k < p.N) ? m0 * dkappa_dlogell<FAM>(r0) : 0.0;
+                const double g1 = (i < p.N && k + 1 < p.N) ? m1 * dkappa_dlogell<FAM>(r1) : 0.0;
+                acc = fma(w, g0 + g1, acc);
+            }
+        }
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (t == 0) p.partial[blockIdx.x] = p.sigma_f2 * (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
+// out[0] = Σ partial (fixed order), out[1] = Σ_{i<N} Kinv[i][i], out[2] = αᵀα, out[3] = αᵀδ
+__global__ void __launch_bounds__(256) nlml_grad_finish_kernel(NlmlGradArgs p, int nblocks) {
+    __shared__ double r[4][256];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s0 += p.partial[i];
+    for (int i = threadIdx.x; i < p.N; i += 256) {
+        s1 += p.Kinv[(int64_t)i * p.ld + i];
+        s2 = fma(p.alpha[i], p.alpha[i], s2);
+        s3 = fma(p.alpha[i], p.delta[i], s3);
+    }
+    r[0][threadIdx.x] = s0; r[1][threadIdx.x] = s1; r[2][threadIdx.x] = s2; r[3][threadIdx.x] = s3;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int q = 0; q < 4; ++q) r[q][threadIdx.x] += r[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) p.out[threadIdx.x] = r[threadIdx.x][0];
+}
+
+template <int FAM>
+static hipError_t launch_grad_fam(const NlmlGradArgs& a, hipStream_t s) {
+    dim3 grid(a.Np / JT), block(256);
+    switch (a.dp) {
+        case 1: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 1>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 2>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 4>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 8>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 16>), grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 32>), grid, block, 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_nlml_grad(const NlmlGradArgs& a, hipStream_t s) {
+    hipError_t e;
+    switch (a.family) {
+        case ABO_KERNEL_SE: e = launch_grad_fam<ABO_KERNEL_SE>(a, s); break;
+        case ABO_KERNEL_MATERN52: e = launch_grad_fam<ABO_KERNEL_MATERN52>(a, s); break;
+        case ABO_KERNEL_MATERN72: e = launch_grad_fam<ABO_KERNEL_MATERN72>(a, s); break;
+        case ABO_KERNEL_MATERN32: e = launch_grad_fam<ABO_KERNEL_MATERN32>(a, s); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nlml_grad_finish_kernel, dim3(1), dim3(256), 0, s, a, a.Np / JT);
+    return hipGetLastError();
+}
+
 // test hook: out[i] = kappa(family, d2[i])
 __global__ void kappa_test_kernel(int family, const double* d2, double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

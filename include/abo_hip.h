@@ -157,6 +157,13 @@ int32_t abo_cand_point(abo_gp* gp, abo_cand* c, int64_t idx, double* x, double* 
  * ½(N log 2π + logdet(K+noise I) + deltaᵀ alpha). */
 int32_t abo_nlml(abo_gp* gp, double* out);
 
+/* NLML and its analytic gradient with respect to (log ell, log sigma_f2) — what Optim's
+ * `autodiff=:forward` computes with ForwardDiff duals in optimize_hyperparameters
+ * (src/bayesian_opt.jl:253-285), which cannot cross a C-ABI:
+ *   dNLML/dθ = ½ tr((K⁻¹ − ααᵀ) ∂K/∂θ),  K⁻¹ = L⁻ᵀL⁻¹ formed on the MFMA GEMM, ∂K/∂log ell generated on
+ *   the fly.  Needs a freshly fitted handle (not an appended view).  Any output may be NULL. */
+int32_t abo_nlml_grad(abo_gp* gp, double* nlml, double* d_log_ell, double* d_log_sigma_f2);
+
 /* --- introspection (tests) ----------------------------------------------------------------------
  * L (N×N row-major, strictly-upper part zero), alpha (N), Linv = L⁻¹ (N×N row-major); any may be
  * NULL.  Host buffers. */

@@ -396,3 +396,45 @@ def test_optimize_acquisition_refinement_stage():
     rng = np.random.default_rng(1)
     grid_only = abo.optimize_acquisition(acq, m, dom, n_grid=2000, n_local=20, rng=rng, refine=False)
     np.testing.assert_array_equal(grid_only, starts[0])
+
+
+@pytest.mark.parametrize("family,d,N", [(O.SE, 2, 40), (O.MATERN52, 4, 300), (O.MATERN72, 3, 130), (O.MATERN32, 1, 77),
+                                        (O.MATERN52, 8, 1024)])
+def test_nlml_gradient_against_oracle_finite_differences(family, d, N):
+    """abo_nlml_grad vs central differences of the CPU oracle's NLML in (log ℓ, log σ_f²) — what the reference
+    obtains with ForwardDiff in optimize_hyperparameters (bayesian_opt.jl:253-285)."""
+    X = synth.points(1, N, d)
+    y = synth.objective(X, 0.1) + 0.3
+    ell, sf2, noise, mean_c = 0.6, 1.7, 1e-2, 0.3
+    gp = make_model(family, 1.0, 1.0, noise, mean_c)
+    p = np.array([np.log(ell), np.log(sf2)])
+    v, g = abo.nlml_and_grad(gp, p, X, y)
+
+    def f(q):
+        return O.nlml(O.fit(family, float(np.exp(q[0])), float(np.exp(q[1])), noise, mean_c, X, y))
+
+    assert abs(v - f(p)) <= 1e-9 * max(1.0, abs(v))
+    h = 1e-5
+    fd = np.array([(f(p + h * e) - f(p - h * e)) / (2 * h) for e in np.eye(2)])
+    np.testing.assert_allclose(g, fd, rtol=2e-6, atol=1e-6 * max(1.0, abs(v)))
+
+
+def test_optimize_hyperparameters_improves_nlml():
+    """test/test_bayesian_opt.jl:597-653: the optimised kernel has a lower NLML than the starting one, stays in
+    the bounds, and length_scale_only keeps the scale."""
+    d, N = 2, 80
+    X = synth.points(1, N, d)
+    y = np.sin(3 * X[:, 0]) + np.cos(2 * X[:, 1])
+    dom = abo.ContinuousDomain(np.zeros(d), np.ones(d))
+    gp = abo.HipStandardGP(1.0 * abo.with_lengthscale(abo.Matern52Kernel(), 0.05), 1e-4)
+    old = [np.log(0.05), np.log(1.0)]
+    v0, _ = abo.nlml_and_grad(gp, old, X, y)
+    new = abo.optimize_hyperparameters(gp, X, y, old, num_restarts=3, domain=dom, rng=np.random.default_rng(0))
+    assert new.gpx is None                                  # un-conditioned, like _update_model_parameters
+    ell, sc = abo.get_lengthscale(new)[0], abo.get_scale(new)[0]
+    v1, g1 = abo.nlml_and_grad(gp, [np.log(ell), np.log(sc)], X, y)
+    assert v1 < v0 - 1.0
+    lo, hi = abo.lengthscale_bounds(X, dom, rng=np.random.default_rng(0))
+    assert max(lo.min(), 1e-6) * 0.999 <= ell <= hi.max() * 1.001 and 1e-3 <= sc <= 1e6
+    only = abo.optimize_hyperparameters(gp, X, y, old, length_scale_only=True, domain=dom, rng=np.random.default_rng(0))
+    assert abo.get_scale(only) == [1.0] and abo.get_lengthscale(only)[0] != 0.05
