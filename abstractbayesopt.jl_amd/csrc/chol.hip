@@ -26,7 +26,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// One workgroup (4 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
+// One workgroup (16 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
 // as an 8×8 grid of 16×16 sub-blocks so that everything but the 16×16 diagonal factorisations runs
 // on the fp64 MFMA (v_mfma_f64_16x16x4_f64) with 24 + 8 workgroup barriers in total:
 //   phase 1  right-looking Cholesky over sub-block columns p = 0..7:
@@ -41,7 +41,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 //                MFMA when its k-steps are taken as {g, g+4, g+8, g+12} — no data movement in between
 //   phase 3  write L back to K (lower, zeros above), X to W (lower) and Xᵀ to WT (upper).
 #define AA(r, c) a[(r) * LDA + (c)]
-__global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, double* WT, int64_t ld, int r0,
+constexpr int DT = 1024;      // threads of the diagonal-block kernel (16 waves: latency hiding for the LDS phases)
+__global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, double* WT, int64_t ld, int r0,
                                                         int64_t* info) {
     __shared__ double a[NB * LDA];
     __shared__ double dinv[NB];
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, do
     if (*info != 0) return;
     if (t == 0) fail = 0;
     double* Kb = K + (int64_t)r0 * ld + r0;
-    for (int idx = t; idx < NB * NB; idx += 256) {
+    for (int idx = t; idx < NB * NB; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         AA(i, j) = Kb[(int64_t)i * ld + j];
     }
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, do
         {                                                  // (3) trailing update on the lower sub-blocks
             const int nb = NSB - 1 - p;                    // sub-block rows/cols left
             const int total = nb * (nb + 1) / 2;
-            for (int e = wave; e < total; e += 4) {
+            for (int e = wave; e < total; e += DT / 64) {
                 int bi = 0, rem = e;                       // e -> (bi ≥ bj) in row-major lower order
                 while (rem > bi) { rem -= bi + 1; ++bi; }
                 const int bj = rem;
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, do
     }
     __syncthreads();
     for (int dl = 1; dl < NSB; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
-        for (int c = wave; c + dl < NSB; c += 4) {
+        for (int c = wave; c + dl < NSB; c += DT / 64) {
             const int i = c + dl;
             const int oc = SB * c, oi = SB * i;
             d4_t tt = {0.0, 0.0, 0.0, 0.0};
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, do
     // ---------------- phase 3: write back ----------------
     double* Wb = W + (int64_t)r0 * ld + r0;
     double* WTb = WT + (int64_t)r0 * ld + r0;
-    for (int idx = t; idx < NB * NB; idx += 256) {
+    for (int idx = t; idx < NB * NB; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         double l, w, wt;
         if (i > j) { l = AA(i, j); w = AA(j, i); wt = 0.0; }
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(256) chol_diag_kernel(double* K, double* W, do
 #undef AA
 
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, s, K, W, WT, ld, r0, info);
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
     return hipGetLastError();
 }
 
