@@ -3,8 +3,9 @@ AbstractSurrogate / AbstractAcquisition interface (hot path only: update → pos
 top-k).  Import as ``import abstractbayesopt.jl_amd as abo``."""
 from . import _lib, acquisition, distributed, incremental, synth
 from ._lib import AboError, DimensionMismatch, PosDefException
-from .acquisition import (AbstractAcquisition, ExpectedImprovement, ProbabilityImprovement, UpperConfidenceBound,
-                          evaluate, latin_hypercube, optimize_acquisition)
+from .acquisition import (AbstractAcquisition, EnsembleAcquisition, ExpectedImprovement, ProbabilityImprovement,
+                          UpperConfidenceBound, device_latin_hypercube, evaluate, latin_hypercube,
+                          optimize_acquisition, refine_starts)
 from .domains import ContinuousDomain
 from .hyperparams import lengthscale_bounds, monte_carlo_fill_distance, nlml_and_grad, optimize_hyperparameters
 from .incremental import ResidentCandidates, append, greedy_qei

@@ -76,16 +76,60 @@ class ProbabilityImprovement(AbstractAcquisition):
         return float(self.best_y)
 
 
+class EnsembleAcquisition(AbstractAcquisition):
+    """EnsembleAcquisition(weights, acqs) (EnsembleAcq.jl:12-27): non-negative weights normalised to sum 1;
+    value = Σ wᵢ·acqᵢ(surrogate, x) (:53-55).  On a HipStandardGP the posterior is computed ONCE on the
+    device and every member's epilogue (abo_score) runs on that same μ, σ²."""
+
+    def __init__(self, weights, acqs):
+        weights = np.asarray(weights, dtype=np.float64)
+        assert len(weights) == len(acqs), "weights and acquisitions must align"
+        assert np.all(weights >= 0), "weights must be non-negative"
+        total = float(weights.sum())
+        assert total > 0, "sum of weights must be positive"
+        self.weights = weights / total
+        self.acquisitions = list(acqs)
+
+    def __call__(self, surrogate: AbstractSurrogate, x):
+        import torch
+        from .surrogate import mean_and_var
+        if np.isscalar(x):
+            x = [float(x)]
+        zp, m, d, zspace, keep = as_points(x)
+        dev = torch.device("cuda", surrogate.device)
+        zt = keep if zspace == DEVICE else torch.from_numpy(keep).to(dev)
+        mu, var = mean_and_var(surrogate, zt)                         # one posterior pass, stays on the device
+        total = torch.zeros(m, dtype=torch.float64, device=dev)
+        sc = torch.empty(m, dtype=torch.float64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        for w, a in zip(self.weights, self.acquisitions):
+            if isinstance(a, EnsembleAcquisition):
+                total += w * torch.as_tensor(a(surrogate, zt), device=dev)
+                continue
+            _lib.check(_lib.lib().abo_score(surrogate.device, mu.data_ptr(), var.data_ptr(), m, a.kind, a._p0(), a._best(),
+                                            sc.data_ptr()))
+            total += w * sc
+        return total if zspace == DEVICE else total.cpu().numpy()
+
+    def __eq__(self, other):
+        return (isinstance(other, EnsembleAcquisition) and np.array_equal(self.weights, other.weights)
+                and self.acquisitions == other.acquisitions)
+
+
 def update(acq: AbstractAcquisition, ys, surrogate: AbstractSurrogate):
     """update(acq, ys, surrogate): EI/PI take best_y = _get_minimum(surrogate, ys)
     (ExpectedImprovement.jl:81-83, ProbabilityImprovement.jl:79-82); UCB is unchanged
     (UpperConfidenceBound.jl:60-62)."""
+    if isinstance(acq, EnsembleAcquisition):                            # EnsembleAcq.jl:57-62
+        return EnsembleAcquisition(acq.weights, [update(a, ys, surrogate) for a in acq.acquisitions])
     if isinstance(acq, (ExpectedImprovement, ProbabilityImprovement)):
         return replace(acq, best_y=_get_minimum(surrogate, ys))
     return acq
 
 
 def copy(acq: AbstractAcquisition):
+    if isinstance(acq, EnsembleAcquisition):                            # EnsembleAcq.jl:36-38
+        return EnsembleAcquisition(acq.weights.copy(), [copy(a) for a in acq.acquisitions])
     return replace(acq)
 
 
@@ -116,6 +160,11 @@ def evaluate(acq: AbstractAcquisition, surrogate: HipStandardGP, x, k: int = 0, 
     return scores, tv, ti
 
 
+def torch_index(idx, like):
+    import torch
+    return torch.as_tensor(idx, dtype=torch.int64, device=like.device)
+
+
 def latin_hypercube(n: int, lower, upper, rng) -> np.ndarray:
     """QuasiMonteCarlo.sample(n, lower, upper, LatinHypercubeSample()) (acq_utils.jl:44-46): one
     point per stratum in every coordinate, strata permuted independently per coordinate.
@@ -127,6 +176,20 @@ def latin_hypercube(n: int, lower, upper, rng) -> np.ndarray:
     for c in range(d):
         u[:, c] = (rng.permutation(n) + rng.random(n)) / n
     return lower + u * (upper - lower)
+
+
+def device_latin_hypercube(n: int, lower, upper, seed: int, device: int = 0, first: int = 0, count: int | None = None):
+    """Rows first .. first+count−1 of an n-point Latin-hypercube design, generated on the GPU (abo_lhs) as a
+    CUDA tensor: the grid of optimize_acquisition without the host LHS and the H2D copy."""
+    import torch
+    lower = np.ascontiguousarray(np.asarray(lower, dtype=np.float64))
+    upper = np.ascontiguousarray(np.asarray(upper, dtype=np.float64))
+    count = n - first if count is None else count
+    Z = torch.empty((count, lower.shape[0]), dtype=torch.float64, device=torch.device("cuda", device))
+    torch.cuda.current_stream(Z.device).synchronize()
+    _lib.check(_lib.lib().abo_lhs(device, n, lower.shape[0], lower.ctypes.data, upper.ctypes.data, int(seed) & (2 ** 64 - 1),
+                                  first, count, Z.data_ptr()))
+    return Z
 
 
 def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, lower, upper, max_iter: int = 100,
@@ -228,16 +291,30 @@ def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, l
 
 
 def optimize_acquisition(acqf: AbstractAcquisition, surrogate: HipStandardGP, domain, n_grid: int = 10_000,
-                         n_local: int = 100, rng=None, return_starts: bool = False, refine: bool = True):
+                         n_local: int = 100, rng=None, return_starts: bool = False, refine: bool = True,
+                         device_grid: bool = False):
     """optimize_acquisition (acq_utils.jl:33-73): LHS grid → fused scores → top `n_local` starts
     (:44-52) → local refinement of every start, best refined point returned (:55-73).  `refine=False`
     stops after the grid stage and returns the best grid point.  With return_starts=True also returns
     the (n_local, d) start points and their grid scores."""
     rng = np.random.default_rng() if rng is None else rng
-    grid = latin_hypercube(n_grid, domain.lower, domain.upper, rng)
     k = min(n_local, n_grid)
-    _, vals, idx = evaluate(acqf, surrogate, grid, k=k, return_scores=False)
-    starts = grid[idx]
+    if device_grid and not isinstance(acqf, EnsembleAcquisition):
+        # the grid is generated, scored and reduced on the GPU; only the k starts come back
+        grid = device_latin_hypercube(n_grid, domain.lower, domain.upper, int(rng.integers(0, 2 ** 63)), surrogate.device)
+        _, vals, idx = evaluate(acqf, surrogate, grid, k=k, return_scores=False)
+        vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+        starts = grid[torch_index(idx, grid)].cpu().numpy()
+    elif isinstance(acqf, EnsembleAcquisition):
+        grid = latin_hypercube(n_grid, domain.lower, domain.upper, rng)
+        scores = acqf(surrogate, grid)
+        nan_first = np.isnan(scores)
+        idx = np.lexsort((np.arange(n_grid), -np.where(nan_first, np.inf, scores), ~nan_first))[:k]
+        vals, starts = scores[idx], grid[idx]
+    else:
+        grid = latin_hypercube(n_grid, domain.lower, domain.upper, rng)
+        _, vals, idx = evaluate(acqf, surrogate, grid, k=k, return_scores=False)
+        starts = grid[idx]
     best = starts[0].copy()
     if refine:
         xr, fr = refine_starts(acqf, surrogate, starts, domain.lower, domain.upper)

@@ -126,6 +126,10 @@ hipError_t launch_downdate(double* mu, double* var, const double* c, int64_t M, 
 hipError_t launch_score(const double* mu, const double* var, double* score, int64_t M, int kind, double p0, double best_y,
                         hipStream_t s);
 
+// Z[(j−j0)·d + c] for j in [j0, j0+count): Latin-hypercube points of an n-point design (device lower/upper)
+hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
+                      int64_t count, hipStream_t s);
+
 struct TopkWork {            // scratch sized by topk_workspace_entries()
     uint64_t* keys[2];
     int64_t* idx[2];

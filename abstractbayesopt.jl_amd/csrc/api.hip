@@ -1078,6 +1078,32 @@ int32_t abo_pool_trim(int32_t device) {
     return ABO_OK;
 }
 
+int32_t abo_lhs(int32_t device, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
+                int64_t count, double* Z_dev) {
+    if (!lower || !upper || !Z_dev) return fail(ABO_EINVAL, "abo_lhs: null argument");
+    if (n < 1 || d < 1 || d > 32 || j0 < 0 || count < 0 || j0 + count > n) return fail(ABO_EINVAL, "abo_lhs: bad sizes");
+    HIPCHK(hipSetDevice(device));
+    DevBuf b;
+    b.dev = device;
+    HIPCHK(b.ensure(sizeof(double) * 64));
+    HIPCHK(hipMemcpyAsync(b.p, lower, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(b.as<double>() + 32, upper, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(launch_lhs(Z_dev, n, d, b.as<double>(), b.as<double>() + 32, seed, j0, count, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    b.release();
+    return ABO_OK;
+}
+
+int32_t abo_score(int32_t device, const double* mu, const double* var, int64_t M, int32_t kind, double p0, double best_y,
+                  double* scores) {
+    if (M < 0 || (M > 0 && (!mu || !var || !scores))) return fail(ABO_EINVAL, "abo_score: bad argument");
+    if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_score: unknown acquisition kind %d", kind);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(launch_score(mu, var, scores, M, kind, p0, best_y, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ABO_OK;
+}
+
 int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n) {
     if (!d2 || !out || n < 0) return fail(ABO_EINVAL, "abo_test_kappa: bad argument");
     if (family < ABO_KERNEL_SE || family > ABO_KERNEL_MATERN32) return fail(ABO_EINVAL, "abo_test_kappa: unknown family");

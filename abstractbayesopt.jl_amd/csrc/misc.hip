@@ -75,6 +75,58 @@ hipError_t launch_score(const double* mu, const double* var, double* score, int6
     return hipGetLastError();
 }
 
+// ---- Latin hypercube grid on the device (acq_utils.jl:44-47 without the PCIe trip) ----------------
+// z[j][c] = lower_c + (π_c(j) + u_jc)/n · (upper_c − lower_c): one point per stratum in every coordinate.
+// π_c is a keyed bijection of [0, n): 4-round Feistel network on ⌈log2 n⌉ bits with cycle walking
+// (counter-based, so any shard of the grid can be generated independently); u from SplitMix64.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t feistel_perm(uint64_t x, uint64_t n, int bits, uint64_t key) {
+    const int hb = (bits + 1) / 2;                       // half width (the domain is 2^(2·hb) ≥ n)
+    const uint64_t hm = (1ull << hb) - 1;
+    do {
+        uint64_t l = x >> hb, r = x & hm;
+#pragma unroll
+        for (int round = 0; round < 4; ++round) {
+            const uint64_t f = mix64(r ^ (key + 0x9E3779B97F4A7C15ull * (round + 1))) & hm;
+            const uint64_t nl = r;
+            r = l ^ f;
+            l = nl;
+        }
+        x = (l << hb) | r;
+    } while (x >= n);                                    // cycle walking: stays a bijection on [0, n)
+    return x;
+}
+
+__global__ void __launch_bounds__(256) lhs_kernel(double* Z, int64_t n, int d, const double* lower, const double* upper,
+                                                   uint64_t seed, int64_t j0, int64_t count, int bits) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count * d) return;
+    const int64_t j = j0 + idx / d;
+    const int c = (int)(idx % d);
+    const uint64_t key = mix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(c + 1)));
+    const uint64_t stratum = feistel_perm((uint64_t)j, (uint64_t)n, bits, key);
+    const double u = (double)(mix64(key ^ (uint64_t)j * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+    Z[idx] = lower[c] + ((double)stratum + u) / (double)n * (upper[c] - lower[c]);
+}
+
+hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
+                      int64_t count, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    int bits = 1;
+    while ((1ull << bits) < (uint64_t)n) ++bits;
+    if (bits & 1) ++bits;                                // even width: two equal Feistel halves
+    const int64_t total = count * d;
+    hipLaunchKernelGGL(lhs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Z, n, d, lower, upper, seed, j0,
+                       count, bits);
+    return hipGetLastError();
+}
+
 // ---- top-k ------------------------------------------------------------------------------------
 // Total order of Julia's stable `sortperm(scores; rev=true)`: isless-descending (NaN first, then
 // +Inf … −Inf, with 0.0 before −0.0), equal scores by ascending index.  Scores are mapped to

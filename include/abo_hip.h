@@ -152,6 +152,18 @@ int32_t abo_cand_acq(abo_gp* gp, abo_cand* c, int32_t kind, double p0, double be
 int32_t abo_cand_get(abo_gp* gp, abo_cand* c, double* mu, double* var, int32_t out_space);
 int32_t abo_cand_point(abo_gp* gp, abo_cand* c, int64_t idx, double* x, double* mu, double* var);
 
+/* --- grid generation and stand-alone epilogue (DEVICE buffers) --------------------------------------
+ * abo_lhs: points j0 .. j0+count−1 of an n-point Latin-hypercube design in the box [lower, upper]
+ * (QuasiMonteCarlo.sample(n, lower, upper, LatinHypercubeSample()), src/acquisition_functions/acq_utils.jl:44-47)
+ * written point-major to Z_dev; counter-based (keyed Feistel permutation per coordinate), so each rank
+ * generates its own shard and the candidate grid never crosses PCIe.  lower/upper: d host doubles.
+ * abo_score: scores[j] = acq(mu[j], var[j]) — the EI / UCB / PI epilogue on an existing posterior
+ * (several acquisition functions on one posterior pass: EnsembleAcquisition, EnsembleAcq.jl:53-55). */
+int32_t abo_lhs(int32_t device, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
+                int64_t j0, int64_t count, double* Z_dev);
+int32_t abo_score(int32_t device, const double* mu, const double* var, int64_t M, int32_t kind, double p0,
+                  double best_y, double* scores);
+
 /* --- scalars ----------------------------------------------------------------------------------
  * nlml (src/surrogates/StandardGP.jl:99-114) of the fitted state:
  * ½(N log 2π + logdet(K+noise I) + deltaᵀ alpha). */

@@ -438,3 +438,48 @@ def test_optimize_hyperparameters_improves_nlml():
     assert max(lo.min(), 1e-6) * 0.999 <= ell <= hi.max() * 1.001 and 1e-3 <= sc <= 1e6
     only = abo.optimize_hyperparameters(gp, X, y, old, length_scale_only=True, domain=dom, rng=np.random.default_rng(0))
     assert abo.get_scale(only) == [1.0] and abo.get_lengthscale(only)[0] != 0.05
+
+
+def test_ensemble_acquisition_is_weighted_sum_on_one_posterior():
+    # test/test_acquisition.jl:223-253: ensemble value == Σ wᵢ·acqᵢ
+    import torch
+    X, y = synth.standardized_problem(200, 3, 0.05)
+    Z = synth.points(2, 1500, 3)
+    m = abo.update(make_model(O.MATERN52, 0.6, 1.0, 1e-3), X, y)
+    ei, ucb, pi = abo.ExpectedImprovement(0.01, float(y.min())), abo.UpperConfidenceBound(2.0), abo.ProbabilityImprovement(0.01, float(y.min()))
+    ens = abo.EnsembleAcquisition([1.0, 2.0, 1.0], [ei, ucb, pi])
+    want = 0.25 * ei(m, Z) + 0.5 * ucb(m, Z) + 0.25 * pi(m, Z)
+    np.testing.assert_allclose(ens(m, Z), want, rtol=0, atol=1e-14)
+    got_dev = ens(m, torch.from_numpy(Z).cuda())
+    np.testing.assert_allclose(got_dev.cpu().numpy(), want, rtol=0, atol=1e-14)
+    best = abo.optimize_acquisition(ens, m, abo.ContinuousDomain(np.zeros(3), np.ones(3)), n_grid=3000, n_local=10,
+                                    rng=np.random.default_rng(0))
+    assert np.all(best >= 0) and np.all(best <= 1)
+
+
+def test_device_latin_hypercube():
+    """abo_lhs: one point per stratum in every coordinate (the LHS property of acq_utils.jl:44-47), shards of
+    the same design are consistent, different seeds/coordinates give different permutations."""
+    for n in (1, 7, 1000, 65537):
+        lower, upper = np.array([0.0, -2.0, 5.0]), np.array([1.0, 2.0, 6.0])
+        Z = abo.device_latin_hypercube(n, lower, upper, seed=12345).cpu().numpy()
+        assert Z.shape == (n, 3)
+        for c in range(3):
+            strata = np.floor((Z[:, c] - lower[c]) / (upper[c] - lower[c]) * n).astype(np.int64)
+            assert sorted(strata.tolist()) == list(range(n)), (n, c)
+    n = 5000
+    full = abo.device_latin_hypercube(n, [0.0, 0.0], [1.0, 1.0], seed=7).cpu().numpy()
+    part = abo.device_latin_hypercube(n, [0.0, 0.0], [1.0, 1.0], seed=7, first=1234, count=777).cpu().numpy()
+    np.testing.assert_array_equal(full[1234:1234 + 777], part)
+    other = abo.device_latin_hypercube(n, [0.0, 0.0], [1.0, 1.0], seed=8).cpu().numpy()
+    assert not np.array_equal(full, other)
+    assert abs(np.corrcoef(full[:, 0], full[:, 1])[0, 1]) < 0.05       # coordinates permuted independently
+    # grid generated, scored and reduced on the device
+    X, y = synth.standardized_problem(100, 2, 0.05)
+    m = abo.update(make_model(O.SE, 0.4, 1.0, 1e-3), X, y)
+    dom = abo.ContinuousDomain([0.0, 0.0], [1.0, 1.0])
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    b, starts, vals = abo.optimize_acquisition(acq, m, dom, n_grid=20000, n_local=50, rng=np.random.default_rng(3),
+                                               device_grid=True, refine=False, return_starts=True)
+    np.testing.assert_allclose(acq(m, starts), vals, rtol=0, atol=1e-15)
+    assert np.all(np.diff(vals) <= 0)

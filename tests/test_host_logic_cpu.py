@@ -122,3 +122,24 @@ def test_input_containers():
     assert (m, d, space) == (4, 3, 0)
     with pytest.raises(TypeError):
         as_points(torch.zeros(4, 3, dtype=torch.float32))
+
+
+def test_ensemble_acquisition_construction_and_update():
+    # test/test_acquisition.jl:223-253 and :255-279
+    ei, ucb = abo.ExpectedImprovement(0.01, 1.0), abo.UpperConfidenceBound(2.0)
+    ens = abo.EnsembleAcquisition([0.5, 0.5], [ei, ucb])
+    np.testing.assert_array_equal(ens.weights, [0.5, 0.5])
+    ens = abo.EnsembleAcquisition([1.0, 3.0], [ei, ucb])
+    np.testing.assert_allclose(ens.weights, [0.25, 0.75])
+    with pytest.raises(AssertionError):
+        abo.EnsembleAcquisition([1.0], [ei, ucb])
+    with pytest.raises(AssertionError):
+        abo.EnsembleAcquisition([-1.0, 2.0], [ei, ucb])
+    with pytest.raises(AssertionError):
+        abo.EnsembleAcquisition([0.0, 0.0], [ei, ucb])
+    gp = abo.HipStandardGP(abo.SqExponentialKernel(), 0.1)
+    up = abo.update(ens, [2.0, 1.5, 0.8], gp)
+    np.testing.assert_array_equal(up.weights, ens.weights)
+    assert up.acquisitions[0].best_y == 0.8 and up.acquisitions[1] is ucb
+    c = abo.copy(ens)
+    assert c == ens and c is not ens and c.acquisitions[0] is not ei
