@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs p) {
     const int64_t gj = p.j0 + j;
     if (gj >= p.M) return;
     double q = 0.0;
-    for (int t = 0; t < p.T; ++t) q += p.partial[(int64_t)t * p.ldp + j];   // row blocks in order
+#pragma unroll 16
+    for (int t = 0; t < p.T; ++t) q += p.partial[(int64_t)t * p.ldp + j];   // row blocks in order (loads hoisted, adds in order)
     const double var = p.sigma_f2 - q + 1e-18;
     const double mu = p.mu_in[j];
     if (p.mu_out) p.mu_out[gj] = mu;
