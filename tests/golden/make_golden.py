@@ -16,7 +16,7 @@ compared against values that do not come from any fp64 implementation.  Expected
 mpmath results rounded once to fp64.  The formulas are evaluated straight from their definitions
 (dense K̃, mp.cholesky_solve) — deliberately not via the L⁻¹ / W route the product takes.
 
-Run:  python tests/golden/make_golden.py      (writes tests/golden/kat.json, random_small.json)
+Run:  python tests/golden/make_golden.py      (writes tests/golden/kat.json, random_small.json, grad_small.json)
 """
 import json
 import os
@@ -135,9 +135,82 @@ def random_cases():
     return cases
 
 
+def grad_case(family, ell, sf2, noise, mean_c, X, Ys, Z):
+    """Gradient-enhanced GP (GradientGP.jl): the multi-output kernel is differentiated numerically in mpmath
+    (mp.diff on the base kernel — independent of the analytic φ', φ'' the implementations use); rows by
+    outputs (q·N + i).  Expected: posterior mean and full covariance of all p outputs at every z in Z."""
+    n, d = len(X), len(X[0])
+    p = d + 1
+
+    def kbase(*args):
+        x, z = args[:d], args[d:]
+        d2 = sum(((a - b) / mp.mpf(ell)) ** 2 for a, b in zip(x, z))
+        return mp.mpf(sf2) * kappa(family, d2)
+
+    def kq(x, q, z, q2):
+        orders = [0] * (2 * d)
+        if q > 0:
+            orders[q - 1] += 1
+        if q2 > 0:
+            orders[d + q2 - 1] += 1
+        pt = [mp.mpf(v) for v in x] + [mp.mpf(v) for v in z]
+        if sum(orders) == 0:
+            return kbase(*pt)
+        return mp.diff(kbase, tuple(pt), tuple(orders))
+
+    R = p * n
+    rows = [(X[i], q) for q in range(p) for i in range(n)]
+    K = mp.matrix(R, R)
+    for a, (xa, qa) in enumerate(rows):
+        for b, (xb, qb) in enumerate(rows):
+            K[a, b] = kq(xa, qa, xb, qb) + (mp.mpf(noise) if a == b else 0)
+    y = mp.matrix([mp.mpf(Ys[i][q]) - mp.mpf(mean_c[q]) for q in range(p) for i in range(n)])
+    alpha = mp.lu_solve(K, y)
+    mus, covs = [], []
+    for z in Z:
+        kz = mp.matrix(R, p)
+        for a, (xa, qa) in enumerate(rows):
+            for q in range(p):
+                kz[a, q] = kq(xa, qa, z, q)          # cov(train row, output q at z)
+        w = mp.matrix(R, p)
+        for q in range(p):                              # mp.lu_solve takes one right-hand side at a time
+            col = mp.lu_solve(K, kz[:, q])
+            for a in range(R):
+                w[a, q] = col[a]
+        mu = [mp.mpf(mean_c[q]) + sum(kz[a, q] * alpha[a] for a in range(R)) for q in range(p)]
+        C = mp.matrix(p, p)
+        for q in range(p):
+            for q2 in range(p):
+                C[q, q2] = kq(z, q, z, q2) - sum(kz[a, q] * w[a, q2] for a in range(R)) + (mp.mpf("1e-18") if q == q2 else 0)
+        mus.append([float(v) for v in mu])
+        covs.append([[float(C[a, b]) for b in range(p)] for a in range(p)])
+    nl = (R * mp.log(2 * mp.pi) + mp.log(mp.det(K)) + (y.T * alpha)[0]) / 2
+    return {"family": family, "ell": ell, "sigma_f2": sf2, "noise_var": noise, "mean_c": mean_c, "X": X, "Ys": Ys, "Z": Z,
+            "mu": mus, "cov": covs, "nlml": float(nl)}
+
+
+def grad_cases():
+    mp.mp.dps = 40
+    out = []
+    # reference KAT: test/test_surrogates.jl:291-348 (SE, p = 3, noise 0.1; grad mean and 3×3 cov at 1e-10)
+    out.append(grad_case(SE, 1.0, 1.0, 0.1, [0.0, 0.0, 0.0], [[0.0, 0.0], [0.5, 0.5], [1.0, 1.0]],
+                         [[1.0, 0.1, 0.1], [0.5, 0.0, 0.0], [0.0, -0.1, -0.1]], [[0.25, 0.25]]))
+    rng = np.random.default_rng(7)
+    for family, d, n in ((SE, 1, 4), (M52, 2, 4), (M72, 2, 3), (M52, 3, 3)):
+        X = rng.uniform(0, 1, (n, d)).tolist()
+        Ys = rng.normal(size=(n, d + 1)).tolist()
+        Z = rng.uniform(0, 1, (2, d)).tolist()
+        mean_c = [float(rng.normal())] + [0.0] * d
+        out.append(grad_case(family, float(rng.uniform(0.4, 1.2)), float(rng.uniform(0.5, 2.0)), 0.05, mean_c, X, Ys, Z))
+    mp.mp.dps = 60
+    return out
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "grad_small.json"), "w") as f:
+        json.dump(grad_cases(), f)
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kats(), f, indent=1)
     with open(os.path.join(HERE, "random_small.json"), "w") as f:
         json.dump(random_cases(), f)
-    print("wrote kat.json, random_small.json")
+    print("wrote kat.json, random_small.json, grad_small.json")

@@ -117,3 +117,48 @@ def test_standardisation_equivalence():
     mu_a, var_a = O.predict(a, Z); mu_b, var_b = O.predict(b, Z)
     np.testing.assert_allclose(mu_a + m, mu_b, atol=1e-10)
     np.testing.assert_allclose(var_a, var_b, atol=1e-10)
+
+
+# ---------------- gradient-enhanced GP oracle (GradientGP) ----------------
+from oracle import grad_oracle as G
+
+GRAD = _load("grad_small.json")
+
+
+@pytest.mark.parametrize("i", range(len(GRAD)))
+def test_grad_oracle_against_mpmath_golden(i):
+    """Posterior mean and full p×p covariance of all outputs; the golden values differentiate the base kernel
+    numerically in 40-digit arithmetic (mp.diff), independent of the analytic φ', φ''.  Case 0 is the reference's
+    own closed-form test (test/test_surrogates.jl:291-348, atol 1e-10)."""
+    c = GRAD[i]
+    st = G.fit(c["family"], c["ell"], c["sigma_f2"], c["noise_var"], c["mean_c"], np.array(c["X"]), c["Ys"])
+    for j, z in enumerate(c["Z"]):
+        mu, C = G.predict_grad(st, [z], cov=True)
+        np.testing.assert_allclose(mu, c["mu"][j], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(C, c["cov"][j], rtol=0, atol=1e-12)
+        mu2, var2 = G.predict_grad(st, [z])
+        np.testing.assert_allclose(var2, np.diag(C), rtol=0, atol=1e-14)
+    assert abs(G.nlml(st) - c["nlml"]) < 1e-11
+    mu_f, var_f = G.predict(st, np.array(c["Z"]))
+    np.testing.assert_allclose(mu_f, [m[0] for m in c["mu"]], atol=1e-12)
+
+
+def test_grad_kernel_blocks_against_finite_differences():
+    # test/test_surrogates.jl:236-287: gradKernel ≡ derivatives of the base kernel
+    rng = np.random.default_rng(0)
+    for fam in (O.SE, O.MATERN52, O.MATERN72):
+        x, z = rng.normal(size=(1, 3)), rng.normal(size=(1, 3))
+        K = G.grad_kernel_matrix(fam, 0.7, 1.9, x, z)
+        k = lambda a, b: O.kernel_matrix(fam, 0.7, 1.9, a, b)[0, 0]
+        h = 1e-5
+        for c in range(3):
+            e = np.zeros((1, 3)); e[0, c] = h
+            assert abs(K[c + 1, 0] - (k(x + e, z) - k(x - e, z)) / (2 * h)) < 1e-8
+            assert abs(K[0, c + 1] - (k(x, z + e) - k(x, z - e)) / (2 * h)) < 1e-8
+            for c2 in range(3):
+                e2 = np.zeros((1, 3)); e2[0, c2] = h
+                fd = (k(x + e, z + e2) - k(x + e, z - e2) - k(x - e, z + e2) + k(x - e, z - e2)) / (4 * h * h)
+                assert abs(K[c + 1, c2 + 1] - fd) < 5e-6
+    Kxx = G.grad_kernel_matrix(O.MATERN52, 0.7, 1.9, rng.normal(size=(5, 2)))
+    np.testing.assert_allclose(Kxx, Kxx.T, atol=1e-15)
+    assert np.all(np.linalg.eigvalsh(Kxx) > -1e-10)
