@@ -7,6 +7,9 @@ from .acquisition import (AbstractAcquisition, EnsembleAcquisition, ExpectedImpr
                           UpperConfidenceBound, device_latin_hypercube, evaluate, latin_hypercube,
                           optimize_acquisition, refine_starts)
 from .domains import ContinuousDomain
+from . import gradient_gp as _g
+from .gradient_gp import (GradientNormUCB, HipGradientGP, gradConstMean, posterior_grad_cov, posterior_grad_mean,
+                          posterior_grad_var)
 from .hyperparams import lengthscale_bounds, monte_carlo_fill_distance, nlml_and_grad, optimize_hyperparameters
 from .incremental import ResidentCandidates, append, greedy_qei
 from .kernels import (ApproxMatern52Kernel, ApproxMatern72Kernel, ConstMean, Kernel, Matern32Kernel, Matern52Kernel,
@@ -17,19 +20,43 @@ from .surrogate import (AbstractSurrogate, HipStandardGP, _get_minimum, _update_
                         nlml, nlml_fitted, nlml_ls, posterior_mean, posterior_var, prep_input, prep_output,
                         rescale_model, std_y, unstandardized_mean_and_var)
 
-StandardGP = HipStandardGP   # drop-in alias
+StandardGP = HipStandardGP   # drop-in aliases
+GradientGP = HipGradientGP
 
 
 def update(obj, a, b):
     """`update` is one generic function in the reference, dispatched on its first argument:
     update(model, xs, ys) (StandardGP.jl:79) / update(acq, ys, surrogate) (ExpectedImprovement.jl:81)."""
+    if isinstance(obj, GradientNormUCB):
+        return obj                                              # gradNormUCB.jl:66-68
     if isinstance(obj, AbstractAcquisition):
         return acquisition.update(obj, a, b)
+    if isinstance(obj, HipGradientGP):
+        return _g.update(obj, a, b)
     return _s.update(obj, a, b)
 
 
 def copy(obj):
     """Base.copy for surrogates (StandardGP.jl:26) and acquisition functions."""
+    if isinstance(obj, GradientNormUCB):
+        return GradientNormUCB(obj.beta)                        # gradNormUCB.jl:24
     if isinstance(obj, AbstractAcquisition):
         return acquisition.copy(obj)
     return _s.copy(obj)
+
+
+def _dispatch(name):
+    """reference methods that exist for both surrogate types dispatch on the model's type"""
+    std, grd = getattr(_s, name), getattr(_g, name)
+
+    def f(model, *args, **kw):
+        return (grd if isinstance(model, HipGradientGP) else std)(model, *args, **kw)
+
+    f.__name__ = name
+    f.__doc__ = std.__doc__
+    return f
+
+
+for _n in ("get_mean_std", "std_y", "rescale_model", "_update_model_parameters", "_get_minimum",
+           "unstandardized_mean_and_var", "prep_output"):
+    globals()[_n] = _dispatch(_n)

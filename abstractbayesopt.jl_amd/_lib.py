@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(PKG, "lib", "libabo_hip.so")
 ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
 HOST, DEVICE = 0, 1
 
-EXPORTS = ["abo_create", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
+EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
            "abo_test_gemm_nt", "abo_test_kappa"]
@@ -70,6 +70,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.abo_create.argtypes = [C.POINTER(AboParams), C.POINTER(vp)]
+    L.abo_create_grad.argtypes = [C.POINTER(AboParams), i32, vp, C.POINTER(vp)]
+    L.abo_predict_grad.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
+    L.abo_predict_grad_cov.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, vp, i32]
     L.abo_retain.argtypes = [vp]
     L.abo_destroy.argtypes = [vp]
     L.abo_fit.argtypes = [vp, vp, i64, i32, vp, i32, C.POINTER(i64)]

@@ -54,6 +54,10 @@ struct KgenArgs {
     int Mc;               // padded chunk rows (multiple of 16)
     int N, Np, d, dp, family;
     double s, sigma_f2, mean_c;
+    // gradient-enhanced GP (pt > 1): training rows are (output q', point i) by outputs, pt = d+1 outputs per
+    // point, Np pads pt·N; candidate rows carry pc outputs each (1 = function value only, pt = all outputs)
+    int pt = 1, pc = 1, point_major = 0;
+    double mean_vec[17] = {0};   // prior mean per output (gradConstMean)
 };
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
 // NLML gradient reduction: Σ_ij (Kinv − ααᵀ)_ij ∂K_ij/∂log ℓ over the lower tiles, plus tr(Kinv), αᵀα, αᵀδ
@@ -116,8 +120,26 @@ struct FinalizeArgs {
     int T, Mc;
     int kind;                // ABO_ACQ_*, or −1 for none
     double sigma_f2, p0, best_y;
+    // gradient-enhanced GP: rows carry pc outputs of Mpts points; prior variance of a gradient output
+    double prior_grad = 0.0;
+    int pc = 1, point_major = 0;
+    int64_t Mpts = 0;
 };
 hipError_t launch_finalize(const FinalizeArgs& a, hipStream_t s);
+
+// gradient-enhanced GP: per-point p×p posterior covariance (+ mean, + GradientNormUCB score) from V = L⁻¹K_XZ
+struct GradCovArgs {
+    const double* V;          // [points·p][ldv], point-major rows
+    const double* mu_rows;    // [points·p]
+    int64_t ldv;
+    int R, p;
+    int64_t pt0;              // global index of the chunk's first point
+    double prior0, prior_g, beta;
+    double* cov_out;          // [M][p][p] or nullptr
+    double* mu_out;           // [M][p] or nullptr
+    double* score_out;        // [M] or nullptr
+};
+hipError_t launch_grad_cov(const GradCovArgs& a, int npoints, hipStream_t s);
 
 // resident-candidate kernels (C5)
 // mu[j] += c[j]·beta ; var[j] −= c[j]²/s2        (posterior down-date after a bordered append)

@@ -194,8 +194,11 @@ struct abo_gp {
     hipStream_t stream = nullptr;      // == ctx->stream
     Storage* st = nullptr;             // null until conditioned on data
     bool fitted = false;
-    int64_t N = 0, Np = 0;             // this view's training size and its 128-padded size
+    int64_t N = 0, Np = 0;             // this view's number of factor rows and its 128-padded size
+    int64_t npts = 0;                  // training points (== N unless gradient-enhanced: N = p_out·npts)
     int d = 0, dp = 0;
+    int p_out = 1;                     // outputs per point: 1 = StandardGP, d+1 = GradientGP (f + gradient)
+    double mean_vec[17] = {0};         // prior mean per output (gradConstMean; [0] = mean_c for p_out == 1)
     double logdet = 0.0, quad = 0.0;
     // bordered-append bookkeeping (valid when this view was produced by abo_append)
     bool from_append = false;
@@ -299,8 +302,9 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     HIPCHK(hipMemsetAsync(WT, 0, sizeof(double) * ld * ld, s));
     KgenArgs ka{};
     ka.Xs = st->Xs.as<double>(); ka.Z = st->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = K; ka.mu = nullptr;
-    ka.ldk = ld; ka.M = N; ka.j0 = 0; ka.Mc = Np; ka.N = N; ka.Np = Np; ka.d = g->d; ka.dp = g->dp;
+    ka.ldk = ld; ka.M = g->npts; ka.j0 = 0; ka.Mc = Np; ka.N = (int)g->npts; ka.Np = Np; ka.d = g->d; ka.dp = g->dp;
     ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
+    ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 0;      // K_XX: rows and columns by outputs → symmetric
     HIPCHK(launch_kgen(ka, s));
     HIPCHK(launch_diag_fix(K, ld, N, (int)ld, noise, s));
     if (ld > Np) {
@@ -389,6 +393,12 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     return ABO_OK;
 }
 
+// k((z,q),(z,q)) of a gradient output: −2σ_f²φ'(0)/ℓ²  (φ'(0) = −1/2 SE, −5/6 Matérn-5/2, −7/10 Matérn-7/2)
+double grad_prior_var(const abo_gp* g) {
+    const double c = g->prm.family == ABO_KERNEL_SE ? 1.0 : (g->prm.family == ABO_KERNEL_MATERN52 ? 5.0 / 3.0 : 7.0 / 5.0);
+    return c * g->prm.sigma_f2 / (g->prm.ell * g->prm.ell);
+}
+
 int64_t pick_chunk(const abo_gp* g, int64_t M) {
     int64_t mc = g->prm.chunk;
     if (mc <= 0) {
@@ -405,8 +415,11 @@ int64_t pick_chunk(const abo_gp* g, int64_t M) {
 }
 
 // mu / var / score for M candidates into device arrays (any may be null)
-int32_t posterior(abo_gp* g, const double* Zd, int64_t M, int kind, double p0, double best_y, double* mu_out,
-                  double* var_out, double* score_out) {
+// pc outputs per candidate (1 = function value; p_out = all outputs of a gradient-enhanced GP), rows by outputs
+// unless point_major; mu/var/score arrays then have pc·M entries.
+int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0, double best_y, double* mu_out,
+                  double* var_out, double* score_out, int pc = 1, int point_major = 0) {
+    const int64_t M = Mpts * pc;                         // candidate rows
     hipStream_t s = g->stream;
     const int64_t Np = g->Np;
     const int T = (int)(Np / TB);
@@ -424,7 +437,9 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t M, int kind, double p0, d
         hipEvent_t* e = &g->evs()[8 + 6 * c];
         KgenArgs ka{};
         ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
-        ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->N;
+        ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = Mpts; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->npts;
+        ka.pt = g->p_out; ka.pc = pc; ka.point_major = point_major;
+        for (int q = 0; q < 17; ++q) ka.mean_vec[q] = g->mean_vec[q];
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
         ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = g->prm.mean_c;
         HIPCHK(hipEventRecord(e[0], s));
@@ -444,6 +459,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t M, int kind, double p0, d
         fa.var_out = var_out; fa.score_out = score_out; fa.ldp = Mc; fa.j0 = j0; fa.M = M;
         fa.T = (var_out || score_out) ? T : 0; fa.Mc = mcp; fa.kind = kind; fa.sigma_f2 = g->prm.sigma_f2;
         fa.p0 = p0; fa.best_y = best_y;
+        fa.prior_grad = grad_prior_var(g); fa.pc = pc; fa.point_major = point_major; fa.Mpts = Mpts;
         HIPCHK(hipEventRecord(e[4], s));
         HIPCHK(launch_finalize(fa, s));
         HIPCHK(hipEventRecord(e[5], s));
@@ -491,7 +507,9 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     if (!st) return fail(ABO_ENOMEM, "abo_fit: host allocation failed");
     st->set_device(g->prm.device);
     st->d = d; st->dp = dp_for(d);
-    const int64_t want = g->prm.n_max > N ? g->prm.n_max : N;
+    const int P = g->p_out;                              // N below = number of training POINTS
+    const int64_t R = (int64_t)P * N;                    // factor rows
+    const int64_t want = (P == 1 && g->prm.n_max > N) ? g->prm.n_max : R;
     st->cap = pad_up(want, TB);
     const int64_t cap = st->cap;
     hipError_t e = hipSuccess;
@@ -499,6 +517,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     if (e == hipSuccess) e = st->Xs.ensure(sizeof(double) * cap * st->dp);
     if (e == hipSuccess) e = st->ybuf.ensure(sizeof(double) * cap);
     if (e == hipSuccess) e = st->delta.ensure(sizeof(double) * cap);
+    (void)R;
     if (e == hipSuccess) e = st->K.ensure(sizeof(double) * cap * cap);
     if (e == hipSuccess) e = st->W.ensure(sizeof(double) * cap * cap);
     if (e == hipSuccess) e = st->WT.ensure(sizeof(double) * cap * cap);
@@ -508,14 +527,14 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     }
     // stage the inputs BEFORE dropping the previous storage: X / y may alias it (refit after append)
     int32_t rc = copy_in(st->Xraw.p, X, sizeof(double) * N * d, space, s);
-    if (!rc) rc = copy_in(st->ybuf.p, y, sizeof(double) * N, space, s);
+    if (!rc) rc = copy_in(st->ybuf.p, y, sizeof(double) * R, space, s);
     if (rc) { storage_unref(st); return rc; }
     HIPCHK(hipStreamSynchronize(s));
     if (g->st && g->fitted) g->st->drop_view(g->N);
     g->fitted = false;
     storage_unref(g->st);
     g->st = st;
-    g->N = N; g->d = d; g->dp = st->dp; g->Np = pad_up(N, TB);
+    g->npts = N; g->N = R; g->d = d; g->dp = st->dp; g->Np = pad_up(R, TB);
     const int64_t Np = g->Np;
     HIPCHK(g->alpha.ensure(sizeof(double) * cap));
     HIPCHK(g->tvec.ensure(sizeof(double) * cap));
@@ -523,7 +542,13 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     HIPCHK(g->info.ensure(sizeof(int64_t)));
     HIPCHK(g->scal.ensure(sizeof(double) * 8));
     HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
-    HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
+    if (P == 1) {
+        HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
+    } else {                                             // rows by outputs: block q is centred by mean_vec[q]
+        HIPCHK(hipMemsetAsync(st->delta.p, 0, sizeof(double) * cap, s));
+        for (int q = 0; q < P; ++q)
+            HIPCHK(launch_center(st->ybuf.as<double>() + q * N, st->delta.as<double>() + q * N, (int)N, (int)N, g->mean_vec[q], s));
+    }
     HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
 
     int64_t inf = 0;
@@ -540,7 +565,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
         noise = g->prm.noise_var + g->prm.jitter * std::pow(10.0, attempt);
     }
     st->noise_used = noise;
-    st->add_view(N);
+    st->add_view(R);
     g->fitted = true;
     return ABO_OK;
 }
@@ -619,7 +644,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     st->refs.fetch_add(1);
     n->st = st;
     st->add_view(N + 1);
-    n->N = N + 1; n->Np = Np1; n->d = d; n->dp = st->dp;
+    n->N = N + 1; n->npts = N + 1; n->Np = Np1; n->d = d; n->dp = st->dp;
     n->from_append = true;
     n->ap_s2 = sc[0]; n->ap_beta = sc[1];
     n->logdet = g->logdet + 2.0 * std::log(sc[2]);
@@ -656,6 +681,7 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
     abo_gp* g = new (std::nothrow) abo_gp();
     if (!g) return fail(ABO_ENOMEM, "abo_create: host allocation failed");
     g->prm = *params;
+    g->mean_vec[0] = params->mean_c;
     g->set_device(params->device);
     {
         std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -673,6 +699,23 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
     e = g->events(8);
     if (e != hipSuccess) { g->free_all(); delete g; return fail(ABO_EHIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     *out = g;
+    return ABO_OK;
+}
+
+int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out) {
+    if (!params || !out) return fail(ABO_EINVAL, "abo_create_grad: null argument");
+    if (p < 2 || p > 17) return fail(ABO_EINVAL, "abo_create_grad: p = %d outputs outside 2..17 (d = p − 1 ≤ 16)", p);
+    if (params->family != ABO_KERNEL_SE && params->family != ABO_KERNEL_MATERN52 && params->family != ABO_KERNEL_MATERN72)
+        return fail(ABO_EINVAL, "abo_create_grad: the gradient-enhanced GP needs a twice-differentiable kernel "
+                                "(SE, Matern-5/2, Matern-7/2)");
+    int32_t rc = abo_create(params, out);
+    if (rc) return rc;
+    (*out)->p_out = p;
+    for (int q = 0; q < p; ++q) {
+        const double c = mean_c ? mean_c[q] : 0.0;
+        if (!std::isfinite(c)) { abo_destroy(*out); *out = nullptr; return fail(ABO_EINVAL, "abo_create_grad: non-finite mean"); }
+        (*out)->mean_vec[q] = c;
+    }
     return ABO_OK;
 }
 
@@ -699,6 +742,9 @@ int32_t abo_fit(abo_gp* g, const double* X, int64_t N, int32_t d, const double* 
     if (N < 1) return fail(ABO_EINVAL, "abo_fit: need at least one training point");
     if (d < 1 || d > 32) return fail(ABO_EINVAL, "abo_fit: input dimension %d outside the supported 1..32", d);
     if (N > (int64_t)1 << 20) return fail(ABO_EINVAL, "abo_fit: N = %lld too large", (long long)N);
+    if (g->p_out > 1 && d + 1 != g->p_out)
+        return fail(ABO_EDIM, "DimensionMismatch: gradient-enhanced model with p = %d outputs needs d = %d inputs, got %d",
+                    g->p_out, g->p_out - 1, d);
     HIPCHK(hipSetDevice(g->prm.device));
     return fit_impl(g, X, N, d, y, space, info);
 }
@@ -708,6 +754,7 @@ int32_t abo_append(abo_gp* g, const double* x, int32_t d, double y, int64_t* inf
     if (!g || !x || !out) return fail(ABO_EINVAL, "abo_append: null argument");
     int32_t rc = check_fitted(g, d);
     if (rc) return rc;
+    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_append: not available for gradient-enhanced models");
     HIPCHK(hipSetDevice(g->prm.device));
     abo_gp* n = nullptr;
     rc = abo_create(&g->prm, &n);
@@ -749,6 +796,85 @@ int32_t abo_predict(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
     collect_posterior_timings(g, M, var != nullptr);
     g->tm.acq_topk_ms = 0.0;
     g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[6]);
+    return ABO_OK;
+}
+
+int32_t abo_predict_grad(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, double* mu, double* var,
+                         int32_t out_space) {
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (g->p_out < 2) return fail(ABO_EINVAL, "abo_predict_grad: the model has no gradient outputs");
+    if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_predict_grad: bad candidate buffer");
+    if (M == 0) return ABO_OK;
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const int P = g->p_out;
+    const double* Zd = nullptr;
+    rc = stage_candidates(g, Z, M, z_space, &Zd);
+    if (rc) return rc;
+    double* mu_d = nullptr;
+    double* var_d = nullptr;
+    if (mu) { if (out_space == ABO_DEVICE) mu_d = mu; else { HIPCHK(g->mu_all.ensure(sizeof(double) * M * P)); mu_d = g->mu_all.as<double>(); } }
+    if (var) { if (out_space == ABO_DEVICE) var_d = var; else { HIPCHK(g->var_all.ensure(sizeof(double) * M * P)); var_d = g->var_all.as<double>(); } }
+    rc = posterior(g, Zd, M, -1, 0.0, 0.0, mu_d, var_d, nullptr, P, 0);
+    if (rc) return rc;
+    if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
+    if (var && out_space == ABO_HOST) { rc = copy_out(var, var_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(s));
+    return ABO_OK;
+}
+
+int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, double beta, double* mu,
+                             double* cov, double* score, int32_t out_space) {
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (g->p_out < 2) return fail(ABO_EINVAL, "abo_predict_grad_cov: the model has no gradient outputs");
+    if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_predict_grad_cov: bad candidate buffer");
+    if (M == 0) return ABO_OK;
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const int P = g->p_out;
+    const int64_t Np = g->Np;
+    const double* Zd = nullptr;
+    rc = stage_candidates(g, Z, M, z_space, &Zd);
+    if (rc) return rc;
+    // points per chunk: V chunk (rows·Np doubles) ≤ 256 MiB, rows padded to 128
+    int64_t pts = (((int64_t)1 << 28) / (Np * (int64_t)sizeof(double))) / P;
+    if (pts < 1) pts = 1;
+    if (pts > M) pts = M;
+    const int64_t rows_pad = pad_up(pts * P, TB);
+    HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
+    HIPCHK(g->partial.ensure(sizeof(double) * rows_pad * Np));       // V
+    HIPCHK(g->mu_c.ensure(sizeof(double) * rows_pad));
+    double* mu_d = nullptr; double* cov_d = nullptr; double* sc_d = nullptr;
+    if (mu) { if (out_space == ABO_DEVICE) mu_d = mu; else { HIPCHK(g->mu_all.ensure(sizeof(double) * M * P)); mu_d = g->mu_all.as<double>(); } }
+    if (cov) { if (out_space == ABO_DEVICE) cov_d = cov; else { HIPCHK(g->var_all.ensure(sizeof(double) * M * P * P)); cov_d = g->var_all.as<double>(); } }
+    if (score) { if (out_space == ABO_DEVICE) sc_d = score; else { HIPCHK(g->score_all.ensure(sizeof(double) * M)); sc_d = g->score_all.as<double>(); } }
+    for (int64_t p0 = 0; p0 < M; p0 += pts) {
+        const int64_t np = (M - p0) < pts ? (M - p0) : pts;
+        const int rows = (int)pad_up(np * P, TB);
+        KgenArgs ka{};
+        ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
+        ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = p0 * P; ka.Mc = rows; ka.N = (int)g->npts;
+        ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
+        ka.sigma_f2 = g->prm.sigma_f2; ka.pt = P; ka.pc = P; ka.point_major = 1;
+        for (int q = 0; q < 17; ++q) ka.mean_vec[q] = g->mean_vec[q];
+        HIPCHK(launch_kgen(ka, s));
+        GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
+        a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
+        a.C = g->partial.as<double>(); a.ldc = Np; a.M = rows; a.N = (int)Np; a.K = (int)Np;
+        a.kmode = K_FULL; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
+        HIPCHK(launch_gemm_nt(a, s));
+        GradCovArgs ca{};
+        ca.V = g->partial.as<double>(); ca.mu_rows = g->mu_c.as<double>(); ca.ldv = Np; ca.R = (int)g->N; ca.p = P;
+        ca.pt0 = p0; ca.prior0 = g->prm.sigma_f2; ca.prior_g = grad_prior_var(g); ca.beta = beta;
+        ca.cov_out = cov_d; ca.mu_out = mu_d; ca.score_out = sc_d;
+        HIPCHK(launch_grad_cov(ca, (int)np, s));
+    }
+    if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
+    if (cov && out_space == ABO_HOST) { rc = copy_out(cov, cov_d, sizeof(double) * M * P * P, ABO_HOST, s); if (rc) return rc; }
+    if (score && out_space == ABO_HOST) { rc = copy_out(score, sc_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(s));
     return ABO_OK;
 }
 
@@ -835,6 +961,7 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     if (!g->fitted) return fail(ABO_EINVAL, "surrogate is not conditioned on data yet (call abo_fit first)");
     if (g->from_append || g->st->max_live() != g->N)
         return fail(ABO_EINVAL, "abo_nlml_grad needs a freshly fitted model (hyper-parameter search refits anyway)");
+    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_nlml_grad: not available for gradient-enhanced models");
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
     const int64_t Np = g->Np, ld = g->st->cap;
@@ -866,7 +993,7 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
 
 int32_t abo_get_n(abo_gp* g, int64_t* N, int32_t* d) {
     if (!g) return fail(ABO_EINVAL, "null handle");
-    if (N) *N = g->fitted ? g->N : 0;
+    if (N) *N = g->fitted ? g->npts : 0;
     if (d) *d = g->fitted ? g->d : 0;
     return ABO_OK;
 }
@@ -950,6 +1077,7 @@ int32_t abo_cand_create(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_
     if (!out) return fail(ABO_EINVAL, "abo_cand_create: null argument");
     int32_t rc = check_fitted(g, d);
     if (rc) return rc;
+    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_cand_create: not available for gradient-enhanced models");
     if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_cand_create: bad candidate buffer");
     HIPCHK(hipSetDevice(g->prm.device));
     abo_cand* c = new (std::nothrow) abo_cand();

@@ -35,7 +35,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs p) {
     double q = 0.0;
 #pragma unroll 16
     for (int t = 0; t < p.T; ++t) q += p.partial[(int64_t)t * p.ldp + j];   // row blocks in order (loads hoisted, adds in order)
-    const double var = p.sigma_f2 - q + 1e-18;
+    double prior = p.sigma_f2;
+    if (p.pc > 1) {                                      // which output this row is
+        const int64_t o = p.point_major ? gj % p.pc : gj / p.Mpts;
+        if (o > 0) prior = p.prior_grad;
+    }
+    const double var = prior - q + 1e-18;
     const double mu = p.mu_in[j];
     if (p.mu_out) p.mu_out[gj] = mu;
     if (p.var_out) p.var_out[gj] = var;
@@ -73,6 +78,60 @@ hipError_t launch_score(const double* mu, const double* var, double* score, int6
                         hipStream_t s) {
     if (M <= 0) return hipSuccess;
     hipLaunchKernelGGL(score_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, mu, var, score, M, kind, p0, best_y);
+    return hipGetLastError();
+}
+
+// ---- per-point posterior covariance of all outputs of a gradient-enhanced GP ----------------------------
+// posterior_grad_cov(model, [x]) (src/surrogates/GradientGP.jl:966-971) and the GradientNormUCB epilogue
+// (src/acquisition_functions/gradNormUCB.jl:43-51).  V rows are point-major: row j·p + q holds L⁻¹k for output q
+// of point j.  One workgroup per point; wave w reduces the (q,q') pairs w, w+4, … (lanes stride the R entries).
+__global__ void __launch_bounds__(256) grad_cov_kernel(GradCovArgs a) {
+    __shared__ double C[17 * 17];
+    __shared__ double m[17];
+    const int j = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int p = a.p;
+    const double* Vj = a.V + (int64_t)j * p * a.ldv;
+    for (int pr = wave; pr < p * p; pr += 4) {
+        const int q = pr / p, q2 = pr % p;
+        if (q2 > q) continue;                                  // symmetric: lower pairs only
+        const double* v1 = Vj + (int64_t)q * a.ldv;
+        const double* v2 = Vj + (int64_t)q2 * a.ldv;
+        double s = 0.0;
+        for (int i = lane; i < a.R; i += 64) s = fma(v1[i], v2[i], s);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const double prior = (q == q2) ? ((q == 0 ? a.prior0 : a.prior_g) + 1e-18) : 0.0;
+            C[q * p + q2] = prior - s;
+            C[q2 * p + q] = prior - s;
+        }
+    }
+    if (t < p) m[t] = a.mu_rows[(int64_t)j * p + t];
+    __syncthreads();
+    const int64_t gp = a.pt0 + j;
+    if (a.cov_out) for (int e = t; e < p * p; e += 256) a.cov_out[gp * p * p + e] = C[e];
+    if (a.mu_out && t < p) a.mu_out[gp * p + t] = m[t];
+    if (a.score_out && t == 0) {
+        // −(mᵀm + trΣ) + β·sqrt(max(4mᵀΣm + 2‖Σ‖_F², 1e-12)) on the gradient block (outputs 1..p−1)
+        double mm = 0.0, tr = 0.0, msm = 0.0, fro = 0.0;
+        for (int q = 1; q < p; ++q) {
+            mm = fma(m[q], m[q], mm);
+            tr += C[q * p + q];
+            double row = 0.0;
+            for (int q2 = 1; q2 < p; ++q2) {
+                row = fma(C[q * p + q2], m[q2], row);
+                fro = fma(C[q * p + q2], C[q * p + q2], fro);
+            }
+            msm = fma(m[q], row, msm);
+        }
+        a.score_out[gp] = -(mm + tr) + a.beta * sqrt(fmax(4.0 * msm + 2.0 * fro, 1e-12));
+    }
+}
+
+hipError_t launch_grad_cov(const GradCovArgs& a, int npoints, hipStream_t s) {
+    if (npoints <= 0) return hipSuccess;
+    hipLaunchKernelGGL(grad_cov_kernel, dim3(npoints), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

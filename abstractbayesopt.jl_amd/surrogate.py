@@ -311,7 +311,7 @@ def get_factor(model: HipStandardGP):
     d = C.c_int32()
     Lb = _lib.lib()
     _lib.check(Lb.abo_get_n(model._require(), C.byref(n), C.byref(d)))
-    N = n.value
+    N = n.value * getattr(model, "p", 1)          # factor rows: p outputs per point for a gradient-enhanced model
     Lm, Li, al = np.empty((N, N)), np.empty((N, N)), np.empty(N)
     _lib.check(Lb.abo_get_factor(model._require(), Lm.ctypes.data, al.ctypes.data, Li.ctypes.data))
     return Lm, al, Li

@@ -84,6 +84,12 @@ typedef struct abo_timings {
  * StandardGP(kernel, noise_var; mean) (src/surrogates/StandardGP.jl:41-64).  The handle starts
  * un-conditioned (gpx === nothing). */
 int32_t abo_create(const abo_params* params, abo_gp** out);
+/* GradientGP(kernel, p, noise_var; mean=gradConstMean(c)) (src/surrogates/GradientGP.jl:617-639): gradient-
+ * enhanced GP with p = d+1 outputs per point (f and ∂f/∂x_c), multi-output kernel gradKernel (:573-606) with
+ * analytic derivatives, rows ordered by outputs (MOInputIsotopicByOutputs).  mean_c: p prior means (NULL = 0).
+ * abo_fit then takes y of length p·N ordered by outputs (prep_output, :893-895); abo_predict / abo_acq address
+ * the function output; abo_append, abo_cand_* and abo_nlml_grad are not available on such a handle. */
+int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out);
 /* Base.copy(::StandardGP) (src/surrogates/StandardGP.jl:26, surrogates_utils.jl:12-14): device
  * state is immutable after fit, so a copy is a shared reference. */
 int32_t abo_retain(abo_gp* gp);
@@ -118,6 +124,16 @@ int32_t abo_append(abo_gp* gp, const double* x, int32_t d, double y, int64_t* in
  * mu / var may each be NULL. */
 int32_t abo_predict(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, double* mu,
                     double* var, int32_t out_space);
+
+/* posterior_grad_mean / posterior_grad_var (src/surrogates/GradientGP.jl:936-956): all p outputs of M points,
+ * ordered by outputs (p·M values each; mu / var may be NULL). */
+int32_t abo_predict_grad(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, double* mu,
+                         double* var, int32_t out_space);
+/* posterior_grad_cov(model, [x]) per point (GradientGP.jl:966-971): mu [M][p], cov [M][p][p] (point-major) and,
+ * if score != NULL, the GradientNormUCB value −(mᵀm + trΣ) + β·sqrt(max(4mᵀΣm + 2‖Σ‖_F², 1e-12)) on the gradient
+ * block (src/acquisition_functions/gradNormUCB.jl:43-51).  Any output may be NULL. */
+int32_t abo_predict_grad_cov(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, double beta,
+                             double* mu, double* cov, double* score, int32_t out_space);
 
 /* --- acquisition over a candidate batch -------------------------------------------------------
  * scores = acqf(surrogate, grid_points); sortperm(scores; rev=true)[1:k]

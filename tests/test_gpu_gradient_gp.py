@@ -1,0 +1,117 @@
+"""GPU parity tests (-m gpu) of the gradient-enhanced surrogate (reference:
+src/surrogates/GradientGP.jl, src/acquisition_functions/gradNormUCB.jl) through the C-ABI, against the mpmath
+golden vectors (incl. the reference's own closed-form test, test/test_surrogates.jl:291-348) and the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import synth
+from oracle import gp_oracle as O
+from oracle import grad_oracle as G
+
+from tests.test_gpu_parity import FAMS
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+GRAD = json.load(open(os.path.join(GOLD, "grad_small.json")))
+
+
+def make_grad(family, ell, sf2, noise, p, mean_c=None, **kw):
+    mean = abo.gradConstMean(mean_c) if mean_c is not None else None
+    return abo.GradientGP(sf2 * abo.with_lengthscale(FAMS[family](), ell), p, noise, mean=mean, **kw)
+
+
+@pytest.mark.parametrize("i", range(len(GRAD)))
+def test_gradient_gp_golden(i):
+    c = GRAD[i]
+    p = len(c["X"][0]) + 1
+    m = abo.update(make_grad(c["family"], c["ell"], c["sigma_f2"], c["noise_var"], p, c["mean_c"]), c["X"], c["Ys"])
+    Z = np.array(c["Z"])
+    M = len(Z)
+    gm = abo.posterior_grad_mean(m, Z).reshape(p, M).T          # by outputs → (M, p)
+    gv = abo.posterior_grad_var(m, Z).reshape(p, M).T
+    mu_pm, cov, _ = abo.posterior_grad_cov(m, Z, return_all=True)
+    for j in range(M):
+        np.testing.assert_allclose(gm[j], c["mu"][j], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(mu_pm[j], c["mu"][j], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(cov[j], c["cov"][j], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(gv[j], np.diag(np.array(c["cov"][j])), rtol=0, atol=1e-11)
+    np.testing.assert_allclose(abo.posterior_mean(m, Z), [v[0] for v in c["mu"]], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(abo.posterior_var(m, Z), [np.array(v)[0, 0] for v in c["cov"]], rtol=0, atol=1e-11)
+    assert abs(abo.nlml_fitted(m) - c["nlml"]) < 1e-10
+    one = abo.posterior_grad_cov(m, [c["Z"][0]])
+    assert one.shape == (p, p)
+
+
+def test_reference_closed_form_case_shapes_and_copy():
+    # test/test_surrogates.jl:289-348 and :399-414
+    gp = abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1)
+    xs = [[0.0, 0.0], [0.5, 0.5], [1.0, 1.0]]
+    ys = [[1.0, 0.1, 0.1], [0.5, 0.0, 0.0], [0.0, -0.1, -0.1]]
+    m = abo.update(gp, xs, ys)
+    assert m.noise_var == 0.1 and m.p == 3 and m.gpx is not None and gp.gpx is None
+    tx = [[0.25, 0.25]]
+    assert abo.posterior_var(m, tx)[0] >= 0.0
+    assert len(abo.posterior_grad_mean(m, tx)) == 3 and len(abo.posterior_grad_var(m, tx)) == 3
+    c = abo.copy(m)
+    assert c.noise_var == m.noise_var and c.p == m.p and c.gp == m.gp and c.gpx is not m.gpx
+    with pytest.raises(abo.DimensionMismatch):
+        abo.update(gp, xs, [[1.0, 0.1], [0.5, 0.0], [0.0, -0.1]])
+    with pytest.raises(abo.DimensionMismatch):
+        abo.update(abo.GradientGP(abo.SqExponentialKernel(), 4, 0.1), xs, [[1.0, 0.1, 0.1, 0.0]] * 3)
+    with pytest.raises(ValueError):
+        abo.append(m, [0.1, 0.2], 0.0)
+
+
+@pytest.mark.parametrize("family,d,N,M,ell,noise", [(O.SE, 2, 60, 500, 0.6, 1e-3), (O.MATERN52, 3, 100, 700, 0.8, 1e-3),
+                                                    (O.MATERN72, 4, 90, 300, 1.1, 1e-2), (O.MATERN52, 8, 150, 400, 1.5, 1e-2)])
+def test_gradient_gp_against_oracle(family, d, N, M, ell, noise):
+    p = d + 1
+    X = synth.points(1, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    gF = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    Ys = np.column_stack([f + 0.4, gF])
+    Z = synth.points(2, M, d)
+    mean_c = np.concatenate([[0.4], np.zeros(d)])
+    st = G.fit(family, ell, 1.2, noise, mean_c, X, Ys)
+    m = abo.update(make_grad(family, ell, 1.2, noise, p, mean_c), X, Ys)
+    L, alpha, Linv = abo.get_factor(m)
+    assert L.shape == (p * N, p * N)
+    assert np.max(np.abs(L - st.L)) < 1e-9 and np.max(np.abs(alpha - st.alpha)) < 1e-6 * max(1, np.max(np.abs(st.alpha)))
+    mu_o, var_o = G.predict_grad(st, Z)
+    assert np.max(np.abs(abo.posterior_grad_mean(m, Z) - mu_o)) < 1e-8
+    assert np.max(np.abs(abo.posterior_grad_var(m, Z) - var_o)) < 1e-8 * max(1.0, 1.2 / ell ** 2)
+    mf, vf = G.predict(st, Z)
+    mu, var = abo.mean_and_var(m, Z)
+    assert np.max(np.abs(mu - mf)) < 1e-8 and np.max(np.abs(var - vf)) < 1e-8
+    # the standard acquisition functions run on the function output of the gradient-enhanced model
+    best = float(f.min() + 0.4)
+    ei = abo.ExpectedImprovement(0.01, best)(m, Z)
+    np.testing.assert_allclose(ei, O.expected_improvement(mu, var, best, 0.01), rtol=1e-9, atol=1e-13)
+    # GradientNormUCB (gradNormUCB.jl:43-51)
+    s = abo.GradientNormUCB(2.0)(m, Z[:64])
+    np.testing.assert_allclose(s, G.grad_norm_ucb(st, Z[:64], 2.0), rtol=1e-7, atol=1e-8)
+
+
+def test_gradient_gp_standardisation_helpers():
+    # test/test_surrogates.jl:363-397
+    gp = abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1)
+    y_train = [[1.0, 0.1, 0.1], [2.0, 0.2, 0.2], [3.0, 0.3, 0.3]]
+    mu, sd = abo.get_mean_std(gp, y_train, "mean_scale")
+    assert mu[0] == pytest.approx(2.0) and mu[1] == 0.0 and mu[2] == 0.0 and sd[0] > 0 and sd[1] == sd[0] == sd[2]
+    ys = abo.std_y(gp, y_train, mu, sd)
+    for yo, y_s in zip(y_train, ys):
+        for q in range(3):
+            assert y_s[q] == pytest.approx((yo[q] - mu[q]) / sd[q], abs=1e-8)
+    r = abo.rescale_model(gp, sd)
+    assert abo.get_scale(r)[0] == pytest.approx(1.0 / sd[0] ** 2) and r.noise_var == pytest.approx(0.1 / sd[0] ** 2)
+    assert abo._get_minimum(gp, y_train) == 1.0
+    g2 = abo.update(gp, [[0.0, 0.0], [1.0, 1.0], [0.3, 0.8]], ys)
+    mu_u, var_u = abo.unstandardized_mean_and_var(g2, [[0.2, 0.2]], (mu, sd))
+    assert mu_u.shape == (1, 3) and var_u.shape == (1, 3)
+    acq = abo.GradientNormUCB(1.5)
+    assert abo.update(acq, y_train, g2) is acq and abo.copy(acq) == acq
