@@ -1,0 +1,39 @@
+"""Soak run: many model lifetimes (refit / append / resident grids / gradient models) in one process; device
+memory in use must stay flat (pool bounded) and results must stay identical."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import synth
+
+def used_mb():
+    free, total = torch.cuda.mem_get_info()
+    return (total - free) / 2**20
+
+X, y = synth.standardized_problem(900, 4, 0.05)
+Z = torch.from_numpy(synth.points(2, 50000, 4)).cuda()
+gp = abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.7), 1e-3, n_max=1024)
+ref = None
+marks = []
+for it in range(300):
+    m = abo.update(gp, X, y)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    s, tv, ti = abo.evaluate(acq, m, Z, k=10)
+    if ref is None:
+        ref = (s.clone(), ti.clone())
+    else:
+        assert torch.equal(s, ref[0]) and torch.equal(ti, ref[1])
+    c = abo.ResidentCandidates(m, Z)
+    m2 = abo.append(m, synth.points(9, 1, 4, first=it)[0], 0.1)
+    c.downdate(m2)
+    if it % 10 == 0:
+        g = abo.update(abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1), synth.points(5, 40, 2), np.ones((40, 3)))
+        abo.posterior_grad_cov(g, [[0.2, 0.3]])
+    if it % 50 == 0:
+        torch.cuda.synchronize()
+        marks.append(used_mb())
+        print(it, f"{marks[-1]:.0f} MiB in use", flush=True)
+assert max(marks[1:]) - min(marks[1:]) < 64, marks
+abo._lib.check(abo._lib.lib().abo_pool_trim(0))
+print("after trim", f"{used_mb():.0f} MiB")
+print("soak ok")
