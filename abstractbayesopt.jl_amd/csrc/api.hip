@@ -517,7 +517,6 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     if (e == hipSuccess) e = st->Xs.ensure(sizeof(double) * cap * st->dp);
     if (e == hipSuccess) e = st->ybuf.ensure(sizeof(double) * cap);
     if (e == hipSuccess) e = st->delta.ensure(sizeof(double) * cap);
-    (void)R;
     if (e == hipSuccess) e = st->K.ensure(sizeof(double) * cap * cap);
     if (e == hipSuccess) e = st->W.ensure(sizeof(double) * cap * cap);
     if (e == hipSuccess) e = st->WT.ensure(sizeof(double) * cap * cap);

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) nlml_terms_kernel(const double* L, int64_
                                                          const double* alpha, int N, double* out) {
     __shared__ double r0[256], r1[256];
     double s0 = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < N; i += 256) {
+    for (int i = (int)threadIdx.x; i < N; i += 256) {
         s0 += 2.0 * log(L[(int64_t)i * ld + i]);
         s1 = fma(delta[i], alpha[i], s1);
     }
@@ -240,7 +240,7 @@ hipError_t launch_nlml_terms(const double* L, int64_t ld, const double* delta, c
 __global__ void __launch_bounds__(1024) append_reduce_kernel(AppendArgs p) {
     __shared__ double r0[1024], r1[1024];
     double a0 = 0.0, a1 = 0.0;
-    for (int i = threadIdx.x; i < p.N; i += 1024) {
+    for (int i = (int)threadIdx.x; i < p.N; i += 1024) {
         a0 = fma(p.lvec[i], p.lvec[i], a0);
         a1 = fma(p.krow[i], p.alpha_old[i], a1);
     }

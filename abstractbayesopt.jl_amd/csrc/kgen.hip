@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) nlml_grad_finish_kernel(NlmlGradArgs p, i
     __shared__ double r[4][256];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 256) s0 += p.partial[i];
-    for (int i = threadIdx.x; i < p.N; i += 256) {
+    for (int i = (int)threadIdx.x; i < p.N; i += 256) {
         s1 += p.Kinv[(int64_t)i * p.ld + i];
         s2 = fma(p.alpha[i], p.alpha[i], s2);
         s3 = fma(p.alpha[i], p.delta[i], s3);
