@@ -1,14 +1,10 @@
-# INTEGRATION — plugging `libabo_hip.so` into AbstractBayesOpt.jl
+# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 1) for AbstractBayesOpt.jl.
+# Drop next to src/surrogates/StandardGP.jl, `include("surrogates/HipStandardGP.jl")` from src/AbstractBayesOpt.jl
+# (after StandardGP.jl and the acquisition functions) and export HipStandardGP.
+# NOTE: written against the reference sources without a Julia toolchain at hand (none in the build image); the
+# Python package abstractbayesopt.jl_amd/ is the same binding over ctypes and is what the parity tests exercise.
+# This file is the code shown in INTEGRATION.md, verbatim.
 
-The reference dispatches everything on `<: AbstractSurrogate` (src/abstract.jl:33).  A maintainer
-adds **one file** (below; also shipped as `integration/julia/HipStandardGP.jl`) next to `src/surrogates/StandardGP.jl`, `include`s it from
-`src/AbstractBayesOpt.jl` and exports `HipStandardGP`.  The BO driver (`optimize`,
-`update(BO, …)`, `standardize_problem`), the domains and the acquisition *types* are untouched.
-No Julia toolchain exists in the build image, so this shim is untested here; the Python package in
-`abstractbayesopt.jl_amd/` is the same binding written with ctypes and is what the parity tests
-exercise.  Build the library with `python __graft_entry__.py` (→ `abstractbayesopt.jl_amd/lib/libabo_hip.so`).
-
-```julia
 # src/surrogates/HipStandardGP.jl   — binds include/abo_hip.h (ABI version 1)
 const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
 
@@ -110,12 +106,8 @@ end
 # get_lengthscale / get_scale / get_kernel_constructor / get_mean_std / std_y / rescale_model /
 # _update_model_parameters / prep_input / prep_output / _get_minimum: identical one-liners to
 # StandardGP.jl:164-287,:301,:315,:418 with `HipStandardGP` in place of `StandardGP`.
-```
 
-Incremental path (optional; BASELINE config 5).  `abo_append` returns a *new* handle sharing the
-factor storage, so it maps onto the functional `update` just as well:
 
-```julia
 function append(m::HipStandardGP, x::AbstractVector{Float64}, y::Float64)          # O(N²) instead of a refit
     h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0)
     GC.@preserve x _check(@ccall(LIBABO.abo_append(m.gpx.ptr::Ptr{Cvoid}, x::Ptr{Float64}, length(x)::Int32, y::Float64,
@@ -125,31 +117,3 @@ end
 # update(BO, x, y, i) (bayesian_opt.jl:113-150) can call `append(BO.model, x, y)` instead of
 # `update(BO.model, BO.xs, BO.ys)`; `prev_gp = copy(BO.model)` stays valid because rows ≤ N are never touched.
 # Resident grids for q-EI: abo_cand_create / abo_cand_acq / abo_cand_downdate / abo_cand_save / abo_cand_restore.
-```
-
-Other entry points and the reference methods they back (all in `include/abo_hip.h`; the Python package binds
-every one of them the same way):
-
-| C-ABI | reference method (file:line) | Julia-side use |
-|---|---|---|
-| `abo_nlml_grad` | `optimize_hyperparameters` objective, bayesian_opt.jl:253-285 (`autodiff=:forward`) | `Optim.optimize(Optim.only_fg!((F,G,p)->…), lb, ub, x0, Fminbox(LBFGS()))` with the value and analytic gradient from one call (refit + gradient per evaluation) |
-| `abo_lhs` | `QuasiMonteCarlo.sample(n, lb, ub, LatinHypercubeSample())`, acq_utils.jl:44-47 | grid generated on the device; `abo_acq(…, ABO_DEVICE, …, k=n_local)` then returns only the starts |
-| `abo_score` | `EnsembleAcquisition`, EnsembleAcq.jl:53-55 | one `abo_predict` into device buffers, one `abo_score` per member, weighted sum |
-| `abo_create_grad`, `abo_predict_grad`, `abo_predict_grad_cov` | `GradientGP`, `posterior_grad_mean/var/cov`, GradientGP.jl:617-639, :936-971; `GradientNormUCB`, gradNormUCB.jl:43-51 | `HipGradientGP <: AbstractSurrogate` built like `HipStandardGP` above; `update` passes `prep_output(model, ys)` (by outputs) as `y`; `posterior_grad_cov(m, [x])` reads the p×p block |
-| `abo_cand_*`, `abo_append` | (none: config 5) | resident grid + greedy q-EI, see `abstractbayesopt.jl_amd/incremental.py` |
-
-Notes for the maintainer
-
-* **Ownership** — host buffers are borrowed for the call (`GC.@preserve`); device state belongs to
-  the handle and is freed by the finaliser when the last `copy` dies.  `update` returns a new model
-  (StandardGP.jl:82), so the driver's rollback (`prev_gp = copy(BO.model)`, bayesian_opt.jl:116)
-  costs one reference count instead of a 512 MiB deep copy.
-* **Errors** — `ABO_ENOTPD` carries LAPACK's `info`; throwing `PosDefException(info)` keeps
-  bayesian_opt.jl:127's `catch` working unchanged.  Nothing is swallowed; the process never aborts.
-* **Large grids** — pass a `d×M Matrix{Float64}` (zero-copy) rather than `Vector{Vector{Float64}}`
-  (M heap objects, acq_utils.jl:47); `optimize_acquisition` can call `_acq(...; k=n_local)` and skip
-  the full `sortperm`.
-* **Multi-GPU** — one process (or one handle) per GPU with `device = i`; shard the candidate matrix
-  by columns, pass `idx_base`, merge the per-device top-k lists by (score desc, index asc).
-* **Hyper-parameter MLE** with `autodiff=:forward` cannot cross a C-ABI (ForwardDiff duals); keep the
-  CPU `StandardGP` for that step or supply a finite-difference / analytic gradient (SURVEY §8(f) #2).
