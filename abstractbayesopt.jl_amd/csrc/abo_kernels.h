@@ -37,6 +37,7 @@ struct VarGemmArgs {
     double* partial;      // [Np/128][ldp]
     int64_t ldw, ldk, ldp;
     int Np, Mc;           // multiples of 128
+    int force128;         // 1: always use the 128×128-tile kernel (A/B comparisons)
     int nvalid;           // rows ≥ nvalid (the view's N) are excluded from the norm
 };
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s);

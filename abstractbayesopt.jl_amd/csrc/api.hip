@@ -449,6 +449,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             VarGemmArgs va{};
             va.W = g->st->W.as<double>(); va.Kxz = g->Kxz.as<double>(); va.partial = g->partial.as<double>();
             va.ldw = g->st->cap; va.ldk = Np; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
+            va.force128 = getenv("ABO_TILE128") ? 1 : 0;
             HIPCHK(hipEventRecord(e[2], s));
             HIPCHK(launch_var_gemm(va, s));
             HIPCHK(hipEventRecord(e[3], s));

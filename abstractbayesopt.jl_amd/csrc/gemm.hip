@@ -275,7 +275,153 @@ __global__ void __launch_bounds__(256, 2) var_gemm_kernel(VarGemmArgs p) {
         p.partial[(int64_t)ti * p.ldp + (int64_t)tj * BN + threadIdx.x] = red[threadIdx.x] + red[128 + threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256×128 variant: one 512-thread workgroup (8 waves as 4(m)×2(n), same 64×64 wave tile and the same
+// one-barrier interleaved pipeline) computes the two vertically adjacent 128×128 tiles that var_gemm_kernel
+// would give to two workgroups, sharing ONE candidate (B) tile in LDS: 25 % fewer operand bytes requested
+// from L2 and 25 % fewer VMEM / LDS-store instructions per MFMA.  The upper 128 rows see zeros of W in the
+// last 128 k of the tile, so their waves (wm < 2) skip the MFMAs of the last 8 stages — every SIMD hosts one
+// upper and one lower wave, the matrix pipe stays busy and no flop is added over the 128×128 tiling.
+// Writes the same two partial rows (2·ti2, 2·ti2+1) with the same summation order: results are bit-identical
+// to var_gemm_kernel.  Used when Np is a multiple of 256.
+constexpr int BM2 = 256;
+constexpr int STAGE2 = (BM2 + BN) * LDT;       // doubles per LDS stage: A rows 0..255, B rows 256..383
+
+__global__ void __launch_bounds__(512, 2) var_gemm256_kernel(VarGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * STAGE2];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int Tj = p.Mc / BN;
+    const int Ti2 = p.Np / BM2;
+    const int b = blockIdx.x;
+    const int ti2 = Ti2 - 1 - b / Tj;
+    const int tj = b % Tj;
+    const double* __restrict__ Ag = p.W + (int64_t)ti2 * BM2 * p.ldw;
+    const double* __restrict__ Bg = p.Kxz + (int64_t)tj * BN * p.ldk;
+    const int nk = (ti2 + 1) * (BM2 / BK);
+    const int srow = t >> 3, skk = (t & 7) * 2;
+    const int aoff = (wm * 64 + r16) * LDT + g * 2;
+    const int boff = (BM2 + wn * 64 + r16) * LDT + g * 2;
+    d2_t sa[4], sb[2];
+    Frag f0, f1;
+    d4_t acc[4][4];
+    acc_zero(acc);
+
+#define G_LOAD(k0)                                                                                              \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                           \
+            sa[q] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)(srow + 64 * q) * p.ldw + (k0) + skk);         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
+            sb[q] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(srow + 64 * q) * p.ldk + (k0) + skk);         \
+    } while (0)
+#define L_STORE(buf)                                                                                            \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                           \
+            *reinterpret_cast<d2_t*>((buf) + (srow + 64 * q) * LDT + skk) = sa[q];                              \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
+            *reinterpret_cast<d2_t*>((buf) + (BM2 + srow + 64 * q) * LDT + skk) = sb[q];                        \
+    } while (0)
+
+    G_LOAD(0);
+    L_STORE(smem);
+    G_LOAD(BK);                                             // nk ≥ 16
+    __syncthreads();
+    frag_read(smem + aoff, smem + boff, 0, f0);
+    int st = 0;
+    for (; st < nk - 8; ++st) {                             // every wave has MFMA work: one basic block
+        double* cur = smem + (st & 1) * STAGE2;
+        double* nxt = smem + ((st + 1) & 1) * STAGE2;
+        L_STORE(nxt);
+        frag_read(cur + aoff, cur + boff, 1, f1);
+        G_LOAD((st + 2) * BK);
+        frag_mma<0>(f0, acc);
+        frag_mma<1>(f0, acc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        frag_read(nxt + aoff, nxt + boff, 0, f0);
+        frag_mma<0>(f1, acc);
+        frag_mma<1>(f1, acc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const bool mma = wm >= 2;                               // last 8 stages: W is zero for the upper 128 rows
+    for (; st < nk; ++st) {
+        double* cur = smem + (st & 1) * STAGE2;
+        double* nxt = smem + ((st + 1) & 1) * STAGE2;
+        if (mma) frag_mma<0>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_read(cur + aoff, cur + boff, 1, f1);
+        if (st + 1 < nk) {
+            L_STORE(nxt);
+            if (st + 2 < nk) G_LOAD((st + 2) * BK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (mma) frag_mma<1>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (st + 1 < nk) frag_read(nxt + aoff, nxt + boff, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mma) { frag_mma<0>(f1, acc); frag_mma<1>(f1, acc); }
+    }
+    __syncthreads();
+#undef G_LOAD
+#undef L_STORE
+
+    double* red = smem;                                     // [4 wm][128]
+    const int row0 = ti2 * BM2 + wm * 64 + g;
+    const bool edge = (ti2 + 1) * BM2 > p.nvalid;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        double s = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = acc[mi][ni][r];
+                if (edge && row0 + mi * 16 + 4 * r >= p.nvalid) v = 0.0;
+                s = fma(v, v, s);
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 16) red[wm * 128 + wn * 64 + ni * 16 + lane] = s;
+    }
+    __syncthreads();
+    if (t < 256) {
+        const int half = t >> 7, c = t & 127;                // the two 128-row blocks of this tile
+        p.partial[(int64_t)(2 * ti2 + half) * p.ldp + (int64_t)tj * BN + c] = red[(2 * half) * 128 + c] + red[(2 * half + 1) * 128 + c];
+    }
+}
+
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s) {
+    if (a.Np % BM2 == 0 && !a.force128) {
+        const int tiles2 = (a.Np / BM2) * (a.Mc / BN);
+        if (tiles2 <= 0) return hipSuccess;
+        hipLaunchKernelGGL(var_gemm256_kernel, dim3(tiles2), dim3(512), 0, s, a);
+        return hipGetLastError();
+    }
     const int tiles = (a.Np / BM) * (a.Mc / BN);
     if (tiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(var_gemm_kernel, dim3(tiles), dim3(256), 0, s, a);
