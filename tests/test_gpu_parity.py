@@ -483,3 +483,26 @@ def test_device_latin_hypercube():
                                                device_grid=True, refine=False, return_starts=True)
     np.testing.assert_allclose(acq(m, starts), vals, rtol=0, atol=1e-15)
     assert np.all(np.diff(vals) <= 0)
+
+
+def test_both_contraction_tilings_agree_bit_for_bit(monkeypatch):
+    """var_gemm256_kernel (256×128 tile, production when Np % 256 == 0) and var_gemm_kernel (128×128) write the
+    same per-row-block partial sums in the same order: switching between them (ABO_TILE128, A/B hook) must not
+    change a single bit, including on an appended view whose last row block carries masked stale rows."""
+    X, y = synth.standardized_problem(700, 5, 0.05)          # Np = 768 = 3 × 256
+    Z = synth.points(2, 3000, 5)
+    m = abo.update(make_model(O.MATERN52, 0.9, 1.0, 1e-3, n_max=768), X, y)
+    m2 = abo.append(abo.append(m, Z[0], 0.3), Z[1], -0.2)
+    dead = abo.append(m2, Z[2], 0.0)                          # a discarded branch leaves a stale factor row
+    del dead
+    out = {}
+    for mode in ("256", "128"):
+        if mode == "128":
+            monkeypatch.setenv("ABO_TILE128", "1")
+        else:
+            monkeypatch.delenv("ABO_TILE128", raising=False)
+        out[mode] = (abo.posterior_var(m, Z), abo.posterior_var(m2, Z))
+    np.testing.assert_array_equal(out["256"][0], out["128"][0])
+    np.testing.assert_array_equal(out["256"][1], out["128"][1])
+    st = O.fit(O.MATERN52, 0.9, 1.0, 1e-3, 0.0, np.vstack([X, Z[:2]]), np.append(y, [0.3, -0.2]))
+    assert np.max(np.abs(out["256"][1] - O.predict(st, Z)[1])) < 1e-9
