@@ -506,3 +506,36 @@ def test_both_contraction_tilings_agree_bit_for_bit(monkeypatch):
     np.testing.assert_array_equal(out["256"][1], out["128"][1])
     st = O.fit(O.MATERN52, 0.9, 1.0, 1e-3, 0.0, np.vstack([X, Z[:2]]), np.append(y, [0.3, -0.2]))
     assert np.max(np.abs(out["256"][1] - O.predict(st, Z)[1])) < 1e-9
+
+
+def test_near_singular_and_extreme_hyperparameters():
+    """test/test_bayesian_opt.jl:889-937: very close points with tiny noise must give a finite prediction or a
+    PosDefException (never garbage or a crash); extreme lengthscales stay finite and differ."""
+    gp = abo.HipStandardGP(abo.SqExponentialKernel(), 1e-12)
+    try:
+        m = abo.update(gp, [0.0, 1e-10, 2e-10], [1.0, 1.001, 1.002])
+        assert np.isfinite(abo.posterior_mean(m, [0.5])[0])
+    except abo.PosDefException as e:
+        assert 1 <= e.info <= 3
+    xs, ys = [-1.0, 0.0, 1.0], [1.0, 0.0, 1.0]
+    big = abo.update(abo.HipStandardGP(abo.SqExponentialKernel(), 0.01), xs, ys)
+    small = abo.update(abo.HipStandardGP(1.0 * abo.with_lengthscale(abo.SqExponentialKernel(), 1e-6), 0.01), xs, ys)
+    pb, ps = abo.posterior_mean(big, [0.5])[0], abo.posterior_mean(small, [0.5])[0]
+    assert np.isfinite(pb) and np.isfinite(ps) and abs(pb - ps) > 0.01
+    huge = abo.update(abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 1e3), 0.01), xs, ys)
+    assert np.isfinite(abo.posterior_var(huge, [0.5])[0])
+    # non-finite inputs do not hang or crash: NaN propagates to a PosDefException (first pivot is NaN)
+    with pytest.raises(abo.PosDefException):
+        abo.update(gp, [0.0, np.nan, 1.0], [1.0, 2.0, 3.0])
+
+
+def test_kernel_matrix_symmetry_and_psd_through_the_factor():
+    # test/test_bayesian_opt.jl:489-510: K symmetric PSD — here: L·Lᵀ reproduces the oracle's K + σ²I
+    X = synth.points(1, 200, 3)
+    for fam in (O.SE, O.MATERN52, O.MATERN72, O.MATERN32):
+        m = abo.update(make_model(fam, 0.7, 1.4, 1e-4), X, synth.objective(X))
+        L, _, _ = abo.get_factor(m)
+        K = L @ L.T
+        Ko = O.kernel_matrix(fam, 0.7, 1.4, X) + 1e-4 * np.eye(200)
+        assert np.max(np.abs(K - Ko)) < 1e-12 and np.max(np.abs(K - K.T)) == 0.0
+        assert np.all(np.diag(L) > 0) and np.all(np.triu(L, 1) == 0)

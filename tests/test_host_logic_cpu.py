@@ -143,3 +143,18 @@ def test_ensemble_acquisition_construction_and_update():
     assert up.acquisitions[0].best_y == 0.8 and up.acquisitions[1] is ucb
     c = abo.copy(ens)
     assert c == ens and c is not ens and c.acquisitions[0] is not ei
+
+
+def test_lengthscale_bounds_reference_cases():
+    # test/test_bayesian_opt.jl:419-456
+    dom = abo.ContinuousDomain([-2.0], [2.0])
+    lo, hi = abo.lengthscale_bounds([-1.0, 1.0], dom, min_frac=0.1, max_frac=2.0)
+    assert len(lo) == 1 and len(hi) == 1
+    assert abs(lo[0] - 0.1 * 2.0) < 1e-8 and abs(hi[0] - 2.0 * 4.0) < 1e-8
+    dom2 = abo.ContinuousDomain([-2.0, -2.0], [2.0, 2.0])
+    lo, hi = abo.lengthscale_bounds([[-1.0, -1.0], [1.0, 1.0]], dom2, min_frac=0.1, max_frac=1.0, n_samples=100_000,
+                                    rng=np.random.default_rng(0))
+    assert len(lo) == 2 and len(hi) == 2
+    assert np.all(np.abs(lo - 0.1 * np.sqrt(10.0)) < 1e-2)
+    with pytest.raises(abo.DimensionMismatch):
+        abo.lengthscale_bounds([[0.0, 0.0, 0.0]], dom2)
