@@ -1,8 +1,9 @@
-// fp64 MFMA tile core for gfx950 and the two kernels built on it:
-//   gemm_nt_kernel   C = alpha·A·Bᵀ + beta·C   (TRSM panel, SYRK trailing update, blocked L⁻¹)
-//   var_gemm_kernel  partial[ti][j] = Σ_{i∈ti} (W·K_XZ)[i][j]²  — the N²·M contraction that is
-//                    >99 % of the flops of posterior_var (reference: src/surrogates/StandardGP.jl:377-379,
-//                    [upstream AbstractGPs] diag_Xt_invA_X(C, K_XZ)).
+// fp64 MFMA tile core for gfx950 and the kernels built on it:
+//   gemm_nt_kernel      C = alpha·A·Bᵀ + beta·C   (TRSM panel, SYRK trailing update, blocked L⁻¹, K⁻¹, V = L⁻¹K_XZ)
+//   var_gemm256_kernel  partial[ti][j] = Σ_{i∈ti} (W·K_XZ)[i][j]²  — the N²·M contraction that is
+//   var_gemm_kernel     >99 % of the flops of posterior_var (reference: src/surrogates/StandardGP.jl:377-379,
+//                       [upstream AbstractGPs] diag_Xt_invA_X(C, K_XZ)); 256×128 tile per 8-wave workgroup
+//                       (production) and 128×128 tile per 4-wave workgroup (Np an odd number of 128-blocks).
 //
 // Design (CDNA4):
 //  * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD (measured: profiles/r01_mfma_f64_probe.txt,
