@@ -154,7 +154,7 @@ def quick_config(abo, synth, torch, dev, local_rank, name, k_top, steps=20, warm
             "value": ms, "unit": "ms", "steps": steps, "warmup": warmup}
 
 
-def run_c5(args, cfg, world, rank, local_rank, dev):
+def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
     """BASELINE config 5.  A step = greedy q-EI over the resident grid (q = 8 picks, each: EI + arg-max,
     fantasy bordered append, O(N·M) down-date), roll the grid posterior back, append the real (noisy)
     observation of the first pick to the parent model, down-date.  The full refresh (refit + grid
@@ -181,7 +181,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev):
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -219,7 +219,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev):
             ph["append_ms"].append((td - tc) * 1e3); ph["downdate_ms"].append((te - td) * 1e3)
     sync()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -281,7 +281,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ABO_FORCE_DIST=1 takes the N>1 code path (process group, barriers, all_gather of the top-k) at world size 1:
+    # that is how the RCCL calls are exercised on a one-GPU box (tests/test_gpu_distributed.py)
+    use_dist = world > 1 or bool(os.environ.get("ABO_FORCE_DIST"))
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -289,8 +292,8 @@ def main():
 
     cfg = CONFIGS[args.config]
     if args.config == "c5":
-        run_c5(args, cfg, world, rank, local_rank, dev)
-        if world > 1:
+        run_c5(args, cfg, world, rank, local_rank, dev, use_dist)
+        if use_dist:
             dist.destroy_process_group()
         return
     fam_name, d, N, M_per, ell, sf2, noise, acq_name, p0 = cfg
@@ -308,7 +311,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -326,12 +329,12 @@ def main():
             t0 = time.perf_counter()
         model = abo.update(gp, Xd, yd)                                          # full refit
         _, tv, ti = abo.evaluate(acq, model, Zd, k=K_TOP, idx_base=lo, return_scores=False)
-        top = D.all_gather_topk(tv, ti, K_TOP) if world > 1 else (tv, ti)
+        top = D.all_gather_topk(tv, ti, K_TOP) if use_dist else (tv, ti)
         if step >= args.warmup:
             phases.append(model.timings())
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         elapsed = reduce_max(elapsed)
     ms_per_step = elapsed * 1e3 / args.steps
 
@@ -395,7 +398,7 @@ def main():
         if world == 1 and args.config == "c3" and not args.no_cpu_baseline:
             out["secondary"] = quick_config(abo, synth, torch, dev, local_rank, "c2", K_TOP)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

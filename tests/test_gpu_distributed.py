@@ -77,3 +77,70 @@ def test_two_ranks_equal_single_process():
         np.testing.assert_array_equal(idxs, idxs1)
         np.testing.assert_allclose(vals, vals1, rtol=0, atol=1e-12)
         np.testing.assert_array_equal(pts, pts1)
+
+
+def _rccl_worker(port, q):
+    """world_size 1 over the nccl (= RCCL) backend: the same calls the 8-GPU run makes, on device tensors."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import abstractbayesopt.jl_amd as abo
+    from abstractbayesopt.jl_amd import distributed as D
+    from abstractbayesopt.jl_amd import incremental as I
+    from abstractbayesopt.jl_amd import synth
+    d, N, M, X, y = _problem()
+    gp = abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.7), 1e-4, device=0, n_max=N + 16)
+    model = abo.update(gp, X, y)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    make = lambda lo, hi: torch.from_numpy(synth.points(2, hi - lo, d, first=lo)).cuda()
+    tv, ti = D.sharded_acquisition(acq, model, make, M, 50)
+    rec = np.array([0.25, 7.0, -0.5, 0.1, 0.2, 0.3, 0.4])
+    got = I._allgather_best(rec, dist, None)
+    t = torch.tensor([3.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put((np.asarray(tv), np.asarray(ti), got, float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_exchange_through_rccl_world_size_one():
+    import torch.multiprocessing as mp
+    import abstractbayesopt.jl_amd as abo
+    from abstractbayesopt.jl_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    tv, ti, got, red = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    d, N, M, X, y = _problem()
+    gp = abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.7), 1e-4, n_max=N + 16)
+    model = abo.update(gp, X, y)
+    _, tv1, ti1 = abo.evaluate(abo.ExpectedImprovement(0.01, float(y.min())), model, synth.points(2, M, d), k=50)
+    np.testing.assert_array_equal(ti, ti1)
+    np.testing.assert_array_equal(tv, tv1)
+    np.testing.assert_array_equal(got, [0.25, 7.0, -0.5, 0.1, 0.2, 0.3, 0.4])
+    assert red == 3.5
+
+
+def test_bench_multi_rank_code_path_over_rccl():
+    """bench.py as the driver launches it (torch.distributed.run), forced onto the N>1 code path at one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ABO_FORCE_DIST="1")
+    for cfg in ("c2", "c5"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+               "--config", cfg, "--no-cpu-baseline"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
