@@ -58,5 +58,5 @@ def _dispatch(name):
 
 
 for _n in ("get_mean_std", "std_y", "rescale_model", "_update_model_parameters", "_get_minimum",
-           "unstandardized_mean_and_var", "prep_output"):
+           "unstandardized_mean_and_var", "prep_output", "nlml", "nlml_ls"):
     globals()[_n] = _dispatch(_n)

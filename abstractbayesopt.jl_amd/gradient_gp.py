@@ -8,6 +8,7 @@ exactly the same factorisation / contraction kernels as the standard GP."""
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -173,6 +174,36 @@ def rescale_model(model: HipGradientGP, sigma):
 def _update_model_parameters(model: HipGradientGP, kernel: Kernel):
     return HipGradientGP(kernel, model.p, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter,
                          chunk=model.chunk)
+
+
+def nlml(model: HipGradientGP, params, xs, ys) -> float:
+    """nlml(model::GradientGP, params, xs, ys) (GradientGP.jl:684-698): params = [log ℓ, log scale]; the kernel is
+    rebuilt with exp.(params), noise and prior mean are kept; −logpdf of the (d+1)N-row system."""
+    from .surrogate import nlml_fitted
+    log_ell, log_scale = params
+    inner = extract_scale_and_lengthscale(model.kernel)[0]
+    k = math.exp(log_scale) * with_lengthscale(inner, math.exp(log_ell))
+    return nlml_fitted(update(_update_model_parameters(model, k), xs, ys))
+
+
+def nlml_ls(model: HipGradientGP, log_ell, log_scale, xs, ys) -> float:
+    """nlml_ls(model::GradientGP, …) (GradientGP.jl:719-739)."""
+    return nlml(model, (log_ell, log_scale), xs, ys)
+
+
+def nlml_and_grad(model: HipGradientGP, params, xs, ys, h: float = 1e-4):
+    """(nlml, [∂/∂log ℓ, ∂/∂log scale]) for the gradient-enhanced model.  The reference differentiates this
+    objective with ForwardDiff (bayesian_opt.jl:284); here the value is one device refit and the two partials
+    are fourth-order central differences of it in log space (8 more refits of the (d+1)N-row system — the
+    scale partial could be had in closed form, but the refits are the cheap part of a BO step)."""
+    p = np.asarray(params, dtype=np.float64)
+    v = nlml(model, p, xs, ys)
+    g = np.zeros(2)
+    for c in range(2):
+        e = np.zeros(2); e[c] = h
+        g[c] = (8.0 * (nlml(model, p + e, xs, ys) - nlml(model, p - e, xs, ys))
+                - (nlml(model, p + 2 * e, xs, ys) - nlml(model, p - 2 * e, xs, ys))) / (12.0 * h)
+    return v, g
 
 
 def _get_minimum(model: HipGradientGP, ys):

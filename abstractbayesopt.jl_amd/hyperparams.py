@@ -80,11 +80,18 @@ def optimize_hyperparameters(model: HipStandardGP, x_train, y_train, old_params,
     eps2 = 2 * np.finfo(np.float64).eps
     start_full = old.copy()
     start_full[:len(lower)] = np.clip(old[:len(lower)], lower + eps2, upper - eps2)
-    xs, ys = prep_input(model, x_train), prep_output(model, y_train)
+    from . import gradient_gp as G
+    grad_model = isinstance(model, G.HipGradientGP)
+    if grad_model:                                   # GradientGP: xs stay points, ys stay (N, p) rows; update() packs them
+        xs, ys = x_train, y_train
+        value_and_grad, rebuild = G.nlml_and_grad, G._update_model_parameters
+    else:
+        xs, ys = prep_input(model, x_train), prep_output(model, y_train)
+        value_and_grad, rebuild = nlml_and_grad, _update_model_parameters
 
     def obj(p):
         full = [p[0], start_full[1]] if length_scale_only else [p[0], p[1]]
-        v, g = nlml_and_grad(model, full, xs, ys)
+        v, g = value_and_grad(model, full, xs, ys)
         return v, (g[:1] if length_scale_only else g)
 
     inits = [start_full[:len(lower)].copy()] + [rng.uniform(lower, upper) for _ in range(num_restarts - 1)]
@@ -101,4 +108,4 @@ def optimize_hyperparameters(model: HipStandardGP, x_train, y_train, old_params,
         return model                                  # all restarts failed (:302-304)
     ell = math.exp(best_p[0])
     scale = get_scale(model)[0] if length_scale_only else math.exp(best_p[1])
-    return _update_model_parameters(model, scale * with_lengthscale(get_kernel_constructor(model), ell))
+    return rebuild(model, scale * with_lengthscale(get_kernel_constructor(model), ell))

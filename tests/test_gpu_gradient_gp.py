@@ -115,3 +115,32 @@ def test_gradient_gp_standardisation_helpers():
     assert mu_u.shape == (1, 3) and var_u.shape == (1, 3)
     acq = abo.GradientNormUCB(1.5)
     assert abo.update(acq, y_train, g2) is acq and abo.copy(acq) == acq
+
+
+def test_gradient_gp_nlml_and_hyperparameter_mle():
+    # nlml(model::GradientGP, params, xs, ys) (GradientGP.jl:684-698) and the generic optimize_hyperparameters
+    # (bayesian_opt.jl:196-328) on the gradient-enhanced model
+    d, N = 2, 40
+    X = synth.points(1, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    gF = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    Ys = np.column_stack([f, gF])
+    gp = make_grad(O.MATERN52, 0.9, 1.0, 1e-3, d + 1)
+    for le, ls in [(np.log(0.9), 0.0), (np.log(0.4), np.log(2.5))]:
+        st = G.fit(O.MATERN52, float(np.exp(le)), float(np.exp(ls)), 1e-3, np.zeros(d + 1), X, Ys)
+        want = G.nlml(st)
+        assert abs(abo.nlml(gp, [le, ls], X, Ys) - want) <= 1e-9 * max(1.0, abs(want))
+        assert abo.nlml_ls(gp, le, ls, X, Ys) == abo.nlml(gp, [le, ls], X, Ys)
+    v0, g0 = abo.gradient_gp.nlml_and_grad(gp, [np.log(0.9), 0.0], X, Ys)
+    h = 1e-5
+    for c in range(2):
+        e = np.zeros(2); e[c] = h
+        pp, pm = np.array([np.log(0.9), 0.0]) + e, np.array([np.log(0.9), 0.0]) - e
+        fd = (G.nlml(G.fit(O.MATERN52, float(np.exp(pp[0])), float(np.exp(pp[1])), 1e-3, np.zeros(d + 1), X, Ys))
+              - G.nlml(G.fit(O.MATERN52, float(np.exp(pm[0])), float(np.exp(pm[1])), 1e-3, np.zeros(d + 1), X, Ys))) / (2 * h)
+        assert abs(g0[c] - fd) <= 1e-5 * max(1.0, abs(fd))
+    dom = abo.ContinuousDomain(np.zeros(d), np.ones(d))
+    new = abo.optimize_hyperparameters(gp, X, Ys, [np.log(0.9), 0.0], domain=dom, rng=np.random.default_rng(0))
+    assert isinstance(new, abo.GradientGP) and new.gpx is None and new.p == d + 1
+    p1 = [np.log(abo.get_lengthscale(new)[0]), np.log(abo.get_scale(new)[0])]
+    assert abo.nlml(new, p1, X, Ys) < v0 - 1e-3
