@@ -8,6 +8,15 @@
 // (gemm.hip) does the panel solve, the trailing SYRK and the blocked L⁻¹.
 #include "abo_kernels.h"
 
+// tools/chol_diag_probe.hip defines ABO_CHOL_PROBE to time the phases of chol_diag_kernel with the 100 MHz
+// constant clock; in the library build the macro is empty.
+#ifdef ABO_CHOL_PROBE
+__device__ long long abo_probe_clk[16];
+#define PROBE(i) do { if (threadIdx.x == 0) abo_probe_clk[i] = wall_clock64(); } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#endif
+
 namespace abo {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -26,12 +35,37 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// wave-uniform broadcast of lane l's double (l a compile-time constant after unrolling): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// piv = sqrt(d), rp = 1/piv for d > 0 in one Goldschmidt chain (v_rsq_f64 seed, two coupled Newton steps, one
+// residual correction each: ≤ 1 ulp) — a third of the dependent instructions of an IEEE sqrt followed by an IEEE
+// divide, and this chain is the serial spine of the whole factorisation.  Valid for every positive NORMAL d (the
+// caller rejects anything else as "not positive definite"); no branches.
+__device__ __forceinline__ void sqrt_and_reciprocal(double d, double& piv, double& rp) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    piv = fma(fma(-g, g, d), h, g);
+    const double q = h + h;
+    rp = fma(fma(-piv, q, 1.0), q, q);
+}
+
 // One workgroup (16 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
 // as an 8×8 grid of 16×16 sub-blocks so that everything but the 16×16 diagonal factorisations runs
-// on the fp64 MFMA (v_mfma_f64_16x16x4_f64) with 24 + 8 workgroup barriers in total:
+// on the fp64 MFMA (v_mfma_f64_16x16x4_f64) with 16 + 8 workgroup barriers in total:
 //   phase 1  right-looking Cholesky over sub-block columns p = 0..7:
-//            (1) wave 0 factors the 16×16 diagonal sub-block in place (16 in-wave steps, pivot check)
-//            (2) one thread per row below solves x·L_ppᵀ = a (16-term forward substitution in registers)
+//            (1)+(2) the 16×16 diagonal sub-block is factored and the rows below it are solved (x·L_ppᵀ = a) in
+//                registers, one row per lane, column values broadcast with v_readlane (pivot check on the way)
 //            (3) trailing sub-blocks C_ij −= L_ip·L_jpᵀ, one MFMA chain per sub-block, spread over the waves
 //   phase 2  X = L⁻¹ in place: column n of X_cc is written into ROW n of the (free) strict upper triangle,
 //            i.e. the upper triangle ends up holding Xᵀ, reciprocals of the diagonal in dinv[]:
@@ -52,54 +86,61 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     const int r16 = lane & 15, g = lane >> 4;
     if (*info != 0) return;
     if (t == 0) fail = 0;
+    PROBE(0);
     double* Kb = K + (int64_t)r0 * ld + r0;
     for (int idx = t; idx < NB * NB; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         AA(i, j) = Kb[(int64_t)i * ld + j];
     }
     __syncthreads();
+    PROBE(1);
 
     // ---------------- phase 1: Cholesky ----------------
     for (int p = 0; p < NSB; ++p) {
         const int o = SB * p;
-        if (wave == 0) {                                   // (1) 16×16 diagonal sub-block, in-wave
-            for (int j = 0; j < SB; ++j) {
-                const double d = AA(o + j, o + j);
-                if (!(d > 0.0)) {                          // also catches NaN; wave-uniform
-                    if (lane == 0) { fail = 1; *info = (int64_t)r0 + o + j + 1; }
-                    break;
-                }
-                const double piv = sqrt(d);
-                const double rp = 1.0 / piv;
-                wave_lds_sync();                           // everyone holds d before a[j][j] changes
-                if (lane < SB && lane > j) AA(o + lane, o + j) *= rp;
-                if (lane == j) { AA(o + j, o + j) = piv; dinv[o + j] = rp; }
-                wave_lds_sync();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = g + 4 * q;
-                    if (k > j && k <= r16) AA(o + r16, o + k) = fma(-AA(o + r16, o + j), AA(o + k, o + j), AA(o + r16, o + k));
-                }
-                wave_lds_sync();
-            }
-        }
-        __syncthreads();
-        if (fail) return;                                  // uniform (LDS flag after the barrier)
         const int below = NB - o - SB;                     // rows under the diagonal sub-block
-        if (t < below) {                                   // (2) panel solve, one row per thread
-            const int i = o + SB + t;
+        // (1)+(2) fused, in registers: lanes 0-15 of a wave hold the 16 rows of the diagonal sub-block, lanes 16-63
+        // hold 48 of the rows below it, one row (16 doubles) per lane.  Column j: the pivot and the scaled column
+        // entries L[k][j] are wave-uniform v_readlane broadcasts from lanes 0-15, so factoring the diagonal block and
+        // solving the rows below it (x·L_ppᵀ = a) are the same instruction stream.  Each wave that owns rows below
+        // redoes the diagonal block itself (identical arithmetic), so there is no LDS traffic and no cross-wave
+        // synchronisation inside the 16 columns.
+        if (wave * 48 < below || wave == 0) {
+            const int row = lane < SB ? o + lane : o + SB + wave * 48 + (lane - SB);
+            const bool valid = row < NB;
             double x[SB];
 #pragma unroll
-            for (int j = 0; j < SB; ++j) {
-                double v = AA(i, o + j);
+            for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
+            int failcol = SB;                              // first column whose pivot is not a positive normal number
+            double myrp = 0.0;
 #pragma unroll
-                for (int k = 0; k < j; ++k) v = fma(-x[k], AA(o + j, o + k), v);
-                x[j] = v * dinv[o + j];
+            for (int j = 0; j < SB; ++j) {                 // straight-line: a failed pivot poisons what follows (never
+                const double d = readlane_f64(x[j], j);    // stored) instead of branching out of the dependent chain
+                failcol = (failcol == SB && !(d >= 2.3e-308)) ? j : failcol;       // also catches NaN; wave-uniform
+                double piv, rp;
+                sqrt_and_reciprocal(d, piv, rp);
+                x[j] = (lane == j) ? piv : x[j] * rp;
+                myrp = (lane == j) ? rp : myrp;
+#pragma unroll
+                for (int k = j + 1; k < SB; ++k) x[k] = fma(-x[j], readlane_f64(x[j], k), x[k]);
             }
+            if (failcol < SB) {
+                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
+            } else if (valid) {
+                if (lane >= SB) {
 #pragma unroll
-            for (int j = 0; j < SB; ++j) AA(i, o + j) = x[j];
+                    for (int c = 0; c < SB; ++c) AA(row, o + c) = x[c];
+                } else if (wave == 0) {
+                    dinv[o + lane] = myrp;
+#pragma unroll
+                    for (int c = 0; c < SB; ++c)
+                        if (c <= lane) AA(row, o + c) = x[c];      // strict upper part of the registers is scratch
+                }
+            }
         }
         __syncthreads();
+        if (p == 0) PROBE(6);
+        if (fail) return;                                  // uniform (LDS flag after the barrier)
         {                                                  // (3) trailing update on the lower sub-blocks
             const int nb = NSB - 1 - p;                    // sub-block rows/cols left
             const int total = nb * (nb + 1) / 2;
@@ -121,6 +162,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         __syncthreads();
     }
 
+    PROBE(2);
     // ---------------- phase 2: X = L⁻¹, Xᵀ into the strict upper triangle ----------------
     if (t < NB) {                                          // (a) diagonal sub-block inverses
         const int o = SB * (t >> 4), n = t & 15;
@@ -137,6 +179,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             if (m > n) AA(o + n, o + m) = x[m];
     }
     __syncthreads();
+    PROBE(3);
     for (int dl = 1; dl < NSB; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
         for (int c = wave; c + dl < NSB; c += DT / 64) {
             const int i = c + dl;
@@ -167,6 +210,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         __syncthreads();
     }
 
+    PROBE(4);
     // ---------------- phase 3: write back ----------------
     double* Wb = W + (int64_t)r0 * ld + r0;
     double* WTb = WT + (int64_t)r0 * ld + r0;
@@ -180,6 +224,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         Wb[(int64_t)i * ld + j] = w;
         WTb[(int64_t)i * ld + j] = wt;
     }
+    PROBE(5);
 }
 #undef AA
 

@@ -1,0 +1,40 @@
+// Phase timing of chol_diag_kernel (128×128 diagonal block: Cholesky + inverse in one workgroup).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I abstractbayesopt.jl_amd/csrc -I include \
+//              -o tools/chol_diag_probe tools/chol_diag_probe.hip
+#define ABO_CHOL_PROBE 1
+#include "../abstractbayesopt.jl_amd/csrc/chol.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+int main() {
+    const int n = 128;
+    std::vector<double> K(n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const double d = (i - j) / 16.0;
+            K[i * n + j] = exp(-0.5 * d * d) + (i == j ? 0.1 : 0.0);
+        }
+    double *dK, *dK0, *dW, *dWT; int64_t* info;
+    CK(hipMalloc(&dK, n * n * 8)); CK(hipMalloc(&dK0, n * n * 8)); CK(hipMalloc(&dW, n * n * 8)); CK(hipMalloc(&dWT, n * n * 8));
+    CK(hipMalloc(&info, 8)); CK(hipMemset(info, 0, 8));
+    CK(hipMemcpy(dK0, K.data(), n * n * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 5; ++rep) {
+        CK(hipMemcpy(dK, dK0, n * n * 8, hipMemcpyDeviceToDevice));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        CK(abo::launch_chol_diag(dK, dW, dWT, n, 0, info, 0));
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        long long c[16];
+        CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(abo_probe_clk), sizeof(c)));
+        int64_t inf; CK(hipMemcpy(&inf, info, 8, hipMemcpyDeviceToHost));
+        printf("rep %d info=%ld event %.1f us | load %.2f  chol %.2f (first fused step %.2f)  inv-diag %.2f  inv-offdiag %.2f  store %.2f  total %.2f us\n",
+               rep, (long)inf, ms * 1e3, (c[1] - c[0]) / 100.0, (c[2] - c[1]) / 100.0, (c[6] - c[1]) / 100.0, (c[3] - c[2]) / 100.0,
+               (c[4] - c[3]) / 100.0, (c[5] - c[4]) / 100.0, (c[5] - c[0]) / 100.0);
+    }
+    return 0;
+}
