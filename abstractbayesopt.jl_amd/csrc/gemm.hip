@@ -28,6 +28,7 @@
 //    memory roles between the two waves of a SIMD is slower still (the memory phase becomes as long
 //    as the MFMA phase).  Static s_setprio between the co-resident workgroups changes nothing.
 #include "abo_kernels.h"
+#include <cstdlib>
 
 namespace abo {
 
@@ -223,10 +224,109 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
             }
 }
 
+// Same product for launches with few 128×128 tiles (late Cholesky panels, the whole factorisation at N ≲ 2048,
+// the first levels of the blocked L⁻¹).  One CU delivers 0.3 TFLOP/s of fp64 MFMA, so a 128×128×128 tile is
+// 14 µs of matrix-pipe time wherever it runs; when the launch cannot give every CU a tile, each 128×128 tile is
+// cut into sixteen 32×32 workgroups (4 waves, one MFMA tile each) instead.  Nothing to share → no LDS and no
+// barriers: a lane loads its own fragments (16 B per MFMA pair) straight from L2.  k runs through the MFMAs in
+// the same order and with the same lane ↔ k map as tile_loop, so the result is bit-identical to gemm_nt_kernel;
+// kmode / lower_only keep their 128-tile granularity.
+__global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmArgs p) {
+    if (p.info != nullptr && *p.info != 0) return;
+    const int sj = blockIdx.x, si = blockIdx.y, bz = blockIdx.z;
+    const int ti = si >> 2, tj = sj >> 2;
+    if (p.lower_only && tj > ti) return;
+    int kbeg = 0, kend = p.K;
+    if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
+    if (p.kmode == K_A_UPPER) kbeg = min(p.K, ti * BM);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const double* Ap = p.A + (int64_t)bz * p.sA + (int64_t)(si * 32 + wm * 16 + r16) * p.lda + 2 * g;
+    const double* Bp = p.B + (int64_t)bz * p.sB + (int64_t)(sj * 32 + wn * 16 + r16) * p.ldb + 2 * g;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = kbeg; k < kend; k += 128) {               // K, kbeg, kend are multiples of 128
+        d2_t a[16], b[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a[q] = *reinterpret_cast<const d2_t*>(Ap + k + 8 * q);
+            b[q] = *reinterpret_cast<const d2_t*>(Bp + k + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b[q][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b[q][1], acc, 0, 0, 0);
+        }
+    }
+    double* Cg = p.C + (int64_t)bz * p.sC;
+    double* Ctg = p.Ct ? p.Ct + (int64_t)bz * p.sCt : nullptr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = (int64_t)si * 32 + wm * 16 + g + 4 * r;
+        const int64_t col = (int64_t)sj * 32 + wn * 16 + r16;
+        double v = p.alpha * acc[r];
+        if (p.beta != 0.0) v += p.beta * Cg[row * p.ldc + col];
+        Cg[row * p.ldc + col] = v;
+        if (Ctg) Ctg[col * p.ldct + row] = v;
+    }
+}
+
+// In-place variant (C aliases A: the TRSM panel solve L[r,p] = A[r,p]·W_ppᵀ with N = K = 128): a workgroup owns
+// 16 complete rows — every wave has read them in full before the barrier that precedes the first store.
+// 4 waves, 16×32 outputs each; same k order as tile_loop.
+__global__ void __launch_bounds__(256) gemm_nt_rowpanel_kernel(GemmArgs p) {
+    if (p.info != nullptr && *p.info != 0) return;
+    const int si = blockIdx.x, bz = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const double* Ap = p.A + (int64_t)bz * p.sA + (int64_t)(si * 16 + r16) * p.lda + 2 * g;
+    const double* Bp = p.B + (int64_t)bz * p.sB + (int64_t)(wave * 32 + r16) * p.ldb + 2 * g;
+    d4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    d2_t a[16], b0[16], b1[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        a[q] = *reinterpret_cast<const d2_t*>(Ap + 8 * q);
+        b0[q] = *reinterpret_cast<const d2_t*>(Bp + 8 * q);
+        b1[q] = *reinterpret_cast<const d2_t*>(Bp + 16 * p.ldb + 8 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b0[q][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b1[q][0], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b0[q][1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b1[q][1], acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+    double* Cg = p.C + (int64_t)bz * p.sC;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = (int64_t)si * 16 + g + 4 * r;
+            const int64_t col = wave * 32 + ni * 16 + r16;
+            double v = p.alpha * acc[ni][r];
+            if (p.beta != 0.0) v += p.beta * Cg[row * p.ldc + col];
+            Cg[row * p.ldc + col] = v;
+        }
+}
+
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
-    dim3 grid(a.N / BN, a.M / BM, a.batch);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
+    const int64_t Tm = a.M / BM, Tn = a.N / BN;
+    const int64_t tiles = (a.lower_only ? Tm * (Tm + 1) / 2 : Tm * Tn) * a.batch;
+    const char* fe = getenv("ABO_GEMM_SMALL");                      // A/B runs and tests: 0 never, 1 always
+    const int force = fe ? atoi(fe) : -1;
+    const bool small = force >= 0 ? force == 1 : tiles <= 128;
+    const bool in_place = a.C == a.A || a.C == a.B;
+    if (small && in_place && a.C == a.A && a.N == BN && a.K == 128 && a.kmode == K_FULL && !a.lower_only && !a.Ct) {
+        hipLaunchKernelGGL(gemm_nt_rowpanel_kernel, dim3(a.M / 16, a.batch), dim3(256), 0, s, a);
+    } else if (small && !in_place && a.K % 128 == 0) {
+        dim3 grid(a.N / 32, a.M / 32, a.batch);
+        hipLaunchKernelGGL(gemm_nt_small_kernel, grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid(a.N / BN, a.M / BM, a.batch);
+        hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
+    }
     return hipGetLastError();
 }
 

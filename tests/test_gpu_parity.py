@@ -55,6 +55,26 @@ def test_mfma_gemm_core_against_fp64_reference(M, N, K):
     assert err < 1e-12 * K, err
 
 
+def test_small_tile_gemm_is_bit_identical_to_the_lds_tiled_one(monkeypatch):
+    """launches with few 128×128 tiles run as 32×32 workgroups without LDS; same k order → same bits"""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(7)
+    out = {}
+    for M, N, K in [(128, 128, 128), (384, 256, 512)]:
+        A = torch.randn(M, K + 6, generator=g, dtype=torch.float64).cuda()
+        B = torch.randn(N, K + 2, generator=g, dtype=torch.float64).cuda()
+        C0 = torch.randn(M, N, generator=g, dtype=torch.float64).cuda()
+        for mode in ("0", "1"):
+            monkeypatch.setenv("ABO_GEMM_SMALL", mode)
+            Cd = C0.clone()
+            torch.cuda.synchronize()
+            abo._lib.check(abo._lib.lib().abo_test_gemm_nt(0, A.data_ptr(), B.data_ptr(), Cd.data_ptr(), M, N, K, K + 6, K + 2, N, -1.5, 0.5))
+            out[mode] = Cd.cpu()
+        assert torch.equal(out["0"], out["1"])
+        ref = -1.5 * (A.cpu()[:, :K] @ B.cpu()[:, :K].T) + 0.5 * C0.cpu()
+        assert (out["1"] - ref).abs().max().item() < 1e-12 * K
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["kat1", "kat3", "kat4", "kat5"])
 def test_kat_closed_forms(name):
