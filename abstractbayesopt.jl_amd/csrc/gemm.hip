@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
 
 // Same product for launches with few 128×128 tiles (late Cholesky panels, the whole factorisation at N ≲ 2048,
 // the first levels of the blocked L⁻¹).  One CU delivers 0.3 TFLOP/s of fp64 MFMA, so a 128×128×128 tile is
-// 14 µs of matrix-pipe time wherever it runs; when the launch cannot give every CU a tile, each 128×128 tile is
+// 14 µs of matrix-pipe time wherever it runs; when the launch cannot give a quarter of the CUs a tile, each tile is
 // cut into sixteen 32×32 workgroups (4 waves, one MFMA tile each) instead.  Nothing to share → no LDS and no
 // barriers: a lane loads its own fragments (16 B per MFMA pair) straight from L2.  k runs through the MFMAs in
 // the same order and with the same lane ↔ k map as tile_loop, so the result is bit-identical to gemm_nt_kernel;
@@ -316,7 +316,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     const int64_t tiles = (a.lower_only ? Tm * (Tm + 1) / 2 : Tm * Tn) * a.batch;
     const char* fe = getenv("ABO_GEMM_SMALL");                      // A/B runs and tests: 0 never, 1 always
     const int force = fe ? atoi(fe) : -1;
-    const bool small = force >= 0 ? force == 1 : tiles <= 128;
+    const bool small = force >= 0 ? force == 1 : tiles <= 64;      // measured crossover: small ≈ tiles·K·1.7 ns, tiled ≈ 6 µs + K·0.11 µs
     const bool in_place = a.C == a.A || a.C == a.B;
     if (small && in_place && a.C == a.A && a.N == BN && a.K == 128 && a.kmode == K_FULL && !a.lower_only && !a.Ct) {
         hipLaunchKernelGGL(gemm_nt_rowpanel_kernel, dim3(a.M / 16, a.batch), dim3(256), 0, s, a);

@@ -193,6 +193,7 @@ hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const do
 // order-preserving u64 keys; each workgroup bitonic-sorts 2048 (key, idx) pairs in LDS and keeps its
 // first KP; passes repeat until one block is left.  No atomics: bit-reproducible.
 constexpr int TK_E = 2048;   // entries per workgroup
+constexpr int TK_T = 1024;   // threads: one compare-exchange per thread and stage (the 66 stages are latency-bound)
 constexpr uint64_t KEY_PAD = 0ull;
 constexpr int64_t IDX_PAD = 0x7fffffffffffffffll;
 
@@ -202,20 +203,28 @@ __device__ __forceinline__ uint64_t score_key(double s) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// ordering point for LDS traffic between the lanes of ONE wave (in-order LDS queue: drained counter + compiler fence)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // true if entry (ka, ia) must come before (kb, ib)
 __device__ __forceinline__ bool before(uint64_t ka, int64_t ia, uint64_t kb, int64_t ib) {
     return (ka > kb) || (ka == kb && ia < ib);
 }
 
 template <bool FIRST>
-__global__ void __launch_bounds__(256) topk_pass_kernel(const double* __restrict__ scores, const uint64_t* __restrict__ kin,
+__global__ void __launch_bounds__(TK_T) topk_pass_kernel(const double* __restrict__ scores, const uint64_t* __restrict__ kin,
                                                         const int64_t* __restrict__ iin, int64_t n, int kp,
                                                         uint64_t* __restrict__ kout, int64_t* __restrict__ iout) {
     __shared__ uint64_t sk[TK_E];
     __shared__ int64_t si[TK_E];
     const int t = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * TK_E;
-    for (int e = t; e < TK_E; e += 256) {
+    for (int e = t; e < TK_E; e += TK_T) {
         const int64_t g = base + e;
         uint64_t k = KEY_PAD;
         int64_t i = IDX_PAD;
@@ -229,7 +238,7 @@ __global__ void __launch_bounds__(256) topk_pass_kernel(const double* __restrict
     __syncthreads();
     for (int size = 2; size <= TK_E; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int e = t; e < TK_E / 2; e += 256) {
+            for (int e = t; e < TK_E / 2; e += TK_T) {
                 const int lo = 2 * e - (e & (stride - 1));   // index with the `stride` bit clear
                 const int hi = lo + stride;
                 const bool up = (lo & size) == 0;            // this run sorts "before-first"
@@ -238,10 +247,15 @@ __global__ void __launch_bounds__(256) topk_pass_kernel(const double* __restrict
                 const bool swap = up ? before(k1, i1, k0, i0) : before(k0, i0, k1, i1);
                 if (swap) { sk[lo] = k1; si[lo] = i1; sk[hi] = k0; si[hi] = i0; }
             }
-            __syncthreads();
+            // a stage with stride ≤ 64 stays inside the 128 entries its wave owns: only stages that cross waves (or
+            // are followed by one that does) need the workgroup barrier — 18 of the 66
+            const int next = stride > 1 ? (stride >> 1) : size;          // first stride of the next size is `size`
+            if (stride > 64 || next > 64) __syncthreads();
+            else wave_lds_sync();
         }
     }
-    for (int e = t; e < kp; e += 256) {
+    __syncthreads();
+    for (int e = t; e < kp; e += TK_T) {
         kout[(int64_t)blockIdx.x * kp + e] = sk[e];
         iout[(int64_t)blockIdx.x * kp + e] = si[e];
     }
@@ -278,12 +292,12 @@ hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base,
     int cur = 0;
     int64_t blocks = (n + TK_E - 1) / TK_E;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((topk_pass_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, scores, nullptr, nullptr, n, kp,
+    hipLaunchKernelGGL((topk_pass_kernel<true>), dim3((unsigned)blocks), dim3(TK_T), 0, s, scores, nullptr, nullptr, n, kp,
                        w.keys[0], w.idx[0]);
     n = blocks * kp;
     while (blocks > 1) {
         blocks = (n + TK_E - 1) / TK_E;
-        hipLaunchKernelGGL((topk_pass_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, nullptr, w.keys[cur],
+        hipLaunchKernelGGL((topk_pass_kernel<false>), dim3((unsigned)blocks), dim3(TK_T), 0, s, nullptr, w.keys[cur],
                            w.idx[cur], n, kp, w.keys[cur ^ 1], w.idx[cur ^ 1]);
         cur ^= 1;
         n = blocks * kp;
