@@ -25,7 +25,8 @@ class AboTimings(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("fit_kernel_matrix_ms", "fit_cholesky_ms", "fit_inverse_ms",
                                           "fit_alpha_ms", "fit_total_ms", "acq_kxz_ms", "acq_var_gemm_ms",
                                           "acq_finalize_ms", "acq_topk_ms", "acq_total_ms")] + \
-               [("var_gemm_launches", C.c_int64), ("var_gemm_flop", C.c_double)]
+               [("var_gemm_launches", C.c_int64), ("var_gemm_flop", C.c_double), ("downdate_ms", C.c_double),
+                ("downdate_bytes", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -145,6 +145,12 @@ hipError_t launch_grad_cov(const GradCovArgs& a, int npoints, hipStream_t s);
 // resident-candidate kernels (C5)
 // mu[j] += c[j]·beta ; var[j] −= c[j]²/s2        (posterior down-date after a bordered append)
 hipError_t launch_downdate(double* mu, double* var, const double* c, int64_t M, double beta, double s2, hipStream_t s);
+// resident K_ZX (candidate-major, ld doubles per candidate) of a candidate set:
+//   newcol: Kzx[j][col] = sigma_f2·kappa(‖s·z_j − Xs[col]‖²) for all M candidates (the column of a just-appended point)
+//   gemv:   c[j] = Σ_{k<n} Kzx[j][k]·v[k]   (the O(N·M) down-date as one streaming pass, no kernel evaluations)
+hipError_t launch_cand_newcol(const double* Xs, const double* Z, double* Kzx, int64_t ld, int64_t M, int col, int d, int dp,
+                              int family, double s, double sigma_f2, hipStream_t st);
+hipError_t launch_cand_gemv(const double* Kzx, int64_t ld, const double* v, int n, int64_t M, double* c, hipStream_t s);
 // score[j] = acq(mu[j], var[j])
 hipError_t launch_score(const double* mu, const double* var, double* score, int64_t M, int kind, double p0, double best_y,
                         hipStream_t s);

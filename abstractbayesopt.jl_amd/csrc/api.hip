@@ -250,14 +250,20 @@ struct abo_cand {
     const Storage* bak_st = nullptr;      // abo_cand_save snapshot
     int64_t bak_N = -1;
     DevBuf Z, mu, var, score, cdot, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx, mu_bak, var_bak;
+    // resident K_ZX (candidate-major, kzx_ld doubles per candidate, column k = training row k of synced_st): kept when
+    // it fits the budget (ABO_CAND_KZX_GIB, default 64), so that a down-date streams it once instead of re-evaluating
+    // N·M kernel values; kzx_ld = 0 → not resident, the down-date recomputes
+    DevBuf Kzx;
+    int64_t kzx_ld = 0;
     void set_device(int dev) {
         device = dev;
-        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak};
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak, &Kzx};
         for (DevBuf* b : all) b->dev = dev;
     }
     void free_all() {
-        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak};
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak, &Kzx};
         for (DevBuf* b : all) b->release();
+        kzx_ld = 0;
     }
 };
 
@@ -417,14 +423,17 @@ int64_t pick_chunk(const abo_gp* g, int64_t M) {
 // mu / var / score for M candidates into device arrays (any may be null)
 // pc outputs per candidate (1 = function value; p_out = all outputs of a gradient-enhanced GP), rows by outputs
 // unless point_major; mu/var/score arrays then have pc·M entries.
+// kstore / ldstore: write K_XZ into a caller-owned candidate-major matrix (pad_up(M,128) rows of ldstore ≥ Np doubles)
+// instead of the per-chunk scratch — the resident K_ZX of a candidate set.
 int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0, double best_y, double* mu_out,
-                  double* var_out, double* score_out, int pc = 1, int point_major = 0) {
+                  double* var_out, double* score_out, int pc = 1, int point_major = 0, double* kstore = nullptr,
+                  int64_t ldstore = 0) {
     const int64_t M = Mpts * pc;                         // candidate rows
     hipStream_t s = g->stream;
     const int64_t Np = g->Np;
     const int T = (int)(Np / TB);
     const int64_t Mc = pick_chunk(g, M);
-    HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
+    if (!kstore) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
     HIPCHK(g->partial.ensure(sizeof(double) * T * Mc));
     HIPCHK(g->mu_c.ensure(sizeof(double) * Mc));
     const int64_t nchunk = (M + Mc - 1) / Mc;
@@ -436,8 +445,10 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         const int mcp = (int)pad_up(m, TB);
         hipEvent_t* e = &g->evs()[8 + 6 * c];
         KgenArgs ka{};
-        ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
-        ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = Mpts; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->npts;
+        double* kchunk = kstore ? kstore + j0 * ldstore : g->Kxz.as<double>();
+        const int64_t ldk = kstore ? ldstore : Np;
+        ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = kchunk;
+        ka.mu = g->mu_c.as<double>(); ka.ldk = ldk; ka.M = Mpts; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->npts;
         ka.pt = g->p_out; ka.pc = pc; ka.point_major = point_major;
         for (int q = 0; q < 17; ++q) ka.mean_vec[q] = g->mean_vec[q];
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
@@ -447,8 +458,8 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         HIPCHK(hipEventRecord(e[1], s));
         if (var_out || score_out) {
             VarGemmArgs va{};
-            va.W = g->st->W.as<double>(); va.Kxz = g->Kxz.as<double>(); va.partial = g->partial.as<double>();
-            va.ldw = g->st->cap; va.ldk = Np; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
+            va.W = g->st->W.as<double>(); va.Kxz = kchunk; va.partial = g->partial.as<double>();
+            va.ldw = g->st->cap; va.ldk = ldk; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
             va.force128 = getenv("ABO_TILE128") ? 1 : 0;
             HIPCHK(hipEventRecord(e[2], s));
             HIPCHK(launch_var_gemm(va, s));
@@ -1059,8 +1070,28 @@ int32_t abo_cand_refresh(abo_gp* g, abo_cand* c) {
     if (g->prm.device != c->device) return fail(ABO_EINVAL, "candidate set lives on device %d, model on %d", c->device, g->prm.device);
     HIPCHK(hipSetDevice(g->prm.device));
     if (c->M > 0) {
+        // keep K_ZX resident when it fits the budget
+        const char* lim = getenv("ABO_CAND_KZX_GIB");
+        const double budget = (lim ? atof(lim) : 64.0) * 1073741824.0;
+        const int64_t rows = pad_up(c->M, TB), ldz = g->st->cap;
+        const double need = (double)rows * (double)ldz * sizeof(double);
+        c->kzx_ld = 0;
+        if (need <= budget) {
+            const void* before = c->Kzx.p;
+            const hipError_t e = c->Kzx.ensure((size_t)need);
+            if (e == hipSuccess) {
+                // columns ≥ Np are never written by the refresh: zero a new allocation once (later appends fill them)
+                if (c->Kzx.p != before) HIPCHK(hipMemsetAsync(c->Kzx.p, 0, c->Kzx.cap, g->stream));
+                c->kzx_ld = ldz;
+            } else {
+                (void)hipGetLastError();              // does not fit next to the model: fall back to recomputation
+            }
+        } else {
+            c->Kzx.release();
+        }
         HIPCHK(hipEventRecord(g->evs()[5], g->stream));
-        rc = posterior(g, c->Z.as<double>(), c->M, -1, 0.0, 0.0, c->mu.as<double>(), c->var.as<double>(), nullptr);
+        rc = posterior(g, c->Z.as<double>(), c->M, -1, 0.0, 0.0, c->mu.as<double>(), c->var.as<double>(), nullptr, 1, 0,
+                       c->kzx_ld ? c->Kzx.as<double>() : nullptr, c->kzx_ld);
         if (rc) return rc;
         HIPCHK(hipEventRecord(g->evs()[6], g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
@@ -1115,8 +1146,18 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
     if (c->M > 0) {
         // c(z) = k(z,x*) − k_zᵀ K⁻¹ k_* = Σ_{k ≤ N} k(z, x_k)·vext[k]: one kernel-evaluation pass, nothing stored
         HIPCHK(c->cdot.ensure(sizeof(double) * pad_up(c->M, 16)));
+        const bool resident = c->kzx_ld > 0 && c->kzx_ld == g->st->cap;
+        HIPCHK(g->events(8));
+        HIPCHK(hipEventRecord(g->evs()[5], s));
+        if (resident) {
+            // the appended point's column, then one streaming mat-vec over the resident K_ZX
+            HIPCHK(launch_cand_newcol(g->st->Xs.as<double>(), c->Z.as<double>(), c->Kzx.as<double>(), c->kzx_ld, c->M,
+                                      (int)g->N - 1, g->d, g->dp, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, s));
+            HIPCHK(launch_cand_gemv(c->Kzx.as<double>(), c->kzx_ld, g->vext.as<double>(), (int)g->N, c->M,
+                                    c->cdot.as<double>(), s));
+        }
         const int64_t step = 65536;
-        for (int64_t j0 = 0; j0 < c->M; j0 += step) {
+        for (int64_t j0 = 0; !resident && j0 < c->M; j0 += step) {
             const int64_t m = (c->M - j0) < step ? (c->M - j0) : step;
             KgenArgs ka{};
             ka.Xs = g->st->Xs.as<double>(); ka.Z = c->Z.as<double>(); ka.alpha = g->vext.as<double>(); ka.Kout = nullptr;
@@ -1125,8 +1166,11 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
             ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
             HIPCHK(launch_kgen(ka, s));
         }
+        HIPCHK(hipEventRecord(g->evs()[6], s));
         HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->cdot.as<double>(), c->M, g->ap_beta, g->ap_s2, s));
         HIPCHK(hipStreamSynchronize(s));
+        g->tm.downdate_ms = ev_ms(g->evs()[5], g->evs()[6]);
+        g->tm.downdate_bytes = resident ? 8.0 * (double)g->N * (double)c->M : 0.0;
     }
     c->synced_N = g->N;
     return ABO_OK;

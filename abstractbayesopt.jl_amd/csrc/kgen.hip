@@ -361,6 +361,36 @@ hipError_t launch_kappa_test(int family, const double* d2, double* out, int64_t 
     return hipGetLastError();
 }
 
+// the 16 candidate rows of a workgroup against this lane's two training points
+template <int FAM, int DP, bool FULL>
+__device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[DP], const double (&x0)[DP], const double (&x1)[DP],
+                                          double s0, double s1, double a0, double a1, int jb, int k, double (&mu)[JT]) {
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        // rows past the last candidate are written as zeros (K_XX relies on it for its identity padding; for K_XZ
+        // they are padding candidates nobody reads); wave-uniform
+        const bool okj = FULL || (p.j0 + jb + jj) < p.M;
+        // keep the candidate coordinates in LDS: without this hipcc hoists all JT·DP broadcast reads out of the
+        // k sweep and pins them in (up to 512) registers
+        asm volatile("" ::: "memory");
+        double v0 = 0.0, v1 = 0.0;
+        if (okj) {
+            double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < DP; ++c) {
+                const double z = zs[jj][c];
+                const double e0 = x0[c] - z, e1 = x1[c] - z;
+                r0 = fma(e0, e0, r0);
+                r1 = fma(e1, e1, r1);
+            }
+            v0 = s0 * kappa_eval<FAM>(r0);
+            v1 = s1 * kappa_eval<FAM>(r1);
+        }
+        if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
+        mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
+    }
+}
+
 template <int FAM, int DP>
 __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
     __shared__ double zs[JT][DP];
@@ -394,30 +424,15 @@ __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
             } else {
                 x0[0] = xp[0]; x1[0] = xp[1];
             }
-            const bool ok0 = k < p.N, ok1 = (k + 1) < p.N;
+            // masks as multipliers (κ is finite everywhere): a select around kappa_eval is compiled into a
+            // branch per candidate row, which cuts the sweep into 16 basic blocks of two dependent chains each
+            const double s0 = k < p.N ? p.sigma_f2 : 0.0, s1 = (k + 1) < p.N ? p.sigma_f2 : 0.0;
             double a0 = 0.0, a1 = 0.0;
             if (p.alpha) { a0 = p.alpha[k]; a1 = p.alpha[k + 1]; }
-#pragma unroll
-            for (int jj = 0; jj < JT; ++jj) {
-                // rows past the last candidate are written as zeros (K_XX relies on it for its
-                // identity padding; for K_XZ they are padding candidates nobody reads)
-                const bool okj = (p.j0 + jb + jj) < p.M;
-                // keep the candidate coordinates in LDS: without this hipcc hoists all JT·DP
-                // broadcast reads out of the k sweep and pins them in (up to 512) registers
-                asm volatile("" ::: "memory");
-                double r0 = 0.0, r1 = 0.0;
-#pragma unroll
-                for (int c = 0; c < DP; ++c) {
-                    const double z = zs[jj][c];
-                    const double e0 = x0[c] - z, e1 = x1[c] - z;
-                    r0 = fma(e0, e0, r0);
-                    r1 = fma(e1, e1, r1);
-                }
-                const double v0 = (ok0 && okj) ? p.sigma_f2 * kappa_eval<FAM>(r0) : 0.0;
-                const double v1 = (ok1 && okj) ? p.sigma_f2 * kappa_eval<FAM>(r1) : 0.0;
-                if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
-                mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
-            }
+            // a workgroup whose 16 rows are all real candidates runs the branch-free body; an edge workgroup (the one-row
+            // launch of a bordered append above all) skips the kernel evaluations of its padding rows
+            if (p.j0 + jb + JT <= p.M) kgen_rows<FAM, DP, true>(p, zs, x0, x1, s0, s1, a0, a1, jb, k, mu);
+            else kgen_rows<FAM, DP, false>(p, zs, x0, x1, s0, s1, a0, a1, jb, k, mu);
         }
     }
     if (p.mu == nullptr) return;
@@ -466,6 +481,37 @@ hipError_t launch_kgen(const KgenArgs& a, hipStream_t s) {
         case ABO_KERNEL_MATERN32: return launch_fam<ABO_KERNEL_MATERN32>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+// Column `col` of a resident K_ZX: one kernel evaluation per candidate (the training point just appended).
+template <int FAM>
+__global__ void __launch_bounds__(256) cand_newcol_kernel(const double* __restrict__ Xs, const double* __restrict__ Z,
+                                                           double* __restrict__ Kzx, int64_t ld, int64_t M, int col, int d,
+                                                           int dp, double s, double sigma_f2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double* x = Xs + (int64_t)col * dp;
+    const double* z = Z + j * d;
+    double r = 0.0;
+    for (int c = 0; c < d; ++c) {
+        const double e = x[c] - z[c] * s;
+        r = fma(e, e, r);
+    }
+    Kzx[j * ld + col] = sigma_f2 * kappa_eval<FAM>(r);
+}
+
+hipError_t launch_cand_newcol(const double* Xs, const double* Z, double* Kzx, int64_t ld, int64_t M, int col, int d, int dp,
+                              int family, double s, double sigma_f2, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((M + 255) / 256)), block(256);
+    switch (family) {
+        case ABO_KERNEL_SE: hipLaunchKernelGGL((cand_newcol_kernel<ABO_KERNEL_SE>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, d, dp, s, sigma_f2); break;
+        case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((cand_newcol_kernel<ABO_KERNEL_MATERN52>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, d, dp, s, sigma_f2); break;
+        case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((cand_newcol_kernel<ABO_KERNEL_MATERN72>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, d, dp, s, sigma_f2); break;
+        case ABO_KERNEL_MATERN32: hipLaunchKernelGGL((cand_newcol_kernel<ABO_KERNEL_MATERN32>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, d, dp, s, sigma_f2); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 __global__ void diag_fix_kernel(double* K, int64_t ld, int N, int Np, double noise) {

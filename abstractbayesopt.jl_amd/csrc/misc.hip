@@ -68,6 +68,55 @@ hipError_t launch_downdate(double* mu, double* var, const double* c, int64_t M, 
     return hipGetLastError();
 }
 
+// c[j] = Σ_{k<n} Kzx[j][k]·v[k]: HBM-streaming mat-vec over the resident K_ZX.  One wave per 4 candidate rows (the
+// 16-byte v loads are shared by the four rows), lanes stride k by 128; per-lane partial sums, then the fixed xor
+// tree: deterministic.  Columns ≥ n hold zeros or stale finite values and meet v = 0.
+__global__ void __launch_bounds__(256) cand_gemv_kernel(const double* __restrict__ Kzx, int64_t ld, const double* __restrict__ v,
+                                                         int n, int64_t M, double* __restrict__ c) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+    if (j0 >= M) return;
+    const double* r0 = Kzx + j0 * ld;
+    const double* r1 = r0 + (j0 + 1 < M ? ld : 0);
+    const double* r2 = r0 + (j0 + 2 < M ? 2 * ld : 0);
+    const double* r3 = r0 + (j0 + 3 < M ? 3 * ld : 0);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const int npair = (n + 1) >> 1;                       // ld is even and ≥ n+1: the pair load stays inside the row
+    for (int q = lane; q < npair; q += 64) {
+        const int k = 2 * q;
+        d2_t vv = *reinterpret_cast<const d2_t*>(v + k);
+        if (k + 1 >= n) vv[1] = 0.0;
+        const d2_t x0 = *reinterpret_cast<const d2_t*>(r0 + k);
+        const d2_t x1 = *reinterpret_cast<const d2_t*>(r1 + k);
+        const d2_t x2 = *reinterpret_cast<const d2_t*>(r2 + k);
+        const d2_t x3 = *reinterpret_cast<const d2_t*>(r3 + k);
+        a0 = fma(x0[1], vv[1], fma(x0[0], vv[0], a0));
+        a1 = fma(x1[1], vv[1], fma(x1[0], vv[0], a1));
+        a2 = fma(x2[1], vv[1], fma(x2[0], vv[0], a2));
+        a3 = fma(x3[1], vv[1], fma(x3[0], vv[0], a3));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+        a3 += __shfl_xor(a3, o);
+    }
+    if (lane == 0) {
+        c[j0] = a0;
+        if (j0 + 1 < M) c[j0 + 1] = a1;
+        if (j0 + 2 < M) c[j0 + 2] = a2;
+        if (j0 + 3 < M) c[j0 + 3] = a3;
+    }
+}
+
+hipError_t launch_cand_gemv(const double* Kzx, int64_t ld, const double* v, int n, int64_t M, double* c, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cand_gemv_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, Kzx, ld, v, n, M, c);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) score_kernel(const double* mu, const double* var, double* score, int64_t M, int kind,
                                                      double p0, double best_y) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

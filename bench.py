@@ -193,7 +193,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
     refresh_ms = (time.perf_counter() - t0) * 1e3
     fit_t = model.timings()
     best_y = float(y.min())
-    ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "restore_ms": []}
+    ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "restore_ms": [], "downdate_pass_ms": [], "downdate_pass_bytes": []}
     picks = None
     for step in range(args.warmup + args.steps):
         if step == args.warmup:
@@ -212,11 +212,13 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
         td = time.perf_counter()
         cands.downdate(model)
         te = time.perf_counter()
+        dd = model.timings()
         best_y = min(best_y, float(y_new))
         picks = (idxs, vals)
         if step >= args.warmup:
             ph["qei_ms"].append((tb - ta) * 1e3); ph["restore_ms"].append((tc - tb) * 1e3)
             ph["append_ms"].append((td - tc) * 1e3); ph["downdate_ms"].append((te - td) * 1e3)
+            ph["downdate_pass_ms"].append(dd["downdate_ms"]); ph["downdate_pass_bytes"].append(dd["downdate_bytes"])
     sync()
     elapsed = time.perf_counter() - t_start
     if use_dist:
@@ -229,6 +231,19 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
         n_now = N + args.warmup + args.steps
         append_bytes = 8.0 * n_now * n_now                 # W (lower) + WT (upper), read once each
         ach = append_bytes / (med["append_ms"] * 1e-3) / 1e9
+        # dominant kernel of the step: the O(N*M) down-date pass, 9 launches per step (8 fantasies + the real point)
+        if med["downdate_pass_bytes"] > 0:
+            gbs = med["downdate_pass_bytes"] / (med["downdate_pass_ms"] * 1e-3) / 1e9
+            roof = {"kernel": "cand_gemv_kernel (c = K_ZX . [-v; 1] over the resident K_ZX) + new-column kernel", "bound": "hbm",
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+                    "algorithmic_bytes_per_launch": med["downdate_pass_bytes"], "avg_launch_ms": med["downdate_pass_ms"],
+                    "launches_per_step": Q + 1,
+                    "note": "algorithmic bytes = 8*N*M (K_ZX read once); duration = HIP events on the library stream"}
+        else:
+            pairs = n_now * M_per / (med["downdate_pass_ms"] * 1e-3)
+            roof = {"kernel": "kgen_kernel, dot-only mode (K_ZX re-evaluated: ABO_CAND_KZX_GIB budget too small)", "bound": "valu",
+                    "achieved": pairs / 1e9, "peak": None, "unit": "Gpair/s", "frac": None, "traffic": None,
+                    "avg_launch_ms": med["downdate_pass_ms"], "launches_per_step": Q + 1}
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
             "value": ms, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -240,10 +255,11 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
                        "sharding": f"grid x{world}, all_gather of (score, index, mu, x) per pick"},
             "refresh_ms": refresh_ms, "value_amortized": ms + refresh_ms / 16.0,
             "refresh_phases_ms": {k: v for k, v in fit_t.items() if k.endswith("_ms")},
-            "roofline": {"kernel": "trmv_kernel x2 (bordered append: l = L^-1 k, v = L^-T l)", "bound": "hbm",
-                         "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
-                         "note": "algorithmic bytes 8*N^2 per append; duration = host wall-clock of the synchronous "
-                                 "abo_append call (includes the k-row kernel and two tiny kernels)"},
+            "roofline": roof,
+            "secondary_roofline": {"kernel": "trmv_kernel x2 (bordered append: l = L^-1 k, v = L^-T l)", "bound": "hbm",
+                                   "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                                   "note": "algorithmic bytes 8*N^2 per append; duration = host wall-clock of the synchronous "
+                                           "abo_append call (includes the k-row kernel, two tiny kernels and two host syncs)"},
             "phases_ms": med, "pairs_per_s_downdate": n_now * M_per / (med["downdate_ms"] * 1e-3),
             "last_batch": {"indices": [int(i) for i in picks[0]], "ei": [float(v) for v in picks[1]]},
         }

@@ -78,6 +78,8 @@ typedef struct abo_timings {
     double acq_kxz_ms, acq_var_gemm_ms, acq_finalize_ms, acq_topk_ms, acq_total_ms;
     int64_t var_gemm_launches;   /* number of launches of the dominant kernel in the last acq */
     double var_gemm_flop;        /* algorithmic flop (N²·M, triangular) those launches performed */
+    double downdate_ms;          /* last abo_cand_downdate on this handle: its O(N·M) pass (K_ZX mat-vec or kernel sweep) */
+    double downdate_bytes;       /* bytes of resident K_ZX that pass streamed (8·N·M); 0 when it re-evaluated the kernel */
 } abo_timings;
 
 /* --- lifetime -------------------------------------------------------------------------------
@@ -149,7 +151,9 @@ int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_spa
 /* --- resident candidate sets (BASELINE config 5: greedy q-EI over a fixed grid) --------------------
  * abo_cand_create copies M candidates to the device and evaluates their posterior with `gp`
  * (same arithmetic as abo_predict).  After `gp2 = abo_append(gp, x*, y*)`, abo_cand_downdate(gp2, c)
- * updates the stored posterior in O(N·M) instead of O(N²·M):
+ * updates the stored posterior in O(N·M) instead of O(N²·M) — as one streaming pass over the K_ZX the set keeps
+ * resident in HBM when M·N_max·8 bytes fit the budget (environment ABO_CAND_KZX_GIB, default 64; 0 = never), else
+ * by re-evaluating the kernel:
  *   c(z) = k(z,x*) − k_zᵀK⁻¹k_*,   σ²(z) −= c(z)²/l_nn²,   μ(z) += c(z)·(y* − μ(x*))/l_nn²
  * (ABO_EINVAL if gp2 is not the one-point append of the model the set was last synced with).
  * abo_cand_acq runs the EI/UCB/PI epilogue + top-k of abo_acq on the stored posterior;

@@ -196,3 +196,35 @@ def test_full_size_c5_append_and_downdate_consistency():
     assert np.max(np.abs(mu_c - mu_r)) < 1e-8 and np.max(np.abs(var_c - var_r)) < 1e-8
     assert abs(abo.nlml_fitted(m) - abo.nlml_fitted(ref)) < 1e-6 * abs(abo.nlml_fitted(ref))
     assert np.all(var_r > 0) and np.all(var_r < 1.0 + 1e-12)
+
+
+def test_resident_kzx_and_recomputed_downdates_agree(monkeypatch):
+    """The down-date streams a resident K_ZX when it fits the budget (ABO_CAND_KZX_GIB) and re-evaluates the kernel
+    otherwise: same posterior either way, including after a rollback that re-uses the appended columns and with
+    appends that cross a 128-row block boundary of the factor."""
+    d, N0 = 6, 250
+    X = synth.points(1, N0 + 12, d)
+    y = synth.objective(X, 0.02)
+    Z = synth.points(2, 3001, d)
+    out = {}
+    for mode in ("64", "0"):
+        monkeypatch.setenv("ABO_CAND_KZX_GIB", mode)
+        m0 = abo.update(make_model(O.MATERN52, 0.8, 1.3, 1e-3, n_max=N0 + 64), X[:N0], y[:N0])
+        cands = abo.ResidentCandidates(m0, Z)
+        cands.save()
+        m = m0
+        for j in range(3):                                   # fantasy branch, then rolled back
+            m = abo.append(m, Z[10 + j], 0.1 * j)
+            cands.downdate(m)
+        del m
+        cands.restore()
+        m = m0
+        for j in range(12):                                  # crosses row 256
+            m = abo.append(m, X[N0 + j], y[N0 + j])
+            cands.downdate(m)
+        out[mode] = cands.mean_and_var()
+    np.testing.assert_allclose(out["64"][0], out["0"][0], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["64"][1], out["0"][1], rtol=0, atol=1e-11)
+    st = O.fit(O.MATERN52, 0.8, 1.3, 1e-3, 0.0, X, y)
+    mu_o, var_o = O.predict(st, Z)
+    assert np.max(np.abs(out["64"][0] - mu_o)) < 1e-9 and np.max(np.abs(out["64"][1] - var_o)) < 1e-9
