@@ -623,12 +623,10 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     HIPCHK(launch_scale_points(Xraw + N * d, st->Xs.as<double>() + N * st->dp, 1, 1, d, st->dp, 1.0 / g->prm.ell, s));
     HIPCHK(launch_center(st->ybuf.as<double>() + N, st->delta.as<double>() + N, 1, 1, g->prm.mean_c, s));
     HIPCHK(hipMemsetAsync(n->info.p, 0, sizeof(int64_t), s));
-    // k = k(X, x*) into row 0 of a 16-row scratch
-    KgenArgs ka{};
-    ka.Xs = st->Xs.as<double>(); ka.Z = Xraw + N * d; ka.alpha = nullptr; ka.Kout = n->Kxz.as<double>(); ka.mu = nullptr;
-    ka.ldk = Np; ka.M = 1; ka.j0 = 0; ka.Mc = 16; ka.N = (int)N; ka.Np = (int)Np; ka.d = d; ka.dp = st->dp;
-    ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
-    HIPCHK(launch_kgen(ka, s));
+    // k = k(X, x*): one kernel evaluation per training point (the training points play the candidates of the
+    // column kernel; same scaled differences and the same kappa as kgen, so the values are bit-identical to a refit's)
+    HIPCHK(launch_cand_newcol(st->Xs.as<double>() + N * st->dp, Xraw, n->Kxz.as<double>(), 1, N, 0, d, st->dp, g->prm.family,
+                              1.0 / g->prm.ell, g->prm.sigma_f2, s));
     double* krow = n->Kxz.as<double>();
     double* lvec = n->tvec.as<double>();
     double* vvec = n->tvec.as<double>() + ld;

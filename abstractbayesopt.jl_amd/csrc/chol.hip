@@ -233,27 +233,54 @@ hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0
     return hipGetLastError();
 }
 
-// one wave per row; lanes stride the row in 16-byte pieces; xor-tree reduction (fixed order)
+// out[r] = Σ_k Wm[r][k]·v[k] over the triangular part of rows r < Np (lower: k ≤ r; upper: r ≤ k < Np).
+// One wave per 4 consecutive rows: the four rows share every 16-byte load of v, lanes stride k by 128, partial sums
+// per lane and then the fixed xor tree (deterministic).  The k range is that of the longest of the four rows — the
+// entries it adds for the shorter ones are structural zeros of the triangular factor — and v is masked at the range
+// end, so stale values beyond Np (the remains of a discarded append) never enter.  HBM-bound: 4·Np² bytes.
 __global__ void __launch_bounds__(256) trmv_kernel(const double* __restrict__ Wm, int64_t ld, const double* __restrict__ v,
                                                    double* __restrict__ out, int Np, int lower) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= Np) return;
-    int kb = lower ? 0 : (row & ~1);
-    int ke = lower ? row + 1 : Np;
-    const double* wr = Wm + (int64_t)row * ld;
-    double s = 0.0;
-    for (int k = kb + 2 * lane; k < ke; k += 128) {
-        s = fma(wr[k], v[k], s);
-        if (k + 1 < ke) s = fma(wr[k + 1], v[k + 1], s);
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= Np) return;
+    const int kb = lower ? 0 : (row0 & ~1);
+    const int ke = lower ? min(row0 + 4, Np) : Np;
+    const double* r0 = Wm + (int64_t)row0 * ld;
+    const double* r1 = r0 + (row0 + 1 < Np ? ld : 0);
+    const double* r2 = r0 + (row0 + 2 < Np ? 2 * ld : 0);
+    const double* r3 = r0 + (row0 + 3 < Np ? 3 * ld : 0);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int k = kb + 2 * lane; k < ke; k += 128) {          // ld is even and > k + 1: the pair load stays inside the row
+        d2_t vv = *reinterpret_cast<const d2_t*>(v + k);
+        if (k + 1 >= ke) vv[1] = 0.0;
+        const d2_t x0 = *reinterpret_cast<const d2_t*>(r0 + k);
+        const d2_t x1 = *reinterpret_cast<const d2_t*>(r1 + k);
+        const d2_t x2 = *reinterpret_cast<const d2_t*>(r2 + k);
+        const d2_t x3 = *reinterpret_cast<const d2_t*>(r3 + k);
+        a0 = fma(x0[1], vv[1], fma(x0[0], vv[0], a0));
+        a1 = fma(x1[1], vv[1], fma(x1[0], vv[0], a1));
+        a2 = fma(x2[1], vv[1], fma(x2[0], vv[0], a2));
+        a3 = fma(x3[1], vv[1], fma(x3[0], vv[0], a3));
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) out[row] = s;
+    for (int o = 32; o >= 1; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+        a3 += __shfl_xor(a3, o);
+    }
+    if (lane == 0) {
+        out[row0] = a0;
+        if (row0 + 1 < Np) out[row0 + 1] = a1;
+        if (row0 + 2 < Np) out[row0 + 2] = a2;
+        if (row0 + 3 < Np) out[row0 + 3] = a3;
+    }
 }
 
 hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* out, int Np, int lower, hipStream_t s) {
-    hipLaunchKernelGGL(trmv_kernel, dim3((Np + 3) / 4), dim3(256), 0, s, Wm, ld, v, out, Np, lower);
+    if (Np <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trmv_kernel, dim3((Np + 15) / 16), dim3(256), 0, s, Wm, ld, v, out, Np, lower);
     return hipGetLastError();
 }
 
