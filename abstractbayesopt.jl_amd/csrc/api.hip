@@ -319,28 +319,49 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     }
     HIPCHK(hipEventRecord(g->evs()[1], s));
 
-    const int T = Np / TB;
-    for (int p = 0; p < T; ++p) {
-        const int r0 = p * TB;
-        HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
-        const int rem = Np - r0 - TB;
-        if (rem <= 0) break;
-        GemmArgs a{};
-        // panel solve  L[r,p] = A[r,p] · Linv_ppᵀ   (in place; each workgroup owns its 128 rows)
-        a.A = K + (int64_t)(r0 + TB) * ld + r0; a.lda = ld;
-        a.B = W + (int64_t)r0 * ld + r0; a.ldb = ld;
-        a.C = K + (int64_t)(r0 + TB) * ld + r0; a.ldc = ld;
-        a.M = rem; a.N = TB; a.K = TB; a.kmode = K_FULL; a.lower_only = 0; a.batch = 1;
-        a.alpha = 1.0; a.beta = 0.0; a.info = info;
-        HIPCHK(launch_gemm_nt(a, s));
-        // trailing update  A[r,c] −= L[r,p]·L[c,p]ᵀ  on the lower triangle
-        GemmArgs u{};
-        u.A = K + (int64_t)(r0 + TB) * ld + r0; u.lda = ld;
-        u.B = u.A; u.ldb = ld;
-        u.C = K + (int64_t)(r0 + TB) * ld + (r0 + TB); u.ldc = ld;
-        u.M = rem; u.N = rem; u.K = TB; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
-        u.alpha = -1.0; u.beta = 1.0; u.info = info;
-        HIPCHK(launch_gemm_nt(u, s));
+    // Two-level blocking: inside a strip of SW columns the 128-wide panels update only the rest of the strip
+    // (K = 128 products on a tall, narrow block); the matrix behind the strip is updated once per strip with
+    // K = SW — a quarter of the read-modify-write passes over the trailing matrix and four times longer k loops
+    // per tile than a panel-by-panel SYRK.
+    const char* swe = getenv("ABO_CHOL_STRIP");
+    const int SW = swe ? atoi(swe) : 512;
+    for (int s0 = 0; s0 < Np; s0 += SW) {
+        const int sw = (Np - s0) < SW ? (Np - s0) : SW;
+        for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
+            HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
+            const int rem = Np - r0 - TB;
+            if (rem <= 0) break;
+            GemmArgs a{};
+            // panel solve  L[r,p] = A[r,p] · Linv_ppᵀ   (in place; each workgroup owns its rows)
+            a.A = K + (int64_t)(r0 + TB) * ld + r0; a.lda = ld;
+            a.B = W + (int64_t)r0 * ld + r0; a.ldb = ld;
+            a.C = K + (int64_t)(r0 + TB) * ld + r0; a.ldc = ld;
+            a.M = rem; a.N = TB; a.K = TB; a.kmode = K_FULL; a.lower_only = 0; a.batch = 1;
+            a.alpha = 1.0; a.beta = 0.0; a.info = info;
+            HIPCHK(launch_gemm_nt(a, s));
+            // in-strip update  A[r,c] −= L[r,p]·L[c,p]ᵀ  for the strip's remaining columns c, lower tiles only
+            const int ncol = s0 + sw - r0 - TB;
+            if (ncol > 0) {
+                GemmArgs u{};
+                u.A = K + (int64_t)(r0 + TB) * ld + r0; u.lda = ld;
+                u.B = u.A; u.ldb = ld;
+                u.C = K + (int64_t)(r0 + TB) * ld + (r0 + TB); u.ldc = ld;
+                u.M = rem; u.N = ncol; u.K = TB; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+                u.alpha = -1.0; u.beta = 1.0; u.info = info;
+                HIPCHK(launch_gemm_nt(u, s));
+            }
+        }
+        const int rest = Np - s0 - sw;
+        if (rest > 0) {
+            // trailing update behind the strip  A[r,c] −= L[r,strip]·L[c,strip]ᵀ  on the lower triangle, K = sw
+            GemmArgs u{};
+            u.A = K + (int64_t)(s0 + sw) * ld + s0; u.lda = ld;
+            u.B = u.A; u.ldb = ld;
+            u.C = K + (int64_t)(s0 + sw) * ld + (s0 + sw); u.ldc = ld;
+            u.M = rest; u.N = rest; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+            u.alpha = -1.0; u.beta = 1.0; u.info = info;
+            HIPCHK(launch_gemm_nt(u, s));
+        }
     }
     HIPCHK(hipEventRecord(g->evs()[2], s));
     HIPCHK(hipMemcpyAsync(info_host, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));

@@ -313,7 +313,12 @@ __global__ void __launch_bounds__(256) gemm_nt_rowpanel_kernel(GemmArgs p) {
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
     const int64_t Tm = a.M / BM, Tn = a.N / BN;
-    const int64_t tiles = (a.lower_only ? Tm * (Tm + 1) / 2 : Tm * Tn) * a.batch;
+    int64_t tiles = Tm * Tn;
+    if (a.lower_only) {                                              // tiles (ti, tj ≤ ti), tj < Tn
+        const int64_t q = Tm < Tn ? Tm : Tn;
+        tiles = q * (q + 1) / 2 + (Tm - q) * Tn;
+    }
+    tiles *= a.batch;
     const char* fe = getenv("ABO_GEMM_SMALL");                      // A/B runs and tests: 0 never, 1 always
     const int force = fe ? atoi(fe) : -1;
     const bool small = force >= 0 ? force == 1 : tiles <= 64;      // measured crossover: small ≈ tiles·K·1.7 ns, tiled ≈ 6 µs + K·0.11 µs
