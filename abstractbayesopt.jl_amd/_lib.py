@@ -10,7 +10,7 @@ ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
 HOST, DEVICE = 0, 1
 
 EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
-           "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
+           "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
            "abo_test_gemm_nt", "abo_test_kappa"]
 
@@ -87,6 +87,7 @@ def lib():
     L.abo_cand_acq.argtypes = [vp, vp, i32, f64, f64, i64, vp, i32, vp, vp, i32]
     L.abo_cand_get.argtypes = [vp, vp, vp, vp, i32]
     L.abo_cand_point.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.abo_cand_exclude.argtypes = [vp, vp, i64]
     L.abo_predict.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
     L.abo_acq.argtypes = [vp, vp, i64, i32, i32, i32, f64, f64, i64, vp, i32, vp, vp, i32]
     L.abo_nlml.argtypes = [vp, C.POINTER(f64)]

@@ -1261,6 +1261,18 @@ int32_t abo_cand_point(abo_gp* g, abo_cand* c, int64_t idx, double* x, double* m
     return ABO_OK;
 }
 
+int32_t abo_cand_exclude(abo_gp* g, abo_cand* c, int64_t idx) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_exclude: null argument");
+    if (idx < 0 || idx >= c->M) return fail(ABO_EINVAL, "abo_cand_exclude: index %lld outside 0..%lld", (long long)idx, (long long)c->M - 1);
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const double excl[2] = {HUGE_VAL, 0.0};                 // μ = +Inf, σ² = 0: EI = PI = 0, UCB = −Inf
+    HIPCHK(hipMemcpyAsync(c->mu.as<double>() + idx, &excl[0], sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->var.as<double>() + idx, &excl[1], sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ABO_OK;
+}
+
 int32_t abo_pool_trim(int32_t device) {
     if (device < 0 || device > 15) return fail(ABO_EINVAL, "abo_pool_trim: bad device %d", device);
     HIPCHK(hipSetDevice(device));

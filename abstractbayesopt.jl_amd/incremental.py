@@ -60,6 +60,10 @@ class ResidentCandidates:
         _lib.check(_lib.lib().abo_cand_refresh(model._require(), self._h.ptr))
         self.model = model
 
+    def exclude(self, idx: int):
+        """Take candidate `idx` (local index) out of the running until the next refresh / restore."""
+        _lib.check(_lib.lib().abo_cand_exclude(self.model._require(), self._h.ptr, int(idx)))
+
     def downdate(self, model: HipStandardGP):
         """`model` must be `append(self.model, x, y)`: O(N·M) update of the stored μ, σ²."""
         _lib.check(_lib.lib().abo_cand_downdate(model._require(), self._h.ptr))
@@ -111,13 +115,15 @@ class ResidentCandidates:
 
 
 def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: float, best_y: float, idx_base: int = 0,
-               group=None):
+               group=None, distinct: bool = False):
     """Greedy q-EI (Kriging believer): for j = 1..q  pick argmax EI over the resident grid, condition on the
     fantasy (z_j, μ(z_j)) with a bordered append, down-date the grid's posterior, repeat.
     With torch.distributed initialised (`group`), every rank holds a shard of the grid: the arg-max is the
     only exchange (one all_gather of (score, global index, μ, x[d]) per pick) and every rank applies the
     same append.  Returns (batch points (q, d), their global indices, their EI values, the final model).
-    `cands` must be in sync with `model`; on return it is in sync with the returned model."""
+    `cands` must be in sync with `model`; on return it is in sync with the returned model.
+    distinct=True takes every picked candidate out of the running (abo_cand_exclude): with observation noise the
+    fantasy does not collapse the variance at a picked point, and the plain rule may return it again."""
     acq = ExpectedImprovement(xi, best_y)
     picks, idxs, vals = [], [], []
     dist = None
@@ -135,6 +141,8 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
         score, gidx, mu, x = rec[0], int(rec[1]), rec[2], rec[3:]
         model = append(model, x, mu)           # fantasy observation y = μ(x): β = 0, only σ² changes
         cands.downdate(model)
+        if distinct and idx_base <= gidx < idx_base + cands.M:
+            cands.exclude(gidx - idx_base)     # the rank that owns the candidate masks it
         picks.append(x.copy()); idxs.append(gidx); vals.append(score)
     return np.array(picks), np.array(idxs, dtype=np.int64), np.array(vals), model
 

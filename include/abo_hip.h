@@ -171,6 +171,10 @@ int32_t abo_cand_acq(abo_gp* gp, abo_cand* c, int32_t kind, double p0, double be
                      double* scores, int32_t k, double* top_val, int64_t* top_idx, int32_t out_space);
 int32_t abo_cand_get(abo_gp* gp, abo_cand* c, double* mu, double* var, int32_t out_space);
 int32_t abo_cand_point(abo_gp* gp, abo_cand* c, int64_t idx, double* x, double* mu, double* var);
+/* takes candidate idx out of the running until the next refresh / restore: its stored posterior becomes (μ = +Inf,
+ * σ² = 0), so EI = PI = 0 and UCB = −Inf there.  Greedy q-EI uses it (opt-in) to return q distinct points: with
+ * observation noise the Kriging-believer fantasy does not collapse the variance at a picked point. */
+int32_t abo_cand_exclude(abo_gp* gp, abo_cand* c, int64_t idx);
 
 /* --- grid generation and stand-alone epilogue (DEVICE buffers) --------------------------------------
  * abo_lhs: points j0 .. j0+count−1 of an n-point Latin-hypercube design in the box [lower, upper]

@@ -116,4 +116,4 @@ function append(m::HipStandardGP, x::AbstractVector{Float64}, y::Float64)       
 end
 # update(BO, x, y, i) (bayesian_opt.jl:113-150) can call `append(BO.model, x, y)` instead of
 # `update(BO.model, BO.xs, BO.ys)`; `prev_gp = copy(BO.model)` stays valid because rows ≤ N are never touched.
-# Resident grids for q-EI: abo_cand_create / abo_cand_acq / abo_cand_downdate / abo_cand_save / abo_cand_restore.
+# Resident grids for q-EI: abo_cand_create / abo_cand_acq / abo_cand_downdate / abo_cand_save / abo_cand_restore / abo_cand_exclude.

@@ -228,3 +228,26 @@ def test_resident_kzx_and_recomputed_downdates_agree(monkeypatch):
     st = O.fit(O.MATERN52, 0.8, 1.3, 1e-3, 0.0, X, y)
     mu_o, var_o = O.predict(st, Z)
     assert np.max(np.abs(out["64"][0] - mu_o)) < 1e-9 and np.max(np.abs(out["64"][1] - var_o)) < 1e-9
+
+
+def test_greedy_qei_distinct_batch_under_noise():
+    """With observation noise the Kriging-believer rule may return a candidate twice; distinct=True excludes picked
+    candidates (their EI becomes 0) and the saved posterior comes back untouched on restore."""
+    d, N = 3, 120
+    X = synth.points(1, N, d)
+    y = synth.objective(X, 0.1)
+    Z = synth.points(2, 4000, d)
+    m = abo.update(make_model(O.MATERN52, 0.6, 1.0, 5e-2, n_max=N + 32), X, y)
+    cands = abo.ResidentCandidates(m, Z)
+    mu0, var0 = cands.mean_and_var()
+    cands.save()
+    pts, idxs, vals, _ = abo.greedy_qei(m, cands, 6, 0.0, float(y.min()), distinct=True)
+    assert len(set(idxs.tolist())) == 6
+    np.testing.assert_array_equal(pts, Z[idxs])
+    assert np.all(np.diff(vals) <= 1e-12) or np.all(vals >= 0)
+    s, _, _ = cands.evaluate(abo.ExpectedImprovement(0.0, float(y.min())), k=1, return_scores=True)
+    assert np.all(s[idxs] == 0.0)
+    cands.restore()
+    mu1, var1 = cands.mean_and_var()
+    np.testing.assert_array_equal(mu1, mu0)
+    np.testing.assert_array_equal(var1, var0)
