@@ -1,9 +1,10 @@
 // fp64 MFMA tile core for gfx950 and the kernels built on it:
 //   gemm_nt_kernel      C = alpha·A·Bᵀ + beta·C   (TRSM panel, SYRK trailing update, blocked L⁻¹, K⁻¹, V = L⁻¹K_XZ)
-//   var_gemm256_kernel  partial[ti][j] = Σ_{i∈ti} (W·K_XZ)[i][j]²  — the N²·M contraction that is
-//   var_gemm_kernel     >99 % of the flops of posterior_var (reference: src/surrogates/StandardGP.jl:377-379,
-//                       [upstream AbstractGPs] diag_Xt_invA_X(C, K_XZ)); 256×128 tile per 8-wave workgroup
-//                       (production) and 128×128 tile per 4-wave workgroup (Np an odd number of 128-blocks).
+//   var_gemm256s_kernel partial[ti][j] = Σ_{i∈ti} (W·K_XZ)[i][j]²  — the N²·M contraction that is
+//   var_gemm256_kernel  >99 % of the flops of posterior_var (reference: src/surrogates/StandardGP.jl:377-379,
+//   var_gemm_kernel     [upstream AbstractGPs] diag_Xt_invA_X(C, K_XZ)); 256×128 tile per 8-wave workgroup with the
+//                       zero sub-tiles of the diagonal blocks skipped (production), the same tile without the
+//                       skipping (A/B reference), and a 128×128 tile per 4-wave workgroup (Np an odd number of blocks).
 //
 // Design (CDNA4):
 //  * v_mfma_f64_16x16x4_f64 issues every 64 cycles per SIMD (measured: profiles/r01_mfma_f64_probe.txt,
@@ -521,11 +522,180 @@ __global__ void __launch_bounds__(512, 2) var_gemm256_kernel(VarGemmArgs p) {
     }
 }
 
+// 256×128 tile with the structural zeros of the diagonal blocks skipped at 16-row granularity (production):
+// same pipeline as var_gemm256_kernel, but wave (wm, wn) owns the 16-row sub-tiles {wm, wm+4, wm+8, wm+12} of the
+// 256 rows instead of 64 consecutive rows, so that every wave — and with it every SIMD — loses the same share of
+// MFMAs when the k loop runs through the two triangular diagonal blocks.  The 128-granular tiling spends a factor
+// 1 + 128/N of the credited flops (1.6 % at N = 8192, 12.5 % at N = 1024); this one 1 + 16/N.  Measured
+// (tools/skip_experiment.sh): C3 contraction 962 → 955 ms, C2 1.17 → 1.12 ms.
+__global__ void __launch_bounds__(512, 2) var_gemm256s_kernel(VarGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * STAGE2];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int Tj = p.Mc / BN;
+    const int Ti2 = p.Np / BM2;
+    const int b = blockIdx.x;
+    const int ti2 = Ti2 - 1 - b / Tj;
+    const int tj = b % Tj;
+    const double* __restrict__ Ag = p.W + (int64_t)ti2 * BM2 * p.ldw;
+    const double* __restrict__ Bg = p.Kxz + (int64_t)tj * BN * p.ldk;
+    const int nk = (ti2 + 1) * (BM2 / BK);
+    const int srow = t >> 3, skk = (t & 7) * 2;
+    const int aoff = (wm * 16 + r16) * LDT + g * 2;           // A fragment i: 16-row sub-tile wm + 4·i of the 256 rows
+    const int boff = (BM2 + wn * 64 + r16) * LDT + g * 2;
+    d2_t sa[4], sb[2];
+    Frag f0, f1;
+    d4_t acc[4][4];
+    acc_zero(acc);
+
+#define G_LOAD(k0)                                                                                              \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                           \
+            sa[q] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)(srow + 64 * q) * p.ldw + (k0) + skk);         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
+            sb[q] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(srow + 64 * q) * p.ldk + (k0) + skk);         \
+    } while (0)
+#define L_STORE(buf)                                                                                            \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                           \
+            *reinterpret_cast<d2_t*>((buf) + (srow + 64 * q) * LDT + skk) = sa[q];                              \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
+            *reinterpret_cast<d2_t*>((buf) + (BM2 + srow + 64 * q) * LDT + skk) = sb[q];                        \
+    } while (0)
+
+#define FRAG_READ(buf, half, f)                                                                                  \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+            (f).a[i] = *reinterpret_cast<const d2_t*>((buf) + aoff + i * 64 * LDT + (half) * 8);                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+            (f).b[i] = *reinterpret_cast<const d2_t*>((buf) + boff + i * 16 * LDT + (half) * 8);                \
+    } while (0)
+#define MMA_FROM(KK, f, a0)                                                                                     \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                        \
+            if (mi >= (a0)) {                                                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64((f).a[mi][KK], (f).b[ni][KK], acc[mi][ni], 0, 0, 0); \
+            }                                                                                                   \
+    } while (0)
+
+    G_LOAD(0);
+    L_STORE(smem);
+    G_LOAD(BK);                                             // nk ≥ 16
+    __syncthreads();
+    FRAG_READ(smem, 0, f0);
+    int st = 0;
+    for (; st < nk - 16; ++st) {                            // left of both diagonal blocks: every sub-tile is dense
+        double* cur = smem + (st & 1) * STAGE2;
+        double* nxt = smem + ((st + 1) & 1) * STAGE2;
+        L_STORE(nxt);
+        FRAG_READ(cur, 1, f1);
+        G_LOAD((st + 2) * BK);
+        frag_mma<0>(f0, acc);
+        frag_mma<1>(f0, acc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        FRAG_READ(nxt, 0, f0);
+        frag_mma<0>(f1, acc);
+        frag_mma<1>(f1, acc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 24, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // The last 16 stages run through the two diagonal 128-blocks of W (upper block: stages nk−16..nk−9, lower block:
+    // the last 8).  In stage s of a diagonal block the 16-row sub-tile m of that block is non-zero only for m ≥ s,
+    // and the upper block is zero throughout the last 8 stages: fragment i of this wave (sub-tiles wm, wm+4 of the
+    // upper block, then wm, wm+4 of the lower block) is skipped when it is structurally zero.  The live set is
+    // always {a0..3}; the interleaved row ↔ wave map keeps the skipped work spread over the four SIMDs.
+    // (Giving these stages the dealt-out schedule of the main loop, one copy per live set, spills 700 VGPRs.)
+    for (; st < nk; ++st) {
+        const int s16 = st - (nk - 16);
+        int a0;
+        if (s16 < 8) a0 = s16 > wm + 4 ? 2 : (s16 > wm ? 1 : 0);
+        else a0 = (s16 - 8) > wm + 4 ? 4 : ((s16 - 8) > wm ? 3 : 2);
+        double* cur = smem + (st & 1) * STAGE2;
+        double* nxt = smem + ((st + 1) & 1) * STAGE2;
+        MMA_FROM(0, f0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        FRAG_READ(cur, 1, f1);
+        if (st + 1 < nk) {
+            L_STORE(nxt);
+            if (st + 2 < nk) G_LOAD((st + 2) * BK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MMA_FROM(1, f0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (st + 1 < nk) FRAG_READ(nxt, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        MMA_FROM(0, f1, a0);
+        MMA_FROM(1, f1, a0);
+    }
+    __syncthreads();
+#undef G_LOAD
+#undef L_STORE
+#undef FRAG_READ
+#undef MMA_FROM
+
+    // column sums of squares per 128-row block: fragments 0,1 belong to the upper block, 2,3 to the lower one;
+    // registers → lanes sharing a column (xor 16, 32) → the four wm waves in order (LDS): fixed order, deterministic
+    double* red = smem;                                     // [2 halves][4 wm][128]
+    const int row0 = ti2 * BM2 + wm * 16 + g;
+    const bool edge = (ti2 + 1) * BM2 > p.nvalid;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            double sq = 0.0;
+#pragma unroll
+            for (int mi = 2 * half; mi < 2 * half + 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = acc[mi][ni][r];
+                    if (edge && row0 + mi * 64 + 4 * r >= p.nvalid) v = 0.0;
+                    sq = fma(v, v, sq);
+                }
+            sq += __shfl_xor(sq, 16);
+            sq += __shfl_xor(sq, 32);
+            if (lane < 16) red[(half * 4 + wm) * 128 + wn * 64 + ni * 16 + lane] = sq;
+        }
+    }
+    __syncthreads();
+    if (t < 256) {
+        const int half = t >> 7, c = t & 127;
+        const double* rh = red + half * 4 * 128 + c;
+        p.partial[(int64_t)(2 * ti2 + half) * p.ldp + (int64_t)tj * BN + c] = ((rh[0] + rh[128]) + rh[256]) + rh[384];
+    }
+}
+
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s) {
     if (a.Np % BM2 == 0 && !a.force128) {
         const int tiles2 = (a.Np / BM2) * (a.Mc / BN);
         if (tiles2 <= 0) return hipSuccess;
-        hipLaunchKernelGGL(var_gemm256_kernel, dim3(tiles2), dim3(512), 0, s, a);
+        if (getenv("ABO_VAR_NOSKIP")) hipLaunchKernelGGL(var_gemm256_kernel, dim3(tiles2), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(var_gemm256s_kernel, dim3(tiles2), dim3(512), 0, s, a);
         return hipGetLastError();
     }
     const int tiles = (a.Np / BM) * (a.Mc / BN);

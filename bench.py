@@ -394,7 +394,7 @@ def main():
                        "sharding": f"candidates x{world}, all_gather top-{K_TOP}"},
             "candidates_per_s": M_total / (ms_per_step * 1e-3),
             "roofline": {
-                "kernel": "var_gemm_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
+                "kernel": "var_gemm256s_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,

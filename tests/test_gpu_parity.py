@@ -505,10 +505,12 @@ def test_device_latin_hypercube():
     assert np.all(np.diff(vals) <= 0)
 
 
-def test_both_contraction_tilings_agree_bit_for_bit(monkeypatch):
-    """var_gemm256_kernel (256×128 tile, production when Np % 256 == 0) and var_gemm_kernel (128×128) write the
-    same per-row-block partial sums in the same order: switching between them (ABO_TILE128, A/B hook) must not
-    change a single bit, including on an appended view whose last row block carries masked stale rows."""
+def test_contraction_tilings_agree(monkeypatch):
+    """Three tilings of the N²·M contraction: the production kernel (256×128 tile, structural zeros of the diagonal
+    blocks skipped at 16-row granularity, interleaved row ↔ wave map), the plain 256×128 kernel (ABO_VAR_NOSKIP) and
+    the 128×128 kernel (ABO_TILE128; used when Np is an odd number of blocks).  The last two sum in the same order and
+    must agree bit for bit; the production kernel sums the same squares in another order (≤ a few ulp of σ_f²) —
+    including on an appended view whose last row block carries masked stale rows."""
     X, y = synth.standardized_problem(700, 5, 0.05)          # Np = 768 = 3 × 256
     Z = synth.points(2, 3000, 5)
     m = abo.update(make_model(O.MATERN52, 0.9, 1.0, 1e-3, n_max=768), X, y)
@@ -516,16 +518,19 @@ def test_both_contraction_tilings_agree_bit_for_bit(monkeypatch):
     dead = abo.append(m2, Z[2], 0.0)                          # a discarded branch leaves a stale factor row
     del dead
     out = {}
-    for mode in ("256", "128"):
+    for mode in ("skip", "256", "128"):
+        monkeypatch.delenv("ABO_TILE128", raising=False)
+        monkeypatch.delenv("ABO_VAR_NOSKIP", raising=False)
         if mode == "128":
             monkeypatch.setenv("ABO_TILE128", "1")
-        else:
-            monkeypatch.delenv("ABO_TILE128", raising=False)
+        if mode == "256":
+            monkeypatch.setenv("ABO_VAR_NOSKIP", "1")
         out[mode] = (abo.posterior_var(m, Z), abo.posterior_var(m2, Z))
-    np.testing.assert_array_equal(out["256"][0], out["128"][0])
-    np.testing.assert_array_equal(out["256"][1], out["128"][1])
+    for v in (0, 1):
+        np.testing.assert_array_equal(out["256"][v], out["128"][v])
+        np.testing.assert_allclose(out["skip"][v], out["128"][v], rtol=0, atol=1e-14)
     st = O.fit(O.MATERN52, 0.9, 1.0, 1e-3, 0.0, np.vstack([X, Z[:2]]), np.append(y, [0.3, -0.2]))
-    assert np.max(np.abs(out["256"][1] - O.predict(st, Z)[1])) < 1e-9
+    assert np.max(np.abs(out["skip"][1] - O.predict(st, Z)[1])) < 1e-9
 
 
 def test_near_singular_and_extreme_hyperparameters():
