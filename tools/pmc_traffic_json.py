@@ -1,0 +1,39 @@
+"""profiles/<tag>_c3_pmc_traffic.json from a pmc summary (tools/pmc_summary.py output): per-launch HBM-side traffic of
+the dominant kernel with the gfx950 correction the micro-architecture guide prescribes (FETCH_SIZE counts 64 B per
+128-B request of a 16-B/lane stream -> x2; WRITE_SIZE exact; both in KB), plus MFMA-busy fraction and held clock.
+usage: python tools/pmc_traffic_json.py <summary.txt> <N> <Mc_per_launch> > profiles/r01_c3_pmc_traffic.json"""
+import json, re, sys
+
+path, N, Mc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+blocks, cur = {}, None
+for line in open(path):
+    if line.startswith("== "):
+        cur = line[3:].strip()
+        blocks[cur] = {}
+    elif line.startswith("dur["):
+        m = re.match(r"dur\[(.*?)\] (.*): n=\d+ mean=([0-9.]+) us", line)
+        if m:
+            blocks.setdefault("_dur", {})[(m.group(1), m.group(2))] = float(m.group(3))
+    elif cur and "mean=" in line:
+        name = line.split()[0]
+        blocks[cur][name] = float(re.search(r"mean=([0-9.e+-]+)", line).group(1))
+kern = next(k for k in blocks if k.startswith("abo::var_gemm"))
+c = blocks[kern]
+fetch_kb, write_kb = c["FETCH_SIZE"], c["WRITE_SIZE"]
+traffic = fetch_kb * 1024 * 2 + write_kb * 1024
+busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)      # per-SIMD busy / per-XCD active
+durs = [v for (p, k), v in blocks.get("_dur", {}).items() if k == kern]
+dur_us = sum(durs) / len(durs) if durs else None
+out = {
+    "source": f"{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ / GRBM, separate passes, tools/run_pmc.sh)",
+    "kernel": kern.replace("abo::", ""), "N": N, "Mc_per_launch": Mc,
+    "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb,
+    "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a 16-B/lane stream -> x2 (MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
+    "traffic_bytes_per_launch": traffic, "traffic_bytes_per_candidate": traffic / Mc,
+    "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + Mc * N + (N / 128) * Mc),
+    "avg_launch_ms_under_pmc": dur_us / 1e3 if dur_us else None,
+    "mfma_busy_frac": busy,
+    "clock_ghz": (c["GRBM_GUI_ACTIVE"] / 8.0) / (dur_us * 1e3) if dur_us else None,
+    "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT"),
+}
+print(json.dumps(out, indent=1))
