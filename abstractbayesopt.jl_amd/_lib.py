@@ -11,7 +11,7 @@ HOST, DEVICE = 0, 1
 
 EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
-           "abo_get_factor", "abo_get_n", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
+           "abo_get_factor", "abo_get_n", "abo_get_data", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
            "abo_test_gemm_nt", "abo_test_kappa"]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.abo_score.argtypes = [i32, vp, vp, i64, i32, f64, f64, vp]
     L.abo_get_factor.argtypes = [vp, vp, vp, vp]
     L.abo_get_n.argtypes = [vp, C.POINTER(i64), C.POINTER(i32)]
+    L.abo_get_data.argtypes = [vp, vp, vp]
     L.abo_get_timings.argtypes = [vp, C.POINTER(AboTimings)]
     L.abo_last_error.argtypes = [C.c_char_p, C.c_size_t]
     L.abo_abi_version.argtypes = []

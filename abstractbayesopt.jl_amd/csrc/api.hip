@@ -1056,6 +1056,17 @@ int32_t abo_get_factor(abo_gp* g, double* L, double* alpha, double* Linv) {
     return ABO_OK;
 }
 
+int32_t abo_get_data(abo_gp* g, double* X, double* y) {
+    if (!g) return fail(ABO_EINVAL, "null handle");
+    if (!g->fitted) return fail(ABO_EINVAL, "surrogate is not conditioned on data yet (call abo_fit first)");
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    if (X) HIPCHK(hipMemcpyAsync(X, g->st->Xraw.p, sizeof(double) * g->npts * g->d, hipMemcpyDeviceToHost, s));
+    if (y) HIPCHK(hipMemcpyAsync(y, g->st->ybuf.p, sizeof(double) * g->N, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ABO_OK;
+}
+
 // ---- resident candidate sets (C5: greedy q-EI on a fixed grid with O(N·M) down-dates) ------------
 static int32_t cand_topk(abo_gp* g, abo_cand* c, const double* sc_d, int32_t k, int64_t idx_base, double* top_val,
                          int64_t* top_idx, int32_t out_space) {

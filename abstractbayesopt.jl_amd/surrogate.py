@@ -123,6 +123,23 @@ class HipStandardGP(AbstractSurrogate):
         _lib.check(_lib.lib().abo_get_timings(self._require(), C.byref(t)))
         return t.as_dict()
 
+    # Checkpoint / resume: the reference has no serialisation code, a BOStruct is rebuilt from (xs, ys, hyper-
+    # parameters) (bayesian_opt.jl:81).  A pickled model is exactly that — hyper-parameters plus the training data
+    # read back from the device — and unpickling refits on the current device.
+    def __getstate__(self):
+        st = {k: v for k, v in self.__dict__.items() if k != "_h"}
+        st["_data"] = training_data(self) if self._h is not None else None
+        return st
+
+    def __setstate__(self, st):
+        data = st.pop("_data", None)
+        self.__dict__.update(st)
+        self._h = None
+        self.device = _current_device()
+        if data is not None:
+            import abstractbayesopt.jl_amd as _pkg
+            self._h = _pkg.update(self, data[0], data[1])._h
+
     def __copy__(self):
         return copy(self)
 
@@ -315,3 +332,16 @@ def get_factor(model: HipStandardGP):
     Lm, Li, al = np.empty((N, N)), np.empty((N, N)), np.empty(N)
     _lib.check(Lb.abo_get_factor(model._require(), Lm.ctypes.data, al.ctypes.data, Li.ctypes.data))
     return Lm, al, Li
+
+
+def training_data(model: HipStandardGP):
+    """(X, y) the model is conditioned on, read back from the device: X (N, d) and y (N,) — for a gradient-enhanced
+    model y is (N, p), one row [f, ∇f] per point, the shape `update` takes."""
+    n = C.c_int64()
+    d = C.c_int32()
+    Lb = _lib.lib()
+    _lib.check(Lb.abo_get_n(model._require(), C.byref(n), C.byref(d)))
+    p = getattr(model, "p", 1)
+    X, y = np.empty((n.value, d.value)), np.empty(n.value * p)
+    _lib.check(Lb.abo_get_data(model._require(), X.ctypes.data, y.ctypes.data))
+    return X, (y if p == 1 else np.ascontiguousarray(y.reshape(p, n.value).T))

@@ -205,6 +205,11 @@ int32_t abo_nlml_grad(abo_gp* gp, double* nlml, double* d_log_ell, double* d_log
  * NULL.  Host buffers. */
 int32_t abo_get_factor(abo_gp* gp, double* L, double* alpha, double* Linv);
 int32_t abo_get_n(abo_gp* gp, int64_t* N, int32_t* d);
+/* the training data the model is conditioned on, back to host buffers: X (points × d, point-major) and y (factor rows:
+ * one per point, or p per point ordered by outputs for a gradient-enhanced model).  The reference keeps no
+ * serialisation code; its BOStruct is rebuilt from (xs, ys, hyper-parameters) (src/bayesian_opt.jl:81,:163-165) —
+ * this is the device-side half of that: checkpoint = hyper-parameters + these arrays, resume = abo_fit. */
+int32_t abo_get_data(abo_gp* gp, double* X, double* y);
 int32_t abo_get_timings(abo_gp* gp, abo_timings* out);
 
 /* --- memory -----------------------------------------------------------------------------------

@@ -564,3 +564,30 @@ def test_kernel_matrix_symmetry_and_psd_through_the_factor():
         Ko = O.kernel_matrix(fam, 0.7, 1.4, X) + 1e-4 * np.eye(200)
         assert np.max(np.abs(K - Ko)) < 1e-12 and np.max(np.abs(K - K.T)) == 0.0
         assert np.all(np.diag(L) > 0) and np.all(np.triu(L, 1) == 0)
+
+
+def test_checkpoint_resume_by_pickle():
+    """Checkpoint = hyper-parameters + the training data read back from the device (abo_get_data); resume = refit.
+    (The reference has no serialisation code: a BOStruct is rebuilt from xs, ys and hyper-parameters.)"""
+    import pickle
+    X, y = synth.standardized_problem(200, 3, 0.05)
+    Z = synth.points(2, 500, 3)
+    m = abo.update(make_model(O.MATERN52, 0.8, 1.4, 1e-3, mean_c=0.2, n_max=256), X, y)
+    Xb, yb = abo.training_data(m)
+    np.testing.assert_array_equal(Xb, X)
+    np.testing.assert_array_equal(yb, y)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2.gp == m.gp and m2.noise_var == m.noise_var and m2.gpx is not None and m2.gpx is not m.gpx
+    np.testing.assert_array_equal(abo.posterior_mean(m2, Z), abo.posterior_mean(m, Z))     # same data, same kernels
+    np.testing.assert_array_equal(abo.posterior_var(m2, Z), abo.posterior_var(m, Z))
+    ma = abo.append(m, Z[0], 0.3)                                                          # appended view → refit
+    mb = pickle.loads(pickle.dumps(ma))
+    assert abo.training_data(mb)[0].shape == (201, 3)
+    np.testing.assert_allclose(abo.posterior_var(mb, Z), abo.posterior_var(ma, Z), rtol=0, atol=1e-11)
+    empty = pickle.loads(pickle.dumps(make_model(O.SE, 1.0, 1.0, 0.1)))
+    assert empty.gpx is None
+    g = abo.update(abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1), [[0.0, 0.0], [0.5, 0.5], [1.0, 1.0]],
+                   [[1.0, 0.1, 0.1], [0.5, 0.0, 0.0], [0.0, -0.1, -0.1]])
+    g2 = pickle.loads(pickle.dumps(g))
+    assert isinstance(g2, abo.GradientGP) and g2.p == 3
+    np.testing.assert_array_equal(abo.posterior_grad_mean(g2, [[0.25, 0.25]]), abo.posterior_grad_mean(g, [[0.25, 0.25]]))
