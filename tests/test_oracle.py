@@ -162,3 +162,13 @@ def test_grad_kernel_blocks_against_finite_differences():
     Kxx = G.grad_kernel_matrix(O.MATERN52, 0.7, 1.9, rng.normal(size=(5, 2)))
     np.testing.assert_allclose(Kxx, Kxx.T, atol=1e-15)
     assert np.all(np.linalg.eigvalsh(Kxx) > -1e-10)
+
+
+def test_c_oracle_under_address_and_ub_sanitizers():
+    """sanitizers run on the CPU build only (none exist for the GPU on this pool).  oracle/selftest.c drives
+    the plain-C restatement through the reference's closed-form cases, the not-PD case, an empty training set and a
+    heap-allocated random case under -fsanitize=address,undefined."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan-check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
