@@ -254,10 +254,10 @@ __global__ void __launch_bounds__(256) trmv_kernel(const double* __restrict__ Wm
     for (int k = kb + 2 * lane; k < ke; k += 128) {          // ld is even and > k + 1: the pair load stays inside the row
         d2_t vv = *reinterpret_cast<const d2_t*>(v + k);
         if (k + 1 >= ke) vv[1] = 0.0;
-        const d2_t x0 = *reinterpret_cast<const d2_t*>(r0 + k);
-        const d2_t x1 = *reinterpret_cast<const d2_t*>(r1 + k);
-        const d2_t x2 = *reinterpret_cast<const d2_t*>(r2 + k);
-        const d2_t x3 = *reinterpret_cast<const d2_t*>(r3 + k);
+        const d2_t x0 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r0 + k));   // read once: stream
+        const d2_t x1 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r1 + k));
+        const d2_t x2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r2 + k));
+        const d2_t x3 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r3 + k));
         a0 = fma(x0[1], vv[1], fma(x0[0], vv[0], a0));
         a1 = fma(x1[1], vv[1], fma(x1[0], vv[0], a1));
         a2 = fma(x2[1], vv[1], fma(x2[0], vv[0], a2));
