@@ -429,10 +429,10 @@ double grad_prior_var(const abo_gp* g) {
 int64_t pick_chunk(const abo_gp* g, int64_t M) {
     int64_t mc = g->prm.chunk;
     if (mc <= 0) {
-        // ~512 MiB of K_XZ per chunk (measured optimum at N = 8192: tools/chunk_sweep.sh — larger
-        // chunks lose L2/MALL reuse of the candidate panels, smaller ones pay launch tails), at least
-        // 2048 and at most 65536 candidates
-        mc = ((int64_t)1 << 29) / (g->Np * (int64_t)sizeof(double));
+        // ~1 GiB of K_XZ per chunk (measured at N = 8192, tools/chunk_sweep.sh: 2048 candidates per chunk 1072 ms,
+        // 4096 1011, 8192 997, 16384 992-995, 32768 998, 65536 996 — small chunks pay launch tails in every kernel,
+        // larger ones lose a little L2/MALL reuse of the candidate panels), at least 2048 and at most 65536 candidates
+        mc = ((int64_t)1 << 30) / (g->Np * (int64_t)sizeof(double));
         if (mc < 2048) mc = 2048;
         if (mc > 65536) mc = 65536;
     }

@@ -17,6 +17,6 @@ echo "kernel trace done"
 bash tools/run_pmc.sh ${TAG}f c3 > gpurun_out/final_pmc_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_run.log; exit 1; }
 cp gpurun_out/pmc_${TAG}f_summary.txt gpurun_out/final_pmc_summary.txt
 echo "pmc done"
-python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_summary.txt 8192 8192 > gpurun_out/final_pmc_traffic.json
+python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_summary.txt 8192 16384 > gpurun_out/final_pmc_traffic.json
 bash tools/run_prof_c5.sh > gpurun_out/final_prof_c5.log 2>&1 || { tail -5 gpurun_out/final_prof_c5.log; exit 1; }
 echo "c5 trace done"
