@@ -169,6 +169,10 @@ CASES = [
     (O.MATERN32, 2, 1000, 4096, 0.6, 0.5, 1e-2, -1.2),
     (O.SE, 4, 1024, 8192, 0.5, 1.0, 1e-4, 0.0),          # C2 training shape
     (O.MATERN52, 16, 1152, 2048, 2.0, 1.0, 1e-2, 0.0),   # C5 dimension, 9 blocks
+    (O.MATERN52, 5, 1664, 700, 0.9, 1.0, 1e-3, 0.3),     # 13 blocks: three 512-wide Cholesky strips + a 128 remainder
+    (O.SE, 7, 2304, 600, 1.2, 1.5, 1e-3, 0.0),           # 18 blocks: both GEMM variants (small-launch and LDS-tiled) in one fit
+    (O.MATERN72, 32, 200, 300, 3.0, 1.0, 1e-3, 0.0),     # largest supported dimension
+    (O.MATERN32, 13, 520, 129, 1.5, 0.7, 1e-2, 0.0),     # odd dimension (padded to 16), ragged everything
 ]
 
 
