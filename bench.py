@@ -348,17 +348,20 @@ def main():
         return float(t.item())
 
     phases = []
+    step_ms = []
     model = None
     top = None
     for step in range(args.warmup + args.steps):
         if step == args.warmup:
             sync()
             t0 = time.perf_counter()
+        ts = time.perf_counter()
         model = abo.update(gp, Xd, yd)                                          # full refit
         _, tv, ti = abo.evaluate(acq, model, Zd, k=K_TOP, idx_base=lo, return_scores=False)
         top = D.all_gather_topk(tv, ti, K_TOP) if use_dist else (tv, ti)
         if step >= args.warmup:
             phases.append(model.timings())
+            step_ms.append((time.perf_counter() - ts) * 1e3)     # the C-ABI calls are synchronous: no extra sync needed
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -415,6 +418,8 @@ def main():
             "phases_ms": {k: v for k, v in med.items() if k.endswith("_ms")},
             "top1": {"score": float(top[0][0]), "index": int(top[1][0])},
             "hip_event_ms_per_step": med["fit_total_ms"] + med["acq_total_ms"],
+            "median_ms_per_step": float(np.median(step_ms)), "min_ms_per_step": float(np.min(step_ms)),
+            "max_ms_per_step": float(np.max(step_ms)),        # this rank's per-step wall clock (median of >= 5)
         }
         if variants:
             out["variants"] = variants
