@@ -364,9 +364,8 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
         }
     }
     HIPCHK(hipEventRecord(g->evs()[2], s));
-    HIPCHK(hipMemcpyAsync(info_host, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (*info_host != 0) return ABO_OK;   // caller decides (retry with jitter or ENOTPD)
+    // no host round trip here: after a failed pivot every later kernel of the fit either exits on `info` (the GEMMs) or
+    // works on finite leftovers whose results are discarded; `info` is read once, with the scalars, at the end
 
     // W = L⁻¹: [[W11,0],[−W22·L21·W11, W22]] level by level (block size s doubles each level)
     double* Tt = g->T.as<double>();
@@ -389,7 +388,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             a.B = K + r2 * ld + r1; a.ldb = ld; a.sB = bstride;
             a.C = Tp; a.ldc = sz; a.sC = sz * sz;
             a.M = (int)sz; a.N = (int)s2; a.K = (int)sz; a.kmode = K_A_UPPER; a.batch = batch;
-            a.alpha = 1.0; a.beta = 0.0;
+            a.alpha = 1.0; a.beta = 0.0; a.info = info;
             HIPCHK(launch_gemm_nt(a, s));
             GemmArgs b{};   // W21[i][j] = −Σ_k W22[i][k]·Tt[j][k]   (+ transposed copy into WT)
             b.A = W + r2 * ld + r2; b.lda = ld; b.sA = bstride;
@@ -397,7 +396,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             b.C = W + r2 * ld + r1; b.ldc = ld; b.sC = bstride;
             b.Ct = WT + r1 * ld + r2; b.ldct = ld; b.sCt = bstride;
             b.M = (int)s2; b.N = (int)sz; b.K = (int)s2; b.kmode = K_A_LOWER; b.batch = batch;
-            b.alpha = -1.0; b.beta = 0.0;
+            b.alpha = -1.0; b.beta = 0.0; b.info = info;
             HIPCHK(launch_gemm_nt(b, s));
         }
     }
@@ -409,7 +408,9 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     HIPCHK(hipEventRecord(g->evs()[4], s));
     double sc[2];
     HIPCHK(hipMemcpyAsync(sc, g->scal.as<double>(), sizeof sc, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(info_host, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (*info_host != 0) return ABO_OK;   // caller decides (retry with jitter or ENOTPD)
     g->logdet = sc[0];
     g->quad = sc[1];
     g->tm.fit_kernel_matrix_ms = ev_ms(g->evs()[0], g->evs()[1]);
