@@ -158,3 +158,37 @@ def test_lengthscale_bounds_reference_cases():
     assert np.all(np.abs(lo - 0.1 * np.sqrt(10.0)) < 1e-2)
     with pytest.raises(abo.DimensionMismatch):
         abo.lengthscale_bounds([[0.0, 0.0, 0.0]], dom2)
+
+
+def test_gradient_gp_host_helpers():
+    """Host-side mirror of the GradientGP helpers (GradientGP.jl:617-639 ctor, :734-794 standardisation, :893-895
+    prep_output) — no device needed for any of it."""
+    from abstractbayesopt.jl_amd import gradient_gp as G
+    gp = abo.GradientGP(2.0 * abo.with_lengthscale(abo.Matern52Kernel(), 0.5), 3, 0.04)
+    assert gp.p == 3 and gp.gpx is None and np.array_equal(gp.mean.c, np.zeros(3))
+    assert abo.get_lengthscale(gp) == [0.5] and abo.get_scale(gp) == [2.0]
+    with pytest.raises(abo.DimensionMismatch):
+        abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1, mean=abo.gradConstMean([0.0, 0.0]))
+    ys = np.array([[1.0, 0.1, -0.2], [3.0, 0.3, 0.4], [5.0, -0.5, 0.0]])
+    # prep_output: all function values, then all ∂₁f, then all ∂₂f (MOInputIsotopicByOutputs order)
+    np.testing.assert_array_equal(G.prep_output(gp, ys), [1.0, 3.0, 5.0, 0.1, 0.3, -0.5, -0.2, 0.4, 0.0])
+    with pytest.raises(abo.DimensionMismatch):
+        G.prep_output(gp, ys[:, :2])
+    mu, sd = abo.get_mean_std(gp, ys, "mean_scale")
+    np.testing.assert_allclose(mu, [3.0, 0.0, 0.0])                  # only the function value is centred
+    np.testing.assert_allclose(sd, [2.0, 2.0, 2.0])                  # gradients share the function's scale
+    mu_s, sd_s = abo.get_mean_std(gp, ys, "scale_only")
+    np.testing.assert_allclose(mu_s, 0.0); np.testing.assert_allclose(sd_s, 2.0)
+    mu_m, sd_m = abo.get_mean_std(gp, ys, "mean_only")
+    np.testing.assert_allclose(mu_m, [3.0, 0.0, 0.0]); np.testing.assert_allclose(sd_m, 1.0)
+    z = abo.std_y(gp, ys, mu, sd)
+    np.testing.assert_allclose(z[:, 0], [-1.0, 0.0, 1.0]); np.testing.assert_allclose(z[:, 1], ys[:, 1] / 2.0)
+    r = abo.rescale_model(abo.GradientGP(2.0 * abo.with_lengthscale(abo.Matern52Kernel(), 0.5), 3, 0.04,
+                                         mean=abo.gradConstMean([1.0, 0.2, 0.0])), sd)
+    assert isinstance(r, abo.GradientGP) and abo.get_scale(r) == [0.5] and abo.get_lengthscale(r) == [0.5]
+    assert r.noise_var == pytest.approx(0.01) and np.allclose(r.mean.c, [0.5, 0.1, 0.0])
+    assert abo._get_minimum(gp, ys) == 1.0
+    u = abo._update_model_parameters(gp, 3.0 * abo.with_lengthscale(abo.Matern52Kernel(), 0.25))
+    assert isinstance(u, abo.GradientGP) and abo.get_scale(u) == [3.0] and u.p == 3 and u.noise_var == 0.04
+    acq = abo.GradientNormUCB(1.5)
+    assert abo.update(acq, ys, gp) is acq and abo.copy(acq) == acq and abo.copy(acq) is not acq
