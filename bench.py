@@ -240,8 +240,10 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
         # dominant kernel of the step: the O(N*M) down-date pass, 9 launches per step (8 fantasies + the real point)
         if med["downdate_pass_bytes"] > 0:
             gbs = med["downdate_pass_bytes"] / (med["downdate_pass_ms"] * 1e-3) / 1e9
+            tr_path = os.path.join(ROOT, "profiles", "r01_c5_pmc_traffic.json")     # committed rocprofv3 FETCH_SIZE pass
+            tr = json.load(open(tr_path))["traffic_bytes_per_launch"] if os.path.exists(tr_path) else None
             roof = {"kernel": "cand_gemv_kernel (c = K_ZX . [-v; 1] over the resident K_ZX) + new-column kernel", "bound": "hbm",
-                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr,
                     "algorithmic_bytes_per_launch": med["downdate_pass_bytes"], "avg_launch_ms": med["downdate_pass_ms"],
                     "launches_per_step": Q + 1,
                     "note": "algorithmic bytes = 8*N*M (K_ZX read once); duration = HIP events on the library stream"}
