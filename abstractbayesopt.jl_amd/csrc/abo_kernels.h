@@ -58,6 +58,7 @@ struct KgenArgs {
     // gradient-enhanced GP (pt > 1): training rows are (output q', point i) by outputs, pt = d+1 outputs per
     // point, Np pads pt·N; candidate rows carry pc outputs each (1 = function value only, pt = all outputs)
     int pt = 1, pc = 1, point_major = 0;
+    int dlogell = 0;      // gradient-enhanced GP only: write dK/dlog(ell) instead of K (hyper-parameter gradient)
     double mean_vec[17] = {0};   // prior mean per output (gradConstMean)
 };
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
@@ -74,6 +75,9 @@ struct NlmlGradArgs {
     double sigma_f2;
 };
 hipError_t launch_nlml_grad(const NlmlGradArgs& a, hipStream_t s);
+// same reductions with dK/dlog(ell) given as a matrix D (gradient-enhanced GP: D comes from kgen with dlogell = 1):
+// out[0] = sum_{i,k<N} (Kinv[i][k] - alpha_i alpha_k) D[i][k]  (lower 128-tiles, strictly-lower ones counted twice), out[1..3] as above
+hipError_t launch_nlml_grad_matrix(const NlmlGradArgs& a, const double* D, int64_t ldd, hipStream_t s);
 // test hook: out[i] = kappa(family, d2[i]) with the device math the generator uses
 hipError_t launch_kappa_test(int family, const double* d2, double* out, int64_t n, hipStream_t s);
 // K[i][i] += noise for i < N; K[i][i] = 1 for N ≤ i < Np (identity padding keeps the factor PD)

@@ -992,7 +992,6 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     if (!g->fitted) return fail(ABO_EINVAL, "surrogate is not conditioned on data yet (call abo_fit first)");
     if (g->from_append || g->st->max_live() != g->N)
         return fail(ABO_EINVAL, "abo_nlml_grad needs a freshly fitted model (hyper-parameter search refits anyway)");
-    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_nlml_grad: not available for gradient-enhanced models");
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
     const int64_t Np = g->Np, ld = g->st->cap;
@@ -1010,7 +1009,20 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     ga.Xs = g->st->Xs.as<double>(); ga.Kinv = g->T.as<double>(); ga.alpha = g->alpha.as<double>();
     ga.delta = g->st->delta.as<double>(); ga.partial = g->partial.as<double>(); ga.out = g->scal.as<double>() + 4;
     ga.ld = Np; ga.N = N; ga.Np = (int)Np; ga.dp = g->dp; ga.family = g->prm.family; ga.sigma_f2 = g->prm.sigma_f2;
-    HIPCHK(launch_nlml_grad(ga, s));
+    if (g->p_out > 1) {
+        // gradient-enhanced GP: dK/dlog(ell) of the multi-output system as a matrix (same generator as K_XX with the
+        // derivative triple), then the weighted sum against K^-1 - alpha alpha^T
+        HIPCHK(g->Kxz.ensure(sizeof(double) * Np * Np));
+        KgenArgs ka{};
+        ka.Xs = g->st->Xs.as<double>(); ka.Z = g->st->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = g->Kxz.as<double>();
+        ka.mu = nullptr; ka.ldk = Np; ka.M = g->npts; ka.j0 = 0; ka.Mc = (int)Np; ka.N = (int)g->npts; ka.Np = (int)Np;
+        ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2;
+        ka.mean_c = 0.0; ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 0; ka.dlogell = 1;
+        HIPCHK(launch_kgen(ka, s));
+        HIPCHK(launch_nlml_grad_matrix(ga, g->Kxz.as<double>(), Np, s));
+    } else {
+        HIPCHK(launch_nlml_grad(ga, s));
+    }
     double o[4];
     HIPCHK(hipMemcpyAsync(o, g->scal.as<double>() + 4, sizeof o, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

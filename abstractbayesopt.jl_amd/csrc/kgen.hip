@@ -113,11 +113,35 @@ __device__ __forceinline__ void phi_derivs(double u, double& p0, double& p1, dou
     }
 }
 
+// d/dlog(ell) of the same blocks.  With du/dlog(ell) = -2u, de/dlog(ell) = -e, d(1/ell)/dlog(ell) = -1/ell every block
+// keeps its form with (phi, phi1, phi2) = (φ, φ', φ'') replaced by
+//     phi  -> -2u phi1          phi1 -> -2u phi2 - 2 phi1          phi2 -> -(2u phi3 + 4 phi2)
+// (u·phi3 is finite at u = 0 for every family: the Matérn third derivative grows like 1/sqrt(u) there).
+template <int FAM>
+__device__ __forceinline__ void phi_derivs_dlogell(double u, double& p0, double& p1, double& p2) {
+    if constexpr (FAM == ABO_KERNEL_SE) {
+        const double e = exp_nonpos(-0.5 * u);
+        p0 = u * e; p1 = fma(-0.5, u, 1.0) * e; p2 = fma(0.25, u, -1.0) * e;
+    } else if constexpr (FAM == ABO_KERNEL_MATERN52) {
+        const double a = 2.23606797749978969640917366873128;
+        const double r = sqrt_pos(u), e = exp_nonpos(-a * r), t = fma(a, r, 1.0);
+        p0 = (5.0 / 3.0) * u * t * e;
+        p1 = fma(5.0 / 3.0, t, (-25.0 / 6.0) * u) * e;
+        p2 = fma(25.0 / 12.0 * a, r, -25.0 / 3.0) * e;
+    } else {
+        const double a = 2.64575131106459059050161575363926;
+        const double r = sqrt_pos(u), e = exp_nonpos(-a * r), t = fma(a, r, 1.0);
+        p0 = (7.0 / 5.0) * u * fma(u, 7.0 / 3.0, t) * e;
+        p1 = fma(7.0 / 5.0, t, fma(49.0 / 15.0, u, (-49.0 / 30.0) * u * t)) * e;
+        p2 = fma(343.0 / 60.0, u, (-49.0 / 15.0) * t) * e;
+    }
+}
+
 // Rows: candidate-output pairs.  Row index g = j0 + (row in chunk); with point_major == 0 it is by outputs
 // (q = g / M, j = g % M — MOInputIsotopicByOutputs, what the reference's posterior_grad_* return), with
 // point_major == 1 it is j = g / pc, q = g % pc (all outputs of a point adjacent: per-point covariance blocks).
 // Columns: training rows r = q'·N + i by outputs (prep_output, GradientGP.jl:893-895).
-template <int FAM, int DP>
+template <int FAM, int DP, bool DLOGELL>
 __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
     __shared__ double zs[JT][DP];
     __shared__ int zq[JT];
@@ -172,8 +196,13 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
                     if (c == qp1) ep1 = e1;
                 }
                 double f0, g0, h0, f1, g1, h1;
-                phi_derivs<FAM>(u0, f0, g0, h0);
-                phi_derivs<FAM>(u1, f1, g1, h1);
+                if constexpr (DLOGELL) {
+                    phi_derivs_dlogell<FAM>(u0, f0, g0, h0);
+                    phi_derivs_dlogell<FAM>(u1, f1, g1, h1);
+                } else {
+                    phi_derivs<FAM>(u0, f0, g0, h0);
+                    phi_derivs<FAM>(u1, f1, g1, h1);
+                }
                 double v0, v1;
                 if (qc < 0) {
                     v0 = qp0 < 0 ? f0 : 2.0 * il * g0 * ep0;
@@ -205,18 +234,23 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
     }
 }
 
-template <int FAM>
-static hipError_t launch_grad_kgen_fam(const KgenArgs& a, hipStream_t s) {
+template <int FAM, bool DLOGELL>
+static hipError_t launch_grad_kgen_fam2(const KgenArgs& a, hipStream_t s) {
     dim3 grid(a.Mc / JT), block(256);
     switch (a.dp) {
-        case 1: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 1>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 2>), grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 4>), grid, block, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 8>), grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 16>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 1, DLOGELL>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 2, DLOGELL>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 4, DLOGELL>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 8, DLOGELL>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 16, DLOGELL>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+template <int FAM>
+static hipError_t launch_grad_kgen_fam(const KgenArgs& a, hipStream_t s) {
+    return a.dlogell ? launch_grad_kgen_fam2<FAM, true>(a, s) : launch_grad_kgen_fam2<FAM, false>(a, s);
 }
 
 // ∂k/∂log ℓ on the squared scaled distance d2 (∂r/∂log ℓ = −r, so dK = −σ_f²·r·κ'(r)):
@@ -338,6 +372,36 @@ hipError_t launch_nlml_grad(const NlmlGradArgs& a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nlml_grad_finish_kernel, dim3(1), dim3(256), 0, s, a, a.Np / JT);
+    return hipGetLastError();
+}
+
+// partial[block] = sum of w (Kinv[i][k] - alpha_i alpha_k) D[i][k] over the block's 16 rows and the columns up to the end
+// of their diagonal 128-tile (w = 2 left of the diagonal tile, 1 inside it): the dK/dlog(ell) term with D given as a matrix.
+__global__ void __launch_bounds__(256) nlml_grad_matrix_kernel(NlmlGradArgs p, const double* __restrict__ D, int64_t ldd) {
+    __shared__ double red[4];
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * JT;
+    const int kend = (ib / 128 + 1) * 128, diag0 = (ib / 128) * 128;
+    double acc = 0.0;
+    for (int k = t; k < kend; k += 256) {
+        if (k >= p.N) continue;
+        const double ak = p.alpha[k], w = k >= diag0 ? 1.0 : 2.0;
+        for (int jj = 0; jj < JT; ++jj) {
+            const int i = ib + jj;
+            if (i < p.N) acc = fma(w * (p.Kinv[(int64_t)i * p.ld + k] - p.alpha[i] * ak), D[(int64_t)i * ldd + k], acc);
+        }
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (t == 0) p.partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+hipError_t launch_nlml_grad_matrix(const NlmlGradArgs& a, const double* D, int64_t ldd, hipStream_t s) {
+    hipLaunchKernelGGL(nlml_grad_matrix_kernel, dim3(a.Np / JT), dim3(256), 0, s, a, D, ldd);
     hipLaunchKernelGGL(nlml_grad_finish_kernel, dim3(1), dim3(256), 0, s, a, a.Np / JT);
     return hipGetLastError();
 }

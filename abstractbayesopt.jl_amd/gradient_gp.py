@@ -191,11 +191,23 @@ def nlml_ls(model: HipGradientGP, log_ell, log_scale, xs, ys) -> float:
     return nlml(model, (log_ell, log_scale), xs, ys)
 
 
-def nlml_and_grad(model: HipGradientGP, params, xs, ys, h: float = 1e-4):
-    """(nlml, [∂/∂log ℓ, ∂/∂log scale]) for the gradient-enhanced model.  The reference differentiates this
-    objective with ForwardDiff (bayesian_opt.jl:284); here the value is one device refit and the two partials
-    are fourth-order central differences of it in log space (8 more refits of the (d+1)N-row system — the
-    scale partial could be had in closed form, but the refits are the cheap part of a BO step)."""
+def nlml_and_grad(model: HipGradientGP, params, xs, ys):
+    """(nlml, [∂/∂log ℓ, ∂/∂log scale]) for the gradient-enhanced model from ONE refit: the library forms K⁻¹ on the
+    MFMA GEMM, generates ∂K/∂log ℓ of the (d+1)N-row system with the analytic derivative blocks and reduces
+    ½ tr((K⁻¹ − ααᵀ) ∂K/∂θ) (abo_nlml_grad).  The reference differentiates this objective with ForwardDiff
+    (bayesian_opt.jl:284)."""
+    log_ell, log_scale = params
+    inner = extract_scale_and_lengthscale(model.kernel)[0]
+    k = math.exp(log_scale) * with_lengthscale(inner, math.exp(log_ell))
+    fitted = update(_update_model_parameters(model, k), xs, ys)
+    v, d1, d2 = C.c_double(), C.c_double(), C.c_double()
+    _lib.check(_lib.lib().abo_nlml_grad(fitted._require(), C.byref(v), C.byref(d1), C.byref(d2)))
+    return v.value, np.array([d1.value, d2.value])
+
+
+def nlml_and_grad_fd(model: HipGradientGP, params, xs, ys, h: float = 1e-4):
+    """The same pair with fourth-order central differences of the device NLML (8 more refits) — cross-check of the
+    analytic gradient."""
     p = np.asarray(params, dtype=np.float64)
     v = nlml(model, p, xs, ys)
     g = np.zeros(2)

@@ -90,7 +90,7 @@ int32_t abo_create(const abo_params* params, abo_gp** out);
  * enhanced GP with p = d+1 outputs per point (f and ∂f/∂x_c), multi-output kernel gradKernel (:573-606) with
  * analytic derivatives, rows ordered by outputs (MOInputIsotopicByOutputs).  mean_c: p prior means (NULL = 0).
  * abo_fit then takes y of length p·N ordered by outputs (prep_output, :893-895); abo_predict / abo_acq address
- * the function output; abo_append, abo_cand_* and abo_nlml_grad are not available on such a handle. */
+ * the function output; abo_append and abo_cand_* are not available on such a handle. */
 int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out);
 /* Base.copy(::StandardGP) (src/surrogates/StandardGP.jl:26, surrogates_utils.jl:12-14): device
  * state is immutable after fit, so a copy is a shared reference. */
@@ -197,7 +197,9 @@ int32_t abo_nlml(abo_gp* gp, double* out);
  * `autodiff=:forward` computes with ForwardDiff duals in optimize_hyperparameters
  * (src/bayesian_opt.jl:253-285), which cannot cross a C-ABI:
  *   dNLML/dθ = ½ tr((K⁻¹ − ααᵀ) ∂K/∂θ),  K⁻¹ = L⁻ᵀL⁻¹ formed on the MFMA GEMM, ∂K/∂log ell generated on
- *   the fly.  Needs a freshly fitted handle (not an appended view).  Any output may be NULL. */
+ *   the fly (for a gradient-enhanced handle: generated as a matrix from the analytic derivative blocks of
+ *   gradKernel, src/surrogates/GradientGP.jl:573-606, whose nlml is :684-698).  Needs a freshly fitted handle (not an
+ *   appended view).  Any output may be NULL. */
 int32_t abo_nlml_grad(abo_gp* gp, double* nlml, double* d_log_ell, double* d_log_sigma_f2);
 
 /* --- introspection (tests) ----------------------------------------------------------------------

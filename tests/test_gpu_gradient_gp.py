@@ -131,7 +131,14 @@ def test_gradient_gp_nlml_and_hyperparameter_mle():
         want = G.nlml(st)
         assert abs(abo.nlml(gp, [le, ls], X, Ys) - want) <= 1e-9 * max(1.0, abs(want))
         assert abo.nlml_ls(gp, le, ls, X, Ys) == abo.nlml(gp, [le, ls], X, Ys)
-    v0, g0 = abo.gradient_gp.nlml_and_grad(gp, [np.log(0.9), 0.0], X, Ys)
+    v0, g0 = abo.gradient_gp.nlml_and_grad(gp, [np.log(0.9), 0.0], X, Ys)          # analytic (abo_nlml_grad)
+    v1, g1 = abo.gradient_gp.nlml_and_grad_fd(gp, [np.log(0.9), 0.0], X, Ys)       # differences of the device NLML
+    assert v0 == v1 and np.max(np.abs(g0 - g1)) <= 1e-7 * max(1.0, np.max(np.abs(g1)))
+    for fam, ell in ((O.SE, 0.7), (O.MATERN72, 1.1)):                              # every family's derivative triple
+        gq = make_grad(fam, ell, 1.3, 1e-3, d + 1)
+        pq = [np.log(ell), np.log(1.3)]
+        ga, gf = abo.gradient_gp.nlml_and_grad(gq, pq, X, Ys)[1], abo.gradient_gp.nlml_and_grad_fd(gq, pq, X, Ys)[1]
+        assert np.max(np.abs(ga - gf)) <= 1e-7 * max(1.0, np.max(np.abs(gf))), (fam, ga, gf)
     h = 1e-5
     for c in range(2):
         e = np.zeros(2); e[c] = h
