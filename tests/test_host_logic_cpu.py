@@ -192,3 +192,26 @@ def test_gradient_gp_host_helpers():
     assert isinstance(u, abo.GradientGP) and abo.get_scale(u) == [3.0] and u.p == 3 and u.noise_var == 0.04
     acq = abo.GradientNormUCB(1.5)
     assert abo.update(acq, ys, gp) is acq and abo.copy(acq) == acq and abo.copy(acq) is not acq
+
+
+def test_committed_bench_lines_keep_the_driver_contract():
+    """The JSON lines under profiles/ are what bench.py printed on the GPU box: every key the driver and the judge
+    read must be there with the right type (the contract in the task statement)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, bound in (("r01_bench_default.json", "mfma"), ("r01_c2_bench_final.json", "mfma"), ("r01_c5_bench_final.json", "hbm")):
+        j = json.load(open(os.path.join(root, "profiles", name)))
+        assert j["metric"].startswith("GP-update+acq-eval ms per BO step") and j["unit"] == "ms"
+        assert j["higher_is_better"] is False and j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None
+        assert j["dtype"] == "f64" and j["data"] == "synthetic" and j["n_gpus"] == 1
+        assert isinstance(j["steps"], int) and isinstance(j["warmup"], int)
+        assert j["value"] == j["ms_per_step"] and j["value"] > 0
+        assert isinstance(j["config"]["workload"], str) and "model" not in j["config"]
+        r = j["roofline"]
+        assert r["bound"] == bound and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] <= 1
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    j = json.load(open(os.path.join(root, "profiles", "r01_bench_default.json")))
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and "unit" in c
+    assert j["roofline"]["traffic"] > j["roofline"]["algorithmic_bytes_per_launch"] > 0
