@@ -595,3 +595,32 @@ def test_checkpoint_resume_by_pickle():
     g2 = pickle.loads(pickle.dumps(g))
     assert isinstance(g2, abo.GradientGP) and g2.p == 3
     np.testing.assert_array_equal(abo.posterior_grad_mean(g2, [[0.25, 0.25]]), abo.posterior_grad_mean(g, [[0.25, 0.25]]))
+
+
+def test_bad_arguments_are_refused_not_crashed():
+    """every C-ABI entry returns a status for unusable arguments (the process never aborts: SURVEY §8(b) error convention)"""
+    L = abo._lib.lib()
+    X, y = synth.standardized_problem(50, 3, 0.05)
+    m = abo.update(make_model(O.SE, 0.8, 1.0, 1e-3, n_max=64), X, y)
+    Z = synth.points(2, 20, 3)
+    assert abo.posterior_mean(m, np.zeros((0, 3))).shape == (0,)                      # empty batch is fine
+    with pytest.raises(abo.DimensionMismatch):
+        abo.posterior_var(m, np.zeros((4, 2)))
+    with pytest.raises((ValueError, abo.AboError)):
+        abo.evaluate(abo.UpperConfidenceBound(2.0), m, Z, k=5000)                   # k outside 0..1024
+    with pytest.raises((ValueError, abo.AboError)):
+        abo.update(make_model(O.SE, 1.0, 1.0, 1e-3), np.zeros((4, 40)), np.zeros(4))  # d > 32
+    with pytest.raises((ValueError, abo.AboError)):
+        abo.update(make_model(O.SE, 1.0, 1.0, 1e-3), np.zeros((0, 3)), np.zeros(0))   # no data
+    cands = abo.ResidentCandidates(m, Z)
+    with pytest.raises((ValueError, abo.AboError)):
+        cands.exclude(20)
+    with pytest.raises((ValueError, abo.AboError)):
+        cands.point(-1)
+    with pytest.raises(abo.DimensionMismatch):
+        abo.append(m, [0.1, 0.2], 0.0)                                               # wrong dimension of the new point
+    for bad in (float("nan"), float("inf")):
+        with pytest.raises((abo.PosDefException, ValueError, abo.AboError)):
+            abo.update(make_model(O.SE, 1.0, 1.0, 1e-3), np.array([[0.0, 0.0], [bad, 1.0]]), np.array([0.0, 1.0]))
+    # the model and the candidate set are still usable afterwards
+    assert np.isfinite(abo.posterior_mean(m, Z)).all() and np.isfinite(cands.mean_and_var()[1]).all()
