@@ -1,7 +1,7 @@
 """abstractbayesopt.jl_amd — MI355X-native GP surrogate backend behind AbstractBayesOpt.jl's
 AbstractSurrogate / AbstractAcquisition interface (hot path only: update → posterior → EI/UCB →
 top-k).  Import as ``import abstractbayesopt.jl_amd as abo``."""
-from . import _lib, acquisition, distributed, incremental, synth
+from . import _lib, acquisition, distributed, incremental, multigpu, synth
 from ._lib import AboError, DimensionMismatch, PosDefException
 from .acquisition import (AbstractAcquisition, EnsembleAcquisition, ExpectedImprovement, ProbabilityImprovement,
                           UpperConfidenceBound, device_latin_hypercube, evaluate, latin_hypercube,
@@ -12,6 +12,7 @@ from .gradient_gp import (GradientNormUCB, HipGradientGP, gradConstMean, posteri
                           posterior_grad_var)
 from .hyperparams import lengthscale_bounds, monte_carlo_fill_distance, nlml_and_grad, optimize_hyperparameters
 from .incremental import ResidentCandidates, append, greedy_qei
+from .multigpu import HipShardedGP, ShardedCandidates
 from .kernels import (ApproxMatern52Kernel, ApproxMatern72Kernel, ConstMean, Kernel, Matern32Kernel, Matern52Kernel,
                       ScaledKernel, SqExponentialKernel, ZeroMean, with_lengthscale)
 from . import surrogate as _s
@@ -33,6 +34,8 @@ def update(obj, a, b):
         return acquisition.update(obj, a, b)
     if isinstance(obj, HipGradientGP):
         return _g.update(obj, a, b)
+    if isinstance(obj, HipShardedGP):
+        return multigpu.update(obj, a, b)
     return _s.update(obj, a, b)
 
 
@@ -42,6 +45,8 @@ def copy(obj):
         return GradientNormUCB(obj.beta)                        # gradNormUCB.jl:24
     if isinstance(obj, AbstractAcquisition):
         return acquisition.copy(obj)
+    if isinstance(obj, HipShardedGP):
+        return multigpu.copy(obj)
     return _s.copy(obj)
 
 

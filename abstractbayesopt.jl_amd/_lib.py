@@ -12,7 +12,12 @@ HOST, DEVICE = 0, 1
 EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_data", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
-           "abo_test_gemm_nt", "abo_test_kappa"]
+           "abo_test_gemm_nt", "abo_test_kappa",
+           "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
+           "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
+           "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
+           "abo_mgpu_cand_qei"]
+ABI_VERSION = 2
 
 
 class AboParams(C.Structure):
@@ -103,6 +108,22 @@ def lib():
     L.abo_pool_trim.argtypes = [i32]
     L.abo_test_kappa.argtypes = [i32, i32, vp, vp, i64]
     L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
+    L.abo_mgpu_create.argtypes = [C.POINTER(AboParams), i32, C.POINTER(i32), C.POINTER(vp)]
+    L.abo_mgpu_clone.argtypes = [vp, C.POINTER(vp)]
+    L.abo_mgpu_destroy.argtypes = [vp]
+    L.abo_mgpu_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.abo_mgpu_get.argtypes = [vp, i32, C.POINTER(vp)]
+    L.abo_mgpu_fit.argtypes = [vp, vp, i64, i32, vp, C.POINTER(i64)]
+    L.abo_mgpu_predict.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.abo_mgpu_acq.argtypes = [vp, vp, i64, i32, i32, f64, f64, vp, i32, vp, vp]
+    L.abo_mgpu_acq_lhs.argtypes = [vp, i64, i32, vp, vp, C.c_uint64, i32, f64, f64, i32, vp, vp, vp]
+    L.abo_mgpu_append.argtypes = [vp, vp, i32, f64, C.POINTER(i64), vp]
+    L.abo_mgpu_cand_create.argtypes = [vp, vp, i64, i32, C.POINTER(vp)]
+    L.abo_mgpu_cand_create_lhs.argtypes = [vp, i64, i32, vp, vp, C.c_uint64, C.POINTER(vp)]
+    L.abo_mgpu_cand_refresh.argtypes = [vp, vp]
+    L.abo_mgpu_cand_destroy.argtypes = [vp]
+    L.abo_mgpu_cand_acq.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp]
+    L.abo_mgpu_cand_qei.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp, vp]
     for name in EXPORTS:
         getattr(L, name).restype = i32
     _lib = L

@@ -142,6 +142,9 @@ def evaluate(acq: AbstractAcquisition, surrogate: HipStandardGP, x, k: int = 0, 
         raise TypeError("the fused acquisition path needs a HipStandardGP surrogate")
     L = _lib.lib()
     zp, m, d, zspace, keep = as_points(x)
+    if hasattr(surrogate, "devices") and zspace == HOST and idx_base == 0:   # HipShardedGP: sharded inside the library
+        from . import multigpu
+        return multigpu.evaluate(acq, surrogate, keep, k=k, return_scores=return_scores)
     if zspace == DEVICE:
         import torch
         dev = keep.device

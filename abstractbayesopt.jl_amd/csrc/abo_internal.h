@@ -1,0 +1,29 @@
+// Internal C++ interface between api.hip (single-device handles) and mgpu.hip (the multi-device driver).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/abo_hip.h"
+
+namespace abo {
+
+// abo_acq / abo_cand_acq with separate memory spaces for the M scores and for the k selected (score, index) pairs
+int32_t acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind, double p0, double best_y,
+               int64_t idx_base, double* scores, int32_t scores_space, int32_t k, double* top_val, int64_t* top_idx,
+               int32_t top_space);
+int32_t cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores,
+                    int32_t scores_space, int32_t k, double* top_val, int64_t* top_idx, int32_t top_space);
+
+hipStream_t gp_stream(abo_gp* g);
+int gp_device(const abo_gp* g);
+const abo_params& gp_params(const abo_gp* g);
+int gp_dim(const abo_gp* g);
+const double* cand_points(const abo_cand* c);      // device, [M][d]
+const double* cand_mu(const abo_cand* c);          // device, [M]
+int64_t cand_size(const abo_cand* c);
+
+// the calling thread's last-error slot (abo_last_error reads it)
+int32_t set_error(int32_t code, const char* text);
+const char* last_error_text();
+
+}  // namespace abo

@@ -7,6 +7,7 @@
 namespace abo {
 
 constexpr int TB = 128;  // block (tile) edge used by every blocked stage; all padded sizes are multiples of it
+constexpr int MAX_P = 33; // outputs per point of a gradient-enhanced GP (f + d ≤ 32 partial derivatives)
 
 inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
@@ -59,7 +60,7 @@ struct KgenArgs {
     // point, Np pads pt·N; candidate rows carry pc outputs each (1 = function value only, pt = all outputs)
     int pt = 1, pc = 1, point_major = 0;
     int dlogell = 0;      // gradient-enhanced GP only: write dK/dlog(ell) instead of K (hyper-parameter gradient)
-    double mean_vec[17] = {0};   // prior mean per output (gradConstMean)
+    double mean_vec[MAX_P] = {0};   // prior mean per output (gradConstMean)
 };
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
 // NLML gradient reduction: Σ_ij (Kinv − ααᵀ)_ij ∂K_ij/∂log ℓ over the lower tiles, plus tr(Kinv), αᵀα, αᵀδ
@@ -158,6 +159,11 @@ hipError_t launch_cand_gemv(const double* Kzx, int64_t ld, const double* v, int 
 // score[j] = acq(mu[j], var[j])
 hipError_t launch_score(const double* mu, const double* var, double* score, int64_t M, int kind, double p0, double best_y,
                         hipStream_t s);
+
+// rec = {tv[0], (double)ti[0], mu[ti[0] − idx_base], Z[ti[0] − idx_base][0..d)} (zeros for ti[0] < 0): a device's pick
+// record of one greedy q-EI sub-step, 3 + d doubles
+hipError_t launch_pick_record(const double* tv, const int64_t* ti, int64_t idx_base, const double* Z, const double* mu, int d,
+                              double* rec, hipStream_t s);
 
 // Z[(j−j0)·d + c] for j in [j0, j0+count): Latin-hypercube points of an n-point design (device lower/upper)
 hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,

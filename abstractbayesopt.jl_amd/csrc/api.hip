@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/abo_hip.h"
+#include "abo_internal.h"
 #include "abo_kernels.h"
 
 using namespace abo;
@@ -129,6 +130,10 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     int dev = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }            // every early return (HIPCHK) hands its buffers back to the pool
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         release();
@@ -146,11 +151,24 @@ struct ExecCtx {
 std::mutex g_ctx_mu;
 std::vector<ExecCtx*> g_ctx_free[16];
 
+// padded coordinate count: 1, 2, 4, 8, 16, 32 (register-resident kernels), beyond that a multiple of 32 (slab kernels)
 int dp_for(int d) {
+    if (d > 32) return (d + 31) / 32 * 32;
     int p = 1;
     while (p < d) p <<= 1;
     return p;
 }
+
+// a local scratch buffer of one call: on every exit path the stream is drained before the block goes back to the pool
+// (an error return must not hand memory that queued work still touches to the next handle)
+struct ScratchBuf {
+    DevBuf b;
+    hipStream_t s;
+    ScratchBuf(int dev, hipStream_t st) : s(st) { b.dev = dev; }
+    ~ScratchBuf() { if (b.p) { (void)hipStreamSynchronize(s); b.release(); } }
+};
+
+std::atomic<uint64_t> g_storage_gen{1};
 
 }  // namespace
 
@@ -159,6 +177,9 @@ int dp_for(int d) {
 // writes row N of the largest live view, so older views stay valid and rollback is free.
 struct Storage {
     std::atomic<int> refs{1};
+    // process-wide unique id: what a candidate set remembers of the factor it is synced with (a freed Storage's address
+    // is readily reused by the next refit of the same size; its id never is)
+    const uint64_t gen = g_storage_gen.fetch_add(1);
     int dev = 0;
     int d = 0, dp = 0;
     int64_t cap = 0;        // padded capacity = leading dimension of K/W/WT (multiple of 128)
@@ -198,7 +219,7 @@ struct abo_gp {
     int64_t npts = 0;                  // training points (== N unless gradient-enhanced: N = p_out·npts)
     int d = 0, dp = 0;
     int p_out = 1;                     // outputs per point: 1 = StandardGP, d+1 = GradientGP (f + gradient)
-    double mean_vec[17] = {0};         // prior mean per output (gradConstMean; [0] = mean_c for p_out == 1)
+    double mean_vec[MAX_P] = {0};      // prior mean per output (gradConstMean; [0] = mean_c for p_out == 1)
     double logdet = 0.0, quad = 0.0;
     // bordered-append bookkeeping (valid when this view was produced by abo_append)
     bool from_append = false;
@@ -245,9 +266,9 @@ struct abo_gp {
 struct abo_cand {
     int device = 0, d = 0;
     int64_t M = 0;
-    const Storage* synced_st = nullptr;   // identity of the factor the mu/var belong to
+    uint64_t synced_gen = 0;              // Storage::gen of the factor the mu/var belong to (0 = none)
     int64_t synced_N = -1;
-    const Storage* bak_st = nullptr;      // abo_cand_save snapshot
+    uint64_t bak_gen = 0;                 // abo_cand_save snapshot
     int64_t bak_N = -1;
     DevBuf Z, mu, var, score, cdot, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx, mu_bak, var_bak;
     // resident K_ZX (candidate-major, kzx_ld doubles per candidate, column k = training row k of synced_st): kept when
@@ -472,7 +493,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = kchunk;
         ka.mu = g->mu_c.as<double>(); ka.ldk = ldk; ka.M = Mpts; ka.j0 = j0; ka.Mc = mcp; ka.N = (int)g->npts;
         ka.pt = g->p_out; ka.pc = pc; ka.point_major = point_major;
-        for (int q = 0; q < 17; ++q) ka.mean_vec[q] = g->mean_vec[q];
+        for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
         ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = g->prm.mean_c;
         HIPCHK(hipEventRecord(e[0], s));
@@ -615,8 +636,9 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     hipStream_t s = n->stream;
     if (N + 1 > st->cap || st->max_live() > N) {
         // gather this view's data on the device and refit with room to grow
-        DevBuf xb, yb;
-        xb.dev = yb.dev = g->prm.device;
+        ScratchBuf xs(g->prm.device, s), ys(g->prm.device, s);
+        DevBuf& xb = xs.b;
+        DevBuf& yb = ys.b;
         HIPCHK(xb.ensure(sizeof(double) * (N + 1) * d));
         HIPCHK(yb.ensure(sizeof(double) * (N + 1)));
         HIPCHK(hipMemcpyAsync(xb.p, st->Xraw.p, sizeof(double) * N * d, hipMemcpyDeviceToDevice, s));
@@ -625,9 +647,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
         HIPCHK(hipMemcpyAsync(yb.as<double>() + N, &y, sizeof(double), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
         if (n->prm.n_max < 2 * (N + 1)) n->prm.n_max = 2 * (N + 1);
-        int32_t rc = fit_impl(n, xb.as<double>(), N + 1, d, yb.as<double>(), ABO_DEVICE, info);
-        xb.release(); yb.release();
-        return rc;
+        return fit_impl(n, xb.as<double>(), N + 1, d, yb.as<double>(), ABO_DEVICE, info);
     }
     const int64_t ld = st->cap;
     const int64_t Np = g->Np;                       // padded size of the OLD view
@@ -735,7 +755,9 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
 
 int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out) {
     if (!params || !out) return fail(ABO_EINVAL, "abo_create_grad: null argument");
-    if (p < 2 || p > 17) return fail(ABO_EINVAL, "abo_create_grad: p = %d outputs outside 2..17 (d = p − 1 ≤ 16)", p);
+    if (p < 2 || p > MAX_P)
+        return fail(ABO_EINVAL, "abo_create_grad: p = %d outputs outside 2..%d (library limit: a gradient-enhanced GP has "
+                                "d = p − 1 ≤ %d inputs)", p, MAX_P, MAX_P - 1);
     if (params->family != ABO_KERNEL_SE && params->family != ABO_KERNEL_MATERN52 && params->family != ABO_KERNEL_MATERN72)
         return fail(ABO_EINVAL, "abo_create_grad: the gradient-enhanced GP needs a twice-differentiable kernel "
                                 "(SE, Matern-5/2, Matern-7/2)");
@@ -771,7 +793,7 @@ int32_t abo_fit(abo_gp* g, const double* X, int64_t N, int32_t d, const double* 
     if (info) *info = 0;
     if (!g || !X || !y) return fail(ABO_EINVAL, "abo_fit: null argument");
     if (N < 1) return fail(ABO_EINVAL, "abo_fit: need at least one training point");
-    if (d < 1 || d > 32) return fail(ABO_EINVAL, "abo_fit: input dimension %d outside the supported 1..32", d);
+    if (d < 1 || d > 65536) return fail(ABO_EINVAL, "abo_fit: input dimension %d outside 1..65536", d);
     if (N > (int64_t)1 << 20) return fail(ABO_EINVAL, "abo_fit: N = %lld too large", (long long)N);
     if (g->p_out > 1 && d + 1 != g->p_out)
         return fail(ABO_EDIM, "DimensionMismatch: gradient-enhanced model with p = %d outputs needs d = %d inputs, got %d",
@@ -889,7 +911,7 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
         ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = p0 * P; ka.Mc = rows; ka.N = (int)g->npts;
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
         ka.sigma_f2 = g->prm.sigma_f2; ka.pt = P; ka.pc = P; ka.point_major = 1;
-        for (int q = 0; q < 17; ++q) ka.mean_vec[q] = g->mean_vec[q];
+        for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
         HIPCHK(launch_kgen(ka, s));
         GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
         a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
@@ -912,11 +934,21 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
 int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind, double p0,
                 double best_y, int64_t idx_base, double* scores, int32_t k, double* top_val, int64_t* top_idx,
                 int32_t out_space) {
+    return abo::acq_ex(g, Z, M, d, z_space, kind, p0, best_y, idx_base, scores, out_space, k, top_val, top_idx, out_space);
+}
+
+}  // extern "C"
+
+// abo_acq with separate memory spaces for the M scores and for the k selected pairs (the multi-device driver keeps the
+// pairs on the device for the RCCL exchange while the scores, when asked for, go to the caller's host array)
+int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind, double p0,
+                    double best_y, int64_t idx_base, double* scores, int32_t out_space, int32_t k, double* top_val,
+                    int64_t* top_idx, int32_t top_space) {
     int32_t rc = check_fitted(g, d);
     if (rc) return rc;
     if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_acq: unknown acquisition kind %d", kind);
     if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_acq: bad candidate buffer");
-    if (k < 0 || k > 1024) return fail(ABO_EINVAL, "abo_acq: k = %d outside 0..1024", k);
+    if (k < 0) return fail(ABO_EINVAL, "abo_acq: k = %d is negative", k);
     if (k > 0 && (!top_val || !top_idx)) return fail(ABO_EINVAL, "abo_acq: k > 0 needs top_val and top_idx");
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
@@ -956,14 +988,14 @@ int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_spac
         TopkWork w{{g->tk_keys0.as<uint64_t>(), g->tk_keys1.as<uint64_t>()}, {g->tk_idx0.as<int64_t>(), g->tk_idx1.as<int64_t>()}};
         double* tv = top_val;
         int64_t* ti = top_idx;
-        if (out_space == ABO_HOST) {
+        if (top_space == ABO_HOST) {
             HIPCHK(g->top_val.ensure(sizeof(double) * k));
             HIPCHK(g->top_idx.ensure(sizeof(int64_t) * k));
             tv = g->top_val.as<double>();
             ti = g->top_idx.as<int64_t>();
         }
         HIPCHK(launch_topk(sc_d, M, k, idx_base, w, tv, ti, s));
-        if (out_space == ABO_HOST) {
+        if (top_space == ABO_HOST) {
             rc = copy_out(top_val, tv, sizeof(double) * k, ABO_HOST, s); if (rc) return rc;
             rc = copy_out(top_idx, ti, sizeof(int64_t) * k, ABO_HOST, s); if (rc) return rc;
         }
@@ -979,6 +1011,8 @@ int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_spac
     g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[7]);
     return ABO_OK;
 }
+
+extern "C" {
 
 int32_t abo_nlml(abo_gp* g, double* out) {
     if (!g || !out) return fail(ABO_EINVAL, "abo_nlml: null argument");
@@ -1142,7 +1176,7 @@ int32_t abo_cand_refresh(abo_gp* g, abo_cand* c) {
         g->tm.acq_topk_ms = 0.0;
         g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[6]);
     }
-    c->synced_st = g->st;
+    c->synced_gen = g->st->gen;
     c->synced_N = g->N;
     return ABO_OK;
 }
@@ -1181,7 +1215,7 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
     if (!c) return fail(ABO_EINVAL, "abo_cand_downdate: null candidate set");
     int32_t rc = check_fitted(g, c->d);
     if (rc) return rc;
-    if (!g->from_append || g->st != c->synced_st || g->N != c->synced_N + 1)
+    if (!g->from_append || g->st->gen != c->synced_gen || g->N != c->synced_N + 1)
         return fail(ABO_EINVAL, "abo_cand_downdate: the model is not the one-point append of the model this candidate set "
                                 "was last evaluated with (call abo_cand_refresh)");
     HIPCHK(hipSetDevice(g->prm.device));
@@ -1221,9 +1255,16 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
 
 int32_t abo_cand_acq(abo_gp* g, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores,
                      int32_t k, double* top_val, int64_t* top_idx, int32_t out_space) {
+    return abo::cand_acq_ex(g, c, kind, p0, best_y, idx_base, scores, out_space, k, top_val, top_idx, out_space);
+}
+
+}  // extern "C"
+
+int32_t abo::cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores,
+                         int32_t out_space, int32_t k, double* top_val, int64_t* top_idx, int32_t top_space) {
     if (!g || !c) return fail(ABO_EINVAL, "abo_cand_acq: null argument");
     if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_cand_acq: unknown acquisition kind %d", kind);
-    if (k < 0 || k > 1024) return fail(ABO_EINVAL, "abo_cand_acq: k = %d outside 0..1024", k);
+    if (k < 0) return fail(ABO_EINVAL, "abo_cand_acq: k = %d is negative", k);
     if (k > 0 && (!top_val || !top_idx)) return fail(ABO_EINVAL, "abo_cand_acq: k > 0 needs top_val and top_idx");
     if (g->prm.device != c->device) return fail(ABO_EINVAL, "candidate set lives on device %d, model on %d", c->device, g->prm.device);
     HIPCHK(hipSetDevice(g->prm.device));
@@ -1231,7 +1272,7 @@ int32_t abo_cand_acq(abo_gp* g, abo_cand* c, int32_t kind, double p0, double bes
     double* sc_d = (scores && out_space == ABO_DEVICE) ? scores : nullptr;
     if (!sc_d) { HIPCHK(c->score.ensure(sizeof(double) * (c->M > 0 ? c->M : 1))); sc_d = c->score.as<double>(); }
     HIPCHK(launch_score(c->mu.as<double>(), c->var.as<double>(), sc_d, c->M, kind, p0, best_y, s));
-    if (k > 0) { int32_t rc = cand_topk(g, c, sc_d, k, idx_base, top_val, top_idx, out_space); if (rc) return rc; }
+    if (k > 0) { int32_t rc = cand_topk(g, c, sc_d, k, idx_base, top_val, top_idx, top_space); if (rc) return rc; }
     if (scores && out_space == ABO_HOST && c->M > 0) {
         int32_t rc = copy_out(scores, sc_d, sizeof(double) * c->M, ABO_HOST, s);
         if (rc) return rc;
@@ -1239,6 +1280,19 @@ int32_t abo_cand_acq(abo_gp* g, abo_cand* c, int32_t kind, double p0, double bes
     HIPCHK(hipStreamSynchronize(s));
     return ABO_OK;
 }
+
+// internal accessors for the multi-device driver (mgpu.hip)
+hipStream_t abo::gp_stream(abo_gp* g) { return g->stream; }
+int abo::gp_device(const abo_gp* g) { return g->prm.device; }
+const abo_params& abo::gp_params(const abo_gp* g) { return g->prm; }
+int abo::gp_dim(const abo_gp* g) { return g->fitted ? g->d : 0; }
+const double* abo::cand_points(const abo_cand* c) { return c->Z.as<double>(); }
+const double* abo::cand_mu(const abo_cand* c) { return c->mu.as<double>(); }
+int64_t abo::cand_size(const abo_cand* c) { return c->M; }
+int32_t abo::set_error(int32_t code, const char* text) { return fail(code, "%s", text); }
+const char* abo::last_error_text() { return g_err; }
+
+extern "C" {
 
 int32_t abo_cand_save(abo_gp* g, abo_cand* c) {
     if (!g || !c) return fail(ABO_EINVAL, "abo_cand_save: null argument");
@@ -1249,7 +1303,7 @@ int32_t abo_cand_save(abo_gp* g, abo_cand* c) {
     HIPCHK(hipMemcpyAsync(c->mu_bak.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(c->var_bak.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
-    c->bak_st = c->synced_st; c->bak_N = c->synced_N;
+    c->bak_gen = c->synced_gen; c->bak_N = c->synced_N;
     return ABO_OK;
 }
 
@@ -1260,7 +1314,7 @@ int32_t abo_cand_restore(abo_gp* g, abo_cand* c) {
     HIPCHK(hipMemcpyAsync(c->mu.p, c->mu_bak.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(c->var.p, c->var_bak.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
-    c->synced_st = c->bak_st; c->synced_N = c->bak_N;
+    c->synced_gen = c->bak_gen; c->synced_N = c->bak_N;
     return ABO_OK;
 }
 
@@ -1308,16 +1362,15 @@ int32_t abo_pool_trim(int32_t device) {
 int32_t abo_lhs(int32_t device, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                 int64_t count, double* Z_dev) {
     if (!lower || !upper || !Z_dev) return fail(ABO_EINVAL, "abo_lhs: null argument");
-    if (n < 1 || d < 1 || d > 32 || j0 < 0 || count < 0 || j0 + count > n) return fail(ABO_EINVAL, "abo_lhs: bad sizes");
+    if (n < 1 || d < 1 || d > 65536 || j0 < 0 || count < 0 || j0 + count > n) return fail(ABO_EINVAL, "abo_lhs: bad sizes");
     HIPCHK(hipSetDevice(device));
-    DevBuf b;
-    b.dev = device;
-    HIPCHK(b.ensure(sizeof(double) * 64));
+    ScratchBuf sb(device, nullptr);
+    DevBuf& b = sb.b;
+    HIPCHK(b.ensure(sizeof(double) * 2 * d));
     HIPCHK(hipMemcpyAsync(b.p, lower, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(hipMemcpyAsync(b.as<double>() + 32, upper, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
-    HIPCHK(launch_lhs(Z_dev, n, d, b.as<double>(), b.as<double>() + 32, seed, j0, count, nullptr));
+    HIPCHK(hipMemcpyAsync(b.as<double>() + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(launch_lhs(Z_dev, n, d, b.as<double>(), b.as<double>() + d, seed, j0, count, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
-    b.release();
     return ABO_OK;
 }
 

@@ -243,6 +243,7 @@ static hipError_t launch_grad_kgen_fam2(const KgenArgs& a, hipStream_t s) {
         case 4: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 4, DLOGELL>), grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 8, DLOGELL>), grid, block, 0, s, a); break;
         case 16: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 16, DLOGELL>), grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 32, DLOGELL>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -347,9 +348,79 @@ __global__ void __launch_bounds__(256) nlml_grad_finish_kernel(NlmlGradArgs p, i
     if (threadIdx.x < 4) p.out[threadIdx.x] = r[threadIdx.x][0];
 }
 
+
+// d > 32: the same reduction with the coordinates in slabs of 32 (see kgen_wide_kernel)
+template <int FAM>
+__global__ void __launch_bounds__(256) nlml_grad_wide_kernel(NlmlGradArgs p) {
+    __shared__ double zs[JT][32];
+    __shared__ double ai[JT];
+    __shared__ double red[4];
+    const int t = threadIdx.x;
+    const int ib = blockIdx.x * JT;
+    if (t < JT) ai[t] = p.alpha[ib + t];
+    const int kend = (ib / 128 + 1) * 128;
+    const int diag0 = (ib / 128) * 128;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < kend; k0 += KSTEP) {
+        const int k = k0 + 2 * t;
+        const bool live = k < kend;
+        double r0[JT], r1[JT];
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) { r0[jj] = 0.0; r1[jj] = 0.0; }
+        for (int c0 = 0; c0 < p.dp; c0 += 32) {
+            __syncthreads();
+            for (int idx = t; idx < JT * 32; idx += 256) zs[idx / 32][idx % 32] = p.Xs[(int64_t)(ib + idx / 32) * p.dp + c0 + idx % 32];
+            __syncthreads();
+            if (live) {
+                double x0[32], x1[32];
+                const double* xp = p.Xs + (int64_t)k * p.dp + c0;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) { x0[c] = xp[c]; x1[c] = xp[p.dp + c]; }
+#pragma unroll
+                for (int jj = 0; jj < JT; ++jj) {
+                    asm volatile("" ::: "memory");
+                    double a = r0[jj], b = r1[jj];
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) {
+                        const double z = zs[jj][c];
+                        const double e0 = x0[c] - z, e1 = x1[c] - z;
+                        a = fma(e0, e0, a);
+                        b = fma(e1, e1, b);
+                    }
+                    r0[jj] = a; r1[jj] = b;
+                }
+            }
+        }
+        if (live) {
+            const double a0 = p.alpha[k], a1 = p.alpha[k + 1];
+            const double w = (k >= diag0) ? 1.0 : 2.0;
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) {
+                const int i = ib + jj;
+                const double* kr = p.Kinv + (int64_t)i * p.ld + k;
+                const double m0 = kr[0] - ai[jj] * a0, m1 = kr[1] - ai[jj] * a1;
+                const double g0 = (i < p.N && k < p.N) ? m0 * dkappa_dlogell<FAM>(r0[jj]) : 0.0;
+                const double g1 = (i < p.N && k + 1 < p.N) ? m1 * dkappa_dlogell<FAM>(r1[jj]) : 0.0;
+                acc = fma(w, g0 + g1, acc);
+            }
+        }
+    }
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (t == 0) p.partial[blockIdx.x] = p.sigma_f2 * (((red[0] + red[1]) + red[2]) + red[3]);
+}
+
 template <int FAM>
 static hipError_t launch_grad_fam(const NlmlGradArgs& a, hipStream_t s) {
     dim3 grid(a.Np / JT), block(256);
+    if (a.dp > 32) {
+        if (a.dp % 32) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((nlml_grad_wide_kernel<FAM>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     switch (a.dp) {
         case 1: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 1>), grid, block, 0, s, a); break;
         case 2: hipLaunchKernelGGL((nlml_grad_kernel<FAM, 2>), grid, block, 0, s, a); break;
@@ -513,9 +584,95 @@ __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
     if (t < JT) p.mu[jb + t] = p.mean_c + (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]);
 }
 
+
+// d > 32 (dp = d rounded up to a multiple of 32): the same lane ↔ k map and the same c = 0..d−1 summation order as
+// kgen_kernel, with the coordinates taken in slabs of 32 — the lane's two training points hold one slab in registers
+// (64 doubles), the 16 candidates' slab sits in LDS, the 2·16 squared distances are carried across slabs.  The
+// reference is dimension-agnostic (src/surrogates/StandardGP.jl:79-83); this path keeps the library so.
+constexpr int SLAB = 32;
+template <int FAM>
+__global__ void __launch_bounds__(256) kgen_wide_kernel(KgenArgs p) {
+    __shared__ double zs[JT][SLAB];
+    __shared__ double red[4][JT];
+    const int t = threadIdx.x;
+    const int jb = blockIdx.x * JT;
+    double mu[JT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) mu[jj] = 0.0;
+    for (int k0 = 0; k0 < p.Np; k0 += KSTEP) {
+        const int k = k0 + 2 * t;
+        const bool live = k < p.Np;                      // the barriers below are taken by every thread
+        double r0[JT], r1[JT];
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) { r0[jj] = 0.0; r1[jj] = 0.0; }
+        for (int c0 = 0; c0 < p.dp; c0 += SLAB) {
+            __syncthreads();
+            for (int idx = t; idx < JT * SLAB; idx += 256) {
+                const int jj = idx / SLAB, c = c0 + idx % SLAB;
+                const int64_t gj = p.j0 + jb + jj;
+                zs[jj][idx % SLAB] = (c < p.d && gj < p.M) ? p.Z[gj * p.d + c] * p.s : 0.0;
+            }
+            __syncthreads();
+            if (live) {
+                double x0[SLAB], x1[SLAB];
+                const double* xp = p.Xs + (int64_t)k * p.dp + c0;
+#pragma unroll
+                for (int c = 0; c < SLAB; c += 2) {
+                    const d2_t v0 = *reinterpret_cast<const d2_t*>(xp + c);
+                    const d2_t v1 = *reinterpret_cast<const d2_t*>(xp + p.dp + c);
+                    x0[c] = v0[0]; x0[c + 1] = v0[1];
+                    x1[c] = v1[0]; x1[c + 1] = v1[1];
+                }
+#pragma unroll
+                for (int jj = 0; jj < JT; ++jj) {
+                    asm volatile("" ::: "memory");
+                    double a = r0[jj], b = r1[jj];
+#pragma unroll
+                    for (int c = 0; c < SLAB; ++c) {
+                        const double z = zs[jj][c];
+                        const double e0 = x0[c] - z, e1 = x1[c] - z;
+                        a = fma(e0, e0, a);
+                        b = fma(e1, e1, b);
+                    }
+                    r0[jj] = a; r1[jj] = b;
+                }
+            }
+        }
+        if (live) {
+            const double s0 = k < p.N ? p.sigma_f2 : 0.0, s1 = (k + 1) < p.N ? p.sigma_f2 : 0.0;
+            double a0 = 0.0, a1 = 0.0;
+            if (p.alpha) { a0 = p.alpha[k]; a1 = p.alpha[k + 1]; }
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj) {
+                const bool okj = (p.j0 + jb + jj) < p.M;
+                const double v0 = okj ? s0 * kappa_eval<FAM>(r0[jj]) : 0.0;
+                const double v1 = okj ? s1 * kappa_eval<FAM>(r1[jj]) : 0.0;
+                if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
+                mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
+            }
+        }
+    }
+    if (p.mu == nullptr) return;
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        double v = mu[jj];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][jj] = v;
+    }
+    __syncthreads();
+    if (t < JT) p.mu[jb + t] = p.mean_c + (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]);
+}
+
 template <int FAM>
 static hipError_t launch_fam(const KgenArgs& a, hipStream_t s) {
     dim3 grid(a.Mc / JT), block(256);
+    if (a.dp > 32) {
+        if (a.dp % SLAB) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((kgen_wide_kernel<FAM>), grid, block, 0, s, a);
+        return hipGetLastError();
+    }
     switch (a.dp) {
         case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1>), grid, block, 0, s, a); break;
         case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2>), grid, block, 0, s, a); break;

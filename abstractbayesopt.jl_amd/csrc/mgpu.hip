@@ -1,0 +1,678 @@
+// Multi-device driver (abo_mgpu_*, include/abo_hip.h): one host process, one host thread per shard, replicated
+// deterministic fit, candidates sharded contiguously, selection merged after ONE all-gather of k × (score, index)
+// per device (RCCL over xGMI; host copies when RCCL cannot be used).
+//
+// Reference behaviour being served: `scores = acqf(surrogate, grid_points)` + `sortperm(scores; rev=true)[1:n_local]`
+// (src/acquisition_functions/acq_utils.jl:50-52) — every candidate's score depends only on (model, that candidate)
+// (src/surrogates/StandardGP.jl:361-379), so the batch shards with no data-path collective; the merge reproduces the
+// stable reverse sort globally (descending score, ties → lowest index, NaN first).  The reference has no multi-device
+// code of its own; BASELINE configs 4 and 5 define this path.
+//
+// No arithmetic lives here: every device runs the single-device entry points of api.hip on its own handle.
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the functions are resolved with dlsym (no link-time dependency)
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "abo_internal.h"
+#include "abo_kernels.h"
+
+namespace {
+
+constexpr int MAXDEV = 16;
+
+int32_t failf(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int32_t failf(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return abo::set_error(code, buf);
+}
+
+// ---- RCCL, loaded at run time ---------------------------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;        // why it is not available
+};
+
+const Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        // the copy the process already has (a PyTorch host brings its own) comes first: two RCCLs in one process would
+        // each spin up their own proxy threads and IPC state
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            x.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (x.handle) break;
+        }
+        for (int i = 0; !x.handle && i < 3; ++i) x.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!x.handle) { x.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?"); return x; }
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(x.handle, "ncclCommInitAll"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
+        if (!x.CommInitAll || !x.CommDestroy || !x.AllGather || !x.GetErrorString) {
+            x.why = "librccl.so.1 lacks ncclCommInitAll / ncclAllGather";
+            x.handle = nullptr;
+        }
+        return x;
+    }();
+    return r;
+}
+
+// ---- one worker thread per shard slot, shared by all groups of the process --------------------------------------
+struct Worker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    Worker() {
+        std::thread([this] {
+            for (;;) {
+                std::function<void()> job;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return !q.empty(); });
+                    job = std::move(q.front());
+                    q.pop_front();
+                }
+                job();
+            }
+        }).detach();          // lives as long as the process; blocked on the condition variable when idle
+    }
+    void post(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); }
+        cv.notify_one();
+    }
+};
+
+Worker* worker(int slot) {
+    static std::mutex mu;
+    static Worker* w[MAXDEV] = {nullptr};
+    std::lock_guard<std::mutex> lk(mu);
+    if (!w[slot]) w[slot] = new Worker();   // never destroyed: a thread parked in it may outlive static destructors
+    return w[slot];
+}
+
+// f(i) for every shard i concurrently; the first failure (lowest shard) becomes the caller's status and error text
+int32_t run_all(int n, const std::function<int32_t(int)>& f) {
+    if (n == 1) return f(0);
+    std::mutex mu;
+    std::condition_variable cv;
+    int left = n;
+    std::vector<int32_t> rc(n, 0);
+    std::vector<std::string> err(n);
+    for (int i = 0; i < n; ++i) {
+        worker(i)->post([&, i] {
+            rc[i] = f(i);
+            if (rc[i]) err[i] = abo::last_error_text();
+            std::lock_guard<std::mutex> lk(mu);
+            if (--left == 0) cv.notify_one();
+        });
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return left == 0; });
+    }
+    for (int i = 0; i < n; ++i)
+        if (rc[i]) return abo::set_error(rc[i], err[i].c_str());
+    return ABO_OK;
+}
+
+// ---- per-device-list exchange state: communicators and device buffers, created once per process -----------------
+struct CommSet {
+    std::vector<int> dev;
+    bool rccl_ok = false;
+    std::string why;
+    ncclComm_t comm[MAXDEV] = {nullptr};
+    void* pack[MAXDEV] = {nullptr};     // this shard's contribution
+    void* gath[MAXDEV] = {nullptr};     // the gathered contributions of all shards
+    size_t pack_cap[MAXDEV] = {0}, gath_cap[MAXDEV] = {0};
+    std::mutex mu;                      // one exchange at a time per device list
+};
+
+CommSet* comm_set(const int* dev, int ndev) {
+    static std::mutex mu;
+    static std::map<std::vector<int>, CommSet*> sets;
+    std::vector<int> key(dev, dev + ndev);
+    const char* ex = getenv("ABO_MGPU_EXCHANGE");
+    const bool force_host = ex && !strcmp(ex, "host");
+    const bool force_rccl = ex && !strcmp(ex, "rccl");
+    key.push_back(force_host ? -1 : (force_rccl ? -2 : 0));      // the override is part of the identity (tests flip it)
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = sets.find(key);
+    if (it != sets.end()) return it->second;
+    CommSet* cs = new CommSet();
+    cs->dev.assign(dev, dev + ndev);
+    bool distinct = true;
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j) distinct = distinct && dev[i] != dev[j];
+    if (force_host) cs->why = "ABO_MGPU_EXCHANGE=host";
+    else if (!distinct) cs->why = "a device is listed twice (RCCL needs distinct devices)";
+    else if (ndev == 1 && !force_rccl) cs->why = "one shard: nothing to exchange";
+    else if (!rccl().handle) cs->why = rccl().why;
+    else {
+        const ncclResult_t r = rccl().CommInitAll(cs->comm, ndev, dev);
+        if (r == ncclSuccess) cs->rccl_ok = true;
+        else cs->why = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
+        (void)hipGetLastError();
+    }
+    sets[key] = cs;
+    return cs;
+}
+
+hipError_t ensure_dev(void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t want = 4096;
+    while (want < bytes) want <<= 1;
+    hipError_t e = hipMalloc(p, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
+void shard_range(int64_t M, int i, int n, int64_t* lo, int64_t* hi) {
+    const int64_t base = M / n, extra = M % n;
+    *lo = i * base + (i < extra ? i : extra);
+    *hi = *lo + base + (i < extra ? 1 : 0);
+}
+
+// Julia's isless-descending order on scores: NaN first, then +Inf … −Inf with 0.0 before −0.0 (misc.hip: score_key)
+uint64_t score_key(double s) {
+    if (s != s) return ~0ull;
+    uint64_t b;
+    memcpy(&b, &s, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+struct Pair { uint64_t key; int64_t idx; double val; };
+
+// merge ndev × k gathered pairs (layout per shard: k values then k indices) into the global top-k
+void merge_pairs(const double* vals, const int64_t* idx, int n, int k, double* top_val, int64_t* top_idx) {
+    std::vector<Pair> v;
+    v.reserve(n);
+    for (int e = 0; e < n; ++e)
+        if (idx[e] >= 0) v.push_back({score_key(vals[e]), idx[e], vals[e]});
+    std::sort(v.begin(), v.end(), [](const Pair& a, const Pair& b) { return a.key > b.key || (a.key == b.key && a.idx < b.idx); });
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    for (int e = 0; e < k; ++e) {
+        if (e < (int)v.size()) { top_val[e] = v[e].val; top_idx[e] = v[e].idx; }
+        else { top_val[e] = nan; top_idx[e] = -1; }
+    }
+}
+
+}  // namespace
+
+struct abo_mgpu {
+    int ndev = 0;
+    int dev[MAXDEV] = {0};
+    abo_gp* gp[MAXDEV] = {nullptr};
+    abo_params prm{};
+    CommSet* cs = nullptr;
+};
+
+struct abo_mcand {
+    int ndev = 0, d = 0;
+    int64_t M = 0;
+    int64_t lo[MAXDEV + 1] = {0};
+    abo_cand* c[MAXDEV] = {nullptr};
+};
+
+namespace {
+
+int32_t check_group(abo_mgpu* mg, const char* fn) {
+    if (!mg) return failf(ABO_EINVAL, "%s: null group", fn);
+    return ABO_OK;
+}
+
+// All shards hold k pairs (k values + k indices) in cs->pack[i] on their device.  RCCL: one all-gather per shard, shard 0
+// copies the gathered block to the host.  Host: every shard copies its own block.  out: ndev blocks of `words` 8-byte words.
+int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
+    CommSet* cs = mg->cs;
+    const int n = mg->ndev;
+    // one collective at a time in the whole process: two device lists that overlap share worker threads, and a shard
+    // parked in its stream synchronisation would otherwise keep the peer of the OTHER collective from ever enqueueing
+    static std::mutex xmu;
+    std::lock_guard<std::mutex> xlk(xmu);
+    if (cs->rccl_ok) {
+        int32_t rc = run_all(n, [&](int i) -> int32_t {
+            if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
+            hipStream_t s = abo::gp_stream(mg->gp[i]);
+            const ncclResult_t r = rccl().AllGather(cs->pack[i], cs->gath[i], words, ncclUint64, cs->comm[i], s);
+            if (r != ncclSuccess) return failf(ABO_EHIP, "ncclAllGather: %s", rccl().GetErrorString(r));
+            if (i == 0 && hipMemcpyAsync(out, cs->gath[0], n * words * 8, hipMemcpyDeviceToHost, s) != hipSuccess)
+                return failf(ABO_EHIP, "exchange: device-to-host copy failed");
+            if (hipStreamSynchronize(s) != hipSuccess) return failf(ABO_EHIP, "exchange: stream synchronisation failed");
+            return ABO_OK;
+        });
+        return rc;
+    }
+    return run_all(n, [&](int i) -> int32_t {
+        if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
+        hipStream_t s = abo::gp_stream(mg->gp[i]);
+        if (hipMemcpyAsync(out + (size_t)i * words, cs->pack[i], words * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            return failf(ABO_EHIP, "exchange: device-to-host copy failed");
+        return ABO_OK;
+    });
+}
+
+int32_t ensure_exchange_buffers(abo_mgpu* mg, int i, size_t words) {
+    CommSet* cs = mg->cs;
+    if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
+    if (ensure_dev(&cs->pack[i], &cs->pack_cap[i], words * 8) != hipSuccess ||
+        (cs->rccl_ok && ensure_dev(&cs->gath[i], &cs->gath_cap[i], (size_t)mg->ndev * words * 8) != hipSuccess))
+        return failf(ABO_ENOMEM, "exchange buffers: device allocation failed");
+    return ABO_OK;
+}
+
+// gathered blocks (k values, k indices per shard) → merged global top-k
+void merge_blocks(const uint64_t* blocks, int ndev, int k, double* top_val, int64_t* top_idx) {
+    std::vector<double> vals((size_t)ndev * k);
+    std::vector<int64_t> idx((size_t)ndev * k);
+    for (int i = 0; i < ndev; ++i) {
+        memcpy(&vals[(size_t)i * k], blocks + (size_t)i * 2 * k, sizeof(double) * k);
+        memcpy(&idx[(size_t)i * k], blocks + (size_t)i * 2 * k + k, sizeof(int64_t) * k);
+    }
+    merge_pairs(vals.data(), idx.data(), ndev * k, k, top_val, top_idx);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t abo_mgpu_create(const abo_params* params, int32_t ndev, const int32_t* dev, abo_mgpu** out) {
+    if (!params || !dev || !out) return failf(ABO_EINVAL, "abo_mgpu_create: null argument");
+    if (ndev < 1 || ndev > MAXDEV) return failf(ABO_EINVAL, "abo_mgpu_create: ndev = %d outside 1..%d", ndev, MAXDEV);
+    abo_mgpu* mg = new (std::nothrow) abo_mgpu();
+    if (!mg) return failf(ABO_ENOMEM, "abo_mgpu_create: host allocation failed");
+    mg->ndev = ndev;
+    mg->prm = *params;
+    for (int i = 0; i < ndev; ++i) {
+        mg->dev[i] = dev[i];
+        abo_params p = *params;
+        p.device = dev[i];
+        const int32_t rc = abo_create(&p, &mg->gp[i]);
+        if (rc) { abo_mgpu_destroy(mg); return rc; }
+    }
+    mg->cs = comm_set(mg->dev, ndev);
+    *out = mg;
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_clone(abo_mgpu* mg, abo_mgpu** out) {
+    if (!mg || !out) return failf(ABO_EINVAL, "abo_mgpu_clone: null argument");
+    abo_mgpu* n = new (std::nothrow) abo_mgpu(*mg);
+    if (!n) return failf(ABO_ENOMEM, "abo_mgpu_clone: host allocation failed");
+    for (int i = 0; i < n->ndev; ++i) abo_retain(n->gp[i]);
+    *out = n;
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_destroy(abo_mgpu* mg) {
+    if (!mg) return ABO_OK;
+    for (int i = 0; i < mg->ndev; ++i) abo_destroy(mg->gp[i]);
+    delete mg;
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_info(abo_mgpu* mg, int32_t* ndev, int32_t* dev, int32_t* exch) {
+    int32_t rc = check_group(mg, "abo_mgpu_info");
+    if (rc) return rc;
+    if (ndev) *ndev = mg->ndev;
+    if (dev) for (int i = 0; i < MAXDEV; ++i) dev[i] = i < mg->ndev ? mg->dev[i] : -1;
+    if (exch) *exch = mg->cs->rccl_ok ? ABO_XCHG_RCCL : ABO_XCHG_HOST;
+    if (!mg->cs->rccl_ok) abo::set_error(ABO_OK, mg->cs->why.c_str());     // why not RCCL: readable through abo_last_error
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_get(abo_mgpu* mg, int32_t i, abo_gp** out) {
+    int32_t rc = check_group(mg, "abo_mgpu_get");
+    if (rc) return rc;
+    if (!out || i < 0 || i >= mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_get: shard %d outside 0..%d", i, mg->ndev - 1);
+    *out = mg->gp[i];
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_fit(abo_mgpu* mg, const double* X, int64_t N, int32_t d, const double* y, int64_t* info) {
+    if (info) *info = 0;
+    int32_t rc = check_group(mg, "abo_mgpu_fit");
+    if (rc) return rc;
+    // update() returns a NEW model (StandardGP.jl:82) and a clone shares its handles with the group it came from: fit
+    // fresh handles and swap them in on success; on failure (PosDefException …) the group keeps its previous state,
+    // which is what the driver's rollback restores anyway (src/bayesian_opt.jl:126-141)
+    int64_t inf[MAXDEV] = {0};
+    abo_gp* nw[MAXDEV] = {nullptr};
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        abo_params p = mg->prm;
+        p.device = mg->dev[i];
+        const int32_t r = abo_create(&p, &nw[i]);
+        return r ? r : abo_fit(nw[i], X, N, d, y, ABO_HOST, &inf[i]);
+    });
+    if (info) for (int i = 0; i < mg->ndev; ++i) if (inf[i]) { *info = inf[i]; break; }
+    if (rc) {
+        const std::string keep = abo::last_error_text();
+        for (int i = 0; i < mg->ndev; ++i) if (nw[i]) abo_destroy(nw[i]);
+        return abo::set_error(rc, keep.c_str());
+    }
+    for (int i = 0; i < mg->ndev; ++i) { abo_destroy(mg->gp[i]); mg->gp[i] = nw[i]; }
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_predict(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, double* mu, double* var) {
+    int32_t rc = check_group(mg, "abo_mgpu_predict");
+    if (rc) return rc;
+    if (M < 0 || (M > 0 && !Z)) return failf(ABO_EINVAL, "abo_mgpu_predict: bad candidate buffer");
+    return run_all(mg->ndev, [&](int i) -> int32_t {
+        int64_t lo, hi;
+        shard_range(M, i, mg->ndev, &lo, &hi);
+        // an empty shard still checks the dimension (same status on every device)
+        return abo_predict(mg->gp[i], Z + lo * d, hi - lo, d, ABO_HOST, mu ? mu + lo : nullptr, var ? var + lo : nullptr, ABO_HOST);
+    });
+}
+
+int32_t abo_mgpu_acq(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, int32_t kind, double p0, double best_y,
+                     double* scores, int32_t k, double* top_val, int64_t* top_idx) {
+    int32_t rc = check_group(mg, "abo_mgpu_acq");
+    if (rc) return rc;
+    if (M < 0 || (M > 0 && !Z)) return failf(ABO_EINVAL, "abo_mgpu_acq: bad candidate buffer");
+    if (k < 0) return failf(ABO_EINVAL, "abo_mgpu_acq: k = %d is negative", k);
+    if (k > 0 && (!top_val || !top_idx)) return failf(ABO_EINVAL, "abo_mgpu_acq: k > 0 needs top_val and top_idx");
+    CommSet* cs = mg->cs;
+    std::lock_guard<std::mutex> lk(cs->mu);
+    const size_t words = 2 * (size_t)k;
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        int64_t lo, hi;
+        shard_range(M, i, mg->ndev, &lo, &hi);
+        double* tv = nullptr;
+        int64_t* ti = nullptr;
+        if (k > 0) {
+            const int32_t r = ensure_exchange_buffers(mg, i, words);
+            if (r) return r;
+            tv = static_cast<double*>(cs->pack[i]);
+            ti = static_cast<int64_t*>(cs->pack[i]) + k;
+        }
+        return abo::acq_ex(mg->gp[i], Z + lo * d, hi - lo, d, ABO_HOST, kind, p0, best_y, lo, scores ? scores + lo : nullptr,
+                           ABO_HOST, k, tv, ti, ABO_DEVICE);
+    });
+    if (rc || k == 0) return rc;
+    std::vector<uint64_t> blocks((size_t)mg->ndev * words);
+    rc = exchange(mg, words, blocks.data());
+    if (rc) return rc;
+    merge_blocks(blocks.data(), mg->ndev, k, top_val, top_idx);
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
+                         int32_t kind, double p0, double best_y, int32_t k, double* top_val, int64_t* top_idx, double* top_x) {
+    int32_t rc = check_group(mg, "abo_mgpu_acq_lhs");
+    if (rc) return rc;
+    if (n < 1 || !lower || !upper) return failf(ABO_EINVAL, "abo_mgpu_acq_lhs: bad grid");
+    if (k < 1 || !top_val || !top_idx) return failf(ABO_EINVAL, "abo_mgpu_acq_lhs: needs k >= 1, top_val and top_idx");
+    CommSet* cs = mg->cs;
+    std::lock_guard<std::mutex> lk(cs->mu);
+    const size_t words = 2 * (size_t)k;
+    double* zdev[MAXDEV] = {nullptr};
+    auto free_grids = [&] {
+        for (int i = 0; i < mg->ndev; ++i)
+            if (zdev[i]) { (void)hipSetDevice(mg->dev[i]); (void)hipFree(zdev[i]); zdev[i] = nullptr; }
+    };
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        int64_t lo, hi;
+        shard_range(n, i, mg->ndev, &lo, &hi);
+        int32_t r = ensure_exchange_buffers(mg, i, words);
+        if (r) return r;
+        if (hi > lo) {
+            if (hipMalloc(reinterpret_cast<void**>(&zdev[i]), sizeof(double) * (hi - lo) * d) != hipSuccess)
+                return failf(ABO_ENOMEM, "abo_mgpu_acq_lhs: device allocation of the grid shard failed");
+            r = abo_lhs(mg->dev[i], n, d, lower, upper, seed, lo, hi - lo, zdev[i]);
+            if (r) return r;
+        }
+        return abo::acq_ex(mg->gp[i], zdev[i], hi - lo, d, ABO_DEVICE, kind, p0, best_y, lo, nullptr, ABO_DEVICE, k,
+                           static_cast<double*>(cs->pack[i]), static_cast<int64_t*>(cs->pack[i]) + k, ABO_DEVICE);
+    });
+    std::vector<uint64_t> blocks((size_t)mg->ndev * words);
+    if (!rc) rc = exchange(mg, words, blocks.data());
+    if (rc) { free_grids(); return rc; }
+    merge_blocks(blocks.data(), mg->ndev, k, top_val, top_idx);
+    if (top_x) {
+        // coordinates of the winners, fetched from the shard that generated them
+        rc = run_all(mg->ndev, [&](int i) -> int32_t {
+            int64_t lo, hi;
+            shard_range(n, i, mg->ndev, &lo, &hi);
+            if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
+            hipStream_t s = abo::gp_stream(mg->gp[i]);
+            for (int e = 0; e < k; ++e) {
+                const int64_t g = top_idx[e];
+                if (g < lo || g >= hi) continue;
+                if (hipMemcpyAsync(top_x + (size_t)e * d, zdev[i] + (g - lo) * d, sizeof(double) * d, hipMemcpyDeviceToHost, s) != hipSuccess)
+                    return failf(ABO_EHIP, "abo_mgpu_acq_lhs: copy of a selected point failed");
+            }
+            if (hipStreamSynchronize(s) != hipSuccess) return failf(ABO_EHIP, "abo_mgpu_acq_lhs: stream synchronisation failed");
+            return ABO_OK;
+        });
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        for (int e = 0; e < k; ++e)
+            if (top_idx[e] < 0) for (int c = 0; c < d; ++c) top_x[(size_t)e * d + c] = nan;
+    }
+    free_grids();
+    return rc;
+}
+
+// ---- config 5 across devices -----------------------------------------------------------------------------------
+int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* mc) {
+    if (info) *info = 0;
+    int32_t rc = check_group(mg, "abo_mgpu_append");
+    if (rc) return rc;
+    if (mc && mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_append: candidate set has %d shards, group %d", mc->ndev, mg->ndev);
+    abo_gp* nw[MAXDEV] = {nullptr};
+    int64_t inf[MAXDEV] = {0};
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        int32_t r = abo_append(mg->gp[i], x, d, y, &inf[i], &nw[i]);
+        if (r) return r;
+        if (mc) r = abo_cand_downdate(nw[i], mc->c[i]);
+        return r;
+    });
+    if (rc) {
+        const std::string keep = abo::last_error_text();
+        for (int i = 0; i < mg->ndev; ++i)
+            if (inf[i] && info && !*info) *info = inf[i];
+        // a shard that had already down-dated its candidates is out of step with its (unchanged) model now
+        bool any = false;
+        for (int i = 0; i < mg->ndev; ++i) any = any || nw[i] != nullptr;
+        for (int i = 0; i < mg->ndev; ++i) if (nw[i]) { abo_destroy(nw[i]); nw[i] = nullptr; }
+        if (mc && any) (void)abo_mgpu_cand_refresh(mg, mc);
+        return abo::set_error(rc, keep.c_str());
+    }
+    for (int i = 0; i < mg->ndev; ++i) { abo_destroy(mg->gp[i]); mg->gp[i] = nw[i]; }
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_cand_destroy(abo_mcand* mc) {
+    if (!mc) return ABO_OK;
+    for (int i = 0; i < mc->ndev; ++i) abo_cand_destroy(mc->c[i]);
+    delete mc;
+    return ABO_OK;
+}
+
+static int32_t mcand_new(abo_mgpu* mg, int64_t M, int32_t d, abo_mcand** out) {
+    abo_mcand* mc = new (std::nothrow) abo_mcand();
+    if (!mc) return failf(ABO_ENOMEM, "candidate set: host allocation failed");
+    mc->ndev = mg->ndev; mc->d = d; mc->M = M;
+    for (int i = 0; i < mg->ndev; ++i) shard_range(M, i, mg->ndev, &mc->lo[i], &mc->lo[i + 1]);
+    *out = mc;
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_cand_create(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, abo_mcand** out) {
+    int32_t rc = check_group(mg, "abo_mgpu_cand_create");
+    if (rc) return rc;
+    if (!out || M < 0 || (M > 0 && !Z)) return failf(ABO_EINVAL, "abo_mgpu_cand_create: bad argument");
+    abo_mcand* mc = nullptr;
+    rc = mcand_new(mg, M, d, &mc);
+    if (rc) return rc;
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        return abo_cand_create(mg->gp[i], Z + mc->lo[i] * d, mc->lo[i + 1] - mc->lo[i], d, ABO_HOST, &mc->c[i]);
+    });
+    if (rc) { const std::string keep = abo::last_error_text(); abo_mgpu_cand_destroy(mc); return abo::set_error(rc, keep.c_str()); }
+    *out = mc;
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_cand_create_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
+                                 abo_mcand** out) {
+    int32_t rc = check_group(mg, "abo_mgpu_cand_create_lhs");
+    if (rc) return rc;
+    if (!out || n < 1 || !lower || !upper) return failf(ABO_EINVAL, "abo_mgpu_cand_create_lhs: bad argument");
+    abo_mcand* mc = nullptr;
+    rc = mcand_new(mg, n, d, &mc);
+    if (rc) return rc;
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        const int64_t m = mc->lo[i + 1] - mc->lo[i];
+        double* z = nullptr;
+        if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
+        if (hipMalloc(reinterpret_cast<void**>(&z), sizeof(double) * (m > 0 ? m : 1) * d) != hipSuccess)
+            return failf(ABO_ENOMEM, "abo_mgpu_cand_create_lhs: device allocation of the grid shard failed");
+        int32_t r = m > 0 ? abo_lhs(mg->dev[i], n, d, lower, upper, seed, mc->lo[i], m, z) : ABO_OK;
+        if (!r) r = abo_cand_create(mg->gp[i], z, m, d, ABO_DEVICE, &mc->c[i]);   // copies the points into the set
+        (void)hipFree(z);
+        return r;
+    });
+    if (rc) { const std::string keep = abo::last_error_text(); abo_mgpu_cand_destroy(mc); return abo::set_error(rc, keep.c_str()); }
+    *out = mc;
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_cand_refresh(abo_mgpu* mg, abo_mcand* mc) {
+    int32_t rc = check_group(mg, "abo_mgpu_cand_refresh");
+    if (rc) return rc;
+    if (!mc || mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_cand_refresh: candidate set does not belong to this group");
+    return run_all(mg->ndev, [&](int i) -> int32_t { return abo_cand_refresh(mg->gp[i], mc->c[i]); });
+}
+
+int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, double best_y, int32_t k, double* top_val,
+                          int64_t* top_idx) {
+    int32_t rc = check_group(mg, "abo_mgpu_cand_acq");
+    if (rc) return rc;
+    if (!mc || mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_cand_acq: candidate set does not belong to this group");
+    if (k < 1 || !top_val || !top_idx) return failf(ABO_EINVAL, "abo_mgpu_cand_acq: needs k >= 1, top_val and top_idx");
+    CommSet* cs = mg->cs;
+    std::lock_guard<std::mutex> lk(cs->mu);
+    const size_t words = 2 * (size_t)k;
+    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        const int32_t r = ensure_exchange_buffers(mg, i, words);
+        if (r) return r;
+        return abo::cand_acq_ex(mg->gp[i], mc->c[i], kind, p0, best_y, mc->lo[i], nullptr, ABO_DEVICE, k,
+                                static_cast<double*>(cs->pack[i]), static_cast<int64_t*>(cs->pack[i]) + k, ABO_DEVICE);
+    });
+    if (rc) return rc;
+    std::vector<uint64_t> blocks((size_t)mg->ndev * words);
+    rc = exchange(mg, words, blocks.data());
+    if (rc) return rc;
+    merge_blocks(blocks.data(), mg->ndev, k, top_val, top_idx);
+    return ABO_OK;
+}
+
+int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, double best_y, int32_t distinct, double* x_out,
+                          int64_t* idx_out, double* ei_out) {
+    int32_t rc = check_group(mg, "abo_mgpu_cand_qei");
+    if (rc) return rc;
+    if (!mc || mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_cand_qei: candidate set does not belong to this group");
+    if (q < 1) return failf(ABO_EINVAL, "abo_mgpu_cand_qei: q = %d", q);
+    const int n = mg->ndev, d = mc->d;
+    CommSet* cs = mg->cs;
+    std::lock_guard<std::mutex> lk(cs->mu);
+    // exchange block per shard: the pick record {score, index, μ, x[d]}; the (score, index) pair of the device top-1 is
+    // parked behind it in the same buffer
+    const size_t words = 3 + (size_t)d;
+    rc = run_all(n, [&](int i) -> int32_t {
+        const int32_t r = ensure_exchange_buffers(mg, i, words + 2);
+        if (r) return r;
+        return abo_cand_save(mg->gp[i], mc->c[i]);
+    });
+    if (rc) return rc;
+    abo_gp* cur[MAXDEV];
+    for (int i = 0; i < n; ++i) cur[i] = mg->gp[i];
+    std::vector<double> recs((size_t)n * words);
+    int32_t status = ABO_OK;
+    std::string keep;
+    for (int j = 0; j < q && !status; ++j) {
+        status = run_all(n, [&](int i) -> int32_t {
+            double* rec = static_cast<double*>(cs->pack[i]);
+            double* tv = rec + words;
+            int64_t* ti = reinterpret_cast<int64_t*>(rec + words + 1);
+            int32_t r = abo::cand_acq_ex(cur[i], mc->c[i], ABO_ACQ_EI, xi, best_y, mc->lo[i], nullptr, ABO_DEVICE, 1, tv, ti, ABO_DEVICE);
+            if (r) return r;
+            if (abo::launch_pick_record(tv, ti, mc->lo[i], abo::cand_points(mc->c[i]), abo::cand_mu(mc->c[i]), d, rec,
+                                        abo::gp_stream(cur[i])) != hipSuccess)
+                return failf(ABO_EHIP, "abo_mgpu_cand_qei: pick-record launch failed");
+            // the exchange runs on the stream of the group's base handle, the record was written on the stream of `cur`
+            if (hipStreamSynchronize(abo::gp_stream(cur[i])) != hipSuccess) return failf(ABO_EHIP, "stream synchronisation failed");
+            return ABO_OK;
+        });
+        if (status) break;
+        status = exchange(mg, words, reinterpret_cast<uint64_t*>(recs.data()));
+        if (status) break;
+        int win = -1;
+        for (int i = 0; i < n; ++i) {
+            const double* r = &recs[(size_t)i * words];
+            if (r[1] < 0) continue;                                   // empty shard
+            if (win < 0) { win = i; continue; }
+            const double* w = &recs[(size_t)win * words];
+            const uint64_t kr = score_key(r[0]), kw = score_key(w[0]);
+            if (kr > kw || (kr == kw && r[1] < w[1])) win = i;
+        }
+        if (win < 0) { status = failf(ABO_EINVAL, "abo_mgpu_cand_qei: the candidate set is empty"); break; }
+        const double* w = &recs[(size_t)win * words];
+        const int64_t gidx = (int64_t)w[1];
+        const double mu = w[2];
+        const double* x = w + 3;
+        ei_out[j] = w[0];
+        idx_out[j] = gidx;
+        memcpy(x_out + (size_t)j * d, x, sizeof(double) * d);
+        abo_gp* nw[MAXDEV] = {nullptr};
+        status = run_all(n, [&](int i) -> int32_t {
+            int64_t inf = 0;
+            int32_t r = abo_append(cur[i], x, d, mu, &inf, &nw[i]);       // fantasy observation y = μ(x): β = 0
+            if (r) return r;
+            r = abo_cand_downdate(nw[i], mc->c[i]);
+            if (!r && distinct && gidx >= mc->lo[i] && gidx < mc->lo[i + 1]) r = abo_cand_exclude(nw[i], mc->c[i], gidx - mc->lo[i]);
+            return r;
+        });
+        if (status) keep = abo::last_error_text();
+        for (int i = 0; i < n; ++i) {
+            if (nw[i]) {
+                if (cur[i] != mg->gp[i]) abo_destroy(cur[i]);
+                cur[i] = nw[i];
+            }
+        }
+    }
+    if (status && keep.empty()) keep = abo::last_error_text();
+    for (int i = 0; i < n; ++i)
+        if (cur[i] != mg->gp[i]) abo_destroy(cur[i]);
+    rc = run_all(n, [&](int i) -> int32_t { return abo_cand_restore(mg->gp[i], mc->c[i]); });
+    if (status) return abo::set_error(status, keep.c_str());
+    return rc;
+}
+
+}  // extern "C"

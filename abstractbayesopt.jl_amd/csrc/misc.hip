@@ -131,13 +131,34 @@ hipError_t launch_score(const double* mu, const double* var, double* score, int6
     return hipGetLastError();
 }
 
+// Greedy q-EI, multi-device: one record per device and pick — {score, global index, μ(z), z[0..d)} of the device's best
+// candidate — assembled on the device so that it can go straight into the RCCL all-gather (or one D2H copy).
+__global__ void pick_record_kernel(const double* tv, const int64_t* ti, int64_t idx_base, const double* Z, const double* mu,
+                                   int d, double* rec) {
+    const int t = threadIdx.x;
+    const int64_t gi = ti[0];
+    const int64_t li = gi - idx_base;
+    if (t == 0) {
+        rec[0] = tv[0];
+        rec[1] = (double)gi;                             // exact below 2^53
+        rec[2] = gi >= 0 ? mu[li] : 0.0;
+    }
+    for (int c = t; c < d; c += blockDim.x) rec[3 + c] = gi >= 0 ? Z[li * d + c] : 0.0;
+}
+
+hipError_t launch_pick_record(const double* tv, const int64_t* ti, int64_t idx_base, const double* Z, const double* mu, int d,
+                              double* rec, hipStream_t s) {
+    hipLaunchKernelGGL(pick_record_kernel, dim3(1), dim3(64), 0, s, tv, ti, idx_base, Z, mu, d, rec);
+    return hipGetLastError();
+}
+
 // ---- per-point posterior covariance of all outputs of a gradient-enhanced GP ----------------------------
 // posterior_grad_cov(model, [x]) (src/surrogates/GradientGP.jl:966-971) and the GradientNormUCB epilogue
 // (src/acquisition_functions/gradNormUCB.jl:43-51).  V rows are point-major: row j·p + q holds L⁻¹k for output q
 // of point j.  One workgroup per point; wave w reduces the (q,q') pairs w, w+4, … (lanes stride the R entries).
 __global__ void __launch_bounds__(256) grad_cov_kernel(GradCovArgs a) {
-    __shared__ double C[17 * 17];
-    __shared__ double m[17];
+    __shared__ double C[MAX_P * MAX_P];
+    __shared__ double m[MAX_P];
     const int j = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int p = a.p;
@@ -266,10 +287,14 @@ __device__ __forceinline__ bool before(uint64_t ka, int64_t ia, uint64_t kb, int
     return (ka > kb) || (ka == kb && ia < ib);
 }
 
+// thr (FIRST pass only, may be null): {key, idx} of the last entry already selected by an earlier round of a k > 1024
+// selection — only entries strictly AFTER it in the total order take part (the order is strict, so "after the last
+// one taken" is exactly "not taken yet").
 template <bool FIRST>
 __global__ void __launch_bounds__(TK_T) topk_pass_kernel(const double* __restrict__ scores, const uint64_t* __restrict__ kin,
                                                         const int64_t* __restrict__ iin, int64_t n, int kp,
-                                                        uint64_t* __restrict__ kout, int64_t* __restrict__ iout) {
+                                                        uint64_t* __restrict__ kout, int64_t* __restrict__ iout,
+                                                        const uint64_t* __restrict__ thr) {
     __shared__ uint64_t sk[TK_E];
     __shared__ int64_t si[TK_E];
     const int t = threadIdx.x;
@@ -279,8 +304,10 @@ __global__ void __launch_bounds__(TK_T) topk_pass_kernel(const double* __restric
         uint64_t k = KEY_PAD;
         int64_t i = IDX_PAD;
         if (g < n) {
-            if (FIRST) { k = score_key(scores[g]); i = g; }
-            else { k = kin[g]; i = iin[g]; }
+            if (FIRST) {
+                k = score_key(scores[g]); i = g;
+                if (thr != nullptr && !before(thr[0], (int64_t)thr[1], k, i)) { k = KEY_PAD; i = IDX_PAD; }
+            } else { k = kin[g]; i = iin[g]; }
         }
         sk[e] = k;
         si[e] = i;
@@ -311,49 +338,69 @@ __global__ void __launch_bounds__(TK_T) topk_pass_kernel(const double* __restric
     }
 }
 
-__global__ void topk_emit_kernel(const double* scores, const int64_t* idx, int64_t M, int k, int64_t idx_base,
-                                 double* top_val, int64_t* top_idx) {
+// entries e0 .. e0+kc−1 of the selection; thr_out (may be null) receives {key, idx} of the round's last entry
+__global__ void topk_emit_kernel(const double* scores, const uint64_t* keys, const int64_t* idx, int64_t M, int kc, int e0,
+                                 int64_t idx_base, double* top_val, int64_t* top_idx, uint64_t* thr_out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= k) return;
+    if (e >= kc) return;
     const int64_t i = idx[e];
     if (i == IDX_PAD || i >= M) {
-        top_val[e] = __longlong_as_double(0x7ff8000000000000ll);
-        top_idx[e] = -1;
+        top_val[e0 + e] = __longlong_as_double(0x7ff8000000000000ll);
+        top_idx[e0 + e] = -1;
     } else {
-        top_val[e] = scores[i];
-        top_idx[e] = i + idx_base;
+        top_val[e0 + e] = scores[i];
+        top_idx[e0 + e] = i + idx_base;
     }
+    if (thr_out != nullptr && e == kc - 1) { thr_out[0] = keys[e]; thr_out[1] = (uint64_t)i; }
+}
+
+__global__ void topk_fill_kernel(double* top_val, int64_t* top_idx, int lo, int hi) {
+    const int e = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < hi) { top_val[e] = __longlong_as_double(0x7ff8000000000000ll); top_idx[e] = -1; }
 }
 
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 
+constexpr int TK_KMAX = TK_E / 2;   // entries one round can select
+
 int64_t topk_workspace_entries(int64_t M, int k) {
-    const int kp = pow2_at_least(k < 1 ? 1 : k);
+    const int kp = pow2_at_least(k < 1 ? 1 : (k > TK_KMAX ? TK_KMAX : k));
     const int64_t blocks = (M + TK_E - 1) / TK_E;
-    return (blocks < 1 ? 1 : blocks) * (int64_t)kp;
+    return (blocks < 1 ? 1 : blocks) * (int64_t)kp + 2;   // + {key, idx} of the last entry taken (k > 1024 rounds)
 }
 
+// k ≤ 1024: one round (block-wise bitonic sort, keep the first kp per block, repeat until one block is left).
+// k > 1024 (n_local is a free Int in the reference, acq_utils.jl:33-52): rounds of 1024 — each round selects, among the
+// entries strictly after the last one taken so far, the next 1024 in order; ⌈k/1024⌉ passes over the scores, no host
+// round trip (the threshold stays on the device).
 hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base, TopkWork w, double* top_val,
                        int64_t* top_idx, hipStream_t s) {
     if (k <= 0) return hipSuccess;
-    if (k > TK_E / 2) return hipErrorInvalidValue;
-    const int kp = pow2_at_least(k);
-    int64_t n = M;
-    int cur = 0;
-    int64_t blocks = (n + TK_E - 1) / TK_E;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((topk_pass_kernel<true>), dim3((unsigned)blocks), dim3(TK_T), 0, s, scores, nullptr, nullptr, n, kp,
-                       w.keys[0], w.idx[0]);
-    n = blocks * kp;
-    while (blocks > 1) {
-        blocks = (n + TK_E - 1) / TK_E;
-        hipLaunchKernelGGL((topk_pass_kernel<false>), dim3((unsigned)blocks), dim3(TK_T), 0, s, nullptr, w.keys[cur],
-                           w.idx[cur], n, kp, w.keys[cur ^ 1], w.idx[cur ^ 1]);
-        cur ^= 1;
+    uint64_t* thr = w.keys[0] + (topk_workspace_entries(M, k) - 2);
+    // sortperm(...)[1:min(n_local, M)] (acq_utils.jl:52): at most M real entries; the tail of a longer request is (NaN, −1)
+    const int kreal = (int64_t)k < M ? k : (int)(M < 1 ? 1 : M);
+    if (kreal < k) hipLaunchKernelGGL(topk_fill_kernel, dim3((k - kreal + 255) / 256), dim3(256), 0, s, top_val, top_idx, kreal, k);
+    k = kreal;
+    for (int e0 = 0; e0 < k; e0 += TK_KMAX) {
+        const int kc = (k - e0) < TK_KMAX ? (k - e0) : TK_KMAX;
+        const int kp = pow2_at_least(kc);
+        int64_t n = M;
+        int cur = 0;
+        int64_t blocks = (n + TK_E - 1) / TK_E;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL((topk_pass_kernel<true>), dim3((unsigned)blocks), dim3(TK_T), 0, s, scores, nullptr, nullptr, n, kp,
+                           w.keys[0], w.idx[0], e0 > 0 ? thr : nullptr);
         n = blocks * kp;
+        while (blocks > 1) {
+            blocks = (n + TK_E - 1) / TK_E;
+            hipLaunchKernelGGL((topk_pass_kernel<false>), dim3((unsigned)blocks), dim3(TK_T), 0, s, nullptr, w.keys[cur],
+                               w.idx[cur], n, kp, w.keys[cur ^ 1], w.idx[cur ^ 1], nullptr);
+            cur ^= 1;
+            n = blocks * kp;
+        }
+        hipLaunchKernelGGL(topk_emit_kernel, dim3((kc + 255) / 256), dim3(256), 0, s, scores, w.keys[cur], w.idx[cur], M, kc, e0,
+                           idx_base, top_val, top_idx, e0 + kc < k ? thr : nullptr);
     }
-    hipLaunchKernelGGL(topk_emit_kernel, dim3((k + 255) / 256), dim3(256), 0, s, scores, w.idx[cur], M, k, idx_base,
-                       top_val, top_idx);
     return hipGetLastError();
 }
 

@@ -78,8 +78,12 @@ def optimize_hyperparameters(model: HipStandardGP, x_train, y_train, old_params,
         lower, upper = np.log([ls_lo, sc_lo]), np.log([ls_hi, sc_hi])
     old = np.asarray(old_params, dtype=np.float64)
     eps2 = 2 * np.finfo(np.float64).eps
-    start_full = old.copy()
-    start_full[:len(lower)] = np.clip(old[:len(lower)], lower + eps2, upper - eps2)
+    if length_scale_only:
+        # `clamp.(old_params, lower_bounds .+ 2eps(), upper_bounds .- 2eps())` (bayesian_opt.jl:247) broadcasts the
+        # 1-element bounds over BOTH old parameters: the fixed log-scale is clamped into the length-scale box too
+        start_full = np.clip(old, lower[0] + eps2, upper[0] - eps2)
+    else:
+        start_full = np.clip(old, lower + eps2, upper - eps2)
     from . import gradient_gp as G
     grad_model = isinstance(model, G.HipGradientGP)
     if grad_model:                                   # GradientGP: xs stay points, ys stay (N, p) rows; update() packs them

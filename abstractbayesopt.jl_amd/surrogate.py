@@ -205,6 +205,10 @@ def _predict(model, x, want_mu, want_var):
     if np.isscalar(x):                       # abstract.jl:67-69 scalar wrapper
         x = [float(x)]
     zp, m, d, zspace, keep = as_points(x)
+    if hasattr(model, "devices") and zspace == HOST:          # HipShardedGP: shard the batch over the group's devices
+        from . import multigpu
+        mu, var = multigpu.mean_and_var(model, keep)
+        return (mu if want_mu else None), (var if want_var else None)
     if zspace == DEVICE:
         import torch
         mu = torch.empty(m, dtype=torch.float64, device=keep.device) if want_mu else None

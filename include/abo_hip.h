@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ABO_ABI_VERSION 1
+#define ABO_ABI_VERSION 2   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted */
 
 /* status codes */
 enum {
@@ -89,6 +89,7 @@ int32_t abo_create(const abo_params* params, abo_gp** out);
 /* GradientGP(kernel, p, noise_var; mean=gradConstMean(c)) (src/surrogates/GradientGP.jl:617-639): gradient-
  * enhanced GP with p = d+1 outputs per point (f and ∂f/∂x_c), multi-output kernel gradKernel (:573-606) with
  * analytic derivatives, rows ordered by outputs (MOInputIsotopicByOutputs).  mean_c: p prior means (NULL = 0).
+ * 2 ≤ p ≤ 33 (d ≤ 32 inputs: the derivative blocks are generated from register-resident coordinates).
  * abo_fit then takes y of length p·N ordered by outputs (prep_output, :893-895); abo_predict / abo_acq address
  * the function output; abo_append and abo_cand_* are not available on such a handle. */
 int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out);
@@ -142,7 +143,8 @@ int32_t abo_predict_grad_cov(abo_gp* gp, const double* Z, int64_t M, int32_t d, 
  * (src/acquisition_functions/acq_utils.jl:50-52) with the EI/UCB/PI epilogue fused behind the
  * posterior.  scores (length M) is optional; top_val/top_idx (length k) are optional when k == 0.
  * Ordering is Julia's stable reverse sort: descending score, ties → lowest index, NaN first.
- * top_idx are global indices idx_base + j (idx_base = this rank's shard offset).  When M < k the
+ * top_idx are global indices idx_base + j (idx_base = this rank's shard offset).  k is free (n_local is a plain Int in
+ * the reference, acq_utils.jl:33-38): k ≤ 1024 is one selection round, larger k takes ⌈k/1024⌉ rounds; when M < k the
  * tail is filled with (NaN, −1).  scores/top_* live in out_space. */
 int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind,
                 double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
@@ -213,6 +215,67 @@ int32_t abo_get_n(abo_gp* gp, int64_t* N, int32_t* d);
  * this is the device-side half of that: checkpoint = hyper-parameters + these arrays, resume = abo_fit. */
 int32_t abo_get_data(abo_gp* gp, double* X, double* y);
 int32_t abo_get_timings(abo_gp* gp, abo_timings* out);
+
+/* --- multi-device handles (BASELINE configs 4 and 5: candidates sharded over the GPUs of one node) -----------------
+ * One host process drives all devices: the Julia host has no process launcher, so the sharding of
+ * `scores = acqf(surrogate, grid)` + `sortperm(scores; rev=true)[1:n_local]` (src/acquisition_functions/acq_utils.jl:50-52)
+ * happens inside the library.  An abo_mgpu owns one abo_gp per listed device (a device may be listed more than once: each
+ * entry is one shard).  Every device fits the same model redundantly (deterministic kernels → bit-identical factors; the
+ * refit is ≈1 % of a config-3 step), candidates are cut into contiguous shards (sizes differ by at most one, earlier
+ * shards take the larger ones), one host thread per shard drives its device, and the only exchange is the selection: each
+ * device's k × (score, global index) go through ONE ncclAllGather (RCCL over xGMI; RCCL has no MAXLOC) and are merged in
+ * the reference's order — descending score, ties → lowest index, NaN first — so the result equals the single-device
+ * abo_acq on the whole batch bit for bit.  RCCL is loaded at run time (librccl.so.1, whichever copy the process already
+ * has); when it is missing, fails to initialise, or the list names one device twice (RCCL refuses that), the pairs are
+ * copied to the host per device instead — same merge, same result (abo_mgpu_info tells which).  Environment
+ * ABO_MGPU_EXCHANGE = host | rccl overrides the choice (rccl on a one-entry list exercises the RCCL calls at world size 1).
+ * All buffers of these entry points are HOST memory.  A handle is not re-entrant. */
+typedef struct abo_mgpu abo_mgpu;     /* opaque: one model replicated on ndev devices */
+typedef struct abo_mcand abo_mcand;   /* opaque: a candidate set sharded over those devices, resident with its posterior */
+enum { ABO_XCHG_HOST = 0, ABO_XCHG_RCCL = 1 };
+
+/* HipStandardGP(kernel, noise_var; mean, devices = [...]) — params->device is ignored, dev[0..ndev) are the HIP ordinals,
+ * 1 ≤ ndev ≤ 16 */
+int32_t abo_mgpu_create(const abo_params* params, int32_t ndev, const int32_t* dev, abo_mgpu** out);
+/* Base.copy (StandardGP.jl:26): a new group sharing every per-device state (abo_retain) */
+int32_t abo_mgpu_clone(abo_mgpu* mg, abo_mgpu** out);
+int32_t abo_mgpu_destroy(abo_mgpu* mg);
+/* ndev, the device list (16 entries, may be NULL) and the exchange transport in use (ABO_XCHG_*) */
+int32_t abo_mgpu_info(abo_mgpu* mg, int32_t* ndev, int32_t* dev, int32_t* exchange);
+/* the per-device handle of shard i (borrowed: valid until the next abo_mgpu_fit / abo_mgpu_append / abo_mgpu_destroy):
+ * abo_get_factor, abo_get_timings, abo_nlml, abo_nlml_grad … apply to it */
+int32_t abo_mgpu_get(abo_mgpu* mg, int32_t i, abo_gp** out);
+/* update(model, xs, ys): the same full refit on every device, concurrently (abo_fit) */
+int32_t abo_mgpu_fit(abo_mgpu* mg, const double* X, int64_t N, int32_t d, const double* y, int64_t* info);
+/* posterior_mean / posterior_var over M candidates, shard i computed on device i (abo_predict) */
+int32_t abo_mgpu_predict(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, double* mu, double* var);
+/* abo_acq over M candidates sharded across the devices; scores (M, optional) land in the caller's array shard by shard,
+ * top_val / top_idx (k) are the merged global selection with 0-based indices into Z */
+int32_t abo_mgpu_acq(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, int32_t kind, double p0, double best_y,
+                     double* scores, int32_t k, double* top_val, int64_t* top_idx);
+/* the grid stage of optimize_acquisition (acq_utils.jl:44-52) without the candidates ever crossing PCIe: device i generates
+ * its shard of the n-point Latin-hypercube design (abo_lhs), scores it and selects; top_x (k × d, optional) receives the
+ * coordinates of the selected points */
+int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
+                         int32_t kind, double p0, double best_y, int32_t k, double* top_val, int64_t* top_idx, double* top_x);
+/* BASELINE config 5 across devices.  abo_mgpu_append: every device applies the same bordered append (abo_append) and the
+ * group moves on to the N+1-point model (clone first to keep the old one); a candidate set, if given, is down-dated in the
+ * same call (abo_cand_downdate).  abo_mgpu_cand_create / _lhs: shard a candidate grid over the devices and evaluate its
+ * posterior; _refresh after a refit.  abo_mgpu_cand_acq: epilogue + merged top-k on the stored posterior.
+ * abo_mgpu_cand_qei: greedy (Kriging-believer) q-EI — q × [EI + arg-max per device, ONE all-gather of the devices' pick
+ * records {score, index, μ, x}, the same fantasy append (y = μ(x)) and O(N·M) down-date on every device] — then the stored
+ * posterior is rolled back and the fantasy models are dropped: on return model and set are as before.  x_out q × d,
+ * idx_out / ei_out q.  distinct != 0 excludes every picked candidate for the rest of the call. */
+int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* cands);
+int32_t abo_mgpu_cand_create(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, abo_mcand** out);
+int32_t abo_mgpu_cand_create_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
+                                 abo_mcand** out);
+int32_t abo_mgpu_cand_refresh(abo_mgpu* mg, abo_mcand* mc);
+int32_t abo_mgpu_cand_destroy(abo_mcand* mc);
+int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, double best_y, int32_t k, double* top_val,
+                          int64_t* top_idx);
+int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, double best_y, int32_t distinct, double* x_out,
+                          int64_t* idx_out, double* ei_out);
 
 /* --- memory -----------------------------------------------------------------------------------
  * Device buffers of destroyed handles are cached per device (update() makes a new model every BO

@@ -1,0 +1,271 @@
+/*
+ * c_abi_harness.c — a torch-free, Python-free host of libabo_hip.so: what a `ccall` host (the Julia shim of
+ * integration/julia/HipStandardGP.jl) does, written in plain C99.  Host arrays only, linked against
+ * libabo_hip.so, which itself pulls in the SYSTEM ROCm runtime (/opt/rocm/lib/libamdhip64.so.7) — no PyTorch in the
+ * process.  tests/test_gpu_c_abi.py writes the fixture (inputs + expected values: the reference's closed-form cases
+ * from tests/golden/kat.json and a seeded problem answered by the CPU oracle), compiles this file with gcc and runs it
+ * as a fresh child process; exit status 0 = every check passed.
+ *
+ * Test infrastructure, not product.  Usage: c_abi_harness <fixture.txt> [device]
+ *
+ * Fixture format: whitespace-separated tokens; a record is  <name> <count> <count numbers>  (%.17g doubles).
+ */
+#define _POSIX_C_SOURCE 200112L   /* setenv */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "abo_hip.h"
+
+typedef struct { char name[48]; long n; double* v; } rec_t;
+static rec_t recs[256];
+static int nrecs = 0;
+static int failures = 0;
+static int device = 0;
+
+static void load(const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) { perror(path); exit(2); }
+    while (nrecs < 256 && fscanf(f, "%47s %ld", recs[nrecs].name, &recs[nrecs].n) == 2) {
+        rec_t* r = &recs[nrecs];
+        r->v = (double*)malloc(sizeof(double) * (size_t)(r->n > 0 ? r->n : 1));
+        for (long i = 0; i < r->n; ++i)
+            if (fscanf(f, "%lf", &r->v[i]) != 1) { fprintf(stderr, "fixture: short record %s\n", r->name); exit(2); }
+        ++nrecs;
+    }
+    fclose(f);
+}
+
+static const rec_t* get(const char* name) {
+    for (int i = 0; i < nrecs; ++i)
+        if (!strcmp(recs[i].name, name)) return &recs[i];
+    fprintf(stderr, "fixture: record %s missing\n", name);
+    exit(2);
+}
+
+static const rec_t* getf(const char* prefix, const char* field) {
+    char b[96];
+    snprintf(b, sizeof b, "%s.%s", prefix, field);
+    return get(b);
+}
+
+static int has(const char* prefix, const char* field) {
+    char b[96];
+    snprintf(b, sizeof b, "%s.%s", prefix, field);
+    for (int i = 0; i < nrecs; ++i)
+        if (!strcmp(recs[i].name, b)) return 1;
+    return 0;
+}
+
+#define CHECK(cond, ...)                                                     \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            ++failures;                                                      \
+            fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__);             \
+            fprintf(stderr, __VA_ARGS__);                                    \
+            fprintf(stderr, "\n");                                           \
+        }                                                                    \
+    } while (0)
+
+static void ok_or_die(int32_t st, const char* what) {
+    if (st == ABO_OK) return;
+    char msg[512];
+    abo_last_error(msg, sizeof msg);
+    fprintf(stderr, "FATAL %s: status %d: %s\n", what, st, msg);
+    exit(1);
+}
+
+static double maxabs(const double* a, const double* b, long n) {
+    double m = 0.0;
+    for (long i = 0; i < n; ++i) {
+        const double e = fabs(a[i] - b[i]);
+        if (!(e <= m)) m = e;      /* NaN-propagating */
+    }
+    return m;
+}
+
+static abo_params params_of(const char* c) {
+    abo_params p;
+    memset(&p, 0, sizeof p);
+    const double* h = getf(c, "hyper")->v;      /* family ell sigma_f2 noise mean_c */
+    p.family = (int32_t)h[0]; p.device = device; p.ell = h[1]; p.sigma_f2 = h[2]; p.noise_var = h[3]; p.mean_c = h[4];
+    return p;
+}
+
+/* the reference's closed-form cases: test/test_surrogates.jl:59-105,:145-170; test/test_acquisition.jl:20-43,:74-95;
+ * test/test_bayesian_opt.jl:461-487,:512-559 */
+static void run_kat(const char* c) {
+    abo_params p = params_of(c);
+    const rec_t *X = getf(c, "X"), *y = getf(c, "y"), *Z = getf(c, "Z"), *mu_e = getf(c, "mu"), *var_e = getf(c, "var");
+    const int64_t N = y->n, M = mu_e->n;
+    const int32_t d = (int32_t)(X->n / N);
+    abo_gp* g = NULL;
+    int64_t info = -1;
+    ok_or_die(abo_create(&p, &g), "abo_create");
+    ok_or_die(abo_fit(g, X->v, N, d, y->v, ABO_HOST, &info), "abo_fit");
+    CHECK(info == 0, "%s: info = %lld", c, (long long)info);
+    double* mu = (double*)malloc(sizeof(double) * M);
+    double* var = (double*)malloc(sizeof(double) * M);
+    ok_or_die(abo_predict(g, Z->v, M, d, ABO_HOST, mu, var, ABO_HOST), "abo_predict");
+    CHECK(maxabs(mu, mu_e->v, M) <= 1e-12, "%s: mu off by %.3e", c, maxabs(mu, mu_e->v, M));
+    CHECK(maxabs(var, var_e->v, M) <= 1e-12, "%s: var off by %.3e", c, maxabs(var, var_e->v, M));
+    double nl = 0.0;
+    ok_or_die(abo_nlml(g, &nl), "abo_nlml");
+    CHECK(fabs(nl - getf(c, "nlml")->v[0]) <= 1e-11, "%s: nlml %.17g vs %.17g", c, nl, getf(c, "nlml")->v[0]);
+    if (has(c, "ei")) {
+        const double* a = getf(c, "acq")->v;    /* xi best_y beta */
+        double* s = (double*)malloc(sizeof(double) * M);
+        double tv[1];
+        int64_t ti[1];
+        ok_or_die(abo_acq(g, Z->v, M, d, ABO_HOST, ABO_ACQ_EI, a[0], a[1], 0, s, 1, tv, ti, ABO_HOST), "abo_acq EI");
+        for (int64_t j = 0; j < M; ++j)
+            CHECK(fabs(s[j] - getf(c, "ei")->v[j]) <= 1e-8 * fabs(getf(c, "ei")->v[j]) + 1e-15, "%s: EI[%lld] %.17g", c, (long long)j, s[j]);
+        ok_or_die(abo_acq(g, Z->v, M, d, ABO_HOST, ABO_ACQ_UCB, a[2], 0.0, 0, s, 0, NULL, NULL, ABO_HOST), "abo_acq UCB");
+        CHECK(maxabs(s, getf(c, "ucb")->v, M) <= 1e-12, "%s: UCB off by %.3e", c, maxabs(s, getf(c, "ucb")->v, M));
+        ok_or_die(abo_acq(g, Z->v, M, d, ABO_HOST, ABO_ACQ_PI, a[0], a[1], 0, s, 0, NULL, NULL, ABO_HOST), "abo_acq PI");
+        for (int64_t j = 0; j < M; ++j)
+            CHECK(fabs(s[j] - getf(c, "pi")->v[j]) <= 1e-8 * fabs(getf(c, "pi")->v[j]) + 1e-15, "%s: PI[%lld] %.17g", c, (long long)j, s[j]);
+        free(s);
+    }
+    /* DimensionMismatch is a status, never a crash (test/test_bayesian_opt.jl:788-817) */
+    CHECK(abo_predict(g, Z->v, 1, d + 1, ABO_HOST, mu, NULL, ABO_HOST) == ABO_EDIM, "%s: wrong-dimension predict not refused", c);
+    free(mu); free(var);
+    ok_or_die(abo_destroy(g), "abo_destroy");
+    printf("ok %s (N=%lld d=%d M=%lld)\n", c, (long long)N, d, (long long)M);
+}
+
+/* test/test_bayesian_opt.jl:749-786: a duplicated point with zero noise must fail as PosDefException(3) */
+static void run_kat6(void) {
+    const char* c = "kat6";
+    abo_params p = params_of(c);
+    const rec_t *X = getf(c, "X"), *y = getf(c, "y");
+    abo_gp* g = NULL;
+    int64_t info = 0;
+    ok_or_die(abo_create(&p, &g), "abo_create");
+    const int32_t st = abo_fit(g, X->v, y->n, (int32_t)(X->n / y->n), y->v, ABO_HOST, &info);
+    char msg[512];
+    abo_last_error(msg, sizeof msg);
+    CHECK(st == ABO_ENOTPD, "kat6: status %d instead of ABO_ENOTPD", st);
+    CHECK(info == 3, "kat6: info = %lld instead of 3", (long long)info);
+    CHECK(strstr(msg, "PosDefException") != NULL, "kat6: message '%s'", msg);
+    double m1;
+    CHECK(abo_predict(g, X->v, 1, 2, ABO_HOST, &m1, NULL, ABO_HOST) == ABO_EINVAL, "kat6: failed handle still predicts");
+    ok_or_die(abo_destroy(g), "abo_destroy");
+    printf("ok kat6 (ABO_ENOTPD, info=3)\n");
+}
+
+/* which shared objects the process really mapped: the HIP runtime must be the system one, nothing of PyTorch or Python */
+static void report_runtime(void) {
+    FILE* f = fopen("/proc/self/maps", "r");
+    char line[1024], hip[512] = "";
+    int foreign = 0;
+    while (f && fgets(line, sizeof line, f)) {
+        char* path = strchr(line, '/');
+        if (!path) continue;
+        path[strcspn(path, "\n")] = 0;
+        if (strstr(path, "libamdhip64") && !hip[0]) snprintf(hip, sizeof hip, "%s", path);
+        if (strstr(path, "torch") || strstr(path, "libpython")) foreign = 1;
+    }
+    if (f) fclose(f);
+    printf("hip_runtime=%s\n", hip[0] ? hip : "(none)");
+    CHECK(!foreign, "PyTorch / Python objects are mapped into this process");
+    CHECK(hip[0] != 0, "no libamdhip64 mapped");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s fixture.txt [device]\n", argv[0]); return 2; }
+    load(argv[1]);
+    report_runtime();
+    if (argc > 2) device = atoi(argv[2]);
+    CHECK(abo_abi_version() == ABO_ABI_VERSION, "library ABI %d, header %d", abo_abi_version(), ABO_ABI_VERSION);
+
+    run_kat("kat1"); run_kat("kat3"); run_kat("kat4"); run_kat("kat5");
+    run_kat6();
+
+    /* --- seeded problem: abo_acq with k = 100 against the CPU oracle's selection ------------------------------- */
+    const char* c = "acq";
+    abo_params p = params_of(c);
+    const rec_t *X = getf(c, "X"), *y = getf(c, "y"), *Z = getf(c, "Z"), *sc_e = getf(c, "scores"), *idx_e = getf(c, "top_idx");
+    const double* a = getf(c, "acq")->v;         /* kind p0 best_y */
+    const int64_t N = y->n, M = sc_e->n;
+    const int32_t d = (int32_t)(X->n / N), K = (int32_t)idx_e->n;
+    p.n_max = N + 8;
+    abo_gp* g = NULL;
+    int64_t info = 0;
+    ok_or_die(abo_create(&p, &g), "abo_create");
+    ok_or_die(abo_fit(g, X->v, N, d, y->v, ABO_HOST, &info), "abo_fit");
+    double* s = (double*)malloc(sizeof(double) * M);
+    double* tv = (double*)malloc(sizeof(double) * K);
+    int64_t* ti = (int64_t*)malloc(sizeof(int64_t) * K);
+    ok_or_die(abo_acq(g, Z->v, M, d, ABO_HOST, (int32_t)a[0], a[1], a[2], 0, s, K, tv, ti, ABO_HOST), "abo_acq");
+    CHECK(maxabs(s, sc_e->v, M) <= 1e-10, "acq: scores off by %.3e", maxabs(s, sc_e->v, M));
+    int same = 1;
+    for (int e = 0; e < K; ++e) same = same && ti[e] == (int64_t)idx_e->v[e] && tv[e] == s[ti[e]];
+    CHECK(same, "acq: top-%d differs from the oracle's sortperm(scores; rev=true)[1:%d]", K, K);
+    printf("ok acq (N=%lld d=%d M=%lld top-%d, max|dscore| %.2e)\n", (long long)N, d, (long long)M, K, maxabs(s, sc_e->v, M));
+
+    /* --- copy = shared reference; append leaves the parent untouched (rollback); refit equals append ------------ */
+    ok_or_die(abo_retain(g), "abo_retain");
+    ok_or_die(abo_destroy(g), "abo_destroy (one of two references)");
+    double* mu0 = (double*)malloc(sizeof(double) * 256);
+    double* var0 = (double*)malloc(sizeof(double) * 256);
+    double* mu1 = (double*)malloc(sizeof(double) * 256);
+    double* var1 = (double*)malloc(sizeof(double) * 256);
+    ok_or_die(abo_predict(g, Z->v, 256, d, ABO_HOST, mu0, var0, ABO_HOST), "abo_predict (retained handle)");
+    const rec_t *xn = getf(c, "x_new"), *mu_a = getf(c, "mu_appended"), *var_a = getf(c, "var_appended");
+    abo_gp* g2 = NULL;
+    ok_or_die(abo_append(g, xn->v, d, getf(c, "y_new")->v[0], &info, &g2), "abo_append");
+    int64_t n2 = 0;
+    ok_or_die(abo_get_n(g2, &n2, NULL), "abo_get_n");
+    CHECK(n2 == N + 1, "append: N = %lld", (long long)n2);
+    ok_or_die(abo_predict(g2, Z->v, 256, d, ABO_HOST, mu1, var1, ABO_HOST), "abo_predict (appended)");
+    CHECK(maxabs(mu1, mu_a->v, 256) <= 1e-9, "append: mu off the oracle's N+1 refit by %.3e", maxabs(mu1, mu_a->v, 256));
+    CHECK(maxabs(var1, var_a->v, 256) <= 1e-9, "append: var off the oracle's N+1 refit by %.3e", maxabs(var1, var_a->v, 256));
+    ok_or_die(abo_predict(g, Z->v, 256, d, ABO_HOST, mu1, var1, ABO_HOST), "abo_predict (parent after append)");
+    CHECK(memcmp(mu0, mu1, sizeof(double) * 256) == 0 && memcmp(var0, var1, sizeof(double) * 256) == 0,
+          "rollback: the parent model changed under an append");
+    ok_or_die(abo_destroy(g2), "abo_destroy (appended)");
+    printf("ok retain / append / rollback\n");
+
+    /* --- multi-device handle: two shards on this device = the single handle, bit for bit ------------------------- */
+    {
+        int32_t devs[2] = {device, device};
+        abo_mgpu* mg = NULL;
+        ok_or_die(abo_mgpu_create(&p, 2, devs, &mg), "abo_mgpu_create");
+        ok_or_die(abo_mgpu_fit(mg, X->v, N, d, y->v, &info), "abo_mgpu_fit");
+        double* s2 = (double*)malloc(sizeof(double) * M);
+        double* tv2 = (double*)malloc(sizeof(double) * K);
+        int64_t* ti2 = (int64_t*)malloc(sizeof(int64_t) * K);
+        ok_or_die(abo_mgpu_acq(mg, Z->v, M, d, (int32_t)a[0], a[1], a[2], s2, K, tv2, ti2), "abo_mgpu_acq");
+        CHECK(memcmp(s, s2, sizeof(double) * M) == 0, "mgpu: sharded scores differ from the single-device ones");
+        CHECK(memcmp(tv, tv2, sizeof(double) * K) == 0 && memcmp(ti, ti2, sizeof(int64_t) * K) == 0,
+              "mgpu: merged top-%d differs from the single-device selection", K);
+        int32_t nd = 0, ex = -1;
+        ok_or_die(abo_mgpu_info(mg, &nd, NULL, &ex), "abo_mgpu_info");
+        CHECK(nd == 2 && ex == ABO_XCHG_HOST, "mgpu: ndev %d exchange %d (two shards on one device exchange through the host)", nd, ex);
+        ok_or_die(abo_mgpu_destroy(mg), "abo_mgpu_destroy");
+        /* one shard with the RCCL transport forced: ncclCommInitAll + ncclAllGather at world size 1 */
+        setenv("ABO_MGPU_EXCHANGE", "rccl", 1);
+        ok_or_die(abo_mgpu_create(&p, 1, devs, &mg), "abo_mgpu_create (rccl)");
+        ok_or_die(abo_mgpu_fit(mg, X->v, N, d, y->v, &info), "abo_mgpu_fit (rccl)");
+        ok_or_die(abo_mgpu_acq(mg, Z->v, M, d, (int32_t)a[0], a[1], a[2], NULL, K, tv2, ti2), "abo_mgpu_acq (rccl)");
+        CHECK(memcmp(tv, tv2, sizeof(double) * K) == 0 && memcmp(ti, ti2, sizeof(int64_t) * K) == 0,
+              "mgpu/rccl: top-%d differs from the single-device selection", K);
+        ok_or_die(abo_mgpu_info(mg, &nd, NULL, &ex), "abo_mgpu_info");
+        char why[512];
+        abo_last_error(why, sizeof why);
+        printf("ok mgpu (2 shards via host; 1 shard via %s%s%s)\n", ex == ABO_XCHG_RCCL ? "RCCL" : "host [RCCL unavailable: ",
+               ex == ABO_XCHG_RCCL ? "" : why, ex == ABO_XCHG_RCCL ? "" : "]");
+        printf("exchange=%s\n", ex == ABO_XCHG_RCCL ? "rccl" : "host");
+        ok_or_die(abo_mgpu_destroy(mg), "abo_mgpu_destroy");
+        unsetenv("ABO_MGPU_EXCHANGE");
+        free(s2); free(tv2); free(ti2);
+    }
+
+    ok_or_die(abo_destroy(g), "abo_destroy (last reference)");
+    ok_or_die(abo_pool_trim(device), "abo_pool_trim");
+    if (failures) { fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
+    printf("all checks passed\n");
+    return 0;
+}

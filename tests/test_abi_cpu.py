@@ -61,3 +61,18 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "gp_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_plain_c_host_links_and_loads_without_python_or_torch():
+    """tests/c_abi_harness.c (the torch-free `ccall`-shaped host) compiles with gcc against libabo_hip.so, and the
+    dynamic loader resolves the library and the SYSTEM HIP runtime for it; without arguments it prints its usage
+    (exit 2) before any GPU call, so this runs on a box without a GPU."""
+    import subprocess
+    from tests import c_harness
+    exe = c_harness.build(force=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libabo_hip.so" in ldd and "not found" not in ldd
+    hip = [ln for ln in ldd.splitlines() if "libamdhip64" in ln]
+    assert hip and "/opt/rocm" in hip[0] and "torch" not in hip[0], ldd

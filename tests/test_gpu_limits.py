@@ -1,0 +1,112 @@
+"""GPU tests (-m gpu): the library carries no size limits the reference does not have — the reference is
+dimension-agnostic (src/surrogates/StandardGP.jl:79-83) and n_local is a free Int (acq_utils.jl:33-52)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import synth
+from oracle import gp_oracle as O
+from oracle import grad_oracle as G
+
+from tests.test_gpu_parity import make_model
+from tests.test_gpu_gradient_gp import make_grad
+
+
+@pytest.mark.parametrize("family,d,N,M,ell", [(O.MATERN52, 40, 300, 700, 4.0), (O.SE, 64, 200, 513, 5.0),
+                                              (O.MATERN72, 33, 130, 100, 3.5), (O.MATERN32, 100, 64, 50, 6.0)])
+def test_dimensions_beyond_32_against_oracle(family, d, N, M, ell):
+    X = synth.points(1, N, d)
+    Z = synth.points(2, M, d) * 1.2 - 0.1
+    y = synth.objective(X, 0.05)
+    sf2, noise = 1.3, 1e-3
+    st = O.fit(family, ell, sf2, noise, 0.0, X, y)
+    mu_o, var_o = O.predict(st, Z)
+    m = abo.update(make_model(family, ell, sf2, noise, n_max=N + 8), X, y)
+    L, alpha, _ = abo.get_factor(m)
+    assert np.max(np.abs(L - st.L)) < 1e-11
+    assert np.max(np.abs(alpha - st.alpha)) < 1e-8 * max(1.0, np.max(np.abs(st.alpha)))
+    mu, var = abo.mean_and_var(m, Z)
+    assert np.max(np.abs(mu - mu_o)) < 1e-10 * max(1.0, np.max(np.abs(mu_o)))
+    assert np.max(np.abs(var - var_o)) < 1e-10 * sf2
+    assert abs(abo.nlml_fitted(m) - O.nlml(st)) < 1e-9 * max(1.0, abs(O.nlml(st)))
+    # incremental path and the NLML gradient take the same wide-d kernels
+    x_new = synth.points(5, 1, d)[0]
+    m2 = abo.append(m, x_new, 0.25)
+    st2 = O.fit(family, ell, sf2, noise, 0.0, np.vstack([X, x_new]), np.append(y, 0.25))
+    mu2, var2 = abo.mean_and_var(m2, Z[:50])
+    mo2, vo2 = O.predict(st2, Z[:50])
+    assert np.max(np.abs(mu2 - mo2)) < 1e-9 and np.max(np.abs(var2 - vo2)) < 1e-9
+    cands = abo.ResidentCandidates(m, Z)
+    cands.downdate(m2)
+    mu_c, var_c = cands.mean_and_var()
+    mo, vo = O.predict(st2, Z)
+    assert np.max(np.abs(mu_c - mo)) < 1e-9 and np.max(np.abs(var_c - vo)) < 1e-9
+    gp = make_model(family, ell, sf2, noise)
+    v, g = abo.nlml_and_grad(gp, [np.log(ell), np.log(sf2)], X, y)
+    h = 1e-5
+    fd = [(O.nlml(O.fit(family, float(np.exp(np.log(ell) + h)), sf2, noise, 0.0, X, y))
+           - O.nlml(O.fit(family, float(np.exp(np.log(ell) - h)), sf2, noise, 0.0, X, y))) / (2 * h),
+          (O.nlml(O.fit(family, ell, float(np.exp(np.log(sf2) + h)), noise, 0.0, X, y))
+           - O.nlml(O.fit(family, ell, float(np.exp(np.log(sf2) - h)), noise, 0.0, X, y))) / (2 * h)]
+    np.testing.assert_allclose(g, fd, rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,k", [(5000, 1025), (5000, 3000), (5000, 5000), (700, 2500), (4096, 2048)])
+def test_selection_of_more_than_1024(M, k):
+    """sortperm(scores; rev=true)[1:min(n_local, M)] for any n_local: rounds of 1024, bit-exact against the oracle's
+    stable sort; the tail of a request longer than the batch is (NaN, −1).  Scores carry ties and NaNs."""
+    d = 2
+    X, y = synth.standardized_problem(50, d)
+    m = abo.update(make_model(O.SE, 0.4, 1.0, 1e-3), X, y)
+    Z = synth.points(2, M, d)
+    Z[M // 3: M // 3 + 40] = Z[7]              # 41 exact ties
+    Z[11, 0] = np.nan
+    s, tv, ti = abo.evaluate(abo.UpperConfidenceBound(1.5), m, Z, k=k, idx_base=10)
+    ov, oi = O.top_k(s, k)
+    kk = min(k, M)
+    np.testing.assert_array_equal(ti[:kk], oi[:kk] + 10)
+    np.testing.assert_array_equal(tv[:kk], ov[:kk])
+    assert np.all(ti[kk:] == -1) and np.all(np.isnan(tv[kk:]))
+    cands = abo.ResidentCandidates(m, Z)
+    s2, tv2, ti2 = cands.evaluate(abo.UpperConfidenceBound(1.5), k=k, idx_base=10, return_scores=True)
+    np.testing.assert_array_equal(ti2, ti)
+
+
+def test_gradient_gp_beyond_sixteen_inputs():
+    d, N, M = 20, 30, 40
+    p = d + 1
+    X = synth.points(1, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    gF = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    Ys = np.column_stack([f, gF])
+    Z = synth.points(2, M, d)
+    mean_c = np.zeros(p)
+    st = G.fit(O.MATERN52, 2.5, 1.2, 1e-3, mean_c, X, Ys)
+    m = abo.update(make_grad(O.MATERN52, 2.5, 1.2, 1e-3, p, mean_c), X, Ys)
+    mu_o, var_o = G.predict_grad(st, Z)
+    assert np.max(np.abs(abo.posterior_grad_mean(m, Z) - mu_o)) < 1e-8
+    assert np.max(np.abs(abo.posterior_grad_var(m, Z) - var_o)) < 1e-8
+    s = abo.GradientNormUCB(2.0)(m, Z[:16])
+    np.testing.assert_allclose(s, G.grad_norm_ucb(st, Z[:16], 2.0), rtol=1e-7, atol=1e-8)
+    with pytest.raises(ValueError) as e:
+        abo.update(abo.GradientGP(abo.SqExponentialKernel(), 40, 0.1), synth.points(1, 4, 39), np.zeros((4, 40)))
+    assert "33" in str(e.value)                 # the message names the limit
+
+
+def test_candidate_set_refuses_a_model_from_another_factor_of_the_same_size():
+    """A candidate set remembers the factor it is synced with by a process-wide generation id, not by address: refits
+    of the same size land at recycled addresses, and a down-date against such a stranger must be refused."""
+    d, N = 3, 100
+    X, y = synth.standardized_problem(N + 1, d)
+    Z = synth.points(2, 500, d)
+    for _ in range(8):
+        a = abo.update(make_model(O.SE, 0.6, 1.0, 1e-3, n_max=N + 16), X[:N], y[:N])
+        cands = abo.ResidentCandidates(a, Z)
+        del a
+        cands.model = None
+        b = abo.update(make_model(O.SE, 0.9, 2.0, 1e-3, n_max=N + 16), X[:N], y[:N])    # same sizes, recycled buffers
+        b1 = abo.append(b, X[N], y[N])
+        with pytest.raises(ValueError):
+            cands.downdate(b1)

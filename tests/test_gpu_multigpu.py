@@ -1,0 +1,163 @@
+"""GPU tests (-m gpu) of the in-library multi-device handle (abo_mgpu_*): sharding, merge and the
+greedy q-EI exchange must equal the single-device path bit for bit.  The test box has one GPU: two or three shards
+on device 0 exercise the sharding, the worker threads and the host exchange; one shard with ABO_MGPU_EXCHANGE=rccl
+exercises ncclCommInitAll + ncclAllGather (RCCL refuses a communicator that lists one device twice)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import multigpu, synth
+from oracle import gp_oracle as O
+
+from tests.test_gpu_parity import FAMS, make_model
+
+
+def sharded(family, ell, sf2, noise, devices, **kw):
+    return abo.HipShardedGP(sf2 * abo.with_lengthscale(FAMS[family](), ell), noise, devices=devices, **kw)
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0)])
+@pytest.mark.parametrize("M", [5000, 2, 1])
+def test_sharded_acquisition_equals_single_device_bit_for_bit(devices, M):
+    d, N = 4, 300
+    X, y = synth.standardized_problem(N, d, 0.02)
+    Z = synth.points(2, M, d)
+    one = abo.update(make_model(O.MATERN52, 0.6, 1.0, 1e-3), X, y)
+    grp = abo.update(sharded(O.MATERN52, 0.6, 1.0, 1e-3, devices), X, y)
+    assert grp.exchange() == "host"
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    k = 100
+    s1, tv1, ti1 = abo.evaluate(acq, one, Z, k=k)
+    s2, tv2, ti2 = abo.evaluate(acq, grp, Z, k=k)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(tv1, tv2)
+    np.testing.assert_array_equal(ti1, ti2)
+    ov, oi = O.top_k(s1, k)
+    np.testing.assert_array_equal(ti2[:min(k, M)], oi)
+    mu1, var1 = abo.mean_and_var(one, Z)
+    mu2, var2 = abo.mean_and_var(grp, Z)
+    np.testing.assert_array_equal(mu1, mu2)
+    np.testing.assert_array_equal(var1, var2)
+    # every shard holds the same factor (deterministic replicated fit)
+    L0 = abo.get_factor(one)[0]
+    for i in range(len(devices)):
+        h = abo.surrogate._Handle(None)
+        m = one._clone(h)
+        h.ptr = grp.shard(i)
+        try:
+            np.testing.assert_array_equal(abo.get_factor(m)[0], L0)
+        finally:
+            h.ptr = None            # borrowed
+
+
+def test_ties_resolve_to_the_lowest_global_index_across_shards():
+    m = abo.update(sharded(O.SE, 0.01, 1.0, 1e-2, (0, 0, 0)), [[0.0, 0.0]], [0.0])
+    Z = np.full((5000, 2), 50.0) + np.arange(5000)[:, None]
+    s, tv, ti = abo.evaluate(abo.UpperConfidenceBound(2.0), m, Z, k=64)
+    assert np.all(s == s[0])
+    np.testing.assert_array_equal(ti, np.arange(64))
+    Zn = Z[:300].copy()
+    Zn[217, 0] = np.nan                     # NaN lives in the last shard and still sorts first
+    s, tv, ti = abo.evaluate(abo.UpperConfidenceBound(2.0), m, Zn, k=4)
+    assert ti[0] == 217 and np.isnan(tv[0]) and ti[1] == 0
+
+
+def test_copy_and_refit_keep_value_semantics():
+    d = 3
+    X, y = synth.standardized_problem(80, d)
+    Z = synth.points(2, 100, d)
+    a = abo.update(sharded(O.SE, 0.7, 1.0, 1e-3, (0, 0)), X, y)
+    mu_a = abo.posterior_mean(a, Z)
+    c = abo.copy(a)
+    b = abo.update(a, X[:40], y[:40])                 # a new model; `a` and its copy are untouched
+    np.testing.assert_array_equal(abo.posterior_mean(a, Z), mu_a)
+    np.testing.assert_array_equal(abo.posterior_mean(c, Z), mu_a)
+    assert np.max(np.abs(abo.posterior_mean(b, Z) - mu_a)) > 1e-6
+    with pytest.raises(abo.PosDefException) as e:
+        abo.update(sharded(O.SE, 1.0, 1.0, 0.0, (0, 0)), [[-1.0, -1.0], [5.0, -5.0], [-1.0 + 1e-12, -1.0 + 1e-12]], [1.0, 2.0, 1.0])
+    assert e.value.info == 3
+    with pytest.raises(abo.DimensionMismatch):
+        abo.posterior_mean(a, [[0.5]])
+
+
+def test_device_generated_grid_stage_equals_single_device():
+    d, N, n_grid, k = 3, 120, 10_000, 100
+    X, y = synth.standardized_problem(N, d, 0.02)
+    lower, upper = np.zeros(d) - 0.5, np.ones(d) * 1.5
+    one = abo.update(make_model(O.MATERN52, 0.5, 1.0, 1e-3), X, y)
+    grp = abo.update(sharded(O.MATERN52, 0.5, 1.0, 1e-3, (0, 0, 0)), X, y)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    Zd = abo.device_latin_hypercube(n_grid, lower, upper, seed=11)
+    _, tv1, ti1 = abo.evaluate(acq, one, Zd, k=k)
+    tv2, ti2, tx2 = multigpu.grid_stage(acq, grp, lower, upper, n_grid=n_grid, n_local=k, seed=11)
+    np.testing.assert_array_equal(tv1.cpu().numpy(), tv2)
+    np.testing.assert_array_equal(ti1.cpu().numpy(), ti2)
+    np.testing.assert_array_equal(Zd.cpu().numpy()[ti2], tx2)
+
+
+def test_sharded_greedy_qei_and_append_equal_single_device():
+    d, N0, M, q = 4, 200, 3000, 5
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    best = float(y.min())
+    fam, ell, sf2, noise = O.MATERN52, 0.6, 1.0, 1e-4
+    one = abo.update(make_model(fam, ell, sf2, noise, n_max=N0 + 32), X, y)
+    c1 = abo.ResidentCandidates(one, Z)
+    c1.save()
+    pts1, idx1, val1, mq = abo.greedy_qei(one, c1, q, 0.01, best)
+    del mq
+    c1.restore()
+    grp = abo.update(sharded(fam, ell, sf2, noise, (0, 0, 0), n_max=N0 + 32), X, y)
+    cg = abo.ShardedCandidates(grp, Z)
+    pts2, idx2, val2 = cg.greedy_qei(grp, q, 0.01, best)
+    np.testing.assert_array_equal(idx1, idx2)
+    np.testing.assert_array_equal(val1, val2)
+    np.testing.assert_array_equal(pts1, pts2)
+    # model and stored posterior are unchanged by the exploration; then the real observation goes in on every device
+    acq = abo.ExpectedImprovement(0.01, best)
+    tv_b, ti_b = cg.evaluate(grp, acq, 10)
+    _, tv_s, ti_s = c1.evaluate(acq, k=10)
+    np.testing.assert_array_equal(ti_b, ti_s)
+    np.testing.assert_array_equal(tv_b, tv_s)
+    y_real = 0.37
+    one2 = abo.append(one, pts1[0], y_real)
+    c1.downdate(one2)
+    grp2 = multigpu.append(grp, pts2[0], y_real, cg)
+    _, tv_s, ti_s = c1.evaluate(acq, k=10)
+    tv_b, ti_b = cg.evaluate(grp2, acq, 10)
+    np.testing.assert_array_equal(ti_b, ti_s)
+    np.testing.assert_array_equal(tv_b, tv_s)
+    st = O.fit(fam, ell, sf2, noise, 0.0, np.vstack([X, pts1[0]]), np.append(y, y_real))
+    mu_o, var_o = O.predict(st, Z[:500])
+    mu_g, var_g = abo.mean_and_var(grp2, Z[:500])
+    assert np.max(np.abs(mu_g - mu_o)) < 1e-9 and np.max(np.abs(var_g - var_o)) < 1e-9
+    # the pre-append group is still the N0-point model (rollback is free)
+    np.testing.assert_array_equal(abo.mean_and_var(grp, Z[:500])[0], abo.mean_and_var(one, Z[:500])[0])
+
+
+def test_rccl_transport_at_world_size_one(monkeypatch):
+    """ncclCommInitAll + ncclAllGather through the dlopen'ed librccl.so.1, one rank: same selection as abo_acq."""
+    monkeypatch.setenv("ABO_MGPU_EXCHANGE", "rccl")
+    d, N, M, k = 4, 300, 20000, 100
+    X, y = synth.standardized_problem(N, d, 0.02)
+    Z = synth.points(2, M, d)
+    one = abo.update(make_model(O.SE, 0.5, 1.0, 1e-4), X, y)
+    grp = abo.update(sharded(O.SE, 0.5, 1.0, 1e-4, (0,)), X, y)
+    assert grp.exchange() == "rccl", grp.exchange_note()
+    acq = abo.UpperConfidenceBound(2.0)
+    s1, tv1, ti1 = abo.evaluate(acq, one, Z, k=k)
+    s2, tv2, ti2 = abo.evaluate(acq, grp, Z, k=k)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(ti1, ti2)
+    np.testing.assert_array_equal(tv1, tv2)
+    cg = abo.ShardedCandidates(grp, Z[:3000])
+    c1 = abo.ResidentCandidates(abo.update(make_model(O.SE, 0.5, 1.0, 1e-4, n_max=N + 16), X, y), Z[:3000])
+    grp_n = abo.update(sharded(O.SE, 0.5, 1.0, 1e-4, (0,), n_max=N + 16), X, y)
+    cg = abo.ShardedCandidates(grp_n, Z[:3000])
+    p2, i2, v2 = cg.greedy_qei(grp_n, 3, 0.01, float(y.min()))
+    c1.save()
+    p1, i1, v1, _ = abo.greedy_qei(c1.model, c1, 3, 0.01, float(y.min()))
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(v1, v2)
