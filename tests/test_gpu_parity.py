@@ -606,10 +606,12 @@ def test_bad_arguments_are_refused_not_crashed():
     assert abo.posterior_mean(m, np.zeros((0, 3))).shape == (0,)                      # empty batch is fine
     with pytest.raises(abo.DimensionMismatch):
         abo.posterior_var(m, np.zeros((4, 2)))
+    _, tv, ti = abo.evaluate(abo.UpperConfidenceBound(2.0), m, Z, k=5000)            # k > M: every candidate, then (NaN, −1)
+    assert sorted(ti[:20].tolist()) == list(range(20)) and np.all(ti[20:] == -1) and np.all(np.isnan(tv[20:]))
     with pytest.raises((ValueError, abo.AboError)):
-        abo.evaluate(abo.UpperConfidenceBound(2.0), m, Z, k=5000)                   # k outside 0..1024
+        abo.evaluate(abo.UpperConfidenceBound(2.0), m, Z, k=-1)
     with pytest.raises((ValueError, abo.AboError)):
-        abo.update(make_model(O.SE, 1.0, 1.0, 1e-3), np.zeros((4, 40)), np.zeros(4))  # d > 32
+        abo.update(make_model(O.SE, 1.0, 1.0, 1e-3), np.zeros((2, 70000)), np.zeros(2))   # d beyond 65536
     with pytest.raises((ValueError, abo.AboError)):
         abo.update(make_model(O.SE, 1.0, 1.0, 1e-3), np.zeros((0, 3)), np.zeros(0))   # no data
     cands = abo.ResidentCandidates(m, Z)
