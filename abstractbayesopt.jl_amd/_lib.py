@@ -64,11 +64,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise AboError(f"{LIB_PATH} not found: the HIP library has not been built "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
-    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.  If this
-    # library were loaded first it would pull in /opt/rocm's copy, torch would then bind to a mix of the
-    # two and no device would be visible.  Loading torch first makes the dynamic linker resolve our
-    # libamdhip64.so.7 dependency to the copy already in the process.  (A Julia host has no torch and
-    # simply uses the system runtime.)
+    # libabo_hip.so has NEEDED libamdhip64.so.7 + RUNPATH /opt/rocm-*/lib: a host without PyTorch (the Julia `ccall`
+    # host; tests/c_abi_harness.c, run as a child process by tests/test_gpu_c_abi.py, which asserts that the system
+    # runtime and nothing of PyTorch is mapped) needs nothing beyond the dynamic loader's defaults.  THIS host is the
+    # special case: PyTorch-ROCm bundles its own libamdhip64.so.7, and a process must hold exactly one HIP runtime —
+    # importing torch first makes the loader resolve our NEEDED entry to the copy already in the process.
     try:
         import torch  # noqa: F401
     except ImportError:

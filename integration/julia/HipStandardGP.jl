@@ -1,23 +1,43 @@
-# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 1) for AbstractBayesOpt.jl.
+# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 2) for AbstractBayesOpt.jl.
+#
 # Drop next to src/surrogates/StandardGP.jl, `include("surrogates/HipStandardGP.jl")` from src/AbstractBayesOpt.jl
-# (after StandardGP.jl and the acquisition functions) and export HipStandardGP.
-# NOTE: written against the reference sources without a Julia toolchain at hand (none in the build image); the
-# Python package abstractbayesopt.jl_amd/ is the same binding over ctypes and is what the parity tests exercise.
-# This file is the code shown in INTEGRATION.md, verbatim.
+# (after StandardGP.jl and the acquisition functions) and export HipStandardGP.  Every method the BO driver calls on
+# its surrogate is defined below for the new type — the driver itself (`optimize`, `update(BO, …)`,
+# `standardize_problem`, `optimize_hyperparameters`), the domains and the acquisition TYPES stay untouched:
+#
+#   driver call site (reference file:line)                          method below
+#   bayesian_opt.jl:81,:116   copy(model)                           Base.copy
+#   bayesian_opt.jl:125,:379,:422; BO_utils.jl:60  update           update
+#   ExpectedImprovement.jl:41-42 … posterior_mean / posterior_var   posterior_mean / posterior_var (vector and scalar)
+#   bayesian_opt.jl:250-259   prep_input, prep_output, nlml, nlml_ls
+#   bayesian_opt.jl:319-327   get_scale, get_kernel_constructor, _update_model_parameters
+#   bayesian_opt.jl:391       get_lengthscale, get_scale
+#   bayesian_opt.jl:428; ExpectedImprovement.jl:82  _get_minimum
+#   BO_utils.jl:48,:55,:59    get_mean_std, rescale_model, std_y
+#   StandardGP.jl:395-404     unstandardized_mean_and_var
+#
+# NOTE: no Julia toolchain exists in the build image, so this file has not been executed there.  What HAS been
+# executed is the same sequence of C-ABI calls from a host with neither Python nor PyTorch in the process
+# (tests/c_abi_harness.c, run by tests/test_gpu_c_abi.py on the GPU box), and the Python package
+# abstractbayesopt.jl_amd/, which is this binding written with ctypes.
 
-# src/surrogates/HipStandardGP.jl   — binds include/abo_hip.h (ABI version 1)
 const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
 
-struct AboParams            # must match `struct abo_params`
+struct AboParams            # must match `struct abo_params` (include/abo_hip.h)
     family::Int32; device::Int32
     ell::Float64; sigma_f2::Float64; noise_var::Float64; mean_c::Float64; jitter::Float64
     n_max::Int64; chunk::Int64
 end
 
-mutable struct AboHandle    # owns one reference to an `abo_gp`
+mutable struct AboHandle    # owns one reference to an `abo_gp` (or, multi = true, to an `abo_mgpu`)
     ptr::Ptr{Cvoid}
-    function AboHandle(p)
-        h = new(p); finalizer(h -> (@ccall LIBABO.abo_destroy(h.ptr::Ptr{Cvoid})::Int32), h); h
+    multi::Bool
+    function AboHandle(p, multi=false)
+        h = new(p, multi)
+        finalizer(h) do x
+            x.multi ? (@ccall LIBABO.abo_mgpu_destroy(x.ptr::Ptr{Cvoid})::Int32) : (@ccall LIBABO.abo_destroy(x.ptr::Ptr{Cvoid})::Int32)
+        end
+        h
     end
 end
 
@@ -25,17 +45,21 @@ struct HipStandardGP{T} <: AbstractSurrogate
     gp::AbstractGPs.GP                   # prior (mean + normal-form kernel), as StandardGP.jl:11-16
     noise_var::T
     gpx::Union{Nothing,AboHandle}        # device state instead of a PosteriorGP
-    device::Int32; jitter::Float64
+    devices::Vector{Int32}               # one entry: single-device handle; several: abo_mgpu (sharding inside the library)
+    jitter::Float64
+    n_max::Int64                         # capacity for `append` (0 = size to the fit)
 end
 
 _family(::SqExponentialKernel) = Int32(0); _family(::Matern52Kernel) = Int32(1)
 _family(::ApproxMatern52Kernel) = Int32(1); _family(::ApproxMatern72Kernel) = Int32(2)
 _family(::Matern32Kernel) = Int32(3)
 
-function HipStandardGP(kernel::Kernel, noise_var; mean=nothing, device=0, jitter=0.0)
+function HipStandardGP(kernel::Kernel, noise_var; mean=nothing, devices=[0], jitter=0.0, n_max=0)
     s = StandardGP(kernel, noise_var; mean=mean)           # reuse the normal-form logic (StandardGP.jl:41-64)
-    HipStandardGP(s.gp, noise_var, nothing, Int32(device), Float64(jitter))
+    HipStandardGP(s.gp, noise_var, nothing, Int32.(devices), Float64(jitter), Int64(n_max))
 end
+_with(m::HipStandardGP, gpx) = HipStandardGP(m.gp, m.noise_var, gpx, m.devices, m.jitter, m.n_max)
+_multi(m::HipStandardGP) = length(m.devices) > 1
 
 function _check(st::Int32, info::Int64=0)
     st == 0 && return
@@ -51,69 +75,182 @@ end
 # pack Vector{Float64} (d = 1) or Vector{<:AbstractVector} into a point-major d×M Matrix
 _pack(x::AbstractVector{<:Real}) = reshape(collect(Float64, x), 1, :)
 function _pack(x::AbstractVector{<:AbstractVector})
-    d = length(first(x)); all(v -> length(v) == d, x) || throw(DimensionMismatch("ragged input"))
+    d = length(first(x)); all(v -> length(v) == d, x) || throw(DimensionMismatch("input points differ in length"))
     reduce(hcat, x)                                         # d×M column-major == point-major
 end
 _pack(x::AbstractMatrix{Float64}) = x                       # ColVecs-style d×M: zero copy
 
-Base.copy(m::HipStandardGP) = m.gpx === nothing ? m : begin     # StandardGP.jl:26
-    _check(@ccall LIBABO.abo_retain(m.gpx.ptr::Ptr{Cvoid})::Int32)
-    HipStandardGP(m.gp, m.noise_var, AboHandle(m.gpx.ptr), m.device, m.jitter)
+# ---- hyper-parameter accessors: read from the prior's normal-form kernel, as StandardGP.jl:261-287 does ------------
+get_lengthscale(m::HipStandardGP) = 1 ./ m.gp.kernel.kernel.transform.s           # 1-element Vector
+get_scale(m::HipStandardGP) = m.gp.kernel.σ²                                      # 1-element Vector
+get_kernel_constructor(m::HipStandardGP) = m.gp.kernel.kernel.kernel
+_mean_c(m::HipStandardGP) = m.gp.mean isa ZeroMean ? 0.0 : Float64(m.gp.mean.c)
+prep_input(::HipStandardGP, xs::Vector) = xs                                      # StandardGP.jl:301
+prep_output(::HipStandardGP, ys::Vector) = ys                                     # StandardGP.jl:315
+_get_minimum(::HipStandardGP, ys::Vector) = minimum(ys)                            # StandardGP.jl:418
+
+# a new un-conditioned model with another kernel, everything else kept (StandardGP.jl:246-248)
+_update_model_parameters(m::HipStandardGP, k::Kernel) =
+    HipStandardGP(k, m.noise_var; mean=m.gp.mean, devices=m.devices, jitter=m.jitter, n_max=m.n_max)
+
+# ---- standardisation helpers (host scalars; semantics of StandardGP.jl:164-232) -------------------------------------
+function get_mean_std(::HipStandardGP, y_train::Vector, choice::String)
+    flat = reduce(vcat, y_train)
+    μ, σ = mean(flat), std(flat)
+    choice == "scale_only" && (μ = zero(μ))
+    choice == "mean_only" && (σ = one(σ))
+    μ, σ
+end
+std_y(::HipStandardGP, ys::Vector, μ, σ) = [(y .- μ) ./ σ for y in ys]
+function rescale_model(m::HipStandardGP, σ)
+    k = (get_scale(m)[1] / σ^2) * with_lengthscale(get_kernel_constructor(m), get_lengthscale(m)[1])
+    mean = m.gp.mean isa ZeroMean ? m.gp.mean : ConstMean(m.gp.mean.c / σ)      # a ConstMean moves with the data
+    HipStandardGP(k, m.noise_var / σ^2; mean=mean, devices=m.devices, jitter=m.jitter, n_max=m.n_max)
+end
+function unstandardized_mean_and_var(m::HipStandardGP, xs::AbstractVector, params::Tuple)   # StandardGP.jl:395-404
+    μ, σ = params[1], params[2]
+    mu, var = _predict(m, xs, true, true)
+    (mu .* σ) .+ μ, var .* σ^2
 end
 
-function update(m::HipStandardGP, xs::AbstractVector, ys::AbstractVector)      # StandardGP.jl:79-83
-    X = _pack(xs); d, N = size(X); length(ys) == N || throw(DimensionMismatch("xs/ys"))
-    p = Ref(AboParams(_family(get_kernel_constructor(m)), m.device, get_lengthscale(m)[1], get_scale(m)[1],
-                      m.noise_var, m.gp.mean isa ZeroMean ? 0.0 : m.gp.mean.c, m.jitter, 0, 0))
-    h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0)
+# ---- copy / update -----------------------------------------------------------------------------------------------
+function Base.copy(m::HipStandardGP)                                              # StandardGP.jl:26
+    m.gpx === nothing && return m
+    if m.gpx.multi
+        h = Ref{Ptr{Cvoid}}()
+        _check(@ccall LIBABO.abo_mgpu_clone(m.gpx.ptr::Ptr{Cvoid}, h::Ptr{Ptr{Cvoid}})::Int32)
+        return _with(m, AboHandle(h[], true))
+    end
+    _check(@ccall LIBABO.abo_retain(m.gpx.ptr::Ptr{Cvoid})::Int32)
+    _with(m, AboHandle(m.gpx.ptr))
+end
+
+_params(m::HipStandardGP) = AboParams(_family(get_kernel_constructor(m)), m.devices[1], get_lengthscale(m)[1],
+                                      get_scale(m)[1], m.noise_var, _mean_c(m), m.jitter, m.n_max, 0)
+
+function update(m::HipStandardGP, xs::AbstractVector, ys::AbstractVector)          # StandardGP.jl:79-83
+    X = _pack(xs); d, N = size(X); length(ys) == N || throw(DimensionMismatch("xs has $N points, ys $(length(ys)) values"))
+    p = Ref(_params(m)); h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0); y = collect(Float64, ys)
+    if _multi(m)
+        devs = m.devices
+        GC.@preserve devs _check(@ccall LIBABO.abo_mgpu_create(p::Ptr{AboParams}, length(devs)::Int32, devs::Ptr{Int32},
+                                                                h::Ptr{Ptr{Cvoid}})::Int32)
+        hd = AboHandle(h[], true)
+        GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_mgpu_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64,
+            d::Int32, y::Ptr{Float64}, info::Ptr{Int64})::Int32), info[])
+        return _with(m, hd)
+    end
     _check(@ccall LIBABO.abo_create(p::Ptr{AboParams}, h::Ptr{Ptr{Cvoid}})::Int32)
-    hd = AboHandle(h[]); y = collect(Float64, ys)
+    hd = AboHandle(h[])
     GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64,
         d::Int32, y::Ptr{Float64}, 0::Int32, info::Ptr{Int64})::Int32), info[])
-    HipStandardGP(m.gp, m.noise_var, hd, m.device, m.jitter)
+    _with(m, hd)
 end
 
+# ---- posterior -----------------------------------------------------------------------------------------------------
 function _predict(m::HipStandardGP, x, want_mu, want_var)
+    m.gpx === nothing && throw(ArgumentError("surrogate is not conditioned on data yet (gpx === nothing)"))
     Z = _pack(x); d, M = size(Z)
     mu = want_mu ? Vector{Float64}(undef, M) : Float64[]; var = want_var ? Vector{Float64}(undef, M) : Float64[]
-    GC.@preserve Z mu var _check(@ccall gc_safe=true LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64},
-        M::Int64, d::Int32, 0::Int32, (want_mu ? pointer(mu) : C_NULL)::Ptr{Float64},
-        (want_var ? pointer(var) : C_NULL)::Ptr{Float64}, 0::Int32)::Int32)
+    pm = want_mu ? pointer(mu) : Ptr{Float64}(C_NULL); pv = want_var ? pointer(var) : Ptr{Float64}(C_NULL)
+    GC.@preserve Z mu var begin
+        if m.gpx.multi
+            _check(@ccall gc_safe=true LIBABO.abo_mgpu_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+                                                                 pm::Ptr{Float64}, pv::Ptr{Float64})::Int32)
+        else
+            _check(@ccall gc_safe=true LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+                                                            0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
+        end
+    end
     mu, var
 end
 posterior_mean(m::HipStandardGP, x::AbstractVector) = _predict(m, x, true, false)[1]     # StandardGP.jl:361
 posterior_var(m::HipStandardGP, x::AbstractVector)  = _predict(m, x, false, true)[2]     # StandardGP.jl:377
-posterior_mean(m::HipStandardGP, x::Real) = posterior_mean(m, [x]); posterior_var(m::HipStandardGP, x::Real) = posterior_var(m, [x])
+posterior_mean(m::HipStandardGP, x::Real) = posterior_mean(m, [x])                        # StandardGP.jl:329
+posterior_var(m::HipStandardGP, x::Real)  = posterior_var(m, [x])                         # StandardGP.jl:345
 
-# fused acquisition: more specific than (EI)(::AbstractSurrogate, x) at ExpectedImprovement.jl:40
-function _acq(m::HipStandardGP, x, kind, p0, best; k=0)
-    Z = _pack(x); d, M = size(Z); s = Vector{Float64}(undef, M)
+# ---- fused acquisition: more specific than (EI)(::AbstractSurrogate, x) at ExpectedImprovement.jl:40 ---------------
+function _acq(m::HipStandardGP, x, kind, p0, best; k=0, scores=true)
+    Z = _pack(x); d, M = size(Z)
+    s = scores ? Vector{Float64}(undef, M) : Float64[]; ps = scores ? pointer(s) : Ptr{Float64}(C_NULL)
     tv = Vector{Float64}(undef, k); ti = Vector{Int64}(undef, k)
-    GC.@preserve Z s tv ti _check(@ccall gc_safe=true LIBABO.abo_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64,
-        d::Int32, 0::Int32, kind::Int32, p0::Float64, best::Float64, 0::Int64, s::Ptr{Float64}, k::Int32,
-        tv::Ptr{Float64}, ti::Ptr{Int64}, 0::Int32)::Int32)
+    GC.@preserve Z s tv ti begin
+        if m.gpx.multi
+            _check(@ccall gc_safe=true LIBABO.abo_mgpu_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+                kind::Int32, p0::Float64, best::Float64, ps::Ptr{Float64}, k::Int32, tv::Ptr{Float64}, ti::Ptr{Int64})::Int32)
+        else
+            _check(@ccall gc_safe=true LIBABO.abo_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, 0::Int32,
+                kind::Int32, p0::Float64, best::Float64, 0::Int64, ps::Ptr{Float64}, k::Int32, tv::Ptr{Float64},
+                ti::Ptr{Int64}, 0::Int32)::Int32)
+        end
+    end
     s, tv, ti .+ 1                                            # C indices are 0-based
 end
-(EI::ExpectedImprovement)(m::HipStandardGP, x::AbstractVector)   = _acq(m, x, Int32(0), EI.ξ, EI.best_y)[1]
-(UCB::UpperConfidenceBound)(m::HipStandardGP, x::AbstractVector) = _acq(m, x, Int32(1), UCB.β, 0.0)[1]
-(PI::ProbabilityImprovement)(m::HipStandardGP, x::AbstractVector) = _acq(m, x, Int32(2), PI.ξ, PI.best_y)[1]
+_acq_args(a::ExpectedImprovement) = (Int32(0), Float64(a.ξ), Float64(a.best_y))
+_acq_args(a::UpperConfidenceBound) = (Int32(1), Float64(a.β), 0.0)
+_acq_args(a::ProbabilityImprovement) = (Int32(2), Float64(a.ξ), Float64(a.best_y))
+(a::ExpectedImprovement)(m::HipStandardGP, x::AbstractVector)    = _acq(m, x, _acq_args(a)...)[1]
+(a::UpperConfidenceBound)(m::HipStandardGP, x::AbstractVector)   = _acq(m, x, _acq_args(a)...)[1]
+(a::ProbabilityImprovement)(m::HipStandardGP, x::AbstractVector) = _acq(m, x, _acq_args(a)...)[1]
 
-function nlml(m::HipStandardGP, params, xs, ys)                                   # StandardGP.jl:99-114 (value)
-    ℓ, s = exp.(params); g = HipStandardGP(s * with_lengthscale(get_kernel_constructor(m), ℓ), m.noise_var;
-                                           mean=m.gp.mean, device=m.device, jitter=m.jitter)
-    out = Ref{Float64}(); _check(@ccall LIBABO.abo_nlml(update(g, xs, ys).gpx.ptr::Ptr{Cvoid}, out::Ptr{Float64})::Int32); out[]
+# The grid stage of optimize_acquisition (acq_utils.jl:44-52) in one call: the Latin-hypercube grid is generated on the
+# devices (shard by shard), scored, and only the n_local best starts come back.  Returns (points::Vector{Vector}, scores).
+function grid_stage(acqf::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityImprovement}, m::HipStandardGP,
+                    lower::Vector{Float64}, upper::Vector{Float64}; n_grid=10_000, n_local=100, seed=rand(UInt64))
+    kind, p0, best = _acq_args(acqf); d = length(lower); k = min(n_local, n_grid)
+    tv = Vector{Float64}(undef, k); ti = Vector{Int64}(undef, k); tx = Matrix{Float64}(undef, d, k)
+    g = m.gpx.multi ? m.gpx : _group_of(m)
+    GC.@preserve lower upper tv ti tx _check(@ccall gc_safe=true LIBABO.abo_mgpu_acq_lhs(g.ptr::Ptr{Cvoid}, n_grid::Int64,
+        d::Int32, lower::Ptr{Float64}, upper::Ptr{Float64}, seed::UInt64, kind::Int32, p0::Float64, best::Float64, k::Int32,
+        tv::Ptr{Float64}, ti::Ptr{Int64}, tx::Ptr{Float64})::Int32)
+    [tx[:, j] for j in 1:k], tv
 end
-# get_lengthscale / get_scale / get_kernel_constructor / get_mean_std / std_y / rescale_model /
-# _update_model_parameters / prep_input / prep_output / _get_minimum: identical one-liners to
-# StandardGP.jl:164-287,:301,:315,:418 with `HipStandardGP` in place of `StandardGP`.
+# a single-device model joins the multi-device entry points as a one-shard group on its data
+function _group_of(m::HipStandardGP)
+    X = Matrix{Float64}(undef, 0, 0)      # training data back from the device (abo_get_data), then a one-shard group
+    n = Ref{Int64}(); d = Ref{Int32}(); _check(@ccall LIBABO.abo_get_n(m.gpx.ptr::Ptr{Cvoid}, n::Ptr{Int64}, d::Ptr{Int32})::Int32)
+    X = Matrix{Float64}(undef, d[], n[]); y = Vector{Float64}(undef, n[])
+    GC.@preserve X y _check(@ccall LIBABO.abo_get_data(m.gpx.ptr::Ptr{Cvoid}, X::Ptr{Float64}, y::Ptr{Float64})::Int32)
+    p = Ref(_params(m)); h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0); devs = m.devices
+    GC.@preserve devs _check(@ccall LIBABO.abo_mgpu_create(p::Ptr{AboParams}, 1::Int32, devs::Ptr{Int32}, h::Ptr{Ptr{Cvoid}})::Int32)
+    g = AboHandle(h[], true)
+    GC.@preserve X y _check(@ccall(LIBABO.abo_mgpu_fit(g.ptr::Ptr{Cvoid}, X::Ptr{Float64}, n[]::Int64, d[]::Int32,
+                                                         y::Ptr{Float64}, info::Ptr{Int64})::Int32), info[])
+    g
+end
 
+# ---- NLML (value; StandardGP.jl:99-114, :133-149) and its analytic gradient ------------------------------------------
+function _fitted_with(m::HipStandardGP, logℓ, logs, xs, ys)
+    g = HipStandardGP(exp(logs) * with_lengthscale(get_kernel_constructor(m), exp(logℓ)), m.noise_var;
+                      mean=m.gp.mean, devices=m.devices[1:1], jitter=m.jitter)
+    update(g, xs, ys)
+end
+function nlml(m::HipStandardGP, params, xs::AbstractVector, ys::AbstractVector)
+    out = Ref{Float64}(); f = _fitted_with(m, params[1], params[2], xs, ys)
+    _check(@ccall LIBABO.abo_nlml(f.gpx.ptr::Ptr{Cvoid}, out::Ptr{Float64})::Int32); out[]
+end
+nlml_ls(m::HipStandardGP, log_ℓ, log_scale, xs::AbstractVector, ys::AbstractVector) = nlml(m, (log_ℓ, log_scale), xs, ys)
+# ForwardDiff duals (autodiff=:forward, bayesian_opt.jl:284) cannot cross a C-ABI: hand Optim `(f, g!)` built on this
+function nlml_and_grad(m::HipStandardGP, params, xs::AbstractVector, ys::AbstractVector)
+    v = Ref{Float64}(); g1 = Ref{Float64}(); g2 = Ref{Float64}(); f = _fitted_with(m, params[1], params[2], xs, ys)
+    _check(@ccall LIBABO.abo_nlml_grad(f.gpx.ptr::Ptr{Cvoid}, v::Ptr{Float64}, g1::Ptr{Float64}, g2::Ptr{Float64})::Int32)
+    v[], [g1[], g2[]]
+end
 
+# ---- incremental update (BASELINE config 5; the reference always refits) ---------------------------------------------
 function append(m::HipStandardGP, x::AbstractVector{Float64}, y::Float64)          # O(N²) instead of a refit
-    h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0)
+    info = Ref{Int64}(0)
+    if m.gpx.multi
+        n = copy(m)                                              # the old model stays valid (rollback is free)
+        GC.@preserve x _check(@ccall(LIBABO.abo_mgpu_append(n.gpx.ptr::Ptr{Cvoid}, x::Ptr{Float64}, length(x)::Int32, y::Float64,
+                                                             info::Ptr{Int64}, C_NULL::Ptr{Cvoid})::Int32), info[])
+        return n
+    end
+    h = Ref{Ptr{Cvoid}}()
     GC.@preserve x _check(@ccall(LIBABO.abo_append(m.gpx.ptr::Ptr{Cvoid}, x::Ptr{Float64}, length(x)::Int32, y::Float64,
                                                      info::Ptr{Int64}, h::Ptr{Ptr{Cvoid}})::Int32), info[])
-    HipStandardGP(m.gp, m.noise_var, AboHandle(h[]), m.device, m.jitter)
+    _with(m, AboHandle(h[]))
 end
 # update(BO, x, y, i) (bayesian_opt.jl:113-150) can call `append(BO.model, x, y)` instead of
 # `update(BO.model, BO.xs, BO.ys)`; `prev_gp = copy(BO.model)` stays valid because rows ≤ N are never touched.
-# Resident grids for q-EI: abo_cand_create / abo_cand_acq / abo_cand_downdate / abo_cand_save / abo_cand_restore / abo_cand_exclude.
+# Resident grids for q-EI: abo_cand_* on one device, abo_mgpu_cand_{create,create_lhs,refresh,acq,qei} across devices.
