@@ -58,11 +58,18 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, sample_m=8192):
+def cpu_baseline(cfg, sample_m=16384, reps=3):
+    """Median of `reps` repetitions of the bounded CPU sample (median of ≥ 3; the full-size variant
+    `--cpu-sample-m 65536 --cpu-reps 3` takes ≈ 3.5 min and is kept under profiles/)."""
     from threadpoolctl import threadpool_limits
     cores = usable_cores()
     with threadpool_limits(limits=cores):
-        out = _cpu_baseline(cfg, sample_m)
+        runs = [_cpu_baseline(cfg, sample_m) for _ in range(max(1, reps))]
+    runs.sort(key=lambda r: r["value"])
+    out = runs[len(runs) // 2]
+    out["repetitions"] = len(runs)
+    out["all_values"] = [r["value"] for r in runs]
+    out["sample"] += f"; median of {len(runs)} repetitions"
     out["cores"] = cores
     out["host_logical_cpus"] = os.cpu_count()
     return out
@@ -123,17 +130,40 @@ def _cpu_baseline(cfg, sample_m):
     }
 
 
+def source_sha(names):
+    """sha256 (16 hex digits) over the kernel sources a PMC figure belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "abstractbayesopt.jl_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+PMC_SOURCES = {"c3": ["gemm.hip"], "c5": ["misc.hip"]}      # the translation unit of each config's dominant kernel
+
+
 def pmc_traffic(config, mc_per_launch):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 PMC pass
     (FETCH_SIZE/WRITE_SIZE collected in their own runs by tools/run_pmc.sh, gfx950 ×2 correction on
     FETCH_SIZE) — PMC counters cannot be read from inside this process, so the figure is the per-candidate
-    traffic of that pass scaled to this run's candidates per launch."""
-    path = os.path.join(ROOT, "profiles", f"r01_{'c3' if config == 'c4' else config}_pmc_traffic.json")   # C4 = C3 per launch
-    if not os.path.exists(path):
-        return None, None
+    traffic of that pass scaled to this run's candidates per launch.  The pass records the hash of the kernel's
+    source file; when the file has changed since, the figure is STALE and `traffic` is reported as null."""
+    key = "c3" if config == "c4" else config                 # C4 = C3 per launch
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc_traffic.json")
+        if os.path.exists(path):
+            break
+    else:
+        return None, {"note": "no PMC pass committed"}
     with open(path) as f:
         d = json.load(f)
-    return d["traffic_bytes_per_candidate"] * mc_per_launch, d
+    d["file"] = os.path.relpath(path, ROOT)
+    if d.get("kernel_source_sha") != source_sha(PMC_SOURCES.get(key, ["gemm.hip"])):
+        d["stale"] = True
+        return None, d
+    per = d.get("traffic_bytes_per_candidate")
+    return (per * mc_per_launch if per is not None else d.get("traffic_bytes_per_launch")), d
 
 
 def quick_config(abo, synth, torch, dev, local_rank, name, k_top, steps=20, warmup=3):
@@ -157,7 +187,7 @@ def quick_config(abo, synth, torch, dev, local_rank, name, k_top, steps=20, warm
             "value": ms, "unit": "ms", "steps": steps, "warmup": warmup}
 
 
-def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
+def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, warmup=None):
     """BASELINE config 5.  A step = greedy q-EI over the resident grid (q = 8 picks, each: EI + arg-max,
     fantasy bordered append, O(N·M) down-date), roll the grid posterior back, append the real (noisy)
     observation of the first pick to the parent model, down-date.  The full refresh (refit + grid
@@ -171,6 +201,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
     from abstractbayesopt.jl_amd import synth
 
     fam_name, d, N, M_per, ell, sf2, noise, _, xi = cfg
+    n_steps = args.steps if steps is None else steps
+    n_warm = args.warmup if warmup is None else warmup
     Q = 8
     M_total = M_per * world
     lo, hi = D.shard_range(M_total, rank, world)
@@ -201,8 +233,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
     best_y = float(y.min())
     ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "restore_ms": [], "downdate_pass_ms": [], "downdate_pass_bytes": []}
     picks = None
-    for step in range(args.warmup + args.steps):
-        if step == args.warmup:
+    for step in range(n_warm + n_steps):
+        if step == n_warm:
             sync()
             t_start = time.perf_counter()
         ta = time.perf_counter()
@@ -221,7 +253,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
         dd = model.timings()
         best_y = min(best_y, float(y_new))
         picks = (idxs, vals)
-        if step >= args.warmup:
+        if step >= n_warm:
             ph["qei_ms"].append((tb - ta) * 1e3); ph["restore_ms"].append((tc - tb) * 1e3)
             ph["append_ms"].append((td - tc) * 1e3); ph["downdate_ms"].append((te - td) * 1e3)
             ph["downdate_pass_ms"].append(dd["downdate_ms"]); ph["downdate_pass_bytes"].append(dd["downdate_bytes"])
@@ -231,19 +263,21 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms = elapsed * 1e3 / args.steps
+    ms = elapsed * 1e3 / n_steps
+    out = None
+    del cands, model
     if rank == 0:
         med = {k: float(np.median(v)) for k, v in ph.items()}
-        n_now = N + args.warmup + args.steps
+        n_now = N + n_warm + n_steps
         append_bytes = 8.0 * n_now * n_now                 # W (lower) + WT (upper), read once each
         ach = append_bytes / (med["append_ms"] * 1e-3) / 1e9
         # dominant kernel of the step: the O(N*M) down-date pass, 9 launches per step (8 fantasies + the real point)
         if med["downdate_pass_bytes"] > 0:
             gbs = med["downdate_pass_bytes"] / (med["downdate_pass_ms"] * 1e-3) / 1e9
-            tr_path = os.path.join(ROOT, "profiles", "r01_c5_pmc_traffic.json")     # committed rocprofv3 FETCH_SIZE pass
-            tr = json.load(open(tr_path))["traffic_bytes_per_launch"] if os.path.exists(tr_path) else None
+            tr, tr_src = pmc_traffic("c5", M_per)                        # committed rocprofv3 FETCH_SIZE pass (null when stale)
             roof = {"kernel": "cand_gemv_kernel (c = K_ZX . [-v; 1] over the resident K_ZX) + new-column kernel", "bound": "hbm",
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr,
+                    "traffic_source": {k: tr_src.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if tr_src and k in tr_src},
                     "algorithmic_bytes_per_launch": med["downdate_pass_bytes"], "avg_launch_ms": med["downdate_pass_ms"],
                     "launches_per_step": Q + 1,
                     "note": "algorithmic bytes = 8*N*M (K_ZX read once); duration = HIP events on the library stream"}
@@ -254,7 +288,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
                     "avg_launch_ms": med["downdate_pass_ms"], "launches_per_step": Q + 1}
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
-            "value": ms, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "value": ms, "unit": "ms", "n_gpus": world, "steps": n_steps, "warmup": n_warm, "ms_per_step": ms,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C5: d={d} {fam_name} ell={ell} noise={noise}, N={N}(+1 per step) train, resident grid "
                                    f"M={M_per} per GPU ({M_total} total), greedy q-EI q={Q} (fantasy append + O(N*M) down-date "
@@ -271,7 +305,53 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False):
             "phases_ms": med, "pairs_per_s_downdate": n_now * M_per / (med["downdate_ms"] * 1e-3),
             "last_batch": {"indices": [int(i) for i in picks[0]], "ei": [float(v) for v in picks[1]]},
         }
-        print(json.dumps(out))
+    return out
+
+
+def run_single_process(args):
+    """`--gpus N --single-process`: the C3/C4-shaped step driven through ONE multi-device handle (abo_mgpu_*), the shape
+    a Julia host uses.  The candidate grid is generated on the devices (Latin hypercube, shard by shard) and stays
+    resident; a step = replicated full refit on every device + posterior/EI over every shard + per-device top-100 +
+    ONE RCCL all-gather + merge.  --share-device puts all shards on GPU 0 (rehearsal on a one-GPU box: RCCL refuses a
+    device listed twice, the exchange then goes through the host)."""
+    import abstractbayesopt.jl_amd as abo
+    from abstractbayesopt.jl_amd import multigpu, synth
+
+    fam_name, d, N, M_per, ell, sf2, noise, acq_name, p0 = CONFIGS[args.config]
+    G = args.gpus
+    strong = args.config == "c4"
+    M_total = M_per if strong else M_per * G
+    devices = [0] * G if args.share_device else list(range(G))
+    X, y = synth.standardized_problem(N, d, 0.03)
+    gp = abo.HipShardedGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, devices=devices, chunk=args.chunk)
+    best_y = float(y.min())
+    acq = abo.ExpectedImprovement(p0, best_y) if acq_name == "ei" else abo.UpperConfidenceBound(p0)
+    model = abo.update(gp, X, y)
+    cands = abo.ShardedCandidates(model, lhs=(M_total, np.zeros(d), np.ones(d), 2))
+    step_ms = []
+    for step in range(args.warmup + args.steps):
+        t0 = time.perf_counter()
+        model = abo.update(gp, X, y)                      # full refit on every device (X, y: 0.5 MiB of host data)
+        cands.refresh(model)                              # posterior of every resident shard
+        tv, ti = cands.evaluate(model, acq, 100)          # epilogue + per-device top-100 + all-gather + merge
+        if step >= args.warmup:
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+    ms = float(np.mean(step_ms))
+    out = {
+        "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
+        "value": ms, "unit": "ms", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": False, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config.upper()} single-process: d={d} {fam_name} ell={ell} noise={noise}, N={N} train, "
+                               f"M={M_total} candidates over {G} shard(s) on devices {devices}, {acq_name.upper()} p0={p0}, "
+                               f"top-100, full refit every step, grid resident (device-generated LHS)",
+                   "N": N, "M_total": M_total, "d": d, "devices": devices, "exchange": model.exchange(),
+                   "exchange_note": model.exchange_note()},
+        "candidates_per_s": M_total / (ms * 1e-3),
+        "median_ms_per_step": float(np.median(step_ms)), "min_ms_per_step": float(np.min(step_ms)),
+        "top1": {"score": float(tv[0]), "index": int(ti[0])},
+    }
+    print(json.dumps(out))
 
 
 def main():
@@ -281,7 +361,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-m", type=int, default=8192)
+    ap.add_argument("--cpu-sample-m", type=int, default=16384,
+                    help="candidates of the CPU-baseline sample (BASELINE.md §4 allows up to 65536 and linear scaling in M)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (median reported)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="drive --gpus N devices from THIS process through the library's multi-device handle (abo_mgpu_*, "
+                         "RCCL all-gather inside the library) instead of one process per GPU under torchrun")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
@@ -298,6 +383,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.single_process:
+        if world != 1:
+            sys.exit("--single-process is for a plain `python bench.py --gpus N --single-process` launch, not torchrun")
+        return run_single_process(args)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
@@ -316,7 +405,9 @@ def main():
 
     cfg = CONFIGS[args.config]
     if args.config == "c5":
-        run_c5(args, cfg, world, rank, local_rank, dev, use_dist)
+        out = run_c5(args, cfg, world, rank, local_rank, dev, use_dist)
+        if rank == 0:
+            print(json.dumps(out))
         if use_dist:
             dist.destroy_process_group()
         return
@@ -411,6 +502,7 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
+                "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
                 "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + (M_per / max(launches, 1)) * N + (N / 128) * (M_per / max(launches, 1))),
                 "flop_per_launch": flop / max(launches, 1), "launches_per_step": launches,
                 "avg_launch_ms": t_kernel_ms / max(launches, 1),
@@ -426,11 +518,20 @@ def main():
         if variants:
             out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_m)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_m, args.cpu_reps)
             out["speedup_vs_cpu_port"] = out["cpu_baseline"]["value"] / ms_per_step
             out["speedup_vs_cpu_blas3_floor"] = out["cpu_baseline"]["blas3_floor"]["value"] / ms_per_step
         if world == 1 and args.config == "c3" and not args.no_cpu_baseline:
-            out["secondary"] = quick_config(abo, synth, torch, dev, local_rank, "c2", K_TOP)
+            # the other single-GPU configurations of BASELINE.json, timed by the same run: C2 (small N) and C5
+            # (incremental update + greedy q-EI on a resident grid; its own roofline is the HBM-streaming down-date)
+            del model, Zd
+            abo._lib.lib().abo_pool_trim(local_rank)
+            c2 = quick_config(abo, synth, torch, dev, local_rank, "c2", K_TOP)
+            c5 = run_c5(args, CONFIGS["c5"], 1, 0, local_rank, dev, False, steps=5, warmup=2)
+            c5_keep = {k: c5[k] for k in ("value", "unit", "steps", "warmup", "roofline", "secondary_roofline", "refresh_ms",
+                                          "value_amortized", "phases_ms", "refresh_phases_ms")}
+            c5_keep["workload"] = c5["config"]["workload"]
+            out["secondary"] = [c2, c5_keep]
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -37,3 +37,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """achieved errors of the GPU parity tests → gpurun_out/parity_r02.json (tests/parity_record.py)"""
+    try:
+        from tests import parity_record
+        parity_record.dump()
+    except Exception:
+        pass

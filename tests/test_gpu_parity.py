@@ -17,6 +17,8 @@ import abstractbayesopt.jl_amd as abo
 from abstractbayesopt.jl_amd import synth
 from oracle import gp_oracle as O
 
+from tests.parity_record import check
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 FAMS = {O.SE: abo.SqExponentialKernel, O.MATERN52: abo.Matern52Kernel, O.MATERN72: abo.ApproxMatern72Kernel,
         O.MATERN32: abo.Matern32Kernel}
@@ -178,6 +180,9 @@ CASES = [
 
 @pytest.mark.parametrize("family,d,N,M,ell,sf2,noise,mean_c", CASES)
 def test_against_oracle(family, d, N, M, ell, sf2, noise, mean_c):
+    """Errors are scaled as DESIGN §4 states (μ by max(1, max|μ|), σ² by σ_f², L by √(σ_f²+σ²_n), α and NLML relative),
+    recorded, and asserted against the hard bar `tol` (a conditioning-aware bound, ≤ the north star's 1e-6) and against
+    100 × the error recorded on an MI355X for this very case (tests/parity_record.py)."""
     X = synth.points(1, N, d)
     Z = synth.points(2, M, d) * 1.2 - 0.1
     y = synth.objective(X, 0.05) + mean_c
@@ -188,13 +193,14 @@ def test_against_oracle(family, d, N, M, ell, sf2, noise, mean_c):
     cond = 1.0 + N * sf2 / noise                 # crude bound on cond(K)
     tol = max(1e-11, 4e-16 * cond)
     assert tol <= 1e-6
-    assert np.max(np.abs(L - st.L)) <= tol * np.sqrt(sf2 + noise)
-    assert np.max(np.abs(Linv @ st.L - np.eye(N))) <= tol * 10
-    assert np.max(np.abs(alpha - st.alpha)) <= tol * 1e3 * max(1.0, np.max(np.abs(st.alpha)))
+    case = f"oracle/fam{family}_d{d}_N{N}"
+    check(case, "L", np.max(np.abs(L - st.L)) / np.sqrt(sf2 + noise), tol)
+    check(case, "LinvL_minus_I", np.max(np.abs(Linv @ st.L - np.eye(N))), tol * 10)
+    check(case, "alpha_rel", np.max(np.abs(alpha - st.alpha)) / max(1.0, np.max(np.abs(st.alpha))), min(1e-6, tol * 1e3))
     mu, var = abo.mean_and_var(m, Z)
-    assert np.max(np.abs(mu - mu_o)) <= tol * 1e2 * max(1.0, np.max(np.abs(mu_o)))
-    assert np.max(np.abs(var - var_o)) <= tol * 1e2 * sf2
-    assert abs(abo.nlml_fitted(m) - O.nlml(st)) <= tol * 1e2 * max(1.0, abs(O.nlml(st)))
+    check(case, "mu", np.max(np.abs(mu - mu_o)) / max(1.0, np.max(np.abs(mu_o))), min(1e-6, tol * 1e2))
+    check(case, "var", np.max(np.abs(var - var_o)) / sf2, min(1e-6, tol * 1e2))
+    check(case, "nlml_rel", abs(abo.nlml_fitted(m) - O.nlml(st)) / max(1.0, abs(O.nlml(st))), min(1e-6, tol * 1e2))
     # separate entry points agree with the fused one bit for bit
     np.testing.assert_array_equal(abo.posterior_mean(m, Z), mu)
     np.testing.assert_array_equal(abo.posterior_var(m, Z), var)
@@ -316,35 +322,46 @@ def test_bo_loop_plumbing_c1():
 
 
 # ------------------------------------------------------------------------------------------------
-def test_full_size_properties_c3():
-    """BASELINE config 3 shape (N = 8192, d = 8, Matérn-5/2): the oracle cannot run this in seconds,
-    so check size-independent properties — interpolation at training points, L·Lᵀ = K on sampled
-    rows, W·L = I on sampled rows, prior recovery far from the data, agreement of a candidate slice
-    with the oracle's posterior computed from the device factor, and determinism."""
-    N, d = 8192, 8
+def test_full_size_parity_c3():
+    """BASELINE config 3 at the size the metric is quoted on (N = 8192, d = 8, Matérn-5/2, M = 2²⁰, EI): an INDEPENDENT
+    oracle refit (O.fit: LAPACK dpotrf on the host, ≈7 s) and the oracle posterior on 2304 candidates taken from the first,
+    a middle and the last chunk of the 2²⁰-candidate batch the device scores in one abo_acq call — nothing on the oracle
+    side comes from the device.  Plus the size-independent properties: prior recovery far from the data, determinism."""
+    N, d, M = 8192, 8, 1 << 20
     ell, sf2, noise = 1.0, 1.0, 1e-3
     X, y = synth.standardized_problem(N, d, 0.03)
+    Z = synth.points(2, M, d)
     m = abo.update(make_model(O.MATERN52, ell, sf2, noise), X, y)
+    st = O.fit(O.MATERN52, ell, sf2, noise, 0.0, X, y)
     L, alpha, Linv = abo.get_factor(m)
+    case = "c3/N8192_d8_M1048576"
+    check(case, "L", np.max(np.abs(L - st.L)) / np.sqrt(sf2 + noise), 1e-9)
+    check(case, "alpha_rel", np.max(np.abs(alpha - st.alpha)) / max(1.0, np.max(np.abs(st.alpha))), 1e-6)
     rows = np.array([0, 1, 127, 128, 129, 4095, 4096, 8000, 8191])
-    Krows = O.kernel_matrix(O.MATERN52, ell, sf2, X[rows], X)
-    Krows[np.arange(len(rows)), rows] += noise
-    assert np.max(np.abs(L[rows] @ L.T - Krows)) < 1e-11
-    assert np.max(np.abs(Linv[rows] @ L - np.eye(N)[rows])) < 1e-9
-    # K α = y
-    assert np.max(np.abs(Krows @ alpha - y[rows])) < 1e-8
-    Z = synth.points(2, 4096, d)
-    mu, var = abo.mean_and_var(m, Z)
-    st = O.GPState(O.MATERN52, ell, sf2, noise, 0.0, X, L, alpha, y)
-    mu_o, var_o = O.predict(st, Z[:256])
-    assert np.max(np.abs(mu[:256] - mu_o)) < 1e-9
-    assert np.max(np.abs(var[:256] - var_o)) < 1e-9
+    check(case, "LinvL_minus_I_rows", np.max(np.abs(Linv[rows] @ st.L - np.eye(N)[rows])), 1e-8)
+    check(case, "nlml_rel", abs(abo.nlml_fitted(m) - O.nlml(st)) / abs(O.nlml(st)), 1e-9)
+    best = float(y.min())
+    acq = abo.ExpectedImprovement(0.01, best)
+    import torch
+    Zd = torch.from_numpy(Z).cuda()
+    s_d, tv, ti = abo.evaluate(acq, m, Zd, k=100)                     # the benchmarked call: all 2²⁰ candidates, top-100
+    mu_d, var_d = abo.mean_and_var(m, Zd)
+    s, mu, var = s_d.cpu().numpy(), mu_d.cpu().numpy(), var_d.cpu().numpy()
+    sl = np.concatenate([np.arange(0, 768), np.arange(M // 2 - 384, M // 2 + 384), np.arange(M - 768, M)])
+    mu_o, var_o = O.predict(st, Z[sl])
+    check(case, "mu", np.max(np.abs(mu[sl] - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
+    check(case, "var", np.max(np.abs(var[sl] - var_o)) / sf2, 1e-8)
+    ei_o = O.expected_improvement(mu_o, var_o, best, 0.01)
+    check(case, "ei_abs", np.max(np.abs(s[sl] - ei_o)), 1e-9)
+    # the selection is the stable reverse sort of the device's own scores, bit for bit, over the full 2²⁰
+    ov, oi = O.top_k(s, 100)
+    np.testing.assert_array_equal(ti.cpu().numpy(), oi)
+    np.testing.assert_array_equal(tv.cpu().numpy(), ov)
     assert np.all(var > 0) and np.all(var <= sf2 + 1e-12)
     far = abo.mean_and_var(m, np.full((3, d), 100.0))
     assert np.max(np.abs(far[0])) < 1e-12 and np.max(np.abs(far[1] - sf2)) < 1e-12
-    mu2, var2 = abo.mean_and_var(m, Z)
-    np.testing.assert_array_equal(mu, mu2)
-    np.testing.assert_array_equal(var, var2)
+    mu2, var2 = abo.mean_and_var(m, Zd)
+    assert torch.equal(mu2, mu_d) and torch.equal(var2, var_d)
 
 
 @pytest.mark.parametrize("family", [O.SE, O.MATERN52, O.MATERN72, O.MATERN32])

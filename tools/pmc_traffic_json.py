@@ -2,7 +2,7 @@
 the dominant kernel with the gfx950 correction the micro-architecture guide prescribes (FETCH_SIZE counts 64 B per
 128-B request of a 16-B/lane stream -> x2; WRITE_SIZE exact; both in KB), plus MFMA-busy fraction and held clock.
 usage: python tools/pmc_traffic_json.py <summary.txt> <N> <Mc_per_launch> > profiles/r01_c3_pmc_traffic.json"""
-import json, re, sys
+import hashlib, json, os, re, sys
 
 path, N, Mc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 blocks, cur = {}, None
@@ -24,7 +24,13 @@ traffic = fetch_kb * 1024 * 2 + write_kb * 1024
 busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)      # per-SIMD busy / per-XCD active
 durs = [v for (p, k), v in blocks.get("_dur", {}).items() if k == kern]
 dur_us = sum(durs) / len(durs) if durs else None
+def _sha(name):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return hashlib.sha256(open(os.path.join(root, "abstractbayesopt.jl_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+
+
 out = {
+    "kernel_source": "abstractbayesopt.jl_amd/csrc/gemm.hip", "kernel_source_sha": _sha("gemm.hip"),   # bench.py drops the figure when the file changes
     "source": f"{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ / GRBM, separate passes, tools/run_pmc.sh)",
     "kernel": kern.replace("abo::", ""), "N": N, "Mc_per_launch": Mc,
     "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb,

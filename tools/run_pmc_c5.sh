@@ -21,4 +21,14 @@ for k in ("abo::cand_gemv_kernel", "abo::trmv_kernel"):
         lines.append(f"{k}: n={len(acc[k])} avg {d:.1f} us  FETCH_SIZE {kb:.6g} KB -> {kb*2048/1e9:.2f} GB per launch, {kb*2048/(d*1e-6)/1e12:.2f} TB/s")
 open("gpurun_out/pmc_c5_fetch_summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+import hashlib, json
+k = "abo::cand_gemv_kernel"
+if k in acc:
+    kb = sum(acc[k]) / len(acc[k]); d = sum(dur[k]) / len(dur[k]) / 1e6
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE, tools/run_pmc_c5.sh", "kernel": "cand_gemv_kernel", "N": 16384, "M": 131072,
+               "kernel_source": "abstractbayesopt.jl_amd/csrc/misc.hip",
+               "kernel_source_sha": hashlib.sha256(open("abstractbayesopt.jl_amd/csrc/misc.hip", "rb").read()).hexdigest()[:16],
+               "FETCH_SIZE_KB_mean": kb, "correction": "gfx950: x2 (64 B counted per 128-B request of a 16-B/lane stream)",
+               "traffic_bytes_per_launch": kb * 2048, "algorithmic_bytes_per_launch": 8.0 * 16384 * 131072,
+               "avg_launch_ms_under_pmc": d}, open("gpurun_out/c5_pmc_traffic.json", "w"), indent=1)
 PY
