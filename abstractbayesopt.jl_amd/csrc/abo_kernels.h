@@ -93,6 +93,12 @@ hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d
 // matching diagonal block of W (lower) and WT (upper = transposed); on a non-positive pivot set
 // *info = r0 + j + 1 (if still 0) and leave.
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
+// the same split for the panel chain: potf2 (factor + the eight 16×16 diagonal sub-block inverses, which go to their final
+// places in W / WT), the panel solve below the block as a blocked triangular solve on L (rows r0+128 … r0+128+nrows), and —
+// once, after the factorisation — the 128×128 inverses of ALL diagonal blocks in one batched launch
+hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
+hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s);
+hipError_t launch_trtri_diag_batched(double* K, double* W, double* WT, int64_t ld, int nblocks, int64_t* info, hipStream_t s);
 // out[i] = Σ_{k ≤ i} Wm[i][k]·v[k]   (lower == 1)   or   Σ_{k ≥ i} Wm[i][k]·v[k]   (lower == 0)
 hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* out, int Np, int lower, hipStream_t s);
 // out[0] = 2·Σ_{i<N} log L[i][i];  out[1] = Σ_{i<N} delta[i]·alpha[i]

@@ -346,12 +346,24 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // per tile than a panel-by-panel SYRK.
     const char* swe = getenv("ABO_CHOL_STRIP");
     const int SW = swe ? atoi(swe) : 512;
+    // Panel chain: potf2 of the diagonal block → triangular solve of the rows below it on L itself → in-strip update.  The
+    // 128×128 inverses of the diagonal blocks (the seeds of the blocked L⁻¹ below) are not on that chain: all of them are
+    // formed by ONE batched launch behind the factorisation.  ABO_CHOL_SPLIT=0 restores the round-1 chain (factor + inverse
+    // in one kernel, panel solve as a product with the inverse) for A/B runs.
+    const char* spe = getenv("ABO_CHOL_SPLIT");
+    const bool split = (!spe || atoi(spe) != 0) && Np > TB;     // a single block has no chain: factor + inverse in one launch
     for (int s0 = 0; s0 < Np; s0 += SW) {
         const int sw = (Np - s0) < SW ? (Np - s0) : SW;
         for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
-            HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
             const int rem = Np - r0 - TB;
-            if (rem <= 0) break;
+            if (split) {
+                HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s));
+                if (rem <= 0) break;
+                HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s));
+            } else {
+                HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
+                if (rem <= 0) break;
+            }
             GemmArgs a{};
             // panel solve  L[r,p] = A[r,p] · Linv_ppᵀ   (in place; each workgroup owns its rows)
             a.A = K + (int64_t)(r0 + TB) * ld + r0; a.lda = ld;
@@ -359,7 +371,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             a.C = K + (int64_t)(r0 + TB) * ld + r0; a.ldc = ld;
             a.M = rem; a.N = TB; a.K = TB; a.kmode = K_FULL; a.lower_only = 0; a.batch = 1;
             a.alpha = 1.0; a.beta = 0.0; a.info = info;
-            HIPCHK(launch_gemm_nt(a, s));
+            if (!split) HIPCHK(launch_gemm_nt(a, s));
             // in-strip update  A[r,c] −= L[r,p]·L[c,p]ᵀ  for the strip's remaining columns c, lower tiles only
             const int ncol = s0 + sw - r0 - TB;
             if (ncol > 0) {
@@ -384,6 +396,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             HIPCHK(launch_gemm_nt(u, s));
         }
     }
+    if (split) HIPCHK(launch_trtri_diag_batched(K, W, WT, ld, Np / TB, info, s));
     HIPCHK(hipEventRecord(g->evs()[2], s));
     // no host round trip here: after a failed pivot every later kernel of the fit either exits on `info` (the GEMMs) or
     // works on finite leftovers whose results are discarded; `info` is read once, with the scalars, at the end

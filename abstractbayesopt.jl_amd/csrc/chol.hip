@@ -74,8 +74,17 @@ __device__ __forceinline__ void sqrt_and_reciprocal(double d, double& piv, doubl
 //                comes out of the MFMA in C/D layout, which is exactly the B-operand layout of the next
 //                MFMA when its k-steps are taken as {g, g+4, g+8, g+12} — no data movement in between
 //   phase 3  write L back to K (lower, zeros above), X to W (lower) and Xᵀ to WT (upper).
+// The kernel comes in three builds of the same phases (MODE):
+//   0  everything (factor + full 128×128 inverse): the reference schedule, kept for A/B runs (ABO_CHOL_SPLIT=0)
+//   1  potf2 only — phase 1, the eight 16×16 diagonal sub-block inverses of phase 2(a), L written back and those
+//      sub-block inverses written to their final places in W / WT.  This is what sits on the panel chain: the 128×128
+//      inverse (a quarter of the kernel's time) is not needed there, because the panel solve is a blocked triangular
+//      solve on L itself (trsm_panel_kernel) that only wants the 16×16 diagonal inverses.
+//   2  trtri, batched — one workgroup per diagonal block (blockIdx.x): reads the finished L block back, runs phase 2 and
+//      writes W / WT.  ONE launch of N/128 workgroups after the factorisation instead of N/128 serial 12 µs phases.
 #define AA(r, c) a[(r) * LDA + (c)]
 constexpr int DT = 1024;      // threads of the diagonal-block kernel (16 waves: latency hiding for the LDS phases)
+template <int MODE>
 __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, double* WT, int64_t ld, int r0,
                                                         int64_t* info) {
     __shared__ double a[NB * LDA];
@@ -86,17 +95,22 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     const int r16 = lane & 15, g = lane >> 4;
     if (*info != 0) return;
     if (t == 0) fail = 0;
+    if constexpr (MODE == 2) r0 = blockIdx.x * NB;
     PROBE(0);
     double* Kb = K + (int64_t)r0 * ld + r0;
     for (int idx = t; idx < NB * NB; idx += DT) {
         const int i = idx >> 7, j = idx & 127;
         AA(i, j) = Kb[(int64_t)i * ld + j];
     }
+    if constexpr (MODE == 2) {
+        __syncthreads();
+        if (t < NB) dinv[t] = 1.0 / AA(t, t);              // the factor's diagonal is positive (a failed fit never gets here)
+    }
     __syncthreads();
     PROBE(1);
 
     // ---------------- phase 1: Cholesky ----------------
-    for (int p = 0; p < NSB; ++p) {
+    for (int p = 0; p < (MODE == 2 ? 0 : NSB); ++p) {
         const int o = SB * p;
         const int below = NB - o - SB;                     // rows under the diagonal sub-block
         // (1)+(2) fused, in registers: lanes 0-15 of a wave hold the 16 rows of the diagonal sub-block, lanes 16-63
@@ -180,6 +194,22 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     }
     __syncthreads();
     PROBE(3);
+    if constexpr (MODE == 1) {
+        // write back: L (lower, zeros above) and the 16×16 diagonal sub-block inverses (final values of those entries of
+        // W and WT; everything else of the W block is written by the batched trtri launch)
+        double* Wd = W + (int64_t)r0 * ld + r0;
+        double* WTd = WT + (int64_t)r0 * ld + r0;
+        for (int idx = t; idx < NB * NB; idx += DT) {
+            const int i = idx >> 7, j = idx & 127;
+            Kb[(int64_t)i * ld + j] = i >= j ? AA(i, j) : 0.0;
+            if ((i >> 4) == (j >> 4)) {
+                const double w = i > j ? AA(j, i) : (i == j ? dinv[i] : 0.0);          // X[i][j] lives at a[j][i]
+                Wd[(int64_t)i * ld + j] = w;
+                WTd[(int64_t)j * ld + i] = w;
+            }
+        }
+        return;
+    }
     for (int dl = 1; dl < NSB; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
         for (int c = wave; c + dl < NSB; c += DT / 64) {
             const int i = c + dl;
@@ -220,7 +250,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         if (i > j) { l = AA(i, j); w = AA(j, i); wt = 0.0; }
         else if (i == j) { l = AA(i, i); w = dinv[i]; wt = dinv[i]; }
         else { l = 0.0; w = 0.0; wt = AA(i, j); }
-        Kb[(int64_t)i * ld + j] = l;
+        if constexpr (MODE == 0) Kb[(int64_t)i * ld + j] = l;
         Wb[(int64_t)i * ld + j] = w;
         WTb[(int64_t)i * ld + j] = wt;
     }
@@ -229,7 +259,97 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
 #undef AA
 
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    hipLaunchKernelGGL(chol_diag_kernel<0>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    return hipGetLastError();
+}
+
+hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
+    hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    return hipGetLastError();
+}
+
+hipError_t launch_trtri_diag_batched(double* K, double* W, double* WT, int64_t ld, int nblocks, int64_t* info, hipStream_t s) {
+    if (nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(chol_diag_kernel<2>, dim3(nblocks), dim3(DT), 0, s, K, W, WT, ld, 0, info);
+    return hipGetLastError();
+}
+
+// Panel solve as a blocked triangular solve:  X = A·L⁻ᵀ  for the rows below a freshly factored 128×128 diagonal block
+// (rows r0+128 … r0+128+nrows, columns r0 … r0+127; in place).  One wave per 16 rows, in transposed space so that every
+// product chains through the matrix pipe without data movement:  with Y_j = X_jᵀ (16 columns of block j × 16 rows),
+//     Y_j = L_jj⁻¹ · (A_jᵀ − Σ_{k<j} L_jk · Y_k)
+// L_jk / L_jj⁻¹ are A operands (staged once per workgroup in LDS, stored [block][kk][m] so that a k-step is one
+// conflict-free 8-byte read per lane), the Y_k are previous MFMA results, whose C/D register r is exactly the B operand
+// of k-step r.  176 MFMAs per wave (64 of them on the dependent path); no 128×128 inverse is needed — only the eight 16×16 diagonal inverses the
+// potf2 kernel leaves in W.  (The GEMM form X = A·W_ppᵀ needed the full inverse first: 12 µs more on the panel chain.)
+constexpr int TRSM_BLK = 36 + 8;          // 36 lower sub-blocks of L_pp (j ≥ k) + 8 diagonal inverses
+__global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double* W, int64_t ld, int r0, int nrows,
+                                                         const int64_t* info) {
+    __shared__ double lt[TRSM_BLK][16][16 + 1];            // [block][kk][m] (+1: the transposing fill stays conflict-poor)
+    if (*info != 0) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const double* Lb = K + (int64_t)r0 * ld + r0;
+    const double* Wb = W + (int64_t)r0 * ld + r0;
+    // fill: 64 + 8 independent loads per thread (fully unrolled: they are all in flight together), coalesced along rows
+    // (the loads are unconditional — every address lies inside the block — so that all of them are issued before the first
+    // one is waited for; a load under the `lower sub-block` condition would be waited for one at a time)
+    double v[64], w[8];
+#pragma unroll
+    for (int e = 0; e < 64; ++e) {
+        const int idx = t + 256 * e;
+        v[e] = Lb[(int64_t)(idx >> 7) * ld + (idx & 127)];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = t + 256 * e;                       // 8 blocks × 16 rows × 16 columns
+        w[e] = Wb[(int64_t)(16 * (idx >> 8) + ((idx >> 4) & 15)) * ld + 16 * (idx >> 8) + (idx & 15)];
+    }
+#pragma unroll
+    for (int e = 0; e < 64; ++e) {
+        const int idx = t + 256 * e;
+        const int i = idx >> 7, c = idx & 127;
+        const int bj = i >> 4, bk = c >> 4;
+        if (bk <= bj) lt[bj * (bj + 1) / 2 + bk][c & 15][i & 15] = v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int idx = t + 256 * e;
+        lt[36 + (idx >> 8)][idx & 15][(idx >> 4) & 15] = w[e];
+    }
+    __syncthreads();
+    const int rb = blockIdx.x * 4 + wave;
+    if (rb * 16 >= nrows) return;
+    double* Arow = K + (int64_t)(r0 + NB + rb * 16 + n) * ld + r0;    // this lane's row, the panel's 128 columns
+    d4_t Y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)                            // right-hand sides first: 32 independent loads per lane
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[j][r] = Arow[16 * j + 4 * r + g];
+    // right-looking order: as soon as Y_k is final every later block takes its update, k-step by k-step over DIFFERENT
+    // accumulators — independent MFMAs that issue back to back; the dependent path is 8 × (4 + 4) MFMAs instead of 176
+    // (each block still receives its updates in the order k = 0, 1, … : same bits as the left-looking loop)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[36 + k][4 * s4 + g][n], Y[k][s4], y, 0, 0, 0);
+        Y[k] = y;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = k + 1; j < 8; ++j)
+                Y[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[j * (j + 1) / 2 + k][4 * s4 + g][n], Y[k][s4], Y[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Arow[16 * j + 4 * r + g] = Y[j][r];
+}
+
+hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s) {
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trsm_panel_kernel, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
     return hipGetLastError();
 }
 
