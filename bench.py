@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 and C5 entries of the default C3 line (profiling runs)")
     ap.add_argument("--cpu-sample-m", type=int, default=16384,
                     help="candidates of the CPU-baseline sample (BASELINE.md §4 allows up to 65536 and linear scaling in M)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (median reported)")
@@ -521,7 +522,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_m, args.cpu_reps)
             out["speedup_vs_cpu_port"] = out["cpu_baseline"]["value"] / ms_per_step
             out["speedup_vs_cpu_blas3_floor"] = out["cpu_baseline"]["blas3_floor"]["value"] / ms_per_step
-        if world == 1 and args.config == "c3" and not args.no_cpu_baseline:
+        if world == 1 and args.config == "c3" and not args.no_secondary:
             # the other single-GPU configurations of BASELINE.json, timed by the same run: C2 (small N) and C5
             # (incremental update + greedy q-EI on a resident grid; its own roofline is the HBM-streaming down-date)
             del model, Zd
