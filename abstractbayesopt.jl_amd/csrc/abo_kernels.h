@@ -93,6 +93,19 @@ hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d
 // matching diagonal block of W (lower) and WT (upper = transposed); on a non-positive pivot set
 // *info = r0 + j + 1 (if still 0) and leave.
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
+// The whole fit of an N ≤ 128, d ≤ 16 model in ONE launch of the diagonal-block kernel (mode 3): writes Xs [128][dp], delta,
+// L (→ K), L⁻¹ (→ W, WT), alpha, scal = {log det, δᵀα}; K / W / WT have leading dimension 128.  *info as launch_chol_diag.
+struct FitSmallArgs {
+    const double* Xraw;   // [N][d] raw inputs (device)
+    const double* y;      // [N]
+    double* Xs;           // [128][dp]
+    double* delta;        // [128]
+    double* alpha;        // [128]
+    double* scal;         // [2]
+    int N, d, dp, family;
+    double s, sigma_f2, noise, mean_c;
+};
+hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, const FitSmallArgs& fs, hipStream_t s);
 // the same split for the panel chain: potf2 (factor + the eight 16×16 diagonal sub-block inverses, which go to their final
 // places in W / WT), the panel solve below the block as a blocked triangular solve on L (rows r0+128 … r0+128+nrows), and —
 // once, after the factorisation — the 128×128 inverses of ALL diagonal blocks in one batched launch

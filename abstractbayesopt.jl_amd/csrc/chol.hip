@@ -7,6 +7,7 @@
 // right-looking, 128-wide panels; this kernel is its potf2 + trtri step, the MFMA GEMM core
 // (gemm.hip) does the panel solve, the trailing SYRK and the blocked L⁻¹.
 #include "abo_kernels.h"
+#include "abo_kappa.h"
 
 // tools/chol_diag_probe.hip defines ABO_CHOL_PROBE to time the phases of chol_diag_kernel with the 100 MHz
 // constant clock; in the library build the macro is empty.
@@ -82,14 +83,33 @@ __device__ __forceinline__ void sqrt_and_reciprocal(double d, double& piv, doubl
 //      solve on L itself (trsm_panel_kernel) that only wants the 16×16 diagonal inverses.
 //   2  trtri, batched — one workgroup per diagonal block (blockIdx.x): reads the finished L block back, runs phase 2 and
 //      writes W / WT.  ONE launch of N/128 workgroups after the factorisation instead of N/128 serial 12 µs phases.
+//   3  the WHOLE fit of a model with N ≤ 128 points (the reference's own regime: its examples and tests run 5 … 50
+//      points, src/acquisition_functions/acq_utils.jl:37 scores 10 000 candidates per step) in this one launch: scaled
+//      inputs, K + σ²I generated straight into LDS (same arithmetic as kgen_kernel, same bits), factor, inverse,
+//      δ = y − m, α = L⁻ᵀ(L⁻¹δ), log-determinant and δᵀα.  Replaces thirteen launches (two memsets, point scaling, centring,
+//      kernel matrix, diagonal fix, this kernel in mode 0, two triangular mat-vecs, the NLML terms) whose launch
+//      boundaries were most of a 90 µs fit.
 #define AA(r, c) a[(r) * LDA + (c)]
 constexpr int DT = 1024;      // threads of the diagonal-block kernel (16 waves: latency hiding for the LDS phases)
+template <int FAM>
+__device__ __forceinline__ double small_kernel_entry(const double* xi, const double* xj, int dp, double sigma_f2) {
+    double r = 0.0;
+    for (int c = 0; c < dp; ++c) {
+        const double e = xj[c] - xi[c];
+        r = fma(e, e, r);
+    }
+    return sigma_f2 * kappa_eval<FAM>(r);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, double* WT, int64_t ld, int r0,
-                                                        int64_t* info) {
+                                                        int64_t* info, FitSmallArgs fs) {
     __shared__ double a[NB * LDA];
     __shared__ double dinv[NB];
     __shared__ int fail;
+    __shared__ double xs[MODE == 3 ? NB * 16 : 1];          // mode 3: scaled inputs, δ and the intermediate of the two solves
+    __shared__ double dl[MODE == 3 ? NB : 1];
+    __shared__ double tv[MODE == 3 ? NB : 1];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -98,9 +118,42 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     if constexpr (MODE == 2) r0 = blockIdx.x * NB;
     PROBE(0);
     double* Kb = K + (int64_t)r0 * ld + r0;
-    for (int idx = t; idx < NB * NB; idx += DT) {
-        const int i = idx >> 7, j = idx & 127;
-        AA(i, j) = Kb[(int64_t)i * ld + j];
+    if constexpr (MODE == 3) {
+        // scaled, zero-padded inputs (also the model's Xs) and centred targets
+        for (int idx = t; idx < NB * fs.dp; idx += DT) {
+            const int i = idx / fs.dp, c = idx % fs.dp;
+            const double v = (i < fs.N && c < fs.d) ? fs.Xraw[(int64_t)i * fs.d + c] * fs.s : 0.0;
+            xs[i * 16 + c] = v;
+            fs.Xs[idx] = v;
+        }
+        if (t < NB) {
+            const double v = t < fs.N ? fs.y[t] - fs.mean_c : 0.0;
+            dl[t] = v;
+            fs.delta[t] = v;
+        }
+        __syncthreads();
+        // K + σ²I with identity padding: element (i, j) exactly as kgen_kernel + diag_fix_kernel give it
+        for (int idx = t; idx < NB * NB; idx += DT) {
+            const int i = idx >> 7, j = idx & 127;
+            double v = i == j ? 1.0 : 0.0;
+            if (i < fs.N && j < fs.N) {
+                const double* xi = xs + i * 16;
+                const double* xj = xs + j * 16;
+                switch (fs.family) {
+                    case ABO_KERNEL_SE: v = small_kernel_entry<ABO_KERNEL_SE>(xi, xj, fs.dp, fs.sigma_f2); break;
+                    case ABO_KERNEL_MATERN52: v = small_kernel_entry<ABO_KERNEL_MATERN52>(xi, xj, fs.dp, fs.sigma_f2); break;
+                    case ABO_KERNEL_MATERN72: v = small_kernel_entry<ABO_KERNEL_MATERN72>(xi, xj, fs.dp, fs.sigma_f2); break;
+                    default: v = small_kernel_entry<ABO_KERNEL_MATERN32>(xi, xj, fs.dp, fs.sigma_f2); break;
+                }
+                if (i == j) v += fs.noise;
+            }
+            AA(i, j) = v;
+        }
+    } else {
+        for (int idx = t; idx < NB * NB; idx += DT) {
+            const int i = idx >> 7, j = idx & 127;
+            AA(i, j) = Kb[(int64_t)i * ld + j];
+        }
     }
     if constexpr (MODE == 2) {
         __syncthreads();
@@ -250,27 +303,58 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         if (i > j) { l = AA(i, j); w = AA(j, i); wt = 0.0; }
         else if (i == j) { l = AA(i, i); w = dinv[i]; wt = dinv[i]; }
         else { l = 0.0; w = 0.0; wt = AA(i, j); }
-        if constexpr (MODE == 0) Kb[(int64_t)i * ld + j] = l;
+        if constexpr (MODE == 0 || MODE == 3) Kb[(int64_t)i * ld + j] = l;
         Wb[(int64_t)i * ld + j] = w;
         WTb[(int64_t)i * ld + j] = wt;
     }
     PROBE(5);
+    if constexpr (MODE == 3) {
+        // α = L⁻ᵀ(L⁻¹δ) from the block in LDS: X = L⁻¹ has its diagonal in dinv and its strict lower part transposed in the
+        // strict upper triangle (a[k][i] = X[i][k], k < i).  One thread per row, sums in index order (deterministic).
+        if (t < NB) {
+            double acc = dinv[t] * dl[t];
+            for (int k = 0; k < t; ++k) acc = fma(AA(k, t), dl[k], acc);
+            tv[t] = acc;
+        }
+        __syncthreads();
+        if (t < NB) {
+            double acc = dinv[t] * tv[t];
+            for (int i = t + 1; i < NB; ++i) acc = fma(AA(t, i), tv[i], acc);
+            fs.alpha[t] = acc;
+            dl[t] = dl[t] * acc;                                     // δ_i α_i (zero on padding rows); dl[t] is this thread's own
+        }
+        __syncthreads();                                             // every tv[i] has been read
+        if (t < NB) tv[t] = t < fs.N ? 2.0 * log(AA(t, t)) : 0.0;    // log-determinant terms
+        __syncthreads();
+        if (t == 0) {
+            double ld2 = 0.0, q = 0.0;
+            for (int i = 0; i < NB; ++i) { ld2 += tv[i]; q += dl[i]; }
+            fs.scal[0] = ld2;
+            fs.scal[1] = q;
+        }
+    }
 }
 #undef AA
 
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
-    hipLaunchKernelGGL(chol_diag_kernel<0>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    hipLaunchKernelGGL(chol_diag_kernel<0>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
     return hipGetLastError();
 }
 
 hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
-    hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
     return hipGetLastError();
 }
 
 hipError_t launch_trtri_diag_batched(double* K, double* W, double* WT, int64_t ld, int nblocks, int64_t* info, hipStream_t s) {
     if (nblocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(chol_diag_kernel<2>, dim3(nblocks), dim3(DT), 0, s, K, W, WT, ld, 0, info);
+    hipLaunchKernelGGL(chol_diag_kernel<2>, dim3(nblocks), dim3(DT), 0, s, K, W, WT, ld, 0, info, FitSmallArgs{});
+    return hipGetLastError();
+}
+
+hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, const FitSmallArgs& fs, hipStream_t s) {
+    if (fs.N < 1 || fs.N > NB || fs.dp < 1 || fs.dp > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chol_diag_kernel<3>, dim3(1), dim3(DT), 0, s, K, W, WT, (int64_t)NB, 0, info, fs);
     return hipGetLastError();
 }
 
