@@ -193,7 +193,11 @@ __device__ __forceinline__ void acc_zero(d4_t (&acc)[4][4]) {
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) double smem[4 * TILE];
     if (p.info != nullptr && *p.info != 0) return;
-    const int tj = blockIdx.x, ti = blockIdx.y, bz = blockIdx.z;
+    // heaviest tiles first: with K_A_LOWER the k range of a tile grows with its row block, so the row blocks are
+    // dealt out from the bottom up (the light tiles then fill the tail of the launch instead of the heavy ones forming it);
+    // K_A_UPPER already starts with its longest rows
+    const int tj = blockIdx.x, bz = blockIdx.z;
+    const int ti = p.kmode == K_A_LOWER ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
     if (p.lower_only && tj > ti) return;
     int kbeg = 0, kend = p.K;
     if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
