@@ -161,3 +161,48 @@ def test_rccl_transport_at_world_size_one(monkeypatch):
     p1, i1, v1, _ = abo.greedy_qei(c1.model, c1, 3, 0.01, float(y.min()))
     np.testing.assert_array_equal(i1, i2)
     np.testing.assert_array_equal(v1, v2)
+
+
+def test_eight_shards_config4_shape_at_reduced_size():
+    """BASELINE config 4's structure — 8 shards, Matérn-5/2 d = 8, EI, top-100 — at a size the one-GPU box runs in a second
+    (N = 1024, M = 100 000 not divisible by 8): merged selection and every score equal the single handle bit for bit."""
+    d, N, M, k = 8, 1024, 100_003, 100
+    X, y = synth.standardized_problem(N, d, 0.03)
+    Z = synth.points(2, M, d)
+    one = abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y)
+    grp = abo.update(sharded(O.MATERN52, 1.0, 1.0, 1e-3, (0,) * 8), X, y)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    s1, tv1, ti1 = abo.evaluate(acq, one, Z, k=k)
+    s2, tv2, ti2 = abo.evaluate(acq, grp, Z, k=k)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(ti1, ti2)
+    np.testing.assert_array_equal(tv1, tv2)
+    # selection only (no scores back), k larger than a shard's share of the winners
+    _, tv3, ti3 = abo.evaluate(acq, grp, Z, k=2000, return_scores=False)
+    ov, oi = O.top_k(s1, 2000)
+    np.testing.assert_array_equal(ti3, oi)
+    np.testing.assert_array_equal(tv3, ov)
+
+
+def test_group_errors_are_statuses_and_leave_the_group_usable():
+    d = 2
+    X = np.array([[-1.0, -1.0], [5.0, -5.0]])
+    grp = abo.update(sharded(O.SE, 1.0, 1.0, 0.0, (0, 0), n_max=16), X, [1.0, 2.0])
+    Z = synth.points(2, 300, d)
+    cg = abo.ShardedCandidates(grp, Z)
+    mu0 = abo.posterior_mean(grp, Z)
+    with pytest.raises(abo.PosDefException) as e:                       # every shard refuses the duplicate point
+        multigpu.append(grp, [-1.0 + 1e-12, -1.0 + 1e-12], 1.0, cg)
+    assert e.value.info == 3
+    with pytest.raises(abo.DimensionMismatch):
+        multigpu.append(grp, [1.0, 2.0, 3.0], 0.0)
+    with pytest.raises(abo.DimensionMismatch):
+        abo.evaluate(abo.UpperConfidenceBound(2.0), grp, np.zeros((5, 3)), k=2)
+    with pytest.raises(ValueError):
+        abo.evaluate(abo.UpperConfidenceBound(2.0), sharded(O.SE, 1.0, 1.0, 0.1, (0, 0)), Z, k=2)     # gpx === nothing
+    np.testing.assert_array_equal(abo.posterior_mean(grp, Z), mu0)      # the group and its grid are as before
+    tv, ti = cg.evaluate(grp, abo.UpperConfidenceBound(2.0), 5)
+    s, tv1, ti1 = abo.evaluate(abo.UpperConfidenceBound(2.0), grp, Z, k=5)
+    np.testing.assert_array_equal(ti, ti1)
+    ok = multigpu.append(grp, [2.0, 2.0], 0.5, cg)
+    assert abs(abo.posterior_mean(ok, [[2.0, 2.0]])[0] - 0.5) < 1e-9

@@ -29,6 +29,14 @@ for it in range(300):
     if it % 10 == 0:
         g = abo.update(abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1), synth.points(5, 40, 2), np.ones((40, 3)))
         abo.posterior_grad_cov(g, [[0.2, 0.3]])
+        # multi-device handle (three shards on this device): worker threads, exchange buffers, fantasy handles of q-EI
+        grp = abo.update(abo.HipShardedGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.7), 1e-3, devices=(0, 0, 0), n_max=1024), X, y)
+        Zh = synth.points(2, 3000, 4)
+        cg = abo.ShardedCandidates(grp, Zh)
+        cg.greedy_qei(grp, 3, 0.01, float(y.min()))
+        abo.multigpu.append(grp, Zh[it % 3000], 0.2, cg)
+        small = abo.update(abo.HipStandardGP(abo.Matern52Kernel(), 1e-6), synth.points(7, 30, 2), np.arange(30.0))   # fused small fit
+        abo.posterior_var(small, Zh[:100, :2])
     if it % 50 == 0:
         torch.cuda.synchronize()
         marks.append(used_mb())
