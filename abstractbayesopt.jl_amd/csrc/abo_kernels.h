@@ -60,6 +60,7 @@ struct KgenArgs {
     // point, Np pads pt·N; candidate rows carry pc outputs each (1 = function value only, pt = all outputs)
     int pt = 1, pc = 1, point_major = 0;
     int dlogell = 0;      // gradient-enhanced GP only: write dK/dlog(ell) instead of K (hyper-parameter gradient)
+    int rvalid = 0;       // gradient-enhanced GP only: valid training rows when not N·pt (a partly appended point)
     double mean_vec[MAX_P] = {0};   // prior mean per output (gradConstMean)
 };
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
@@ -118,6 +119,11 @@ hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* ou
 hipError_t launch_nlml_terms(const double* L, int64_t ld, const double* delta, const double* alpha, int N, double* out, hipStream_t s);
 // delta[i] = y[i] − c (i < N), 0 for padding
 hipError_t launch_center(const double* y, double* delta, int N, int Np, double c, hipStream_t s);
+// gradient-enhanced GP: targets arrive by outputs (y_abi[q·N + i], prep_output of the reference) and are kept point-major
+// (ybuf[i·p + q]); delta[r] = ybuf[r] − mean[r % p] for r < N·p, 0 up to Np
+struct MeanVec { double c[MAX_P]; };
+hipError_t launch_center_grad(const double* y_abi, double* ybuf, double* delta, int N, int p, int Np, MeanVec mean, int y_point_major,
+                              hipStream_t s);
 
 // bordered append (chol.hip): given k = k(X,x*), l = W·k, v = Wᵀ·l, write row N of L and W, column N of WT,
 // the new alpha and the down-date vector vext = [−v ; 1]; scal = {l_nn², β, l_nn, kᵀα}; *info = N+1 if l_nn² ≤ 0

@@ -332,7 +332,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     ka.Xs = st->Xs.as<double>(); ka.Z = st->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = K; ka.mu = nullptr;
     ka.ldk = ld; ka.M = g->npts; ka.j0 = 0; ka.Mc = Np; ka.N = (int)g->npts; ka.Np = Np; ka.d = g->d; ka.dp = g->dp;
     ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
-    ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 0;      // K_XX: rows and columns by outputs → symmetric
+    ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 1;      // K_XX: rows and columns point-major → symmetric
     HIPCHK(launch_kgen(ka, s));
     HIPCHK(launch_diag_fix(K, ld, N, (int)ld, noise, s));
     if (ld > Np) {
@@ -600,8 +600,11 @@ int32_t stage_candidates(abo_gp* g, const double* Z, int64_t M, int32_t z_space,
     return ABO_OK;
 }
 
-// Full refit into a fresh Storage of capacity max(N, n_max).  X/y: caller buffers (host or device).
-int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, int32_t space, int64_t* info) {
+// Full refit into a fresh Storage of capacity max(N, n_max) points.  X/y: caller buffers (host or device).
+// Gradient-enhanced models (p_out > 1): y holds p_out values per point, by outputs at the ABI (y[q·N + i]) or — internal
+// callers, y_point_major — already in the factor's point-major order (y[i·p + q]).
+int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, int32_t space, int64_t* info,
+                 int y_point_major = 0) {
     hipStream_t s = g->stream;
     g->from_append = false;
     Storage* st = new (std::nothrow) Storage();
@@ -610,7 +613,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     st->d = d; st->dp = dp_for(d);
     const int P = g->p_out;                              // N below = number of training POINTS
     const int64_t R = (int64_t)P * N;                    // factor rows
-    const int64_t want = (P == 1 && g->prm.n_max > N) ? g->prm.n_max : R;
+    const int64_t want = (int64_t)P * (g->prm.n_max > N ? g->prm.n_max : N);
     st->cap = pad_up(want, TB);
     const int64_t cap = st->cap;
     hipError_t e = hipSuccess;
@@ -627,7 +630,8 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     }
     // stage the inputs BEFORE dropping the previous storage: X / y may alias it (refit after append)
     int32_t rc = copy_in(st->Xraw.p, X, sizeof(double) * N * d, space, s);
-    if (!rc) rc = copy_in(st->ybuf.p, y, sizeof(double) * R, space, s);
+    // (gradient-enhanced: staged in K — overwritten by the kernel matrix later — and reordered into ybuf below)
+    if (!rc) rc = copy_in(P == 1 ? st->ybuf.p : st->K.p, y, sizeof(double) * R, space, s);
     if (rc) { storage_unref(st); return rc; }
     HIPCHK(hipStreamSynchronize(s));
     if (g->st && g->fitted) g->st->drop_view(g->N);
@@ -665,10 +669,11 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
     if (P == 1) {
         HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
-    } else {                                             // rows by outputs: block q is centred by mean_vec[q]
-        HIPCHK(hipMemsetAsync(st->delta.p, 0, sizeof(double) * cap, s));
-        for (int q = 0; q < P; ++q)
-            HIPCHK(launch_center(st->ybuf.as<double>() + q * N, st->delta.as<double>() + q * N, (int)N, (int)N, g->mean_vec[q], s));
+    } else {                                             // point-major rows i·p + q, output q centred by mean_vec[q]
+        MeanVec mv{};
+        for (int q = 0; q < P; ++q) mv.c[q] = g->mean_vec[q];
+        HIPCHK(launch_center_grad(st->K.as<double>(), st->ybuf.as<double>(), st->delta.as<double>(), (int)N, P, (int)cap, mv,
+                                  y_point_major, s));
     }
     HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
 
@@ -1118,7 +1123,7 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
         ka.Xs = g->st->Xs.as<double>(); ka.Z = g->st->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = g->Kxz.as<double>();
         ka.mu = nullptr; ka.ldk = Np; ka.M = g->npts; ka.j0 = 0; ka.Mc = (int)Np; ka.N = (int)g->npts; ka.Np = (int)Np;
         ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2;
-        ka.mean_c = 0.0; ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 0; ka.dlogell = 1;
+        ka.mean_c = 0.0; ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 1; ka.dlogell = 1;
         HIPCHK(launch_kgen(ka, s));
         HIPCHK(launch_nlml_grad_matrix(ga, g->Kxz.as<double>(), Np, s));
     } else {
@@ -1133,6 +1138,13 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     if (d_log_ell) *d_log_ell = 0.5 * o[0];
     if (d_log_sigma_f2) *d_log_sigma_f2 = 0.5 * ((double)N - noise * o[1] - o[3] + noise * o[2]);
     return ABO_OK;
+}
+
+// host vector of a gradient-enhanced model: the library's point-major order v[i·p + q] → the ABI's by-outputs order v[q·N + i]
+static void to_by_outputs(double* v, int64_t N, int p) {
+    std::vector<double> t(v, v + N * p);
+    for (int64_t i = 0; i < N; ++i)
+        for (int q = 0; q < p; ++q) v[(int64_t)q * N + i] = t[i * p + q];
 }
 
 int32_t abo_get_n(abo_gp* g, int64_t* N, int32_t* d) {
@@ -1164,6 +1176,7 @@ int32_t abo_get_factor(abo_gp* g, double* L, double* alpha, double* Linv) {
     }
     if (alpha) HIPCHK(hipMemcpyAsync(alpha, g->alpha.p, sizeof(double) * N, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (alpha && g->p_out > 1) to_by_outputs(alpha, g->npts, g->p_out);
     if (L)   // off-diagonal upper blocks of the in-place factor still hold K: present a clean L
         for (int64_t i = 0; i < N; ++i)
             for (int64_t j = i + 1; j < N; ++j) L[i * N + j] = 0.0;
@@ -1178,6 +1191,7 @@ int32_t abo_get_data(abo_gp* g, double* X, double* y) {
     if (X) HIPCHK(hipMemcpyAsync(X, g->st->Xraw.p, sizeof(double) * g->npts * g->d, hipMemcpyDeviceToHost, s));
     if (y) HIPCHK(hipMemcpyAsync(y, g->st->ybuf.p, sizeof(double) * g->N, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (y && g->p_out > 1) to_by_outputs(y, g->npts, g->p_out);
     return ABO_OK;
 }
 

@@ -575,6 +575,25 @@ __global__ void center_kernel(const double* y, double* delta, int N, int Np, dou
     if (i < Np) delta[i] = (i < N) ? y[i] - c : 0.0;
 }
 
+__global__ void center_grad_kernel(const double* y_in, double* ybuf, double* delta, int N, int p, int Np, MeanVec mean, int y_point_major) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= Np) return;
+    if (r < N * p) {
+        const int i = r / p, q = r % p;
+        const double v = y_point_major ? y_in[r] : y_in[(int64_t)q * N + i];
+        ybuf[r] = v;
+        delta[r] = v - mean.c[q];
+    } else {
+        delta[r] = 0.0;
+    }
+}
+
+hipError_t launch_center_grad(const double* y_abi, double* ybuf, double* delta, int N, int p, int Np, MeanVec mean, int y_point_major,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(center_grad_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, y_abi, ybuf, delta, N, p, Np, mean, y_point_major);
+    return hipGetLastError();
+}
+
 hipError_t launch_center(const double* y, double* delta, int N, int Np, double c, hipStream_t s) {
     hipLaunchKernelGGL(center_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, y, delta, N, Np, c);
     return hipGetLastError();

@@ -78,7 +78,10 @@ __device__ __forceinline__ void phi_derivs_dlogell(double u, double& p0, double&
 // Rows: candidate-output pairs.  Row index g = j0 + (row in chunk); with point_major == 0 it is by outputs
 // (q = g / M, j = g % M — MOInputIsotopicByOutputs, what the reference's posterior_grad_* return), with
 // point_major == 1 it is j = g / pc, q = g % pc (all outputs of a point adjacent: per-point covariance blocks).
-// Columns: training rows r = q'·N + i by outputs (prep_output, GradientGP.jl:893-895).
+// Columns: training rows in the library's POINT-MAJOR factor order r = i·pt + q' (all outputs of training point i
+// adjacent), so that a new observation appends pt rows at the END of the factor (bordered updates, abo_append_grad);
+// the reference's by-outputs order (prep_output, GradientGP.jl:893-895) stays at the ABI.  rvalid (when > 0) is the number of
+// valid training rows — a point whose outputs are only partly appended yet.
 template <int FAM, int DP, bool DLOGELL>
 __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
     __shared__ double zs[JT][DP];
@@ -102,13 +105,13 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
     double mu[JT];
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) mu[jj] = 0.0;
-    const int R = p.N * p.pt;                           // valid training rows
+    const int R = p.rvalid > 0 ? p.rvalid : p.N * p.pt;  // valid training rows
     for (int k0 = 0; k0 < p.Np; k0 += KSTEP) {
         const int k = k0 + 2 * t;
         if (k < p.Np) {
             double x0[DP], x1[DP];
-            const int i0 = k % p.N, i1 = (k + 1) % p.N;
-            const int qp0 = k / p.N - 1, qp1 = (k + 1) / p.N - 1;      // training output's coordinate (−1: f itself)
+            const int i0 = k / p.pt, i1 = (k + 1) / p.pt;
+            const int qp0 = k % p.pt - 1, qp1 = (k + 1) % p.pt - 1;    // training output's coordinate (−1: f itself)
             const bool ok0 = k < R, ok1 = (k + 1) < R;
 #pragma unroll
             for (int c = 0; c < DP; ++c) {

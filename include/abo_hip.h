@@ -91,7 +91,9 @@ int32_t abo_create(const abo_params* params, abo_gp** out);
  * analytic derivatives, rows ordered by outputs (MOInputIsotopicByOutputs).  mean_c: p prior means (NULL = 0).
  * 2 ≤ p ≤ 33 (d ≤ 32 inputs: the derivative blocks are generated from register-resident coordinates).
  * abo_fit then takes y of length p·N ordered by outputs (prep_output, :893-895); abo_predict / abo_acq address
- * the function output; abo_append and abo_cand_* are not available on such a handle. */
+ * the function output.  Inside the library the (d+1)N-row system is kept POINT-MAJOR (row i·p + q: all outputs of point i
+ * adjacent), so that a new observation appends p rows at the end of the factor (abo_append_grad); every vector that crosses
+ * the ABI (y, alpha) is by outputs, abo_get_factor's L / Linv are in the library's row order. */
 int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out);
 /* Base.copy(::StandardGP) (src/surrogates/StandardGP.jl:26, surrogates_utils.jl:12-14): device
  * state is immutable after fit, so a copy is a shared reference. */

@@ -81,7 +81,14 @@ def test_gradient_gp_against_oracle(family, d, N, M, ell, noise):
     m = abo.update(make_grad(family, ell, 1.2, noise, p, mean_c), X, Ys)
     L, alpha, Linv = abo.get_factor(m)
     assert L.shape == (p * N, p * N)
-    assert np.max(np.abs(L - st.L)) < 1e-9 and np.max(np.abs(alpha - st.alpha)) < 1e-6 * max(1, np.max(np.abs(st.alpha)))
+    # the library keeps the (d+1)N-row system point-major (row i·p + q) where the reference orders by outputs (q·N + i):
+    # the Cholesky factor of a permuted matrix is a different matrix, so compare what both factorise; α crosses the ABI
+    # by outputs
+    idx = np.array([q * N + i for i in range(N) for q in range(p)])
+    K_o = st.L @ st.L.T
+    assert np.max(np.abs(L @ L.T - K_o[np.ix_(idx, idx)])) < 1e-9
+    assert np.max(np.abs(Linv @ L - np.eye(p * N))) < 1e-8
+    assert np.max(np.abs(alpha - st.alpha)) < 1e-6 * max(1, np.max(np.abs(st.alpha)))
     mu_o, var_o = G.predict_grad(st, Z)
     assert np.max(np.abs(abo.posterior_grad_mean(m, Z) - mu_o)) < 1e-8
     assert np.max(np.abs(abo.posterior_grad_var(m, Z) - var_o)) < 1e-8 * max(1.0, 1.2 / ell ** 2)
