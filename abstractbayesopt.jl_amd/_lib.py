@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(PKG, "lib", "libabo_hip.so")
 ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
 HOST, DEVICE = 0, 1
 
-EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_cand_create", "abo_cand_destroy",
+EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_append_grad", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_data", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
            "abo_test_gemm_nt", "abo_test_kappa",
@@ -83,6 +83,7 @@ def lib():
     L.abo_destroy.argtypes = [vp]
     L.abo_fit.argtypes = [vp, vp, i64, i32, vp, i32, C.POINTER(i64)]
     L.abo_append.argtypes = [vp, vp, i32, f64, C.POINTER(i64), C.POINTER(vp)]
+    L.abo_append_grad.argtypes = [vp, vp, i32, vp, C.POINTER(i64), C.POINTER(vp)]
     L.abo_cand_create.argtypes = [vp, vp, i64, i32, i32, C.POINTER(vp)]
     L.abo_cand_destroy.argtypes = [vp]
     L.abo_cand_refresh.argtypes = [vp, vp]

@@ -180,6 +180,9 @@ hipError_t launch_downdate(double* mu, double* var, const double* c, int64_t M, 
 //   gemv:   c[j] = Σ_{k<n} Kzx[j][k]·v[k]   (the O(N·M) down-date as one streaming pass, no kernel evaluations)
 hipError_t launch_cand_newcol(const double* Xs, const double* Z, double* Kzx, int64_t ld, int64_t M, int col, int d, int dp,
                               int family, double s, double sigma_f2, hipStream_t st);
+// gradient-enhanced model: column `col` = training row (point pt, output q) against the function value of every candidate
+hipError_t launch_cand_newcol_grad(const double* Xs, const double* Z, double* Kzx, int64_t ld, int64_t M, int col, int pt, int q,
+                                   int d, int dp, int family, double s, double sigma_f2, hipStream_t st);
 hipError_t launch_cand_gemv(const double* Kzx, int64_t ld, const double* v, int n, int64_t M, double* c, hipStream_t s);
 // score[j] = acq(mu[j], var[j])
 hipError_t launch_score(const double* mu, const double* var, double* score, int64_t M, int kind, double p0, double best_y,

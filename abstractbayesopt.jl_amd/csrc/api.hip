@@ -224,6 +224,7 @@ struct abo_gp {
     // bordered-append bookkeeping (valid when this view was produced by abo_append)
     bool from_append = false;
     double ap_s2 = 0.0, ap_beta = 0.0; // Schur complement l_nn² and (y* − μ(x*))/l_nn²
+    double ap_s2v[MAX_P] = {0}, ap_betav[MAX_P] = {0};   // gradient-enhanced append: the same per appended row (p_out of them)
     DevBuf alpha, vext, tvec, T, info, scal;
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
@@ -776,6 +777,94 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     return ABO_OK;
 }
 
+// Gradient-enhanced model: one more observation (f and its gradient at x) = p_out more rows at the END of the point-major
+// factor, appended one row at a time with the bordered update above; row (N, q) sees the rows (N, q' < q) appended just
+// before it.  The kernel row comes from the multi-output generator (analytic derivative blocks), everything else is the
+// single-row machinery.  yv: p_out host values {f, ∂f/∂x_1 …}.
+int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv, int64_t* info) {
+    Storage* st = g->st;
+    const int d = g->d, P = g->p_out;
+    const int64_t R = g->N, npts = g->npts;
+    hipStream_t s = n->stream;
+    if (R + P > st->cap || st->max_live() > R) {
+        ScratchBuf xs(g->prm.device, s), ys(g->prm.device, s);
+        DevBuf& xb = xs.b;
+        DevBuf& yb = ys.b;
+        HIPCHK(xb.ensure(sizeof(double) * (npts + 1) * d));
+        HIPCHK(yb.ensure(sizeof(double) * (R + P)));
+        HIPCHK(hipMemcpyAsync(xb.p, st->Xraw.p, sizeof(double) * npts * d, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(yb.p, st->ybuf.p, sizeof(double) * R, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(xb.as<double>() + npts * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(yb.as<double>() + R, yv, sizeof(double) * P, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (n->prm.n_max < 2 * (npts + 1)) n->prm.n_max = 2 * (npts + 1);
+        return fit_impl(n, xb.as<double>(), npts + 1, d, yb.as<double>(), ABO_DEVICE, info, /*y_point_major=*/1);
+    }
+    const int64_t ld = st->cap;
+    HIPCHK(n->alpha.ensure(sizeof(double) * ld));
+    HIPCHK(n->T.ensure(sizeof(double) * ld));              // second alpha buffer (the rows alternate between the two)
+    HIPCHK(n->vext.ensure(sizeof(double) * ld * P));
+    HIPCHK(n->tvec.ensure(sizeof(double) * ld * 2));
+    HIPCHK(n->Kxz.ensure(sizeof(double) * 16 * ld));
+    HIPCHK(n->info.ensure(sizeof(int64_t)));
+    HIPCHK(n->scal.ensure(sizeof(double) * 4 * MAX_P));
+    double* Xraw = st->Xraw.as<double>();
+    HIPCHK(hipMemcpyAsync(Xraw + npts * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->ybuf.as<double>() + R, yv, sizeof(double) * P, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_scale_points(Xraw + npts * d, st->Xs.as<double>() + npts * st->dp, 1, 1, d, st->dp, 1.0 / g->prm.ell, s));
+    for (int q = 0; q < P; ++q)
+        HIPCHK(launch_center(st->ybuf.as<double>() + R + q, st->delta.as<double>() + R + q, 1, 1, g->mean_vec[q], s));
+    HIPCHK(hipMemsetAsync(n->info.p, 0, sizeof(int64_t), s));
+    double* krow = n->Kxz.as<double>();
+    double* lvec = n->tvec.as<double>();
+    double* vvec = n->tvec.as<double>() + ld;
+    const double* alpha_cur = g->alpha.as<double>();
+    for (int q = 0; q < P; ++q) {
+        const int64_t Rq = R + q;                          // rows in front of the one being appended
+        KgenArgs ka{};
+        ka.Xs = st->Xs.as<double>(); ka.Z = Xraw + npts * d; ka.alpha = nullptr; ka.Kout = krow; ka.mu = nullptr;
+        ka.ldk = ld; ka.M = 1; ka.j0 = q; ka.Mc = 16; ka.N = (int)(npts + 1); ka.Np = (int)pad_up(Rq, TB); ka.d = d; ka.dp = st->dp;
+        ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
+        ka.pt = P; ka.pc = P; ka.point_major = 1; ka.rvalid = (int)Rq;
+        HIPCHK(launch_kgen(ka, s));
+        HIPCHK(launch_trmv(st->W.as<double>(), ld, krow, lvec, (int)Rq, 1, s));
+        HIPCHK(launch_trmv(st->WT.as<double>(), ld, lvec, vvec, (int)Rq, 0, s));
+        double* alpha_new = (q & 1) == ((P - 1) & 1) ? n->alpha.as<double>() : n->T.as<double>();   // the last row lands in n->alpha
+        AppendArgs aa{};
+        aa.L = st->K.as<double>(); aa.W = st->W.as<double>(); aa.WT = st->WT.as<double>(); aa.ld = ld;
+        aa.krow = krow; aa.lvec = lvec; aa.vvec = vvec; aa.alpha_old = alpha_cur; aa.alpha_new = alpha_new;
+        aa.vext = n->vext.as<double>() + (int64_t)q * ld; aa.delta = st->delta.as<double>(); aa.N = (int)Rq; aa.cap = (int)ld;
+        aa.kss = (q == 0 ? g->prm.sigma_f2 : grad_prior_var(g)) + st->noise_used;
+        aa.scal = n->scal.as<double>() + 4 * q; aa.info = n->info.as<int64_t>();
+        HIPCHK(launch_append(aa, s));
+        alpha_cur = alpha_new;
+    }
+    double sc[4 * MAX_P];
+    int64_t inf = 0;
+    HIPCHK(hipMemcpyAsync(sc, n->scal.p, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&inf, n->info.p, sizeof inf, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (inf != 0) {
+        if (info) *info = inf;
+        return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
+                    (long long)inf);
+    }
+    storage_unref(n->st);
+    st->refs.fetch_add(1);
+    n->st = st;
+    st->add_view(R + P);
+    n->N = R + P; n->npts = npts + 1; n->Np = pad_up(R + P, TB); n->d = d; n->dp = st->dp;
+    n->from_append = true;
+    n->logdet = g->logdet; n->quad = g->quad;
+    for (int q = 0; q < P; ++q) {
+        n->ap_s2v[q] = sc[4 * q]; n->ap_betav[q] = sc[4 * q + 1];
+        n->logdet += 2.0 * std::log(sc[4 * q + 2]);
+        n->quad += sc[4 * q + 1] * sc[4 * q + 1] * sc[4 * q];
+    }
+    n->fitted = true;
+    return ABO_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -879,12 +968,30 @@ int32_t abo_append(abo_gp* g, const double* x, int32_t d, double y, int64_t* inf
     if (!g || !x || !out) return fail(ABO_EINVAL, "abo_append: null argument");
     int32_t rc = check_fitted(g, d);
     if (rc) return rc;
-    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_append: not available for gradient-enhanced models");
+    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_append: a gradient-enhanced model takes p values per observation (abo_append_grad)");
     HIPCHK(hipSetDevice(g->prm.device));
     abo_gp* n = nullptr;
     rc = abo_create(&g->prm, &n);
     if (rc) return rc;
     rc = append_impl(g, n, x, y, info);
+    if (rc) { abo_destroy(n); return rc; }
+    *out = n;
+    return ABO_OK;
+}
+
+int32_t abo_append_grad(abo_gp* g, const double* x, int32_t d, const double* y, int64_t* info, abo_gp** out) {
+    if (info) *info = 0;
+    if (!g || !x || !y || !out) return fail(ABO_EINVAL, "abo_append_grad: null argument");
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (g->p_out < 2) return fail(ABO_EINVAL, "abo_append_grad: the model has no gradient outputs (abo_append)");
+    HIPCHK(hipSetDevice(g->prm.device));
+    abo_gp* n = nullptr;
+    rc = abo_create(&g->prm, &n);
+    if (rc) return rc;
+    n->p_out = g->p_out;
+    for (int q = 0; q < MAX_P; ++q) n->mean_vec[q] = g->mean_vec[q];
+    rc = append_grad_impl(g, n, x, y, info);
     if (rc) { abo_destroy(n); return rc; }
     *out = n;
     return ABO_OK;
@@ -1266,7 +1373,6 @@ int32_t abo_cand_create(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_
     if (!out) return fail(ABO_EINVAL, "abo_cand_create: null argument");
     int32_t rc = check_fitted(g, d);
     if (rc) return rc;
-    if (g->p_out > 1) return fail(ABO_EINVAL, "abo_cand_create: not available for gradient-enhanced models");
     if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_cand_create: bad candidate buffer");
     HIPCHK(hipSetDevice(g->prm.device));
     abo_cand* c = new (std::nothrow) abo_cand();
@@ -1296,7 +1402,8 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
     if (!c) return fail(ABO_EINVAL, "abo_cand_downdate: null candidate set");
     int32_t rc = check_fitted(g, c->d);
     if (rc) return rc;
-    if (!g->from_append || g->st->gen != c->synced_gen || g->N != c->synced_N + 1)
+    const int P = g->p_out;                                // rows the append added: 1, or p for a gradient-enhanced model
+    if (!g->from_append || g->st->gen != c->synced_gen || g->N != c->synced_N + P)
         return fail(ABO_EINVAL, "abo_cand_downdate: the model is not the one-point append of the model this candidate set "
                                 "was last evaluated with (call abo_cand_refresh)");
     HIPCHK(hipSetDevice(g->prm.device));
@@ -1307,28 +1414,42 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
         const bool resident = c->kzx_ld > 0 && c->kzx_ld == g->st->cap;
         HIPCHK(g->events(8));
         HIPCHK(hipEventRecord(g->evs()[5], s));
-        if (resident) {
-            // the appended point's column, then one streaming mat-vec over the resident K_ZX
-            HIPCHK(launch_cand_newcol(g->st->Xs.as<double>(), c->Z.as<double>(), c->Kzx.as<double>(), c->kzx_ld, c->M,
-                                      (int)g->N - 1, g->d, g->dp, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, s));
-            HIPCHK(launch_cand_gemv(c->Kzx.as<double>(), c->kzx_ld, g->vext.as<double>(), (int)g->N, c->M,
-                                    c->cdot.as<double>(), s));
+        double pass_ms = 0.0;
+        for (int q = 0; q < P; ++q) {                      // one rank-1 down-date per appended row, in append order
+            const int64_t Rq = g->N - P + q;               // index of the appended row
+            const double* vext = g->vext.as<double>() + (P > 1 ? (int64_t)q * g->st->cap : 0);
+            const double s2 = P > 1 ? g->ap_s2v[q] : g->ap_s2, beta = P > 1 ? g->ap_betav[q] : g->ap_beta;
+            if (resident) {
+                // the appended row's column, then one streaming mat-vec over the resident K_ZX
+                if (P == 1) {
+                    HIPCHK(launch_cand_newcol(g->st->Xs.as<double>(), c->Z.as<double>(), c->Kzx.as<double>(), c->kzx_ld, c->M,
+                                              (int)Rq, g->d, g->dp, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, s));
+                } else {
+                    HIPCHK(launch_cand_newcol_grad(g->st->Xs.as<double>(), c->Z.as<double>(), c->Kzx.as<double>(), c->kzx_ld, c->M,
+                                                   (int)Rq, (int)(g->npts - 1), q, g->d, g->dp, g->prm.family, 1.0 / g->prm.ell,
+                                                   g->prm.sigma_f2, s));
+                }
+                HIPCHK(launch_cand_gemv(c->Kzx.as<double>(), c->kzx_ld, vext, (int)(Rq + 1), c->M, c->cdot.as<double>(), s));
+            }
+            const int64_t step = 65536;
+            for (int64_t j0 = 0; !resident && j0 < c->M; j0 += step) {
+                const int64_t m = (c->M - j0) < step ? (c->M - j0) : step;
+                KgenArgs ka{};
+                ka.Xs = g->st->Xs.as<double>(); ka.Z = c->Z.as<double>(); ka.alpha = vext; ka.Kout = nullptr;
+                ka.mu = c->cdot.as<double>() + j0; ka.ldk = 0; ka.M = c->M; ka.j0 = j0; ka.Mc = (int)pad_up(m, 16);
+                ka.N = (int)g->npts; ka.Np = (int)pad_up(Rq + 1, TB); ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family;
+                ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
+                if (P > 1) { ka.pt = P; ka.pc = 1; ka.point_major = 0; ka.rvalid = (int)(Rq + 1); }
+                else { ka.N = (int)(Rq + 1); }
+                HIPCHK(launch_kgen(ka, s));
+            }
+            if (q == P - 1) HIPCHK(hipEventRecord(g->evs()[6], s));
+            HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->cdot.as<double>(), c->M, beta, s2, s));
         }
-        const int64_t step = 65536;
-        for (int64_t j0 = 0; !resident && j0 < c->M; j0 += step) {
-            const int64_t m = (c->M - j0) < step ? (c->M - j0) : step;
-            KgenArgs ka{};
-            ka.Xs = g->st->Xs.as<double>(); ka.Z = c->Z.as<double>(); ka.alpha = g->vext.as<double>(); ka.Kout = nullptr;
-            ka.mu = c->cdot.as<double>() + j0; ka.ldk = 0; ka.M = c->M; ka.j0 = j0; ka.Mc = (int)pad_up(m, 16);
-            ka.N = (int)g->N; ka.Np = (int)g->Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family;
-            ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
-            HIPCHK(launch_kgen(ka, s));
-        }
-        HIPCHK(hipEventRecord(g->evs()[6], s));
-        HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->cdot.as<double>(), c->M, g->ap_beta, g->ap_s2, s));
         HIPCHK(hipStreamSynchronize(s));
-        g->tm.downdate_ms = ev_ms(g->evs()[5], g->evs()[6]);
-        g->tm.downdate_bytes = resident ? 8.0 * (double)g->N * (double)c->M : 0.0;
+        pass_ms = ev_ms(g->evs()[5], g->evs()[6]);
+        g->tm.downdate_ms = pass_ms;
+        g->tm.downdate_bytes = resident ? 8.0 * (double)g->N * (double)c->M * P : 0.0;
     }
     c->synced_N = g->N;
     return ABO_OK;

@@ -529,7 +529,7 @@ __global__ void __launch_bounds__(1024) append_reduce_kernel(AppendArgs p) {
     }
     if (threadIdx.x == 0) {
         const double s2 = p.kss - r0[0];
-        if (!(s2 > 0.0)) { *p.info = (int64_t)p.N + 1; p.scal[0] = s2; return; }
+        if (!(s2 > 0.0)) { if (*p.info == 0) *p.info = (int64_t)p.N + 1; p.scal[0] = s2; return; }   // the FIRST failing row is reported
         const double lnn = sqrt(s2);
         const double beta = (p.delta[p.N] - r1[0]) / s2;
         p.scal[0] = s2; p.scal[1] = beta; p.scal[2] = lnn; p.scal[3] = r1[0];

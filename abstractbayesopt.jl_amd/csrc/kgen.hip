@@ -676,6 +676,41 @@ hipError_t launch_cand_newcol(const double* Xs, const double* Z, double* Kzx, in
     return hipGetLastError();
 }
 
+// The same column for a gradient-enhanced model: training row (point `pt`, output q) against the FUNCTION value of every
+// candidate — cov(f(z), f(x)) = σ_f²φ for q = 0, cov(f(z), ∂f(x)/∂x_c) = σ_f²φ'·2e_c/ℓ, e = (x − z)/ℓ, for q = c + 1
+// (the qc < 0 branch of kgen_grad_kernel; same arithmetic).
+template <int FAM>
+__global__ void __launch_bounds__(256) cand_newcol_grad_kernel(const double* __restrict__ Xs, const double* __restrict__ Z,
+                                                                double* __restrict__ Kzx, int64_t ld, int64_t M, int col, int pt,
+                                                                int q, int d, int dp, double s, double sigma_f2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double* x = Xs + (int64_t)pt * dp;
+    const double* z = Z + j * d;
+    double u = 0.0, ep = 0.0;
+    for (int c = 0; c < d; ++c) {
+        const double e = x[c] - z[c] * s;
+        u = fma(e, e, u);
+        if (c == q - 1) ep = e;
+    }
+    double f0, g0, h0;
+    phi_derivs<FAM>(u, f0, g0, h0);
+    Kzx[j * ld + col] = sigma_f2 * (q == 0 ? f0 : 2.0 * s * g0 * ep);
+}
+
+hipError_t launch_cand_newcol_grad(const double* Xs, const double* Z, double* Kzx, int64_t ld, int64_t M, int col, int pt, int q,
+                                   int d, int dp, int family, double s, double sigma_f2, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    dim3 grid((unsigned)((M + 255) / 256)), block(256);
+    switch (family) {
+        case ABO_KERNEL_SE: hipLaunchKernelGGL((cand_newcol_grad_kernel<ABO_KERNEL_SE>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, pt, q, d, dp, s, sigma_f2); break;
+        case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((cand_newcol_grad_kernel<ABO_KERNEL_MATERN52>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, pt, q, d, dp, s, sigma_f2); break;
+        case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((cand_newcol_grad_kernel<ABO_KERNEL_MATERN72>), grid, block, 0, st, Xs, Z, Kzx, ld, M, col, pt, q, d, dp, s, sigma_f2); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 __global__ void diag_fix_kernel(double* K, int64_t ld, int N, int Np, double noise) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Np) return;

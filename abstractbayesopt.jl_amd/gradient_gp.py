@@ -36,8 +36,8 @@ class HipGradientGP(HipStandardGP):
     """GradientGP(kernel, p, noise_var; mean=gradConstMean(zeros(p))) (GradientGP.jl:617-639)."""
 
     def __init__(self, kernel: Kernel, p: int, noise_var: float, mean=None, device: int | None = None, jitter: float = 0.0,
-                 chunk: int = 0):
-        super().__init__(kernel, noise_var, mean=None, device=device, jitter=jitter, chunk=chunk)
+                 chunk: int = 0, n_max: int = 0):
+        super().__init__(kernel, noise_var, mean=None, device=device, jitter=jitter, chunk=chunk, n_max=n_max)
         self.p = int(p)
         self.mean = gradConstMean(np.zeros(self.p)) if mean is None else mean
         if len(self.mean.c) != self.p:
@@ -47,7 +47,7 @@ class HipGradientGP(HipStandardGP):
         from ._lib import AboParams
         return AboParams(family=self.kernel.family, device=self.device, ell=float(self.kernel.lengthscale),
                          sigma_f2=float(self.kernel.scale), noise_var=float(self.noise_var), mean_c=float(self.mean.c[0]),
-                         jitter=self.jitter, n_max=0, chunk=self.chunk)
+                         jitter=self.jitter, n_max=self.n_max, chunk=self.chunk)
 
     def _clone(self, handle):
         m = object.__new__(HipGradientGP)
@@ -168,12 +168,12 @@ def rescale_model(model: HipGradientGP, sigma):
     inner, scale, ell = extract_scale_and_lengthscale(model.kernel)
     k = (scale / s1 ** 2) * with_lengthscale(inner, ell)
     return HipGradientGP(k, model.p, model.noise_var / s1 ** 2, mean=gradConstMean(model.mean.c / s1), device=model.device,
-                         jitter=model.jitter, chunk=model.chunk)
+                         jitter=model.jitter, chunk=model.chunk, n_max=model.n_max)
 
 
 def _update_model_parameters(model: HipGradientGP, kernel: Kernel):
     return HipGradientGP(kernel, model.p, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter,
-                         chunk=model.chunk)
+                         chunk=model.chunk, n_max=model.n_max)
 
 
 def nlml(model: HipGradientGP, params, xs, ys) -> float:

@@ -17,7 +17,7 @@ from .acquisition import AbstractAcquisition, ExpectedImprovement
 from .surrogate import HipStandardGP, _Handle, as_points
 
 
-def append(model: HipStandardGP, x, y: float) -> HipStandardGP:
+def append(model: HipStandardGP, x, y) -> HipStandardGP:
     """Condition on one more observation (x, y) in O(N²): returns a new model sharing the factor storage;
     `model` stays valid (free rollback).  Raises PosDefException(N+1) if the bordered pivot is ≤ 0.
     Give the model capacity with HipStandardGP(..., n_max=N_max) to avoid refit fallbacks."""
@@ -25,7 +25,14 @@ def append(model: HipStandardGP, x, y: float) -> HipStandardGP:
     xa = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
     hp = C.c_void_p()
     info = C.c_int64(0)
-    st = L.abo_append(model._require(), xa.ctypes.data, xa.shape[0], float(y), C.byref(info), C.byref(hp))
+    if hasattr(model, "p"):
+        # gradient-enhanced model: y = [f(x), ∇f(x)…] (one row of the ys `update` takes); p rows join the factor
+        ya = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        if ya.shape[0] != model.p:
+            raise _lib.DimensionMismatch(f"the observation must hold p = {model.p} values (f and its gradient)")
+        st = L.abo_append_grad(model._require(), xa.ctypes.data, xa.shape[0], ya.ctypes.data, C.byref(info), C.byref(hp))
+    else:
+        st = L.abo_append(model._require(), xa.ctypes.data, xa.shape[0], float(y), C.byref(info), C.byref(hp))
     _lib.check(st, info.value)
     return model._clone(_Handle(hp.value))
 

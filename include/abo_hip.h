@@ -121,6 +121,13 @@ int32_t abo_fit(abo_gp* gp, const double* X, int64_t N, int32_t d, const double*
  * (destroying the fantasy models of a q-EI exploration makes their parent appendable in place again).
  * x: d host doubles. */
 int32_t abo_append(abo_gp* gp, const double* x, int32_t d, double y, int64_t* info, abo_gp** out);
+/* the same for a gradient-enhanced model (abo_create_grad): y holds the p observed values {f(x), ∂f/∂x_1 … ∂f/∂x_d}; the
+ * p rows are appended one after the other at the end of the point-major factor (each a bordered update whose kernel row
+ * comes from the analytic derivative blocks of gradKernel, src/surrogates/GradientGP.jl:573-606), O(p·N²p²) instead of the
+ * O(N³p³) refit the reference does per step (update(::GradientGP), :659-668).  params.n_max counts POINTS.  On failure
+ * *info is the order of the failing leading minor in the library's row order (N·p + q + 1).  abo_cand_* work on such a
+ * handle too (function-value grid; a down-date after abo_append_grad is p rank-1 down-dates). */
+int32_t abo_append_grad(abo_gp* gp, const double* x, int32_t d, const double* y, int64_t* info, abo_gp** out);
 
 /* --- posterior ------------------------------------------------------------------------------
  * posterior_mean / posterior_var (src/surrogates/StandardGP.jl:361-363, :377-379), fused as in

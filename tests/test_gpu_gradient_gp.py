@@ -14,6 +14,7 @@ from abstractbayesopt.jl_amd import synth
 from oracle import gp_oracle as O
 from oracle import grad_oracle as G
 
+from tests.parity_record import check
 from tests.test_gpu_parity import FAMS
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -63,8 +64,8 @@ def test_reference_closed_form_case_shapes_and_copy():
         abo.update(gp, xs, [[1.0, 0.1], [0.5, 0.0], [0.0, -0.1]])
     with pytest.raises(abo.DimensionMismatch):
         abo.update(abo.GradientGP(abo.SqExponentialKernel(), 4, 0.1), xs, [[1.0, 0.1, 0.1, 0.0]] * 3)
-    with pytest.raises(ValueError):
-        abo.append(m, [0.1, 0.2], 0.0)
+    with pytest.raises(abo.DimensionMismatch):
+        abo.append(m, [0.1, 0.2], 0.0)              # an observation of a gradient-enhanced model has p values
 
 
 @pytest.mark.parametrize("family,d,N,M,ell,noise", [(O.SE, 2, 60, 500, 0.6, 1e-3), (O.MATERN52, 3, 100, 700, 0.8, 1e-3),
@@ -158,3 +159,83 @@ def test_gradient_gp_nlml_and_hyperparameter_mle():
     assert isinstance(new, abo.GradientGP) and new.gpx is None and new.p == d + 1
     p1 = [np.log(abo.get_lengthscale(new)[0]), np.log(abo.get_scale(new)[0])]
     assert abo.nlml(new, p1, X, Ys) < v0 - 1e-3
+
+
+@pytest.mark.parametrize("family,d,N0,n_app,ell,noise,n_max", [
+    (O.SE, 2, 20, 6, 0.6, 1e-3, 64),
+    (O.MATERN52, 3, 40, 9, 0.8, 1e-3, 64),          # 160 rows → 196: crosses the 128-row padding boundary twice
+    (O.MATERN72, 4, 30, 5, 1.1, 1e-2, 0),           # no spare capacity: the first append refits with room to grow
+])
+def test_gradient_gp_append_matches_full_refit(family, d, N0, n_app, ell, noise, n_max):
+    """abo_append_grad: p bordered row-appends per observation on the point-major factor.  The reference refits per step
+    (update(::GradientGP), GradientGP.jl:659-668), so parity is the from-scratch path on the N + j points: this library's own
+    refit and the CPU oracle (oracle/grad_oracle.py)."""
+    p = d + 1
+    N = N0 + n_app
+    X = synth.points(1, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    gF = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    Ys = np.column_stack([f + 0.3, gF])
+    mean_c = np.concatenate([[0.3], np.zeros(d)])
+    Z = synth.points(2, 300, d)
+    m = abo.update(make_grad(family, ell, 1.2, noise, p, mean_c, n_max=n_max), X[:N0], Ys[:N0])
+    models = [m]
+    for j in range(n_app):
+        m = abo.append(m, X[N0 + j], Ys[N0 + j])
+        models.append(m)
+    ref = abo.update(make_grad(family, ell, 1.2, noise, p, mean_c), X, Ys)
+    st = G.fit(family, ell, 1.2, noise, mean_c, X, Ys)
+    mu_o, var_o = G.predict_grad(st, Z)
+    case = f"grad_append/fam{family}_d{d}_N{N0}+{n_app}"
+    check(case, "grad_mu", np.max(np.abs(abo.posterior_grad_mean(m, Z) - mu_o)), 1e-7)
+    check(case, "grad_var", np.max(np.abs(abo.posterior_grad_var(m, Z) - var_o)) / max(1.0, 1.2 / ell ** 2), 1e-7)
+    check(case, "grad_mu_vs_own_refit", np.max(np.abs(abo.posterior_grad_mean(m, Z) - abo.posterior_grad_mean(ref, Z))), 1e-7)
+    check(case, "nlml_rel", abs(abo.nlml_fitted(m) - G.nlml(st)) / max(1.0, abs(G.nlml(st))), 1e-8)
+    L, alpha, Linv = abo.get_factor(m)
+    Lr, alpha_r, _ = abo.get_factor(ref)
+    check(case, "L_vs_own_refit", np.max(np.abs(L - Lr)), 1e-8)
+    check(case, "alpha_rel", np.max(np.abs(alpha - st.alpha)) / max(1.0, np.max(np.abs(st.alpha))), 1e-6)
+    assert np.max(np.abs(Linv @ L - np.eye(p * N))) < 1e-7
+    Xb, Yb = abo.training_data(m)
+    np.testing.assert_array_equal(Xb, X)
+    np.testing.assert_array_equal(Yb, Ys)
+    # every intermediate model is still valid and unchanged (free rollback)
+    k = n_app // 2
+    st_k = G.fit(family, ell, 1.2, noise, mean_c, X[:N0 + k], Ys[:N0 + k])
+    mu_k, var_k = G.predict(st_k, Z[:50])
+    mu_g, var_g = abo.mean_and_var(models[k], Z[:50])
+    assert np.max(np.abs(mu_g - mu_k)) < 1e-7 and np.max(np.abs(var_g - var_k)) < 1e-7
+    # the NLML gradient needs a freshly fitted model; an appended view says so
+    with pytest.raises(ValueError):
+        abo._lib.check(abo._lib.lib().abo_nlml_grad(m._require(), None, None, None))
+
+
+def test_gradient_gp_resident_grid_downdates(monkeypatch):
+    """A function-value candidate grid resident with a gradient-enhanced model: after abo_append_grad its posterior is
+    down-dated by p rank-1 steps (one per appended row) — through the resident K_ZX and by re-evaluating the kernel — and
+    equals the oracle's posterior on the N + j points; EI epilogue and top-k run on the stored posterior."""
+    d, N0, n_app = 3, 50, 4
+    p = d + 1
+    X = synth.points(1, N0 + n_app, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    gF = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    Ys = np.column_stack([f, gF])
+    Z = synth.points(2, 2000, d)
+    out = {}
+    for mode in ("64", "0"):
+        monkeypatch.setenv("ABO_CAND_KZX_GIB", mode)
+        m = abo.update(make_grad(O.MATERN52, 0.8, 1.0, 1e-3, p, np.zeros(p), n_max=N0 + 16), X[:N0], Ys[:N0])
+        cands = abo.ResidentCandidates(m, Z)
+        for j in range(n_app):
+            m = abo.append(m, X[N0 + j], Ys[N0 + j])
+            cands.downdate(m)
+        out[mode] = cands.mean_and_var()
+        if mode == "64":
+            acq = abo.ExpectedImprovement(0.01, float(f.min()))
+            s_r, tv_r, ti_r = cands.evaluate(acq, k=10, return_scores=True)
+            s_f, tv_f, ti_f = abo.evaluate(acq, m, Z, k=10)
+            np.testing.assert_allclose(s_r, s_f, rtol=0, atol=1e-9)
+    st = G.fit(O.MATERN52, 0.8, 1.0, 1e-3, np.zeros(p), X, Ys)
+    mu_o, var_o = G.predict(st, Z)
+    for mode in ("64", "0"):
+        assert np.max(np.abs(out[mode][0] - mu_o)) < 1e-8 and np.max(np.abs(out[mode][1] - var_o)) < 1e-8

@@ -29,6 +29,9 @@ for it in range(300):
     if it % 10 == 0:
         g = abo.update(abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1), synth.points(5, 40, 2), np.ones((40, 3)))
         abo.posterior_grad_cov(g, [[0.2, 0.3]])
+        g2 = abo.append(abo.update(abo.GradientGP(abo.SqExponentialKernel(), 3, 0.1, n_max=64), synth.points(5, 40, 2), np.ones((40, 3))),
+                        [0.3, 0.7], [1.0, 0.0, 0.0])
+        abo.posterior_grad_mean(g2, [[0.2, 0.3]])
         # multi-device handle (three shards on this device): worker threads, exchange buffers, fantasy handles of q-EI
         grp = abo.update(abo.HipShardedGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.7), 1e-3, devices=(0, 0, 0), n_max=1024), X, y)
         Zh = synth.points(2, 3000, 4)
