@@ -200,7 +200,8 @@ def test_committed_bench_lines_keep_the_driver_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name, bound in (("r01_bench_default.json", "mfma"), ("r01_c2_bench_final.json", "mfma"), ("r01_c5_bench_final.json", "hbm")):
+    for name, bound in (("r02_bench_default.json", "mfma"), ("r02_c2_bench.json", "mfma"), ("r02_c5_bench.json", "hbm"),
+                        ("r01_bench_default.json", "mfma")):
         j = json.load(open(os.path.join(root, "profiles", name)))
         assert j["metric"].startswith("GP-update+acq-eval ms per BO step") and j["unit"] == "ms"
         assert j["higher_is_better"] is False and j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None
@@ -211,7 +212,33 @@ def test_committed_bench_lines_keep_the_driver_contract():
         r = j["roofline"]
         assert r["bound"] == bound and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] <= 1
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
-    j = json.load(open(os.path.join(root, "profiles", "r01_bench_default.json")))
+    j = json.load(open(os.path.join(root, "profiles", "r02_bench_default.json")))
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and "unit" in c
-    assert j["roofline"]["traffic"] > j["roofline"]["algorithmic_bytes_per_launch"] > 0
+    assert c["repetitions"] >= 3 and len(c["all_values"]) == c["repetitions"]
+    # the default line times all three single-GPU configurations: C3 (headline) + C2 and C5 as secondary entries, C5 with
+    # its own roofline
+    sec = j["secondary"]
+    assert len(sec) == 2 and sec[0]["workload"].startswith("C2") and sec[1]["workload"].startswith("C5")
+    assert sec[1]["roofline"]["bound"] == "hbm" and 0 < sec[1]["roofline"]["frac"] <= 1
+
+
+def test_pmc_traffic_is_dropped_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    """bench.py reports the committed PMC traffic figure only while the kernel's source file still has the hash the PMC pass
+    recorded; a stale figure becomes null instead of silently describing another kernel."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    rec = json.load(open(os.path.join(root, "profiles", "r02_c3_pmc_traffic.json")))
+    traffic, src = b.pmc_traffic("c3", 16384)
+    if rec["kernel_source_sha"] == b.source_sha(["gemm.hip"]):
+        assert traffic == pytest.approx(rec["traffic_bytes_per_candidate"] * 16384) and not src.get("stale")
+    else:
+        assert traffic is None and src["stale"] is True
+    monkeypatch.setattr(b, "source_sha", lambda names: "0" * 16)
+    traffic, src = b.pmc_traffic("c3", 16384)
+    assert traffic is None and src["stale"] is True
