@@ -110,3 +110,46 @@ def test_candidate_set_refuses_a_model_from_another_factor_of_the_same_size():
         b1 = abo.append(b, X[N], y[N])
         with pytest.raises(ValueError):
             cands.downdate(b1)
+
+
+def _random_cases():
+    rng = np.random.default_rng(20260)
+    cases = [(1, 1, 7), (2, 3, 1), (127, 2, 130), (128, 5, 129), (129, 16, 257), (255, 33, 64), (256, 1, 2049), (257, 7, 100)]
+    for _ in range(10):
+        cases.append((int(rng.integers(3, 700)), int(rng.integers(1, 41)), int(rng.integers(1, 1500))))
+    return cases
+
+
+@pytest.mark.parametrize("N,d,M", _random_cases())
+def test_edge_and_random_shapes_against_oracle(N, d, M):
+    """Shapes around every internal boundary (one point, 127 / 128 / 129 rows: fused small fit vs panel chain; 255 / 256 /
+    257: 128- vs 256-row contraction tiles; d = 33: slab kernels) and seeded random ones, all kernel families in turn,
+    against the oracle; selection bit-exact."""
+    fam = [O.SE, O.MATERN52, O.MATERN72, O.MATERN32][(N + d + M) % 4]
+    ell = 0.4 * np.sqrt(d) + 0.2
+    sf2, noise, mean_c = 1.7, 1e-3, 0.25 * ((N % 3) - 1)
+    X = synth.points(1, N, d)
+    Z = synth.points(2, M, d) * 1.3 - 0.15
+    y = synth.objective(X, 0.05) + mean_c
+    st = O.fit(fam, ell, sf2, noise, mean_c, X, y)
+    mu_o, var_o = O.predict(st, Z)
+    m = abo.update(make_model(fam, ell, sf2, noise, mean_c), X, y)
+    mu, var = abo.mean_and_var(m, Z)
+    assert np.max(np.abs(mu - mu_o)) <= 1e-9 * max(1.0, np.max(np.abs(mu_o)))
+    assert np.max(np.abs(var - var_o)) <= 1e-9 * sf2
+    assert abs(abo.nlml_fitted(m) - O.nlml(st)) <= 1e-9 * max(1.0, abs(O.nlml(st)))
+    L, alpha, Linv = abo.get_factor(m)
+    assert np.max(np.abs(L - st.L)) <= 1e-10 and np.max(np.abs(Linv @ st.L - np.eye(N))) <= 1e-8
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    k = min(M, 37)
+    s, tv, ti = abo.evaluate(acq, m, Z, k=k)
+    np.testing.assert_allclose(s, O.expected_improvement(mu, var, float(y.min()), 0.01), rtol=1e-10, atol=1e-14)
+    ov, oi = O.top_k(s, k)
+    np.testing.assert_array_equal(ti, oi)
+    # one bordered append on top (refit fallback when the storage has no spare row, in place otherwise)
+    x_new = synth.points(9, 1, d)[0]
+    m2 = abo.append(m, x_new, 0.1)
+    st2 = O.fit(fam, ell, sf2, noise, mean_c, np.vstack([X, x_new]), np.append(y, 0.1))
+    mu2, var2 = abo.mean_and_var(m2, Z[:64])
+    mo2, vo2 = O.predict(st2, Z[:64])
+    assert np.max(np.abs(mu2 - mo2)) <= 1e-8 * max(1.0, np.max(np.abs(mo2))) and np.max(np.abs(var2 - vo2)) <= 1e-8 * sf2
