@@ -634,7 +634,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     // (gradient-enhanced: staged in K — overwritten by the kernel matrix later — and reordered into ybuf below)
     if (!rc) rc = copy_in(P == 1 ? st->ybuf.p : st->K.p, y, sizeof(double) * R, space, s);
     if (rc) { storage_unref(st); return rc; }
-    HIPCHK(hipStreamSynchronize(s));
+    if (g->st) HIPCHK(hipStreamSynchronize(s));         // a fresh handle (what update() makes) has nothing the inputs could alias
     if (g->st && g->fitted) g->st->drop_view(g->N);
     g->fitted = false;
     storage_unref(g->st);
