@@ -58,9 +58,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, sample_m=16384, reps=3):
-    """Median of `reps` repetitions of the bounded CPU sample (median of ≥ 3; the full-size variant
-    `--cpu-sample-m 65536 --cpu-reps 3` takes ≈ 3.5 min and is kept under profiles/)."""
+def cpu_baseline(cfg, sample_m=21846, reps=3):
+    """Median of `reps` repetitions of the bounded CPU sample (median of ≥ 3 steps, up to 65 536
+    candidates timed and scaled linearly in M): by default 3 × 21 846 = 65 538 candidates in all, ≈ 80 s of host time
+    at C3 — each repetition is a full N-point refit + the posterior / acquisition over its candidates."""
     from threadpoolctl import threadpool_limits
     cores = usable_cores()
     with threadpool_limits(limits=cores):
@@ -122,7 +123,7 @@ def _cpu_baseline(cfg, sample_m):
         "kind": "port",
         "sample": f"CPU restatement (NumPy/SciPy LAPACK), not the Julia reference: full N={N} refit measured "
                   f"({fit_ms:.0f} ms) + posterior/acq over M'={sample_m} candidates measured ({acq_ms:.0f} ms), "
-                  f"acq part scaled x{M // sample_m} to M={M}",
+                  f"acq part scaled x{M / sample_m:.2f} to M={M}",
         "measured_fit_ms": fit_ms, "measured_acq_ms_sample": acq_ms, "sample_m": sample_m,
         "blas3_floor": {"value": potrf_ms + trsm_s * 1e3 * (M / sample_m), "unit": "ms per BO step (extrapolated)",
                         "measured_potrf_ms": potrf_ms, "measured_trsm_ms_sample": trsm_s * 1e3,
@@ -362,8 +363,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C2 and C5 entries of the default C3 line (profiling runs)")
-    ap.add_argument("--cpu-sample-m", type=int, default=16384,
-                    help="candidates of the CPU-baseline sample (BASELINE.md §4 allows up to 65536 and linear scaling in M)")
+    ap.add_argument("--cpu-sample-m", type=int, default=21846,
+                    help="candidates PER REPETITION of the CPU-baseline sample (default 3 x 21846 = 65538 in all; BASELINE.md §4 "
+                         "allows timing 65536 candidates and scaling linearly in M)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (median reported)")
     ap.add_argument("--single-process", action="store_true",
                     help="drive --gpus N devices from THIS process through the library's multi-device handle (abo_mgpu_*, "
