@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             }
         }
         __syncthreads();
-        if (p == 0) PROBE(6);
+        if (p < 4) PROBE(6 + 2 * p);                       // probe build only: end of the register potf2 + row solve of sub-step p
         if (fail) return;                                  // uniform (LDS flag after the barrier)
         {                                                  // (3) trailing update on the lower sub-blocks
             const int nb = NSB - 1 - p;                    // sub-block rows/cols left
@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             }
         }
         __syncthreads();
+        if (p < 4) PROBE(7 + 2 * p);                       // probe build only: end of the trailing update of sub-step p
     }
 
     PROBE(2);

@@ -32,9 +32,13 @@ int main() {
         long long c[16];
         CK(hipMemcpyFromSymbol(c, HIP_SYMBOL(abo_probe_clk), sizeof(c)));
         int64_t inf; CK(hipMemcpy(&inf, info, 8, hipMemcpyDeviceToHost));
-        printf("rep %d info=%ld event %.1f us | load %.2f  chol %.2f (first fused step %.2f)  inv-diag %.2f  inv-offdiag %.2f  store %.2f  total %.2f us\n",
-               rep, (long)inf, ms * 1e3, (c[1] - c[0]) / 100.0, (c[2] - c[1]) / 100.0, (c[6] - c[1]) / 100.0, (c[3] - c[2]) / 100.0,
+        printf("rep %d info=%ld event %.1f us | load %.2f  chol %.2f  inv-diag %.2f  inv-offdiag %.2f  store %.2f  total %.2f us\n",
+               rep, (long)inf, ms * 1e3, (c[1] - c[0]) / 100.0, (c[2] - c[1]) / 100.0, (c[3] - c[2]) / 100.0,
                (c[4] - c[3]) / 100.0, (c[5] - c[4]) / 100.0, (c[5] - c[0]) / 100.0);
+        printf("      sub-steps 0..3: potf2+solve / trailing update (us):");
+        long long prev = c[1];
+        for (int p = 0; p < 4; ++p) { printf("  %.2f / %.2f", (c[6 + 2 * p] - prev) / 100.0, (c[7 + 2 * p] - c[6 + 2 * p]) / 100.0); prev = c[7 + 2 * p]; }
+        printf("\n");
     }
     return 0;
 }
