@@ -43,6 +43,37 @@ struct VarGemmArgs {
 };
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s);
 
+// ---- the same contraction on the int8 matrix pipe (ozaki.hip): exact products of fixed-point images of W and K_XZ through
+// residues modulo n coprime moduli ≤ 256, Chinese-remainder reconstruction in fp64
+constexpr int OZ_MAXMOD = 16;
+struct OzPlan {
+    int n;                       // number of moduli (2 … 16)
+    int p[OZ_MAXMOD];            // 256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193
+    double invp[OZ_MAXMOD];
+    double s1[OZ_MAXMOD], s2[OZ_MAXMOD];   // (P/p)·((P/p)⁻¹ mod p) split into a 41-bit head on a common grid and the rest
+    double P1, P2, invP;         // P = Π p split the same way; 1/P
+    int eP;                      // 2^eP ≤ P/4: the bound every exact integer dot product is kept under
+};
+bool oz_make_plan(int n, OzPlan* out);
+size_t oz_w_bytes(int n, int Np);            // residue planes of W: n × pad256(Np)²
+size_t oz_k_bytes(int n, int Np, int Mc);    // residue planes of a candidate chunk (and of its U): n × pad256(Mc) × pad256(Np)
+int oz_k_scale(double kmax);                 // sK with rint(K·2^sK) < 2^53 for 0 ≤ K ≤ kmax
+// W (lower-triangular, [Np][ldw]) → WR [n][Np256][Np256] int8, sexp[Np256] (row scales s_i), bad_row[Np256] (non-finite rows)
+hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int8_t* WR, int* sexp, int* bad_row, hipStream_t s);
+struct OzVarArgs {
+    const OzPlan* plan;
+    const double* Kxz;     // [Mc][ldk] candidate-major chunk (fp64, as launch_var_gemm takes it)
+    int64_t ldk;
+    const int8_t* WR; const int* sexp; const int* bad_row;
+    int8_t* KR;            // scratch: oz_k_bytes
+    int8_t* U;             // scratch: oz_k_bytes
+    int* bad_col;          // scratch: pad256(Mc) ints
+    double* partial;       // [Np/128][ldp]
+    int64_t ldp;
+    int Np, Mc, nvalid, sK;
+};
+hipError_t launch_var_ozaki(const OzVarArgs& a, hipStream_t s);
+
 // ---- kernel-matrix generation (kgen.hip) ----------------------------------------------------
 struct KgenArgs {
     const double* Xs;     // [Np][dp]   training points, pre-scaled by 1/ell, zero padded

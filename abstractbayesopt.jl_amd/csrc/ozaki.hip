@@ -1,0 +1,446 @@
+// The N²·M variance contraction on the int8 matrix pipe: V = W·K_XZ computed EXACTLY on fixed-point images of the two fp64
+// operands, through residues modulo n pairwise-coprime moduli ≤ 256 (one int8 GEMM per modulus, int32 accumulation, no
+// rounding anywhere in the products) and a Chinese-remainder reconstruction in fp64.  Reference arithmetic replaced:
+// posterior_var, src/surrogates/StandardGP.jl:377-379 → [upstream AbstractGPs] diag_Xt_invA_X(C, K_XZ) — the same
+// partial[ti][j] = Σ_{i∈ti} (Σ_k W[i][k]·K_XZ[j][k])² the fp64 kernels of gemm.hip produce.
+//
+// Why: the fp64 matrix pipe of gfx950 peaks at 78.6 TFLOP/s, `v_mfma_i32_32x32x32_i8` at ≈ 4.9 POP/s (tools/mfma_i8_probe.hip).
+// Scheme (Ozaki, Uchino, Imamura: "Ozaki scheme II", 2025 — restated here from the published algorithm, no code of theirs):
+//   1. W'[i][k] = rint(W[i][k]·2^s_i), K'[j][k] = rint(K[j][k]·2^sK): integers below 2^52 / 2^53.  s_i is chosen per row from
+//      the row's L1 norm so that |Σ_k W'[i][k]·K'[j][k]| < P/4 for P = Π p_l; sK from the kernel's upper bound σ_f².
+//      This is the ONLY approximation: every W entry keeps ≥ 50 bits below its row's L1 norm, every K entry 52–53 bits below
+//      σ_f² — the entries that carry a product's weight are represented exactly.
+//   2. per modulus p_l: residues in [−128, 127] (one byte per entry), C_l = W_l·K_lᵀ in int32 (|C_l| ≤ k·2^14, exact for
+//      k ≤ 2^17), U_l = C_l mod p_l (symmetric) — one byte per output and modulus.
+//   3. C' = Σ_l U_l·s_l mod P with s_l = (P/p_l)·((P/p_l)⁻¹ mod p_l): the constants are split s_l = s1_l + s2_l with s1_l on a
+//      2^t grid of 41 bits, so that Σ U_l·s1_l is exact in fp64; Q = rint((C1 + C2)/P); C' = (C1 − Q·P1) + (C2 − Q·P2) with
+//      P = P1 + P2 split the same way (C1 − Q·P1 exact under fma).  V = C'·2^−(s_i+sK); Σ_i V² in fp64.
+// With n = 14 (P ≈ 2^110) the result differs from the exactly rounded product by about what the fp64 MFMA kernel's own
+// accumulation error is (tests/test_gpu_ozaki.py records both against a long-double product).
+//
+// Kernels: oz_rowscale_kernel (L1 / max per row of W → s_i), oz_quant_kernel (fp64 → n residue planes; W once per model,
+// K_XZ per chunk), oz_gemm_kernel (int8 NT GEMM, 256×256 tile per 8-wave workgroup, triangular k-range, epilogue = symmetric
+// mod + byte pack + LDS transpose), oz_crt_kernel (reconstruction + squares + per-row-block column sums).
+#include "abo_kernels.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace abo {
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+
+// ---- host: moduli and reconstruction constants --------------------------------------------------------------------------------
+namespace {
+typedef unsigned __int128 u128;
+
+int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+int bitlen(u128 x) { int n = 0; while (x) { ++n; x >>= 1; } return n; }
+
+double u128_to_double(u128 x) {          // correctly rounded for x < 2^64·2^53 is not needed: two exact halves, one rounding
+    const uint64_t hi = (uint64_t)(x >> 64), lo = (uint64_t)x;
+    return std::ldexp((double)hi, 64) + (double)lo;
+}
+}  // namespace
+
+bool oz_make_plan(int n, OzPlan* out) {
+    if (n < 2 || n > OZ_MAXMOD) return false;
+    OzPlan pl{};
+    pl.n = n;
+    int c = 256, m = 0;
+    while (m < n) {                                   // 256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193
+        bool ok = true;
+        for (int q = 0; q < m; ++q) ok = ok && gcd_i(c, pl.p[q]) == 1;
+        if (ok) pl.p[m++] = c;
+        --c;
+    }
+    u128 P = 1;
+    for (int l = 0; l < n; ++l) P *= (u128)pl.p[l];   // < 2^125.4 for n = 16
+    const int t = bitlen(P) - 41;                     // grid of the high parts: 41 significant bits
+    for (int l = 0; l < n; ++l) {
+        const u128 Mi = P / (u128)pl.p[l];
+        const int r = (int)(Mi % (u128)pl.p[l]);
+        int q = 1;
+        while ((r * q) % pl.p[l] != 1) ++q;           // (P/p)⁻¹ mod p by search (p ≤ 256)
+        const u128 s = Mi * (u128)q;                  // < P
+        const u128 hi = (s >> t) << t;
+        pl.s1[l] = std::ldexp((double)(uint64_t)(s >> t), t);
+        pl.s2[l] = u128_to_double(s - hi);
+        pl.invp[l] = 1.0 / (double)pl.p[l];
+    }
+    const u128 P1 = (P >> t) << t;
+    pl.P1 = std::ldexp((double)(uint64_t)(P >> t), t);
+    pl.P2 = u128_to_double(P - P1);
+    pl.invP = 1.0 / u128_to_double(P);
+    pl.eP = bitlen(P) - 3;                            // 2^eP ≤ P/4
+    *out = pl;
+    return true;
+}
+
+// ---- device helpers --------------------------------------------------------------------------------------------------------------
+// symmetric residue of an integer-valued double |x| < 2^53 modulo p (odd p: result in [−(p−1)/2, (p−1)/2]; p = 256: any
+// representative in [−130, 130], whose low byte is the residue)
+__device__ __forceinline__ int sym_residue(double x, double invp, double pd, int p) {
+    const double q = __builtin_rint(x * invp);        // off by one only when x/p is within 0.0104 of a half-integer
+    int r = (int)__builtin_fma(-q, pd, x);            // exact: |r| ≤ 0.5104·p
+    const int h = (p - 1) >> 1;
+    if (p & 1) {
+        r += (r < -h) ? p : 0;
+        r -= (r > h) ? p : 0;
+    }
+    return r;
+}
+
+// ---- row scales of W ---------------------------------------------------------------------------------------------------------------
+// one wave per row i < Np: L1 = Σ_{k≤i} |W[i][k]|, mx = max; s_i = min(eP − 53 − e(L1), 51 − e(mx)) with e(x) the frexp exponent
+// (x < 2^e), so that 2^s_i·L1·2^53 ≤ P/4 and |W'| < 2^52.  sexp[i] = s_i; rows ≥ Np (padding to 256) get 0.
+__global__ void __launch_bounds__(256) oz_rowscale_kernel(const double* __restrict__ W, int64_t ldw, int Np, int Np256, int eP,
+                                                          int* __restrict__ sexp) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= Np256) return;
+    double l1 = 0.0, mx = 0.0;
+    if (row < Np) {
+        const double* w = W + (int64_t)row * ldw;
+        for (int k = lane; k <= row; k += 64) {
+            const double a = __builtin_fabs(w[k]);
+            l1 += a;
+            mx = a > mx ? a : mx;
+        }
+    }
+    for (int o = 32; o; o >>= 1) {
+        l1 += __shfl_xor(l1, o);
+        const double m2 = __shfl_xor(mx, o);
+        mx = m2 > mx ? m2 : mx;
+    }
+    if (lane == 0) {
+        int s = 0;
+        if (mx > 0.0 && l1 < 1.0e300) {                // a NaN/Inf row keeps s = 0: its residues are garbage, its V is flagged
+            int e1, e2;
+            (void)frexp(l1, &e1);
+            (void)frexp(mx, &e2);
+            const int sa = eP - 53 - e1, sb = 52 - e2;
+            s = sa < sb ? sa : sb;
+        }
+        sexp[row] = s;
+    }
+}
+
+// ---- fp64 → residue planes -----------------------------------------------------------------------------------------------------------
+// out[l][r][k] (int8, ld bytes per row, plane stride `plane`) = sym_residue(rint(in[r][k]·2^s), p_l) for r < rows_in, k < cols_in;
+// zeros elsewhere up to rows_out × cols_out.  s = srow[r] when given, else sconst.  A thread converts 16 consecutive k of one row.
+// bad[r] is set when a row holds a non-finite value (its residues mean nothing; the reconstruction writes NaN for that row).
+struct OzQuantArgs {
+    const double* in;
+    int64_t ldin;
+    int rows_in, cols_in, rows_out, cols_out;
+    int lower;                 // 1: entries with k > r are zero (W = L⁻¹; the stored zeros are not even read)
+    const int* srow;
+    int sconst;
+    int8_t* out;
+    int64_t ld, plane;
+    int* bad;                  // [rows_out] or nullptr
+    OzPlan pl;
+};
+
+__global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = a.cols_out >> 4;                   // 16-byte groups per output row
+    const int r = (int)(gid / cpr), kc = (int)(gid % cpr) * 16;
+    if (r >= a.rows_out) return;
+    double x[16];
+    const bool live = r < a.rows_in && kc < a.cols_in && !(a.lower && kc > r);
+    bool bad = false;
+    if (live) {
+        const double sc = __builtin_ldexp(1.0, a.srow ? a.srow[r] : a.sconst);
+        const double* src = a.in + (int64_t)r * a.ldin + kc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const bool in = kc + q < a.cols_in && !(a.lower && kc + q > r);
+            const double v = in ? src[q] : 0.0;
+            bad = bad || !(__builtin_fabs(v) < 1.0e300);
+            x[q] = __builtin_rint(v * sc);
+        }
+    }
+    if (bad && a.bad) a.bad[r] = 1;
+    int8_t* dst = a.out + (int64_t)r * a.ld + kc;
+    for (int l = 0; l < a.pl.n; ++l) {
+        v4i_t w = {0, 0, 0, 0};
+        if (live) {
+            const double invp = a.pl.invp[l], pd = (double)a.pl.p[l];
+            const int p = a.pl.p[l];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int rr = sym_residue(x[q], invp, pd, p) & 0xff;
+                w[q >> 2] |= rr << (8 * (q & 3));
+            }
+        }
+        *reinterpret_cast<v4i_t*>(dst + (int64_t)l * a.plane) = w;
+    }
+}
+
+// ---- int8 NT GEMM with the symmetric-mod epilogue --------------------------------------------------------------------------------------
+// U[l][i][j] = (Σ_{k < 256(ti+1)} WR[l][i][k]·KR[l][j][k]) mod p_l for the 256×256 tile (ti, tj) of modulus l.
+// MFMA roles: D[m = j][n = i] — the A operand is the candidate tile, the B operand the W tile, so that a lane's four
+// consecutive accumulator registers are four consecutive candidates of one row i (one packed dword of U).
+// Workgroup = 8 waves as 4 (j) × 2 (i); wave tile 64 (j) × 128 (i) = 2 × 4 MFMA tiles of 32×32 = 128 accumulator registers.
+// LDS: two stages of [256 rows][128 B of k] per operand, rows padded to 144 B (conflict-free ds_read_b128: the four 16-lane
+// groups of a read each hit 16 distinct 16-byte slots; ds_write_b128 writes whole rows).  One barrier per stage.
+// Lane l of a fragment read takes 16 k-bytes at offset 16·(l/32) of its 32-byte k-group, from row l%32 — the same k-assignment
+// on both operands, which is all the product needs.
+constexpr int OZ_T = 256;                  // tile edge
+constexpr int OZ_BK = 128;                 // k-bytes per stage
+constexpr int OZ_ROW = OZ_BK + 16;         // LDS row stride
+constexpr int OZ_STAGE = OZ_T * OZ_ROW;    // bytes per operand stage (36 864)
+constexpr int OZ_UROW = OZ_T + 8;          // row stride of the epilogue's transpose buffer (264: 2-way on ds_write_b32 = free)
+
+struct OzGemmArgs {
+    const int8_t* KR;      // [n][Mc256][ldk]
+    const int8_t* WR;      // [n][Np256][ldw]
+    int8_t* U;             // [n][Np256][ldu]
+    int64_t ldk, ldw, ldu, sK, sW, sU;
+    int Ti, Tj, n;
+    int tjg;               // column blocks per group (multiple of 8; 64 unless Tj is smaller)
+    double invp[OZ_MAXMOD];
+    int p[OZ_MAXMOD];
+};
+
+__global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char oz_lds[4 * OZ_STAGE];
+    // ---- tile decode: groups of (4 row blocks × tjg column blocks) of ONE modulus, heaviest row blocks first; inside a
+    //      group the workgroups that land on one XCD (blockIdx % 8) form a 4 × (tjg/8) patch that shares its panels in L2
+    const int per_group = 4 * a.tjg;
+    const int grp = blockIdx.x / per_group, s = blockIdx.x % per_group;
+    const int ngj = (a.Tj + a.tjg - 1) / a.tjg;
+    const int gh = grp % ngj, gl = (grp / ngj) % a.n, gg = grp / (ngj * a.n);
+    const int ngi = (a.Ti + 3) / 4;
+    const int xcd = s & 7, c = s >> 3;
+    const int cols_x = a.tjg >> 3;                     // column blocks per XCD patch
+    const int ti = 4 * (ngi - 1 - gg) + c / cols_x;
+    const int tj = gh * a.tjg + xcd * cols_x + c % cols_x;
+    if (ti >= a.Ti || tj >= a.Tj) return;
+    const int l = gl;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = wave & 3, wi = wave >> 2;
+    char* As = oz_lds;                                 // [2][256][144]  candidates
+    char* Bs = oz_lds + 2 * OZ_STAGE;                  // [2][256][144]  W rows
+
+    const int lr = tid >> 3, lc = (tid & 7) * 16;
+    const int8_t* ap = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T + lr) * a.ldk + lc;
+    const int8_t* bp = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T + lr) * a.ldw + lc;
+    const int nst = 2 * (ti + 1);
+
+    v4i_t ra[4], rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ra[q] = *reinterpret_cast<const v4i_t*>(ap + (int64_t)(64 * q) * a.ldk);
+        rb[q] = *reinterpret_cast<const v4i_t*>(bp + (int64_t)(64 * q) * a.ldw);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<v4i_t*>(As + (lr + 64 * q) * OZ_ROW + lc) = ra[q];
+        *reinterpret_cast<v4i_t*>(Bs + (lr + 64 * q) * OZ_ROW + lc) = rb[q];
+    }
+    __syncthreads();
+
+    v16i_t acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0;
+
+    const int foff = (lane & 31) * OZ_ROW + (lane >> 5) * 16;
+    const char* afr = As + (64 * wj) * OZ_ROW + foff;
+    const char* bfr = Bs + (128 * wi) * OZ_ROW + foff;
+
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
+        if (more) {
+            const int k1 = (st + 1) * OZ_BK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra[q] = *reinterpret_cast<const v4i_t*>(ap + (int64_t)(64 * q) * a.ldk + k1);
+                rb[q] = *reinterpret_cast<const v4i_t*>(bp + (int64_t)(64 * q) * a.ldw + k1);
+            }
+        }
+        const char* af = afr + buf * OZ_STAGE;
+        const char* bf = bfr + buf * OZ_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            v4i_t fa[2], fb[4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const v4i_t*>(af + (32 * m) * OZ_ROW + 32 * ks);
+#pragma unroll
+            for (int nn = 0; nn < 4; ++nn) fb[nn] = *reinterpret_cast<const v4i_t*>(bf + (32 * nn) * OZ_ROW + 32 * ks);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+                    acc[m][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[nn], acc[m][nn], 0, 0, 0);
+        }
+        if (more) {
+            char* aw = As + (buf ^ 1) * OZ_STAGE;
+            char* bw = Bs + (buf ^ 1) * OZ_STAGE;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<v4i_t*>(aw + (lr + 64 * q) * OZ_ROW + lc) = ra[q];
+                *reinterpret_cast<v4i_t*>(bw + (lr + 64 * q) * OZ_ROW + lc) = rb[q];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS so that rows of U leave as 256-byte
+    //      segments.  D layout of v_mfma_i32_32x32x32_i8: lane → column n = lane % 32, register r → row m = 8(r/4) + 4(lane/32) + r%4
+    const double invp = a.invp[l], pd = (double)a.p[l];
+    char* Ut = oz_lds;                                  // [256 i][264]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            const int il = 128 * wi + 32 * nn + (lane & 31);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int w = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double x = (double)acc[m][nn][4 * g + b];
+                    const double q = __builtin_rint(x * invp);
+                    const int r = (int)__builtin_fma(-q, pd, x);   // exact quotient: |x| < 2^31 ⇒ r in [−p/2, p/2]
+                    w |= (r & 0xff) << (8 * b);
+                }
+                const int jl = 64 * wj + 32 * m + 8 * g + 4 * (lane >> 5);
+                *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
+            }
+        }
+    __syncthreads();
+    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
+    const int ur = tid >> 4, uc = (tid & 15) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = ur + 32 * q;
+        const char* src = Ut + i * OZ_UROW + uc;
+        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+}
+
+// ---- reconstruction + squares + column sums ------------------------------------------------------------------------------------------
+// partial[tb][j] = Σ_{i in row block tb (128 rows), i < nvalid} V[i][j]²,  V = CRT(U[·][i][j])·2^−(s_i + sK).
+// A thread owns four consecutive candidates (one dword of every residue plane per row).
+struct OzCrtArgs {
+    const int8_t* U;
+    int64_t ldu, sU;
+    const int* sexp;       // s_i
+    int sK;
+    const int* bad_row;    // [Np256] W rows holding non-finite values (or nullptr)
+    const int* bad_col;    // [Mc256] candidates holding non-finite kernel values (or nullptr)
+    double* partial;       // [Np/128][ldp]
+    int64_t ldp;
+    int Mc;                // columns to write (multiple of 128)
+    int nvalid;
+    OzPlan pl;
+};
+
+__global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
+    const int tb = blockIdx.y;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= a.Mc) return;
+    const int i0 = tb * 128;
+    int i1 = i0 + 128;
+    if (i1 > a.nvalid) i1 = a.nvalid;
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    bool bad = false;
+    const int n = a.pl.n;
+    for (int i = i0; i < i1; ++i) {
+        const int8_t* u = a.U + (int64_t)i * a.ldu + j;
+        double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int l = 0; l < n; ++l) {
+            const int w = *reinterpret_cast<const int*>(u + (int64_t)l * a.sU);
+            const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double ud = (double)((w << (24 - 8 * b)) >> 24);
+                c1[b] = __builtin_fma(ud, s1, c1[b]);
+                c2[b] = __builtin_fma(ud, s2, c2[b]);
+            }
+        }
+        const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
+        if (a.bad_row && a.bad_row[i]) bad = true;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
+            const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
+            const double v = cp * sc;
+            sum[b] = __builtin_fma(v, v, sum[b]);
+        }
+    }
+    const double nan = __builtin_nan("");
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const bool bb = bad || (a.bad_col && a.bad_col[j + b]);
+        a.partial[(int64_t)tb * a.ldp + j + b] = bb ? nan : sum[b];
+    }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------------------------
+size_t oz_w_bytes(int n, int Np) { const int64_t q = pad_up(Np, OZ_T); return (size_t)n * q * q; }
+size_t oz_k_bytes(int n, int Np, int Mc) { return (size_t)n * pad_up(Mc, OZ_T) * pad_up(Np, OZ_T); }
+
+hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int8_t* WR, int* sexp, int* bad_row, hipStream_t s) {
+    const int Np256 = (int)pad_up(Np, OZ_T);
+    hipError_t e = hipMemsetAsync(bad_row, 0, sizeof(int) * Np256, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(oz_rowscale_kernel, dim3((Np256 + 3) / 4), dim3(256), 0, s, W, ldw, Np, Np256, pl.eP, sexp);
+    OzQuantArgs q{};
+    q.in = W; q.ldin = ldw; q.rows_in = Np; q.cols_in = Np; q.rows_out = Np256; q.cols_out = Np256; q.lower = 1;
+    q.srow = sexp; q.sconst = 0; q.out = WR; q.ld = Np256; q.plane = (int64_t)Np256 * Np256; q.bad = bad_row; q.pl = pl;
+    const int64_t threads = (int64_t)Np256 * (Np256 / 16);
+    hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
+
+// sK: K' = rint(K·2^sK) < 2^53 for K ≤ kmax (kmax = σ_f²: the stationary kernels of this library peak at distance 0)
+int oz_k_scale(double kmax) {
+    int e;
+    (void)std::frexp(kmax * (1.0 + 1e-12), &e);        // kmax < 2^e
+    return 52 - e;                                      // K' < 2^52·(1+…) < 2^53
+}
+
+hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
+    const OzPlan& pl = *v.plan;
+    const int Np256 = (int)pad_up(v.Np, OZ_T), Mc256 = (int)pad_up(v.Mc, OZ_T);
+    hipError_t e = hipMemsetAsync(v.bad_col, 0, sizeof(int) * Mc256, s);
+    if (e != hipSuccess) return e;
+    OzQuantArgs q{};
+    q.in = v.Kxz; q.ldin = v.ldk; q.rows_in = v.Mc; q.cols_in = v.Np; q.rows_out = Mc256; q.cols_out = Np256; q.lower = 0;
+    q.srow = nullptr; q.sconst = v.sK; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
+    const int64_t threads = (int64_t)Mc256 * (Np256 / 16);
+    hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
+
+    OzGemmArgs g{};
+    g.KR = v.KR; g.WR = v.WR; g.U = v.U;
+    g.ldk = Np256; g.ldw = Np256; g.ldu = Mc256;
+    g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256; g.sU = (int64_t)Np256 * Mc256;
+    g.Ti = Np256 / OZ_T; g.Tj = Mc256 / OZ_T; g.n = pl.n;
+    g.tjg = g.Tj >= 64 ? 64 : (int)pad_up(g.Tj, 8);
+    for (int l = 0; l < pl.n; ++l) { g.invp[l] = pl.invp[l]; g.p[l] = pl.p[l]; }
+    const int ngj = (g.Tj + g.tjg - 1) / g.tjg, ngi = (g.Ti + 3) / 4;
+    const unsigned blocks = (unsigned)(ngi * pl.n * ngj * 4 * g.tjg);
+    hipLaunchKernelGGL(oz_gemm_kernel, dim3(blocks), dim3(512), 0, s, g);
+
+    OzCrtArgs c{};
+    c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
+    c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
+    hipLaunchKernelGGL(oz_crt_kernel, dim3((v.Mc / 4 + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
+    return hipGetLastError();
+}
+
+}  // namespace abo
