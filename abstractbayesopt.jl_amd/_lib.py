@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(PKG, "lib", "libabo_hip.so")
 ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
 HOST, DEVICE = 0, 1
 
-EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_append_grad", "abo_cand_create", "abo_cand_destroy",
+EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_append_grad", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_data", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
            "abo_test_gemm_nt", "abo_test_kappa",
@@ -17,7 +17,8 @@ EXPORTS = ["abo_create", "abo_create_grad", "abo_predict_grad", "abo_predict_gra
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
            "abo_mgpu_cand_qei"]
-ABI_VERSION = 2
+ABI_VERSION = 3
+CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
 
 class AboParams(C.Structure):
@@ -31,7 +32,8 @@ class AboTimings(C.Structure):
                                           "fit_alpha_ms", "fit_total_ms", "acq_kxz_ms", "acq_var_gemm_ms",
                                           "acq_finalize_ms", "acq_topk_ms", "acq_total_ms")] + \
                [("var_gemm_launches", C.c_int64), ("var_gemm_flop", C.c_double), ("downdate_ms", C.c_double),
-                ("downdate_bytes", C.c_double)]
+                ("downdate_bytes", C.c_double), ("contraction_engine", C.c_int64), ("oz_nmod", C.c_int64)] + \
+               [(n, C.c_double) for n in ("oz_prepare_ms", "oz_quant_ms", "oz_gemm_ms", "oz_crt_ms", "oz_gemm_ops")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -76,6 +78,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.abo_create.argtypes = [C.POINTER(AboParams), C.POINTER(vp)]
+    L.abo_set_contraction.argtypes = [vp, i32, i32]
     L.abo_create_grad.argtypes = [C.POINTER(AboParams), i32, vp, C.POINTER(vp)]
     L.abo_predict_grad.argtypes = [vp, vp, i64, i32, i32, vp, vp, i32]
     L.abo_predict_grad_cov.argtypes = [vp, vp, i64, i32, i32, f64, vp, vp, vp, i32]

@@ -59,7 +59,8 @@ size_t oz_w_bytes(int n, int Np);            // residue planes of W: n × pad256
 size_t oz_k_bytes(int n, int Np, int Mc);    // residue planes of a candidate chunk (and of its U): n × pad256(Mc) × pad256(Np)
 int oz_k_scale(double kmax);                 // sK with rint(K·2^sK) < 2^53 for 0 ≤ K ≤ kmax
 // W (lower-triangular, [Np][ldw]) → WR [n][Np256][Np256] int8, sexp[Np256] (row scales s_i), bad_row[Np256] (non-finite rows)
-hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int8_t* WR, int* sexp, int* bad_row, hipStream_t s);
+// rows ≥ nvalid (identity padding, or the remains of a discarded appended branch) become zero planes
+hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s);
 struct OzVarArgs {
     const OzPlan* plan;
     const double* Kxz;     // [Mc][ldk] candidate-major chunk (fp64, as launch_var_gemm takes it)
@@ -71,6 +72,7 @@ struct OzVarArgs {
     double* partial;       // [Np/128][ldp]
     int64_t ldp;
     int Np, Mc, nvalid, sK;
+    hipEvent_t ev_quant = nullptr, ev_gemm = nullptr;   // optional: recorded after the quantisation / after the GEMM
 };
 hipError_t launch_var_ozaki(const OzVarArgs& a, hipStream_t s);
 

@@ -170,6 +170,30 @@ struct ScratchBuf {
 
 std::atomic<uint64_t> g_storage_gen{1};
 
+// contraction engine of the posterior variance: process default (ABO_CONTRACTION = auto | fp64 | int8 | int8:<moduli>),
+// overridable per handle (abo_set_contraction)
+constexpr int OZ_DEFAULT_NMOD = 14;   // P ≈ 2^110: the fixed-point images keep 50+ bits of W per row and 52–53 bits of K_XZ
+constexpr int OZ_AUTO_MIN_NP = 2048;  // below this the contraction is launch-bound and the fp64 kernels win
+std::atomic<int> g_oz_engine{-1}, g_oz_nmod{OZ_DEFAULT_NMOD};
+void oz_defaults(int* engine, int* nmod) {
+    int e = g_oz_engine.load();
+    if (e < 0) {
+        e = ABO_CONTRACT_AUTO;
+        int n = OZ_DEFAULT_NMOD;
+        if (const char* v = getenv("ABO_CONTRACTION")) {
+            if (!strncmp(v, "fp64", 4)) e = ABO_CONTRACT_FP64;
+            else if (!strncmp(v, "int8", 4)) {
+                e = ABO_CONTRACT_INT8;
+                if (v[4] == ':') { const int q = atoi(v + 5); if (q >= 8 && q <= OZ_MAXMOD) n = q; }
+            }
+        }
+        g_oz_nmod.store(n);
+        g_oz_engine.store(e);
+    }
+    *engine = e;
+    *nmod = g_oz_nmod.load();
+}
+
 }  // namespace
 
 // Heavy device state, shared by every view (copy / appended model) that descends from one fit.
@@ -228,6 +252,13 @@ struct abo_gp {
     DevBuf alpha, vext, tvec, T, info, scal;
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
+    // int8-residue contraction (ozaki.hip): engine choice, the residue planes of this view's W (valid for oz_gen / oz_N /
+    // oz_plan.n) and the per-chunk scratch
+    int oz_engine = ABO_CONTRACT_AUTO, oz_nmod = 0;
+    OzPlan oz_plan{};
+    uint64_t oz_gen = 0;
+    int64_t oz_N = -1;
+    DevBuf oz_WR, oz_sexp, oz_badr, oz_KR, oz_U, oz_badc;
     abo_timings tm{};
 
     std::vector<hipEvent_t>& evs() { return ctx->ev; }
@@ -235,14 +266,17 @@ struct abo_gp {
 
     void set_device(int dev) {
         DevBuf* all[] = {&alpha, &vext, &tvec, &T, &info, &scal, &Zdev, &Kxz, &partial, &mu_c, &mu_all, &var_all,
-                         &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx};
+                         &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx,
+                         &oz_WR, &oz_sexp, &oz_badr, &oz_KR, &oz_U, &oz_badc};
         for (DevBuf* b : all) b->dev = dev;
     }
 
     void free_all() {
         DevBuf* all[] = {&alpha, &vext, &tvec, &T, &info, &scal, &Zdev, &Kxz, &partial, &mu_c, &mu_all, &var_all,
-                         &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx};
+                         &score_all, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx,
+                         &oz_WR, &oz_sexp, &oz_badr, &oz_KR, &oz_U, &oz_badc};
         for (DevBuf* b : all) b->release();
+        oz_N = -1;
         if (st && fitted) st->drop_view(N);
         storage_unref(st);
         st = nullptr;
@@ -495,6 +529,9 @@ double grad_prior_var(const abo_gp* g) {
     return c * g->prm.sigma_f2 / (g->prm.ell * g->prm.ell);
 }
 
+constexpr size_t EV_BASE = 10;        // 0-4 fit phases, 5-7 acquisition call, 8-9 residue planes of W
+constexpr size_t EV_PER_CHUNK = 8;   // kgen 0-1, contraction 2-3, epilogue 4-5, int8 pipeline: end of quantisation 6, end of GEMM 7
+
 int64_t pick_chunk(const abo_gp* g, int64_t M) {
     int64_t mc = g->prm.chunk;
     if (mc <= 0) {
@@ -527,13 +564,42 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     HIPCHK(g->partial.ensure(sizeof(double) * T * Mc));
     HIPCHK(g->mu_c.ensure(sizeof(double) * Mc));
     const int64_t nchunk = (M + Mc - 1) / Mc;
-    HIPCHK(g->events(8 + 6 * (size_t)nchunk));
+    HIPCHK(g->events(EV_BASE + EV_PER_CHUNK * (size_t)nchunk));
     g->tm.var_gemm_launches = 0;
+    // engine of the contraction: the int8-residue pipeline for a StandardGP large enough to fill the chip with 256×256 tiles
+    const bool want_var = var_out || score_out;
+    bool oz = false;
+    if (want_var && pc == 1 && g->p_out == 1) {
+        int eng = g->oz_engine, nm = g->oz_nmod;
+        if (eng == ABO_CONTRACT_AUTO) { int de, dn; oz_defaults(&de, &dn); eng = de; if (!nm) nm = dn; }
+        if (!nm) { int de, dn; oz_defaults(&de, &dn); nm = dn; }
+        oz = eng == ABO_CONTRACT_INT8 || (eng == ABO_CONTRACT_AUTO && Np >= OZ_AUTO_MIN_NP);
+        if (oz) {
+            if (g->oz_plan.n != nm && !oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
+            if (g->oz_gen != g->st->gen || g->oz_N != g->N) {      // residue planes of this view's W, once per model
+                const int64_t q = pad_up(Np, 256);
+                HIPCHK(g->oz_WR.ensure(oz_w_bytes(nm, (int)Np)));
+                HIPCHK(g->oz_sexp.ensure(sizeof(int) * q));
+                HIPCHK(g->oz_badr.ensure(sizeof(int) * q));
+                HIPCHK(hipEventRecord(g->evs()[8], s));
+                HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
+                                    g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s));
+                HIPCHK(hipEventRecord(g->evs()[9], s));
+                g->oz_gen = g->st->gen; g->oz_N = g->N;
+                g->tm.oz_prepare_ms = -1.0;                        // collected with the posterior timings
+            }
+            HIPCHK(g->oz_KR.ensure(oz_k_bytes(nm, (int)Np, (int)Mc)));
+            HIPCHK(g->oz_U.ensure(oz_k_bytes(nm, (int)Np, (int)Mc)));
+            HIPCHK(g->oz_badc.ensure(sizeof(int) * pad_up(Mc, 256)));
+        }
+    }
+    g->tm.contraction_engine = want_var ? (oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64) : 0;
+    g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
     for (int64_t c = 0; c < nchunk; ++c) {
         const int64_t j0 = c * Mc;
         const int64_t m = (M - j0) < Mc ? (M - j0) : Mc;
         const int mcp = (int)pad_up(m, TB);
-        hipEvent_t* e = &g->evs()[8 + 6 * c];
+        hipEvent_t* e = &g->evs()[EV_BASE + EV_PER_CHUNK * c];
         KgenArgs ka{};
         double* kchunk = kstore ? kstore + j0 * ldstore : g->Kxz.as<double>();
         const int64_t ldk = kstore ? ldstore : Np;
@@ -546,7 +612,18 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         HIPCHK(hipEventRecord(e[0], s));
         HIPCHK(launch_kgen(ka, s));
         HIPCHK(hipEventRecord(e[1], s));
-        if (var_out || score_out) {
+        if (oz) {
+            OzVarArgs oa{};
+            oa.plan = &g->oz_plan; oa.Kxz = kchunk; oa.ldk = ldk; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
+            oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
+            oa.bad_col = g->oz_badc.as<int>(); oa.partial = g->partial.as<double>(); oa.ldp = Mc; oa.Np = (int)Np; oa.Mc = mcp;
+            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->prm.sigma_f2);
+            oa.ev_quant = e[6]; oa.ev_gemm = e[7];
+            HIPCHK(hipEventRecord(e[2], s));
+            HIPCHK(launch_var_ozaki(oa, s));
+            HIPCHK(hipEventRecord(e[3], s));
+            g->tm.var_gemm_launches += 1;
+        } else if (want_var) {
             VarGemmArgs va{};
             va.W = g->st->W.as<double>(); va.Kxz = kchunk; va.partial = g->partial.as<double>();
             va.ldw = g->st->cap; va.ldk = ldk; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
@@ -572,16 +649,25 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
 void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
     const int64_t Mc = pick_chunk(g, M);
     const int64_t nchunk = (M + Mc - 1) / Mc;
-    double kx = 0, vg = 0, fi = 0;
+    double kx = 0, vg = 0, fi = 0, oq = 0, og = 0, oc = 0;
+    const bool oz = with_var && g->tm.contraction_engine == ABO_CONTRACT_INT8;
     for (int64_t c = 0; c < nchunk; ++c) {
-        hipEvent_t* e = &g->evs()[8 + 6 * c];
+        hipEvent_t* e = &g->evs()[EV_BASE + EV_PER_CHUNK * c];
         kx += ev_ms(e[0], e[1]);
         if (with_var) vg += ev_ms(e[2], e[3]);
+        if (oz) { oq += ev_ms(e[2], e[6]); og += ev_ms(e[6], e[7]); oc += ev_ms(e[7], e[3]); }
         fi += ev_ms(e[4], e[5]);
     }
     g->tm.acq_kxz_ms = kx;
     g->tm.acq_var_gemm_ms = vg;
     g->tm.acq_finalize_ms = fi;
+    g->tm.oz_quant_ms = oq; g->tm.oz_gemm_ms = og; g->tm.oz_crt_ms = oc;
+    if (g->tm.oz_prepare_ms < 0.0) g->tm.oz_prepare_ms = ev_ms(g->evs()[8], g->evs()[9]);
+    // int8 operations the residue GEMMs performed: n moduli × M × 2·256²·Σ_{ti}(ti+1)·256 per 256-candidate block
+    if (oz) {
+        const double T = (double)(pad_up(g->Np, 256) / 256);
+        g->tm.oz_gemm_ops = 2.0 * g->tm.oz_nmod * (double)pad_up(M, 256) * 256.0 * 256.0 * T * (T + 1.0) / 2.0;
+    } else g->tm.oz_gemm_ops = 0.0;
     // algorithmic (triangular) flop of the contraction: N²·M, N = true training size
     g->tm.var_gemm_flop = with_var ? (double)g->N * (double)g->N * (double)M : 0.0;
 }
@@ -895,6 +981,7 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
     g->prm = *params;
     g->mean_vec[0] = params->mean_c;
     g->set_device(params->device);
+    oz_defaults(&g->oz_engine, &g->oz_nmod);
     {
         std::lock_guard<std::mutex> lk(g_ctx_mu);
         auto& fl = g_ctx_free[params->device & 15];
@@ -930,6 +1017,21 @@ int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_
         if (!std::isfinite(c)) { abo_destroy(*out); *out = nullptr; return fail(ABO_EINVAL, "abo_create_grad: non-finite mean"); }
         (*out)->mean_vec[q] = c;
     }
+    return ABO_OK;
+}
+
+int32_t abo_set_contraction(abo_gp* gp, int32_t engine, int32_t nmod) {
+    if (engine < ABO_CONTRACT_AUTO || engine > ABO_CONTRACT_INT8) return fail(ABO_EINVAL, "abo_set_contraction: unknown engine %d", engine);
+    if (nmod != 0 && (nmod < 8 || nmod > OZ_MAXMOD)) return fail(ABO_EINVAL, "abo_set_contraction: 8 to %d moduli (0 = default)", OZ_MAXMOD);
+    if (!gp) {
+        int e, n;
+        oz_defaults(&e, &n);
+        g_oz_nmod.store(nmod ? nmod : OZ_DEFAULT_NMOD);
+        g_oz_engine.store(engine);
+        return ABO_OK;
+    }
+    gp->oz_engine = engine;
+    gp->oz_nmod = nmod ? nmod : OZ_DEFAULT_NMOD;
     return ABO_OK;
 }
 
@@ -973,6 +1075,7 @@ int32_t abo_append(abo_gp* g, const double* x, int32_t d, double y, int64_t* inf
     abo_gp* n = nullptr;
     rc = abo_create(&g->prm, &n);
     if (rc) return rc;
+    n->oz_engine = g->oz_engine; n->oz_nmod = g->oz_nmod;
     rc = append_impl(g, n, x, y, info);
     if (rc) { abo_destroy(n); return rc; }
     *out = n;

@@ -394,13 +394,13 @@ __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
 size_t oz_w_bytes(int n, int Np) { const int64_t q = pad_up(Np, OZ_T); return (size_t)n * q * q; }
 size_t oz_k_bytes(int n, int Np, int Mc) { return (size_t)n * pad_up(Mc, OZ_T) * pad_up(Np, OZ_T); }
 
-hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int8_t* WR, int* sexp, int* bad_row, hipStream_t s) {
+hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s) {
     const int Np256 = (int)pad_up(Np, OZ_T);
     hipError_t e = hipMemsetAsync(bad_row, 0, sizeof(int) * Np256, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(oz_rowscale_kernel, dim3((Np256 + 3) / 4), dim3(256), 0, s, W, ldw, Np, Np256, pl.eP, sexp);
+    hipLaunchKernelGGL(oz_rowscale_kernel, dim3((Np256 + 3) / 4), dim3(256), 0, s, W, ldw, nvalid, Np256, pl.eP, sexp);
     OzQuantArgs q{};
-    q.in = W; q.ldin = ldw; q.rows_in = Np; q.cols_in = Np; q.rows_out = Np256; q.cols_out = Np256; q.lower = 1;
+    q.in = W; q.ldin = ldw; q.rows_in = nvalid; q.cols_in = Np; q.rows_out = Np256; q.cols_out = Np256; q.lower = 1;
     q.srow = sexp; q.sconst = 0; q.out = WR; q.ld = Np256; q.plane = (int64_t)Np256 * Np256; q.bad = bad_row; q.pl = pl;
     const int64_t threads = (int64_t)Np256 * (Np256 / 16);
     hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
@@ -424,6 +424,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     q.srow = nullptr; q.sconst = v.sK; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
     const int64_t threads = (int64_t)Mc256 * (Np256 / 16);
     hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
+    if (v.ev_quant && (e = hipEventRecord(v.ev_quant, s)) != hipSuccess) return e;
 
     OzGemmArgs g{};
     g.KR = v.KR; g.WR = v.WR; g.U = v.U;
@@ -435,6 +436,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     const int ngj = (g.Tj + g.tjg - 1) / g.tjg, ngi = (g.Ti + 3) / 4;
     const unsigned blocks = (unsigned)(ngi * pl.n * ngj * 4 * g.tjg);
     hipLaunchKernelGGL(oz_gemm_kernel, dim3(blocks), dim3(512), 0, s, g);
+    if (v.ev_gemm && (e = hipEventRecord(v.ev_gemm, s)) != hipSuccess) return e;
 
     OzCrtArgs c{};
     c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;

@@ -76,7 +76,7 @@ class HipStandardGP(AbstractSurrogate):
     """StandardGP(kernel, noise_var; mean=nothing) (src/surrogates/StandardGP.jl:41-64)."""
 
     def __init__(self, kernel: Kernel, noise_var: float, mean=None, device: int | None = None, jitter: float = 0.0,
-                 chunk: int = 0, n_max: int = 0):
+                 chunk: int = 0, n_max: int = 0, contraction: str | None = None):
         if mean is None:
             mean = ZeroMean()
         inner, scale, ell = extract_scale_and_lengthscale(kernel)
@@ -87,6 +87,9 @@ class HipStandardGP(AbstractSurrogate):
         self.jitter = float(jitter)
         self.chunk = int(chunk)
         self.n_max = int(n_max)          # capacity for incremental appends (0 = size to the fit)
+        # engine of the variance contraction: None = the library default (auto), "fp64", "int8" or "int8:<moduli>"
+        self.contraction = contraction
+        parse_contraction(contraction)
         if device is None:
             device = _current_device()
         self.device = int(device)
@@ -110,6 +113,7 @@ class HipStandardGP(AbstractSurrogate):
         m = object.__new__(HipStandardGP)
         m.kernel, m.noise_var, m.mean, m.jitter, m.chunk, m.device, m.n_max = (self.kernel, self.noise_var, self.mean,
                                                                               self.jitter, self.chunk, self.device, self.n_max)
+        m.contraction = getattr(self, "contraction", None)
         m._h = handle
         return m
 
@@ -145,6 +149,22 @@ class HipStandardGP(AbstractSurrogate):
 
     def __repr__(self):
         return f"HipStandardGP({self.kernel!r}, noise_var={self.noise_var}, mean={self.mean}, fitted={self._h is not None})"
+
+
+def parse_contraction(spec):
+    """"auto" | "fp64" | "int8" | "int8:<moduli>" → (engine, moduli) of abo_set_contraction (include/abo_hip.h)."""
+    if spec is None:
+        return _lib.CONTRACT_AUTO, 0
+    name, _, n = str(spec).partition(":")
+    engines = {"auto": _lib.CONTRACT_AUTO, "fp64": _lib.CONTRACT_FP64, "int8": _lib.CONTRACT_INT8}
+    if name not in engines or (n and not n.isdigit()):
+        raise ValueError(f"contraction must be auto, fp64, int8 or int8:<moduli>, not {spec!r}")
+    return engines[name], int(n) if n else 0
+
+
+def set_default_contraction(spec) -> None:
+    """Process-wide default engine of the variance contraction for handles created from now on."""
+    _lib.check(_lib.lib().abo_set_contraction(None, *parse_contraction(spec)))
 
 
 def _current_device() -> int:
@@ -192,6 +212,8 @@ def update(model: HipStandardGP, xs, ys) -> HipStandardGP:
     prm = model._params()
     _lib.check(L.abo_create(C.byref(prm), C.byref(hp)))
     h = _Handle(hp.value)
+    if getattr(model, "contraction", None) is not None:
+        _lib.check(L.abo_set_contraction(h.ptr, *parse_contraction(model.contraction)))
     info = C.c_int64(0)
     st = L.abo_fit(h.ptr, xp, n, d, yp, xspace, C.byref(info))
     _lib.check(st, info.value)

@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define ABO_ABI_VERSION 2   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted */
+#define ABO_ABI_VERSION 3   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
+                               3: abo_set_contraction, abo_timings grew (contraction engine and its phases) */
 
 /* status codes */
 enum {
@@ -55,6 +56,15 @@ enum {
 
 enum { ABO_HOST = 0, ABO_DEVICE = 1 };
 
+/* engine of the N²·M contraction V = L⁻¹K_XZ behind posterior_var (src/surrogates/StandardGP.jl:377-379):
+ *   ABO_CONTRACT_FP64  v_mfma_f64_16x16x4_f64 kernels (78.6 TFLOP/s pipe)
+ *   ABO_CONTRACT_INT8  exact products of 52/53-bit fixed-point images of the two fp64 operands on v_mfma_i32_32x32x32_i8,
+ *                      through residues modulo `nmod` coprime moduli ≤ 256 and a Chinese-remainder reconstruction in fp64
+ *                      (14 moduli: errors of the size of the fp64 kernels' own rounding; each modulus less ≈ 14× more error,
+ *                      7 % less time).  StandardGP handles only; a gradient-enhanced model stays on the fp64 kernels.
+ *   ABO_CONTRACT_AUTO  INT8 for a StandardGP with ≥ 2048 (padded) training points, FP64 otherwise */
+enum { ABO_CONTRACT_AUTO = 0, ABO_CONTRACT_FP64 = 1, ABO_CONTRACT_INT8 = 2 };
+
 typedef struct abo_gp abo_gp;     /* opaque, reference-counted: one (immutable) conditioned model */
 typedef struct abo_cand abo_cand; /* opaque: a candidate set resident in HBM together with its posterior */
 
@@ -80,6 +90,11 @@ typedef struct abo_timings {
     double var_gemm_flop;        /* algorithmic flop (N²·M, triangular) those launches performed */
     double downdate_ms;          /* last abo_cand_downdate on this handle: its O(N·M) pass (K_ZX mat-vec or kernel sweep) */
     double downdate_bytes;       /* bytes of resident K_ZX that pass streamed (8·N·M); 0 when it re-evaluated the kernel */
+    /* ABI 3: which engine ran the contraction of the last posterior call (ABO_CONTRACT_FP64 / _INT8; 0 = none), and for the
+     * int8 engine its moduli count, its phases (acq_var_gemm_ms is their sum: quantisation of K_XZ, residue GEMMs,
+     * reconstruction) and the int8 operations the GEMM launches performed (one launch per chunk covers all moduli) */
+    int64_t contraction_engine, oz_nmod;
+    double oz_prepare_ms, oz_quant_ms, oz_gemm_ms, oz_crt_ms, oz_gemm_ops;
 } abo_timings;
 
 /* --- lifetime -------------------------------------------------------------------------------
@@ -95,6 +110,11 @@ int32_t abo_create(const abo_params* params, abo_gp** out);
  * adjacent), so that a new observation appends p rows at the end of the factor (abo_append_grad); every vector that crosses
  * the ABI (y, alpha) is by outputs, abo_get_factor's L / Linv are in the library's row order. */
 int32_t abo_create_grad(const abo_params* params, int32_t p, const double* mean_c, abo_gp** out);
+/* Engine of the variance contraction for this handle and the models appended from it (gp == NULL: the process default, which
+ * new handles start from; the environment variable ABO_CONTRACTION = auto | fp64 | int8 | int8:<nmod> seeds it).  nmod: 8 … 16
+ * moduli, 0 = 14.  No reference counterpart: the reference computes this product in fp64 BLAS ([upstream AbstractGPs]
+ * diag_Xt_invA_X); both engines meet the same parity bounds (tests/test_gpu_ozaki.py). */
+int32_t abo_set_contraction(abo_gp* gp, int32_t engine, int32_t nmod);
 /* Base.copy(::StandardGP) (src/surrogates/StandardGP.jl:26, surrogates_utils.jl:12-14): device
  * state is immutable after fit, so a copy is a shared reference. */
 int32_t abo_retain(abo_gp* gp);

@@ -1,0 +1,158 @@
+"""GPU parity of the int8-residue contraction engine (csrc/ozaki.hip, ABO_CONTRACT_INT8) — the N²·M product behind
+posterior_var (reference: src/surrogates/StandardGP.jl:377-379) computed exactly on fixed-point images of its operands.
+Checked against the CPU oracle on the same seeded inputs AND against the fp64 MFMA engine of the same library; errors are
+scaled as everywhere else (|Δσ²| / σ_f²), recorded by tests/parity_record.py and held to the same kind of bound: a hard bar
+(≤ the north star's 1e-6) and 100 × the error recorded on an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import synth
+from oracle import gp_oracle as O
+
+from tests.parity_record import check
+from tests.test_gpu_parity import make_model
+
+
+def _fit_pair(family, ell, sf2, noise, X, y, **kw):
+    a = abo.update(make_model(family, ell, sf2, noise, contraction="fp64", **kw), X, y)
+    b = abo.update(make_model(family, ell, sf2, noise, contraction="int8", **kw), X, y)
+    return a, b
+
+
+CASES = [
+    # family, d, N, M, ell, sf2, noise: sizes around the 256-tile borders of the residue GEMM, forced onto the int8 engine
+    (O.SE, 2, 40, 100, 0.7, 1.0, 1e-6),          # one partial tile each way
+    (O.MATERN52, 3, 256, 256, 0.8, 1.0, 1e-4),   # exactly one tile
+    (O.MATERN52, 4, 300, 700, 1.0, 2.5, 1e-3),   # Np = 384 pads to 512; M = 700 pads to 768
+    (O.SE, 4, 1024, 3000, 0.5, 1.0, 1e-4),       # C2 training shape (cond ≈ 1e7)
+    (O.MATERN72, 8, 1500, 1025, 1.2, 0.5, 1e-3),
+    (O.MATERN52, 8, 2304, 2049, 1.0, 1.0, 1e-3), # nine row blocks: the size the AUTO engine switches at and beyond
+    (O.MATERN32, 6, 2100, 515, 0.9, 1.0, 1e-2),
+]
+
+
+@pytest.mark.parametrize("family,d,N,M,ell,sf2,noise", CASES)
+def test_int8_engine_against_oracle_and_fp64_engine(family, d, N, M, ell, sf2, noise):
+    X = synth.points(1, N, d)
+    Z = synth.points(2, M, d) * 1.2 - 0.1
+    y = synth.objective(X, 0.05)
+    st = O.fit(family, ell, sf2, noise, 0.0, X, y)
+    mu_o, var_o = O.predict(st, Z)
+    m64, m8 = _fit_pair(family, ell, sf2, noise, X, y)
+    mu64, var64 = abo.mean_and_var(m64, Z)
+    mu8, var8 = abo.mean_and_var(m8, Z)
+    assert m64.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    t8 = m8.timings()
+    assert t8["contraction_engine"] == abo._lib.CONTRACT_INT8 and t8["oz_nmod"] == 14
+    np.testing.assert_array_equal(mu8, mu64)          # the mean never goes through the contraction
+    cond = 1.0 + N * sf2 / noise
+    tol = min(1e-6, max(1e-11, 4e-16 * cond) * 1e2)
+    case = f"int8/fam{family}_d{d}_N{N}"
+    e8 = np.max(np.abs(var8 - var_o)) / sf2
+    e64 = np.max(np.abs(var64 - var_o)) / sf2
+    check(case, "var", e8, tol)
+    check(case, "var_fp64_engine", e64, tol)
+    check(case, "var_between_engines", np.max(np.abs(var8 - var64)) / sf2, tol)
+    # scores and the selection agree with the oracle's on the int8 engine's posterior
+    best = float(np.min(y))
+    acq = abo.ExpectedImprovement(0.01, best)
+    s, tv, ti = abo.evaluate(acq, m8, Z, k=min(50, M))
+    np.testing.assert_allclose(s, O.acquisition(O.ACQ_EI, mu8, var8, 0.01, best), rtol=1e-10, atol=1e-14)
+    ov, oi = O.top_k(s, min(50, M))
+    np.testing.assert_array_equal(ti, oi)
+
+
+def test_moduli_count_trades_accuracy():
+    """each modulus less costs about 3.85 bits per operand: the error against the oracle grows monotonically from 14 moduli
+    down, and 14 sits at the fp64 engine's own level"""
+    N, d, M = 1024, 4, 2048
+    X = synth.points(1, N, d)
+    Z = synth.points(2, M, d)
+    y = synth.objective(X, 0.05)
+    st = O.fit(O.MATERN52, 0.8, 1.0, 1e-4, 0.0, X, y)
+    _, var_o = O.predict(st, Z)
+    errs = {}
+    for n in (10, 11, 12, 13, 14, 16):
+        m = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-4, contraction=f"int8:{n}"), X, y)
+        var = abo.posterior_var(m, Z)
+        assert m.timings()["oz_nmod"] == n
+        errs[n] = float(np.max(np.abs(var - var_o)))
+        check("int8/moduli_sweep", f"var_n{n}", errs[n], 1e-6 if n >= 11 else 1e-4)
+    assert errs[10] > errs[12] > errs[14] * 0.5
+    m64 = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-4, contraction="fp64"), X, y)
+    e64 = float(np.max(np.abs(abo.posterior_var(m64, Z) - var_o)))
+    assert errs[14] <= max(10 * e64, 1e-13) and errs[16] <= max(10 * e64, 1e-13)
+
+
+def test_int8_engine_is_chunk_independent_and_deterministic():
+    """exact integer products: the result cannot depend on how the candidates are cut into chunks, nor on the run"""
+    N, d, M = 700, 5, 3000
+    X = synth.points(1, N, d)
+    Z = synth.points(2, M, d)
+    y = synth.objective(X, 0.05)
+    ref = None
+    for chunk in (0, 256, 1024, 1152):
+        m = abo.update(make_model(O.MATERN52, 0.9, 1.0, 1e-3, contraction="int8", chunk=chunk), X, y)
+        var = abo.posterior_var(m, Z)
+        var2 = abo.posterior_var(m, Z)
+        np.testing.assert_array_equal(var, var2)
+        if ref is None:
+            ref = var
+        np.testing.assert_array_equal(var, ref)
+
+
+def test_non_finite_candidates_stay_nan_on_the_int8_engine():
+    X = synth.points(1, 300, 3)
+    y = synth.objective(X, 0.05)
+    Z = synth.points(2, 600, 3)
+    Z[17, 1] = np.nan
+    Z[400, 0] = np.inf
+    m64, m8 = _fit_pair(O.SE, 0.7, 1.0, 1e-4, X, y)
+    mu8, var8 = abo.mean_and_var(m8, Z)
+    mu64, var64 = abo.mean_and_var(m64, Z)
+    assert np.isnan(var8[17]) and np.isnan(var64[17])
+    assert np.isnan(var8[400]) == np.isnan(var64[400])
+    ok = np.ones(600, bool)
+    ok[[17, 400]] = False
+    np.testing.assert_allclose(var8[ok], var64[ok], rtol=0, atol=1e-12)
+    s, tv, ti = abo.evaluate(abo.UpperConfidenceBound(2.0), m8, Z, k=3)
+    assert ti[0] == 17 and np.isnan(tv[0])            # NaN sorts first, as on the fp64 engine
+
+
+def test_appended_model_and_resident_grid_on_the_int8_engine():
+    """a bordered append adds a row to W: the residue planes are rebuilt for the larger view, and the refreshed grid of a
+    candidate set goes through the same engine"""
+    N, d, M = 600, 4, 2000
+    X = synth.points(1, N + 2, d)
+    y = synth.objective(X, 0.05)
+    Z = synth.points(2, M, d)
+    base = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="int8", n_max=N + 8), X[:N], y[:N])
+    v0 = abo.posterior_var(base, Z)
+    m1 = abo.append(base, X[N], y[N])
+    m2 = abo.append(m1, X[N + 1], y[N + 1])
+    v2 = abo.posterior_var(m2, Z)
+    assert m2.timings()["contraction_engine"] == abo._lib.CONTRACT_INT8
+    st = O.fit(O.MATERN52, 0.8, 1.0, 1e-3, 0.0, X, y)
+    _, var_o = O.predict(st, Z)
+    check("int8/append_N600", "var", np.max(np.abs(v2 - var_o)), 1e-9)
+    np.testing.assert_array_equal(abo.posterior_var(base, Z), v0)        # the older view still answers for its own N
+    cands = abo.ResidentCandidates(m2, Z)
+    mu_c, var_c = cands.mean_and_var()
+    np.testing.assert_array_equal(var_c, v2)
+
+
+def test_auto_engine_switches_on_size():
+    X = synth.points(1, 2100, 4)
+    y = synth.objective(X, 0.05)
+    Z = synth.points(2, 512, 4)
+    big = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3), X, y)
+    abo.posterior_var(big, Z)
+    assert big.timings()["contraction_engine"] == abo._lib.CONTRACT_INT8
+    small = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3), X[:1000], y[:1000])
+    abo.posterior_var(small, Z)
+    assert small.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    with pytest.raises(ValueError):
+        make_model(O.SE, 1.0, 1.0, 1e-3, contraction="fp32")
