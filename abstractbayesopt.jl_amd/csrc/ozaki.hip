@@ -206,10 +206,12 @@ struct OzGemmArgs {
     int p[OZ_MAXMOD];
 };
 
-__global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char oz_lds[4 * OZ_STAGE];
-    // ---- tile decode: groups of (4 row blocks × tjg column blocks) of ONE modulus, heaviest row blocks first; inside a
-    //      group the workgroups that land on one XCD (blockIdx % 8) form a 4 × (tjg/8) patch that shares its panels in L2
+// tile decode: groups of (4 row blocks × tjg column blocks) of ONE modulus, heaviest row blocks first; inside a group the
+// workgroups that land on one XCD (blockIdx % 8) form a 4 × (tjg/8) patch that shares its panels in L2.
+// Row-block offsets inside a group alternate direction from group to group: the CUs that ran a group's lightest tiles are free
+// first and take the next group's first workgroups — which are then its heaviest, so the four row blocks of a patch do not drift
+// apart in k (the candidate panels they share stay in L2 only while they walk k together; L2 hit rate 60 % → 78 %).
+__device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj, int& l) {
     const int per_group = 4 * a.tjg;
     const int grp = blockIdx.x / per_group, s = blockIdx.x % per_group;
     const int ngj = (a.Tj + a.tjg - 1) / a.tjg;
@@ -217,33 +219,75 @@ __global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
     const int ngi = (a.Ti + 3) / 4;
     const int xcd = s & 7, c = s >> 3;
     const int cols_x = a.tjg >> 3;                     // column blocks per XCD patch
-    const int ti = 4 * (ngi - 1 - gg) + c / cols_x;
-    const int tj = gh * a.tjg + xcd * cols_x + c % cols_x;
-    if (ti >= a.Ti || tj >= a.Tj) return;
-    const int l = gl;
+    const int ro = c / cols_x;
+    ti = 4 * (ngi - 1 - gg) + ((grp & 1) ? 3 - ro : ro);
+    tj = gh * a.tjg + xcd * cols_x + c % cols_x;
+    l = gl;
+    return ti < a.Ti && tj < a.Tj;
+}
+
+// fragments of one 32-byte k-group: two candidate row-groups (A operand), four W row-groups (B operand)
+struct OzFrag { v4i_t a[2], b[4]; };
+
+__device__ __forceinline__ void oz_frag_read(const char* af, const char* bf, int ks, OzFrag& f) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) f.a[m] = *reinterpret_cast<const v4i_t*>(af + (32 * m) * OZ_ROW + 32 * ks);
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(bf + (32 * nn) * OZ_ROW + 32 * ks);
+}
+
+__device__ __forceinline__ void oz_frag_mma(const OzFrag& f, v16i_t (&acc)[2][4]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[m], f.b[nn], acc[m][nn], 0, 0, 0);
+}
+
+struct OzStage { v4i_t a[4], b[4]; };      // one thread's share of a stage: 4 × 16 B of each operand
+
+__device__ __forceinline__ void oz_gload(const int8_t* __restrict__ ab, const int8_t* __restrict__ bb, const unsigned (&ao)[4],
+                                         const unsigned (&bo)[4], int k, OzStage& r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        r.a[q] = *reinterpret_cast<const v4i_t*>(ab + k + ao[q]);
+        r.b[q] = *reinterpret_cast<const v4i_t*>(bb + k + bo[q]);
+    }
+}
+
+__device__ __forceinline__ void oz_lstore(char* As, char* Bs, int lr, int lc, const OzStage& r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<v4i_t*>(As + (lr + 64 * q) * OZ_ROW + lc) = r.a[q];
+        *reinterpret_cast<v4i_t*>(Bs + (lr + 64 * q) * OZ_ROW + lc) = r.b[q];
+    }
+}
+
+// Software pipeline, iteration t (stage = 128 k-bytes = four 32-byte k-groups; LDS holds two stages):
+//     8 MFMA on F0 = fragments(t, group 0)   and behind them: 8 ds_write  S(stage t+1) → LDS[(t+1)&1], 6 ds_read group 1 → F1
+//     8 MFMA on F1                            and behind them: 8 global_load stage t+2 → S,             6 ds_read group 2 → F0
+//     8 MFMA on F0                            and behind them:                                           6 ds_read group 3 → F1
+//     barrier   (stage t+1 complete in LDS; nobody still reads stage t)
+//     8 MFMA on F1                            and behind them: 6 ds_read fragments(t+1, group 0) → F0
+// so the matrix pipe has a fragment set in registers on both sides of the barrier, and every memory instruction is issued
+// directly behind one of the wave's own MFMAs (the sched_group_barrier sequences pin that order).
+__global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char oz_lds[4 * OZ_STAGE];
+    int ti, tj, l;
+    if (!oz_decode(a, ti, tj, l)) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wj = wave & 3, wi = wave >> 2;
-    char* As = oz_lds;                                 // [2][256][144]  candidates
-    char* Bs = oz_lds + 2 * OZ_STAGE;                  // [2][256][144]  W rows
-
+    // LDS: stage buffer b = [A tile | B tile], each [256][144]
     const int lr = tid >> 3, lc = (tid & 7) * 16;
-    const int8_t* ap = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T + lr) * a.ldk + lc;
-    const int8_t* bp = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T + lr) * a.ldw + lc;
+    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T) * a.ldk;
+    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
+    unsigned ao[4], bo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ao[q] = (unsigned)((lr + 64 * q) * (int)a.ldk + lc);
+        bo[q] = (unsigned)((lr + 64 * q) * (int)a.ldw + lc);
+    }
     const int nst = 2 * (ti + 1);
-
-    v4i_t ra[4], rb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        ra[q] = *reinterpret_cast<const v4i_t*>(ap + (int64_t)(64 * q) * a.ldk);
-        rb[q] = *reinterpret_cast<const v4i_t*>(bp + (int64_t)(64 * q) * a.ldw);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<v4i_t*>(As + (lr + 64 * q) * OZ_ROW + lc) = ra[q];
-        *reinterpret_cast<v4i_t*>(Bs + (lr + 64 * q) * OZ_ROW + lc) = rb[q];
-    }
-    __syncthreads();
 
     v16i_t acc[2][4];
 #pragma unroll
@@ -254,46 +298,84 @@ __global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0;
 
     const int foff = (lane & 31) * OZ_ROW + (lane >> 5) * 16;
-    const char* afr = As + (64 * wj) * OZ_ROW + foff;
-    const char* bfr = Bs + (128 * wi) * OZ_ROW + foff;
+    const int afo = (64 * wj) * OZ_ROW + foff;                  // in the A tile
+    const int bfo = OZ_STAGE + (128 * wi) * OZ_ROW + foff;      // in the B tile
 
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nst;
-        if (more) {
-            const int k1 = (st + 1) * OZ_BK;
+    OzStage S;
+    OzFrag f0, f1;
+    oz_gload(ab, bb, ao, bo, 0, S);
+    oz_lstore(oz_lds, oz_lds + OZ_STAGE, lr, lc, S);
+    oz_gload(ab, bb, ao, bo, OZ_BK, S);                         // nst ≥ 2 always
+    __syncthreads();
+    oz_frag_read(oz_lds + afo, oz_lds + bfo, 0, f0);
+    int t = 0;
+    for (; t + 2 < nst; ++t) {
+        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE);
+        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE);
+        oz_lstore(nxt, nxt + OZ_STAGE, lr, lc, S);
+        oz_frag_read(cur + afo, cur + bfo, 1, f1);
+        oz_frag_mma(f0, acc);
+        oz_gload(ab, bb, ao, bo, (t + 2) * OZ_BK, S);
+        oz_frag_read(cur + afo, cur + bfo, 2, f0);
+        oz_frag_mma(f1, acc);
+        oz_frag_read(cur + afo, cur + bfo, 3, f1);
+        oz_frag_mma(f0, acc);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ra[q] = *reinterpret_cast<const v4i_t*>(ap + (int64_t)(64 * q) * a.ldk + k1);
-                rb[q] = *reinterpret_cast<const v4i_t*>(bp + (int64_t)(64 * q) * a.ldw + k1);
-            }
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
         }
-        const char* af = afr + buf * OZ_STAGE;
-        const char* bf = bfr + buf * OZ_STAGE;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            v4i_t fa[2], fb[4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) fa[m] = *reinterpret_cast<const v4i_t*>(af + (32 * m) * OZ_ROW + 32 * ks);
-#pragma unroll
-            for (int nn = 0; nn < 4; ++nn) fb[nn] = *reinterpret_cast<const v4i_t*>(bf + (32 * nn) * OZ_ROW + 32 * ks);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int nn = 0; nn < 4; ++nn)
-                    acc[m][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[nn], acc[m][nn], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
-        if (more) {
-            char* aw = As + (buf ^ 1) * OZ_STAGE;
-            char* bw = Bs + (buf ^ 1) * OZ_STAGE;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<v4i_t*>(aw + (lr + 64 * q) * OZ_ROW + lc) = ra[q];
-                *reinterpret_cast<v4i_t*>(bw + (lr + 64 * q) * OZ_ROW + lc) = rb[q];
-            }
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        oz_frag_read(nxt + afo, nxt + bfo, 0, f0);
+        oz_frag_mma(f1, acc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    for (; t < nst; ++t) {                                      // the last two stages: nothing left to load
+        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE);
+        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE);
+        oz_frag_read(cur + afo, cur + bfo, 1, f1);
+        if (t + 1 < nst) oz_lstore(nxt, nxt + OZ_STAGE, lr, lc, S);
+        oz_frag_mma(f0, acc);
+        oz_frag_read(cur + afo, cur + bfo, 2, f0);
+        oz_frag_mma(f1, acc);
+        oz_frag_read(cur + afo, cur + bfo, 3, f1);
+        oz_frag_mma(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (t + 1 < nst) oz_frag_read(nxt + afo, nxt + bfo, 0, f0);
+        oz_frag_mma(f1, acc);
+    }
+    __syncthreads();
 
     // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS so that rows of U leave as 256-byte
     //      segments.  D layout of v_mfma_i32_32x32x32_i8: lane → column n = lane % 32, register r → row m = 8(r/4) + 4(lane/32) + r%4
@@ -317,6 +399,332 @@ __global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
                 const int jl = 64 * wj + 32 * m + 8 * g + 4 * (lane >> 5);
                 *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
             }
+        }
+    __syncthreads();
+    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
+    const int ur = tid >> 4, uc = (tid & 15) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = ur + 32 * q;
+        const char* src = Ut + i * OZ_UROW + uc;
+        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+}
+
+
+// ---- the same GEMM on v_mfma_i32_16x16x64_i8 -------------------------------------------------------------------------------------------
+// On random operands the chip holds a higher clock with the 16×16×64 shape than with 32×32×32 (tools/mfma_i8_power_probe.hip:
+// 3.41 against 3.11 POP/s sustained).  Wave tile as above (64 candidates × 128 W rows) = 4 × 8 MFMA tiles of 16×16.
+// LDS rows are 128 B unpadded with the 16-byte chunks XOR-swizzled: chunk c of row r sits at position c ^ ((r >> 1) & 7) —
+// conflict-free for ds_read_b128 with lane → (row l%16, chunk l/16 + 4·group) and for the row-wise ds_write_b128.
+// D layout of v_mfma_i32_16x16x64_i8: lane → column n = lane % 16, register r → row m = 4(lane/16) + r.
+// Pipeline per iteration (stage = two 64-byte k-groups g0, g1; a unit = 4 A fragments × 4 B fragments = 16 MFMAs):
+//     unit (g0, B0-3) | 8 ds_write S(t+1), 4 ds_read B4-7(g0)
+//     unit (g0, B4-7) | 8 global_load stage t+2, 8 ds_read A(g1), B0-3(g1)
+//     unit (g1, B0-3) | 4 ds_read B4-7(g1)
+//     barrier
+//     unit (g1, B4-7) | 8 ds_read A(g0), B0-3(g0) of stage t+1
+constexpr int OZ_STAGE16 = OZ_T * OZ_BK;      // 32 768 bytes per operand stage
+
+struct OzFragA { v4i_t a[4]; };
+struct OzFragB { v4i_t b[4]; };
+
+__device__ __forceinline__ void oz16_read_a(const char* p, OzFragA& f) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) f.a[m] = *reinterpret_cast<const v4i_t*>(p + (16 * m) * OZ_BK);
+}
+__device__ __forceinline__ void oz16_read_b(const char* p, int half, OzFragB& f) {
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(p + (16 * (4 * half + nn)) * OZ_BK);
+}
+__device__ __forceinline__ void oz16_mma(const OzFragA& fa, const OzFragB& fb, int half, v4i_t (&acc)[4][8]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn)
+            acc[m][4 * half + nn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.a[m], fb.b[nn], acc[m][4 * half + nn], 0, 0, 0);
+}
+__device__ __forceinline__ void oz16_lstore(char* As, char* Bs, int lr, int pos, const OzStage& r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<v4i_t*>(As + (lr + 64 * q) * OZ_BK + pos) = r.a[q];
+        *reinterpret_cast<v4i_t*>(Bs + (lr + 64 * q) * OZ_BK + pos) = r.b[q];
+    }
+}
+
+#define OZ_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+__global__ void __launch_bounds__(512) oz_gemm16_kernel(OzGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char oz_lds[4 * OZ_STAGE16];
+    int ti, tj, l;
+    if (!oz_decode(a, ti, tj, l)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = wave & 3, wi = wave >> 2;
+    const int lr = tid >> 3, lc = (tid & 7) * 16;
+    const int wpos = ((tid & 7) ^ ((lr >> 1) & 7)) * 16;         // swizzled position of this thread's chunk in its rows
+    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T) * a.ldk;
+    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
+    unsigned ao[4], bo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ao[q] = (unsigned)((lr + 64 * q) * (int)a.ldk + lc);
+        bo[q] = (unsigned)((lr + 64 * q) * (int)a.ldw + lc);
+    }
+    const int nst = 2 * (ti + 1);
+
+    v4i_t acc[4][8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) acc[m][nn] = v4i_t{0, 0, 0, 0};
+
+    // per-lane read offsets of the two k-groups of a stage: row lane%16, chunk (lane/16 + 4g) ^ swizzle
+    const int sw = (lane >> 1) & 7;
+    const int c0 = ((lane >> 4) ^ sw) * 16;
+    const int ro0 = (lane & 15) * OZ_BK + c0, ro1 = (lane & 15) * OZ_BK + (c0 ^ 64);
+    const int abase = (64 * wj) * OZ_BK;
+    const int bbase = OZ_STAGE16 + (128 * wi) * OZ_BK;
+
+    OzStage S;
+    OzFragA A0, A1;
+    OzFragB Bx, By;
+    oz_gload(ab, bb, ao, bo, 0, S);
+    oz16_lstore(oz_lds, oz_lds + OZ_STAGE16, lr, wpos, S);
+    oz_gload(ab, bb, ao, bo, OZ_BK, S);
+    __syncthreads();
+    oz16_read_a(oz_lds + abase + ro0, A0);
+    oz16_read_b(oz_lds + bbase + ro0, 0, Bx);
+    int t = 0;
+    for (; t + 2 < nst; ++t) {
+        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE16);
+        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE16);
+        oz16_lstore(nxt, nxt + OZ_STAGE16, lr, wpos, S);
+        oz16_read_b(cur + bbase + ro0, 1, By);
+        oz16_mma(A0, Bx, 0, acc);
+        oz_gload(ab, bb, ao, bo, (t + 2) * OZ_BK, S);
+        oz16_read_a(cur + abase + ro1, A1);
+        oz16_read_b(cur + bbase + ro1, 0, Bx);
+        oz16_mma(A0, By, 1, acc);
+        oz16_read_b(cur + bbase + ro1, 1, By);
+        oz16_mma(A1, Bx, 0, acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x200, 1); OZ_SGB(0x100, 1); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x200, 1); }
+        OZ_SGB(0x008, 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x020, 1); OZ_SGB(0x100, 1); }
+        OZ_SGB(0x008, 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
+        OZ_SGB(0x008, 12);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        oz16_read_a(nxt + abase + ro0, A0);
+        oz16_read_b(nxt + bbase + ro0, 0, Bx);
+        oz16_mma(A1, By, 1, acc);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; t < nst; ++t) {                                      // the last two stages: nothing left to load
+        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE16);
+        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE16);
+        oz16_read_b(cur + bbase + ro0, 1, By);
+        if (t + 1 < nst) oz16_lstore(nxt, nxt + OZ_STAGE16, lr, wpos, S);
+        oz16_mma(A0, Bx, 0, acc);
+        oz16_read_a(cur + abase + ro1, A1);
+        oz16_read_b(cur + bbase + ro1, 0, Bx);
+        oz16_mma(A0, By, 1, acc);
+        oz16_read_b(cur + bbase + ro1, 1, By);
+        oz16_mma(A1, Bx, 0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (t + 1 < nst) {
+            oz16_read_a(nxt + abase + ro0, A0);
+            oz16_read_b(nxt + bbase + ro0, 0, Bx);
+        }
+        oz16_mma(A1, By, 1, acc);
+    }
+    __syncthreads();
+
+    // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS (rows of U leave as 256-byte segments)
+    const double invp = a.invp[l], pd = (double)a.p[l];
+    char* Ut = oz_lds;                                  // [256 i][264]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) {
+            const int il = 128 * wi + 16 * nn + (lane & 15);
+            int w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double x = (double)acc[m][nn][b];
+                const double q = __builtin_rint(x * invp);
+                const int r = (int)__builtin_fma(-q, pd, x);
+                w |= (r & 0xff) << (8 * b);
+            }
+            const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
+            *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
+        }
+    __syncthreads();
+    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
+    const int ur = tid >> 4, uc = (tid & 15) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = ur + 32 * q;
+        const char* src = Ut + i * OZ_UROW + uc;
+        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+}
+
+
+// ---- 16×16×64 GEMM fed by LDS-DMA --------------------------------------------------------------------------------------------------------
+// The register-staged kernels above can keep only half a stage of global loads in flight (246–253 VGPRs); an L2 miss (22 % of the
+// requests) is then waited for with the matrix pipe idle (SQ_WAIT_ANY 33 % of wave time).  Here the tiles go global → LDS directly
+// (global_load_lds_dwordx4: no staging registers, no ds_write), in HALF-stages of 64 k-bytes through a ring of four 32 KB slots,
+// three half-stages ahead of the one being multiplied.
+// LDS image of a slot: [A tile: 256 rows × 64 B][B tile: 256 rows × 64 B], the four 16-byte chunks of a row XOR-swizzled,
+// chunk c at position c ^ ((row >> 1) & 3).  A DMA wave-instruction writes 1 KiB lane-linearly (16 rows), so the swizzle is applied to
+// the per-lane SOURCE address: lane L fills row L/4, position L%4, and fetches chunk (L%4) ^ ((L>>3)&3) of that row.
+// Iteration h (half-stage h in slot h%4; a unit = 4 A fragments × 4 B fragments = 16 MFMAs):
+//     issue 4 DMA pieces of half-stage h+3 → slot (h+3)%4        (last read in iteration h−1, behind the barrier just passed)
+//     MFMA unit (h−1, B4-7)   | 8 ds_read: A(h), B0-3(h)
+//     MFMA unit (h,   B0-3)   | 4 ds_read: B4-7(h)
+//     s_waitcnt vmcnt(8) — this wave's pieces of half-stage h+1 have landed — and lgkmcnt(0); raw s_barrier
+// (a DMA'd buffer is read only behind the counted vmcnt of the issuing waves and a barrier the reader has passed.)
+constexpr int OZ_HS = 64;                       // k-bytes per half-stage
+constexpr int OZ_SLOT = 2 * OZ_T * OZ_HS;       // 32 768 bytes: A tile + B tile
+typedef __attribute__((address_space(3))) void* oz_lds_ptr;
+
+struct OzDmaCtx {
+    const int8_t* ab; const int8_t* bb;         // tile bases (uniform)
+    unsigned ao[2], bo[2];                      // per-lane source offsets of the wave's two pieces per operand
+    int wave;
+};
+
+template <int SLOT>
+__device__ __forceinline__ void oz_dma_issue(char* lds, const OzDmaCtx& c, int h) {
+    const int k = h * OZ_HS;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        char* da = lds + SLOT * OZ_SLOT + (c.wave + 8 * q) * 1024;
+        char* db = da + OZ_T * OZ_HS;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.ab + k + c.ao[q]), (oz_lds_ptr)da, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.bb + k + c.bo[q]), (oz_lds_ptr)db, 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void oz16d_read_a(const char* p, OzFragA& f) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) f.a[m] = *reinterpret_cast<const v4i_t*>(p + (16 * m) * OZ_HS);
+}
+__device__ __forceinline__ void oz16d_read_b(const char* p, int half, OzFragB& f) {
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(p + (16 * (4 * half + nn)) * OZ_HS);
+}
+
+// every step issues (past the end of the tile: a harmless re-fetch of the last half-stage into a slot nobody reads any more), so
+// the in-flight count is the same in every iteration and one loop body serves the whole tile
+template <int SLOT>
+__device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, int hmax, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
+                                           OzFragB& By, v4i_t (&acc)[4][8]) {
+    oz_dma_issue<(SLOT + 3) & 3>(lds, c, h + 3 < hmax ? h + 3 : hmax);
+    const char* slot = lds + SLOT * OZ_SLOT;
+    oz16d_read_a(slot + ra, A[SLOT & 1]);
+    oz16d_read_b(slot + rb, 0, Bx);
+    oz16_mma(A[(SLOT & 1) ^ 1], By, 1, acc);
+    oz16d_read_b(slot + rb, 1, By);
+    oz16_mma(A[SLOT & 1], Bx, 0, acc);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
+    OZ_SGB(0x008, 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
+    OZ_SGB(0x008, 12);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
+    __shared__ __attribute__((aligned(1024))) char oz_lds[4 * OZ_SLOT];
+    int ti, tj, l;
+    if (!oz_decode(a, ti, tj, l)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = wave & 3, wi = wave >> 2;
+    OzDmaCtx c;
+    c.ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T) * a.ldk;
+    c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
+    c.wave = __builtin_amdgcn_readfirstlane(wave);
+    {
+        const int chunk = (lane & 3) ^ ((lane >> 3) & 3);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = 16 * (wave + 8 * q) + (lane >> 2);
+            c.ao[q] = (unsigned)(row * (int)a.ldk + 16 * chunk);
+            c.bo[q] = (unsigned)(row * (int)a.ldw + 16 * chunk);
+        }
+    }
+    const int nh = 4 * (ti + 1);                     // half-stages of this tile
+
+    v4i_t acc[4][8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) acc[m][nn] = v4i_t{0, 0, 0, 0};
+
+    // per-lane fragment read offset inside a tile: row lane%16, chunk position (lane/16) ^ ((lane>>1)&3)
+    const int ro = (lane & 15) * OZ_HS + (((lane >> 4) ^ ((lane >> 1) & 3)) * 16);
+    const int ra = (64 * wj) * OZ_HS + ro;
+    const int rb = OZ_T * OZ_HS + (128 * wi) * OZ_HS + ro;
+
+    OzFragA A[2];
+    OzFragB Bx, By;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { A[1].a[m] = v4i_t{0, 0, 0, 0}; By.b[m] = v4i_t{0, 0, 0, 0}; }   // the first step's held-back unit adds 0
+    oz_dma_issue<0>(oz_lds, c, 0);
+    oz_dma_issue<1>(oz_lds, c, 1);
+    oz_dma_issue<2>(oz_lds, c, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int hb = 0; hb < nh; hb += 4) {
+        oz16d_step<0>(oz_lds, c, hb, nh - 1, ra, rb, A, Bx, By, acc);
+        oz16d_step<1>(oz_lds, c, hb + 1, nh - 1, ra, rb, A, Bx, By, acc);
+        oz16d_step<2>(oz_lds, c, hb + 2, nh - 1, ra, rb, A, Bx, By, acc);
+        oz16d_step<3>(oz_lds, c, hb + 3, nh - 1, ra, rb, A, Bx, By, acc);
+    }
+    oz16_mma(A[1], By, 1, acc);                       // the held-back unit of the last half-stage (slot 3 → A[1])
+    __syncthreads();
+
+    // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS (rows of U leave as 256-byte segments)
+    const double invp = a.invp[l], pd = (double)a.p[l];
+    char* Ut = oz_lds;                                  // [256 i][264]
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) {
+            const int il = 128 * wi + 16 * nn + (lane & 15);
+            int w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double x = (double)acc[m][nn][b];
+                const double q = __builtin_rint(x * invp);
+                const int r = (int)__builtin_fma(-q, pd, x);
+                w |= (r & 0xff) << (8 * b);
+            }
+            const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
+            *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
         }
     __syncthreads();
     int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
@@ -435,7 +843,11 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     for (int l = 0; l < pl.n; ++l) { g.invp[l] = pl.invp[l]; g.p[l] = pl.p[l]; }
     const int ngj = (g.Tj + g.tjg - 1) / g.tjg, ngi = (g.Ti + 3) / 4;
     const unsigned blocks = (unsigned)(ngi * pl.n * ngj * 4 * g.tjg);
-    hipLaunchKernelGGL(oz_gemm_kernel, dim3(blocks), dim3(512), 0, s, g);
+    static const int shape32 = getenv("ABO_OZ_MFMA32") ? 1 : 0;       // A/B: the 32×32×32 kernel
+    static const int regstage = getenv("ABO_OZ_REGSTAGE") ? 1 : 0;    // A/B: the register-staged 16×16×64 kernel
+    if (shape32) hipLaunchKernelGGL(oz_gemm_kernel, dim3(blocks), dim3(512), 0, s, g);
+    else if (regstage) hipLaunchKernelGGL(oz_gemm16_kernel, dim3(blocks), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(oz_gemm16d_kernel, dim3(blocks), dim3(512), 0, s, g);
     if (v.ev_gemm && (e = hipEventRecord(v.ev_gemm, s)) != hipSuccess) return e;
 
     OzCrtArgs c{};

@@ -4,6 +4,7 @@
 // Run:   tools/oz_dev [nmod] [Nbig] [Mcbig]
 #include "../abstractbayesopt.jl_amd/csrc/ozaki.hip"
 #include <cstdio>
+#include <algorithm>
 #include <random>
 #include <vector>
 using namespace abo;
@@ -142,15 +143,23 @@ int main(int argc, char** argv) {
         OzVarArgs v{};
         v.plan = &pl; v.Kxz = dK; v.ldk = Np; v.WR = WR; v.sexp = sexp; v.bad_row = badr; v.KR = KR; v.U = U; v.bad_col = badc;
         v.partial = dP; v.ldp = Mc; v.Np = Np; v.Mc = Mc; v.nvalid = Np; v.sK = oz_k_scale(1.0);
-        for (int rep = 0; rep < 4; ++rep) {
+        hipEvent_t eq, eg; CK(hipEventCreate(&eq)); CK(hipEventCreate(&eg));
+        v.ev_quant = eq; v.ev_gemm = eg;
+        const int reps = argc > 4 ? atoi(argv[4]) : 40;
+        std::vector<float> tq, tg, tc, tt;
+        for (int rep = 0; rep < reps; ++rep) {
             CK(hipEventRecord(e0, s));
             CK(launch_var_ozaki(v, s));
             CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
-            CK(hipEventElapsedTime(&ms, e0, e1));
-            const double macs = (double)nmod * Mc256 * 256.0 * 256.0 * (Np256 / 256) * (Np256 / 256 + 1) / 2.0;
-            printf("var_ozaki N=%d Mc=%d n=%d: %.3f ms total (%.1f TOP/s on the whole call; fp64-equivalent %.1f TFLOP/s)\n", Np, Mc, nmod,
-                   ms, 2.0 * macs / ms * 1e-9, (double)Np * Np * Mc / ms * 1e-9);
+            float a, b, c, d;
+            CK(hipEventElapsedTime(&a, e0, eq)); CK(hipEventElapsedTime(&b, eq, eg)); CK(hipEventElapsedTime(&c, eg, e1)); CK(hipEventElapsedTime(&d, e0, e1));
+            if (rep >= reps / 2) { tq.push_back(a); tg.push_back(b); tc.push_back(c); tt.push_back(d); }
         }
+        auto med = [](std::vector<float> x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
+        const double macs = (double)nmod * Mc256 * 256.0 * 256.0 * (Np256 / 256) * (Np256 / 256 + 1) / 2.0;
+        printf("var_ozaki N=%d Mc=%d n=%d (median of the last %d of %d back-to-back calls): total %.3f ms = quant %.3f + gemm %.3f + crt %.3f;"
+               " gemm %.1f TOP/s; fp64-equivalent of the call %.1f TFLOP/s\n", Np, Mc, nmod, (int)tt.size(), reps, med(tt), med(tq), med(tg), med(tc),
+               2.0 * macs / med(tg) * 1e-9, (double)Np * Np * Mc / med(tt) * 1e-9);
     }
     return 0;
 }

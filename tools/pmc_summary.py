@@ -18,5 +18,5 @@ for k in sorted(acc, key=lambda k: -sum(sum(v) for v in acc[k].values())):
     for c, v in sorted(acc[k].items()):
         print(f"   {c:34s} n={len(v):5d} mean={sum(v)/len(v):.6g} sum={sum(v):.6g}")
 for (p, k), v in sorted(dur.items()):
-    if "var_gemm" in k or "kgen" in k or "chol" in k:
+    if "var_gemm" in k or "kgen" in k or "chol" in k or "oz_" in k:
         print(f"dur[{p}] {k}: n={len(v)} mean={sum(v)/len(v)/1e3:.1f} us")
