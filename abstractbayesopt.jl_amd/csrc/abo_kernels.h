@@ -50,6 +50,7 @@ struct OzPlan {
     int n;                       // number of moduli (2 … 16)
     int p[OZ_MAXMOD];            // 256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193
     double invp[OZ_MAXMOD];
+    double c26[OZ_MAXMOD];       // 2^26 mod p (symmetric): the quantiser reduces x = xh·2^26 + xl as xh·c26 + xl
     double s1[OZ_MAXMOD], s2[OZ_MAXMOD];   // (P/p)·((P/p)⁻¹ mod p) split into a 41-bit head on a common grid and the rest
     double P1, P2, invP;         // P = Π p split the same way; 1/P
     int eP;                      // 2^eP ≤ P/4: the bound every exact integer dot product is kept under
@@ -72,6 +73,7 @@ struct OzVarArgs {
     double* partial;       // [Np/128][ldp]
     int64_t ldp;
     int Np, Mc, nvalid, sK;
+    int planes_ready = 0;  // 1: KR / bad_col were written by the generator (KgenArgs::res), skip the quantisation pass
     hipEvent_t ev_quant = nullptr, ev_gemm = nullptr;   // optional: recorded after the quantisation / after the GEMM
 };
 hipError_t launch_var_ozaki(const OzVarArgs& a, hipStream_t s);
@@ -95,7 +97,17 @@ struct KgenArgs {
     int dlogell = 0;      // gradient-enhanced GP only: write dK/dlog(ell) instead of K (hyper-parameter gradient)
     int rvalid = 0;       // gradient-enhanced GP only: valid training rows when not N·pt (a partly appended point)
     double mean_vec[MAX_P] = {0};   // prior mean per output (gradConstMean)
+    // int8-residue engine: write the residue planes of the kernel values in the same pass (StandardGP, dp ≤ 32):
+    // res[l][j][k] = sym_residue(rint(K[j][k]·2^res_sK), p_l), res_bad[j] = 1 for a candidate with a non-finite kernel value
+    // (zeroed by the launcher); Kout may then be nullptr
+    int8_t* res = nullptr;
+    int64_t res_ld = 0, res_plane = 0;
+    int* res_bad = nullptr;
+    int res_n = 0, res_sK = 0;
+    double res_p[OZ_MAXMOD], res_invp[OZ_MAXMOD], res_c26[OZ_MAXMOD];
 };
+// true when launch_kgen honours KgenArgs::res for this shape
+inline bool kgen_writes_residues(const KgenArgs& a) { return a.pt == 1 && a.dp <= 32; }
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
 // NLML gradient reduction: Σ_ij (Kinv − ααᵀ)_ij ∂K_ij/∂log ℓ over the lower tiles, plus tr(Kinv), αᵀα, αᵀδ
 struct NlmlGradArgs {

@@ -1,0 +1,24 @@
+// device helpers shared by the quantisers of the int8-residue engine (ozaki.hip, and kgen.hip's fused residue output)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace abo {
+
+// symmetric residue of an integer-valued double |x| < 2^53 modulo p, from the split x = xh·2^26 + xl (|xh| ≤ 2^27, |xl| ≤ 2^25):
+// t = xh·(2^26 mod p) + xl is exact and below 2^35, so rint(t/p) is the exact nearest quotient (t/p is at least 1/(2p) away from
+// a half-integer for odd p, the fp64 product errs by < 1e-7) and r = t − q·p lies in [−(p−1)/2, (p−1)/2]; for p = 256 the low
+// byte of any representative is the residue.  Five fp64 operations per modulus, no range fix-ups.
+__device__ __forceinline__ int sym_residue(double xh, double xl, double c26, double invp, double pd) {
+    const double t = __builtin_fma(xh, c26, xl);
+    const double q = __builtin_rint(t * invp);
+    return (int)__builtin_fma(-q, pd, t);
+}
+
+// x = rint(v·sc) split into xh·2^26 + xl
+__device__ __forceinline__ void oz_split(double v, double sc, double& xh, double& xl) {
+    const double x = __builtin_rint(v * sc);
+    xh = __builtin_rint(x * 0x1p-26);
+    xl = __builtin_fma(-xh, 0x1p26, x);
+}
+
+}  // namespace abo

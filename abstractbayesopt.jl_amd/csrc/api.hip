@@ -609,6 +609,18 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
         ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = g->prm.mean_c;
+        // int8 engine: the generator writes the residue planes of the chunk itself (the fp64 K_XZ is then only materialised for a
+        // caller that keeps it — the resident K_ZX of a candidate set)
+        const bool fused = oz && kgen_writes_residues(ka) && !getenv("ABO_OZ_UNFUSED");
+        if (fused) {
+            const int64_t q = pad_up(Np, 256);
+            ka.res = g->oz_KR.as<int8_t>(); ka.res_ld = q; ka.res_plane = pad_up(mcp, 256) * q;
+            ka.res_bad = g->oz_badc.as<int>(); ka.res_n = g->oz_plan.n; ka.res_sK = oz_k_scale(g->prm.sigma_f2);
+            for (int l = 0; l < g->oz_plan.n; ++l) {
+                ka.res_p[l] = (double)g->oz_plan.p[l]; ka.res_invp[l] = g->oz_plan.invp[l]; ka.res_c26[l] = g->oz_plan.c26[l];
+            }
+            if (!kstore) ka.Kout = nullptr;
+        }
         HIPCHK(hipEventRecord(e[0], s));
         HIPCHK(launch_kgen(ka, s));
         HIPCHK(hipEventRecord(e[1], s));
@@ -618,7 +630,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
             oa.bad_col = g->oz_badc.as<int>(); oa.partial = g->partial.as<double>(); oa.ldp = Mc; oa.Np = (int)Np; oa.Mc = mcp;
             oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->prm.sigma_f2);
-            oa.ev_quant = e[6]; oa.ev_gemm = e[7];
+            oa.ev_quant = e[6]; oa.ev_gemm = e[7]; oa.planes_ready = fused ? 1 : 0;
             HIPCHK(hipEventRecord(e[2], s));
             HIPCHK(launch_var_ozaki(oa, s));
             HIPCHK(hipEventRecord(e[3], s));

@@ -22,6 +22,7 @@
 // K_XZ per chunk), oz_gemm_kernel (int8 NT GEMM, 256×256 tile per 8-wave workgroup, triangular k-range, epilogue = symmetric
 // mod + byte pack + LDS transpose), oz_crt_kernel (reconstruction + squares + per-row-block column sums).
 #include "abo_kernels.h"
+#include "abo_oz_dev.h"
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -69,6 +70,9 @@ bool oz_make_plan(int n, OzPlan* out) {
         pl.s1[l] = std::ldexp((double)(uint64_t)(s >> t), t);
         pl.s2[l] = u128_to_double(s - hi);
         pl.invp[l] = 1.0 / (double)pl.p[l];
+        int c26 = (int)((1u << 26) % (unsigned)pl.p[l]);
+        if (2 * c26 > pl.p[l]) c26 -= pl.p[l];
+        pl.c26[l] = (double)c26;                      // 2^26 mod p, symmetric
     }
     const u128 P1 = (P >> t) << t;
     pl.P1 = std::ldexp((double)(uint64_t)(P >> t), t);
@@ -80,19 +84,6 @@ bool oz_make_plan(int n, OzPlan* out) {
 }
 
 // ---- device helpers --------------------------------------------------------------------------------------------------------------
-// symmetric residue of an integer-valued double |x| < 2^53 modulo p (odd p: result in [−(p−1)/2, (p−1)/2]; p = 256: any
-// representative in [−130, 130], whose low byte is the residue)
-__device__ __forceinline__ int sym_residue(double x, double invp, double pd, int p) {
-    const double q = __builtin_rint(x * invp);        // off by one only when x/p is within 0.0104 of a half-integer
-    int r = (int)__builtin_fma(-q, pd, x);            // exact: |r| ≤ 0.5104·p
-    const int h = (p - 1) >> 1;
-    if (p & 1) {
-        r += (r < -h) ? p : 0;
-        r -= (r > h) ? p : 0;
-    }
-    return r;
-}
-
 // ---- row scales of W ---------------------------------------------------------------------------------------------------------------
 // one wave per row i < Np: L1 = Σ_{k≤i} |W[i][k]|, mx = max; s_i = min(eP − 53 − e(L1), 51 − e(mx)) with e(x) the frexp exponent
 // (x < 2^e), so that 2^s_i·L1·2^53 ≤ P/4 and |W'| < 2^52.  sexp[i] = s_i; rows ≥ Np (padding to 256) get 0.
@@ -149,7 +140,7 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
     const int cpr = a.cols_out >> 4;                   // 16-byte groups per output row
     const int r = (int)(gid / cpr), kc = (int)(gid % cpr) * 16;
     if (r >= a.rows_out) return;
-    double x[16];
+    double xh[16], xl[16];
     const bool live = r < a.rows_in && kc < a.cols_in && !(a.lower && kc > r);
     bool bad = false;
     if (live) {
@@ -160,7 +151,7 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
             const bool in = kc + q < a.cols_in && !(a.lower && kc + q > r);
             const double v = in ? src[q] : 0.0;
             bad = bad || !(__builtin_fabs(v) < 1.0e300);
-            x[q] = __builtin_rint(v * sc);
+            oz_split(v, sc, xh[q], xl[q]);
         }
     }
     if (bad && a.bad) a.bad[r] = 1;
@@ -168,11 +159,10 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
     for (int l = 0; l < a.pl.n; ++l) {
         v4i_t w = {0, 0, 0, 0};
         if (live) {
-            const double invp = a.pl.invp[l], pd = (double)a.pl.p[l];
-            const int p = a.pl.p[l];
+            const double invp = a.pl.invp[l], pd = (double)a.pl.p[l], c26 = a.pl.c26[l];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int rr = sym_residue(x[q], invp, pd, p) & 0xff;
+                const int rr = sym_residue(xh[q], xl[q], c26, invp, pd) & 0xff;
                 w[q >> 2] |= rr << (8 * (q & 3));
             }
         }
@@ -742,7 +732,6 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
 
 // ---- reconstruction + squares + column sums ------------------------------------------------------------------------------------------
 // partial[tb][j] = Σ_{i in row block tb (128 rows), i < nvalid} V[i][j]²,  V = CRT(U[·][i][j])·2^−(s_i + sK).
-// A thread owns four consecutive candidates (one dword of every residue plane per row).
 struct OzCrtArgs {
     const int8_t* U;
     int64_t ldu, sU;
@@ -757,44 +746,65 @@ struct OzCrtArgs {
     OzPlan pl;
 };
 
+// A workgroup = 4 waves × 64 lanes × 16 candidates over one 128-row block: each wave reconstructs 32 of the rows (one 16-byte load
+// per residue plane and row), the four partial column sums meet in LDS in a fixed order.
 __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
+    __shared__ double red[3][64][17];
     const int tb = blockIdx.y;
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (j >= a.Mc) return;
-    const int i0 = tb * 128;
-    int i1 = i0 + 128;
-    if (i1 > a.nvalid) i1 = a.nvalid;
-    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = (blockIdx.x * 64 + lane) * 16;
+    const bool live = j < a.Mc;                             // Mc is a multiple of 128: a thread's 16 candidates are all in or all out
+    double sum[16];
+#pragma unroll
+    for (int b = 0; b < 16; ++b) sum[b] = 0.0;
     bool bad = false;
     const int n = a.pl.n;
-    for (int i = i0; i < i1; ++i) {
-        const int8_t* u = a.U + (int64_t)i * a.ldu + j;
-        double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int l = 0; l < n; ++l) {
-            const int w = *reinterpret_cast<const int*>(u + (int64_t)l * a.sU);
-            const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+    const int i0 = tb * 128 + wave * 32;
+    int i1 = i0 + 32;
+    if (i1 > a.nvalid) i1 = a.nvalid;
+    if (live) {
+        for (int i = i0; i < i1; ++i) {
+            const int8_t* u = a.U + (int64_t)i * a.ldu + j;
+            double c1[16], c2[16];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const double ud = (double)((w << (24 - 8 * b)) >> 24);
-                c1[b] = __builtin_fma(ud, s1, c1[b]);
-                c2[b] = __builtin_fma(ud, s2, c2[b]);
+            for (int b = 0; b < 16; ++b) { c1[b] = 0.0; c2[b] = 0.0; }
+            for (int l = 0; l < n; ++l) {
+                const v4i_t w = *reinterpret_cast<const v4i_t*>(u + (int64_t)l * a.sU);
+                const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const double ud = (double)((w[b >> 2] << (24 - 8 * (b & 3))) >> 24);
+                    c1[b] = __builtin_fma(ud, s1, c1[b]);
+                    c2[b] = __builtin_fma(ud, s2, c2[b]);
+                }
+            }
+            const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
+            if (a.bad_row && a.bad_row[i]) bad = true;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
+                const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
+                const double v = cp * sc;
+                sum[b] = __builtin_fma(v, v, sum[b]);
             }
         }
-        const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
-        if (a.bad_row && a.bad_row[i]) bad = true;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
-            const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
-            const double v = cp * sc;
-            sum[b] = __builtin_fma(v, v, sum[b]);
-        }
     }
-    const double nan = __builtin_nan("");
+    if (bad) sum[0] = __builtin_nan("");                    // a non-finite W row poisons the whole block of rows, as it does in fp64
+    if (wave > 0) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const bool bb = bad || (a.bad_col && a.bad_col[j + b]);
-        a.partial[(int64_t)tb * a.ldp + j + b] = bb ? nan : sum[b];
+        for (int b = 0; b < 16; ++b) red[wave - 1][lane][b] = sum[b];
+    }
+    __syncthreads();
+    if (wave == 0 && live) {
+        const bool anybad = sum[0] != sum[0] || red[0][lane][0] != red[0][lane][0] || red[1][lane][0] != red[1][lane][0] ||
+                            red[2][lane][0] != red[2][lane][0];
+        const double nan = __builtin_nan("");
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const double t = ((sum[b] + red[0][lane][b]) + red[1][lane][b]) + red[2][lane][b];
+            const bool bb = anybad || (a.bad_col && a.bad_col[j + b]);
+            a.partial[(int64_t)tb * a.ldp + j + b] = bb ? nan : t;
+        }
     }
 }
 
@@ -825,13 +835,15 @@ int oz_k_scale(double kmax) {
 hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     const OzPlan& pl = *v.plan;
     const int Np256 = (int)pad_up(v.Np, OZ_T), Mc256 = (int)pad_up(v.Mc, OZ_T);
-    hipError_t e = hipMemsetAsync(v.bad_col, 0, sizeof(int) * Mc256, s);
-    if (e != hipSuccess) return e;
-    OzQuantArgs q{};
-    q.in = v.Kxz; q.ldin = v.ldk; q.rows_in = v.Mc; q.cols_in = v.Np; q.rows_out = Mc256; q.cols_out = Np256; q.lower = 0;
-    q.srow = nullptr; q.sconst = v.sK; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
-    const int64_t threads = (int64_t)Mc256 * (Np256 / 16);
-    hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
+    hipError_t e = hipSuccess;
+    if (!v.planes_ready && (e = hipMemsetAsync(v.bad_col, 0, sizeof(int) * Mc256, s)) != hipSuccess) return e;
+    if (!v.planes_ready) {       // the generator did not write the residue planes itself (d > 32, or a caller-made K_XZ)
+        OzQuantArgs q{};
+        q.in = v.Kxz; q.ldin = v.ldk; q.rows_in = v.Mc; q.cols_in = v.Np; q.rows_out = Mc256; q.cols_out = Np256; q.lower = 0;
+        q.srow = nullptr; q.sconst = v.sK; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
+        const int64_t threads = (int64_t)Mc256 * (Np256 / 16);
+        hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
+    }
     if (v.ev_quant && (e = hipEventRecord(v.ev_quant, s)) != hipSuccess) return e;
 
     OzGemmArgs g{};
@@ -853,7 +865,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     OzCrtArgs c{};
     c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
     c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
-    hipLaunchKernelGGL(oz_crt_kernel, dim3((v.Mc / 4 + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
+    hipLaunchKernelGGL(oz_crt_kernel, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
     return hipGetLastError();
 }
 

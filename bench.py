@@ -30,6 +30,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak: 256 CU × 4 SIMD × 2048 flop / 64 clk × 2.4 GHz
+# MI355X dense int8 matrix peak: 256 CU × 4 SIMD × 1024 MAC/clk × 2 × 2.4 GHz (MI355X_MICROARCH.md: I8 = 2 × BF16 per clock,
+# BF16 ≈ 2.5 PFLOP/s dense).  On random operands the chip holds 1.7 – 2.1 GHz under this load: tools/mfma_i8_power_probe.hip
+# sustains 3.1 (32×32×32) / 3.4 POP/s (16×16×64) from registers — quoted beside the peak, never instead of it.
+PEAK_INT8_MFMA_TOPS = 5033.0
+SUSTAINED_INT8_MFMA_TOPS = 3409.0
                                # (v_mfma_f64_16x16x4_f64 measured at 64 clk/SIMD: profiles/r01_mfma_f64_probe.txt)
 
 CONFIGS = {
@@ -141,7 +146,7 @@ def source_sha(names):
     return h.hexdigest()[:16]
 
 
-PMC_SOURCES = {"c3": ["gemm.hip"], "c5": ["misc.hip"]}      # the translation unit of each config's dominant kernel
+PMC_SOURCES = {"c3": ["gemm.hip"], "c3_int8": ["ozaki.hip"], "c5": ["misc.hip"]}      # the translation unit of each config's dominant kernel
 
 
 def pmc_traffic(config, mc_per_launch):
@@ -150,7 +155,7 @@ def pmc_traffic(config, mc_per_launch):
     FETCH_SIZE) — PMC counters cannot be read from inside this process, so the figure is the per-candidate
     traffic of that pass scaled to this run's candidates per launch.  The pass records the hash of the kernel's
     source file; when the file has changed since, the figure is STALE and `traffic` is reported as null."""
-    key = "c3" if config == "c4" else config                 # C4 = C3 per launch
+    key = config.replace("c4", "c3")                         # C4 = C3 per launch
     for tag in ("r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc_traffic.json")
         if os.path.exists(path):
@@ -371,6 +376,8 @@ def main():
                     help="drive --gpus N devices from THIS process through the library's multi-device handle (abo_mgpu_*, "
                          "RCCL all-gather inside the library) instead of one process per GPU under torchrun")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
+    ap.add_argument("--contraction", default=None,
+                    help="engine of the N^2*M variance contraction: auto (library default), fp64, int8 or int8:<moduli>")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
@@ -427,7 +434,8 @@ def main():
     X, y = synth.standardized_problem(N, d, 0.03)
     Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
     Zd = torch.from_numpy(synth.points(2, hi - lo, d, first=lo)).to(dev)
-    gp = abo.HipStandardGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, device=local_rank, chunk=args.chunk)
+    gp = abo.HipStandardGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, device=local_rank, chunk=args.chunk,
+                           contraction=args.contraction)
     best_y = float(y.min())
     acq = abo.ExpectedImprovement(p0, best_y) if acq_name == "ei" else abo.UpperConfidenceBound(p0)
     K_TOP = 100
@@ -481,6 +489,23 @@ def main():
         torch.cuda.synchronize(dev)
         variants = {"topk_only_ms": ms_per_step, "scores_to_host_ms": (time.perf_counter() - t1) * 1e3 / 2,
                     "scores_bytes_d2h": 8 * M_per}
+        # the same step on the library's other contraction engine (two untimed-for-`value` steps), and how far the two
+        # engines' selections and scores are apart on this very workload
+        used = int(phases[0]["contraction_engine"])
+        other = "fp64" if used == abo._lib.CONTRACT_INT8 else "int8"
+        gp2 = abo.HipStandardGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, device=local_rank,
+                                chunk=args.chunk, contraction=other)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(2):
+            m2 = abo.update(gp2, Xd, yd)
+            _, tv2, ti2 = abo.evaluate(acq, m2, Zd, k=K_TOP, idx_base=lo, return_scores=False)
+        torch.cuda.synchronize(dev)
+        variants[f"{other}_engine_ms"] = (time.perf_counter() - t2) * 1e3 / 2
+        host = lambda v: v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        variants["engines_top100_same_indices"] = bool(np.array_equal(host(ti2), host(top[1])))
+        variants["engines_top100_max_abs_score_diff"] = float(np.max(np.abs(host(tv2) - host(top[0]))))
+        del m2, gp2
 
     if rank == 0:
         med = {k: float(np.median([p[k] for p in phases])) for k in phases[0]}
@@ -488,7 +513,52 @@ def main():
         flop = med["var_gemm_flop"]                       # N²·M_per (triangular credit), all launches of one step
         t_kernel_ms = med["acq_var_gemm_ms"]
         achieved = flop / (t_kernel_ms * 1e-3) / 1e12 if t_kernel_ms > 0 else 0.0
-        traffic, pmc = pmc_traffic(args.config, M_per / max(launches, 1))
+        int8 = int(med["contraction_engine"]) == abo._lib.CONTRACT_INT8
+        traffic, pmc = pmc_traffic(args.config + ("_int8" if int8 else ""), M_per / max(launches, 1))
+        mc = M_per / max(launches, 1)
+        if int8:
+            # dominant kernel = the residue GEMM (one launch per chunk covers all moduli): int8 operations actually issued
+            # (n moduli × 2·256²·Σ(ti+1)·256 per 256-candidate block, diagonal blocks in full) ÷ its HIP-event duration
+            nmod = int(med["oz_nmod"])
+            tops = med["oz_gemm_ops"] / (med["oz_gemm_ms"] * 1e-3) / 1e12 if med["oz_gemm_ms"] > 0 else 0.0
+            np256 = -(-N // 256) * 256
+            roofline = {
+                "kernel": f"oz_gemm16d_kernel (V = L^-1 K_XZ as {nmod} exact int8 residue GEMMs, v_mfma_i32_16x16x64_i8, "
+                          "triangular k-range, symmetric-mod epilogue)",
+                "bound": "mfma", "achieved": tops, "peak": PEAK_INT8_MFMA_TOPS, "unit": "TOP/s", "frac": tops / PEAK_INT8_MFMA_TOPS,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
+                "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
+                # residue planes read once + U written once: n·(Np²/2 + Mc·Np) + n·Np·Mc bytes
+                "algorithmic_bytes_per_launch": float(nmod) * (np256 * np256 / 2 + 2 * mc * np256),
+                "ops_per_launch": med["oz_gemm_ops"] / max(launches, 1), "launches_per_step": launches,
+                "avg_launch_ms": med["oz_gemm_ms"] / max(launches, 1),
+                "sustained_peak_random_operands": SUSTAINED_INT8_MFMA_TOPS,
+                "frac_of_sustained": tops / SUSTAINED_INT8_MFMA_TOPS,
+                "engine": {"name": "int8-residue (ABO_CONTRACT_INT8)", "moduli": nmod,
+                           "pipeline_ms_per_chunk": {"quantise_K_XZ": med["oz_quant_ms"] / max(launches, 1),
+                                                     "residue_gemm": med["oz_gemm_ms"] / max(launches, 1),
+                                                     "reconstruct_and_square": med["oz_crt_ms"] / max(launches, 1)},
+                           "residue_planes_of_W_ms": med["oz_prepare_ms"],
+                           "fp64_equivalent_tflops": achieved, "fp64_equivalent_over_fp64_mfma_peak": achieved / PEAK_FP64_MFMA_TFLOPS},
+                "note": "achieved = int8 operations of the residue GEMM launches / their HIP-event duration (library stream, median "
+                        "over timed steps); peak = dense int8 MFMA at 2.4 GHz; sustained_peak = the same instruction on random "
+                        "operands from registers, clock as the chip holds it (profiles/r02_mfma_i8_power_probe.txt); "
+                        "fp64_equivalent = N^2*M / time of the whole contraction pipeline",
+            }
+        else:
+            roofline = {
+                "kernel": "var_gemm256s_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
+                "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
+                "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + mc * N + (N / 128) * mc),
+                "flop_per_launch": flop / max(launches, 1), "launches_per_step": launches,
+                "avg_launch_ms": t_kernel_ms / max(launches, 1),
+                "note": "algorithmic flop = N^2*M (triangular credit, SURVEY 8(d)); duration = HIP events on the "
+                        "library stream around each launch, median over timed steps",
+            }
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -498,20 +568,11 @@ def main():
                                    f"N={N} train, M={M_per} candidates per GPU ({M_total} total), "
                                    f"{acq_name.upper()} p0={p0}, top-{K_TOP}, full refit every step",
                        "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "kernel": fam_name, "acq": acq_name,
-                       "sharding": f"candidates x{world}, all_gather top-{K_TOP}"},
+                       "sharding": f"candidates x{world}, all_gather top-{K_TOP}",
+                       "contraction": (f"int8-residue, {int(med['oz_nmod'])} moduli (exact products of 52/53-bit fixed-point images "
+                                       "of the fp64 operands; results fp64)") if int8 else "fp64 MFMA"},
             "candidates_per_s": M_total / (ms_per_step * 1e-3),
-            "roofline": {
-                "kernel": "var_gemm256s_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
-                "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
-                "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + (M_per / max(launches, 1)) * N + (N / 128) * (M_per / max(launches, 1))),
-                "flop_per_launch": flop / max(launches, 1), "launches_per_step": launches,
-                "avg_launch_ms": t_kernel_ms / max(launches, 1),
-                "note": "algorithmic flop = N^2*M (triangular credit, SURVEY 8(d)); duration = HIP events on the "
-                        "library stream around each launch, median over timed steps",
-            },
+            "roofline": roofline,
             "phases_ms": {k: v for k, v in med.items() if k.endswith("_ms")},
             "top1": {"score": float(top[0][0]), "index": int(top[1][0])},
             "hip_event_ms_per_step": med["fit_total_ms"] + med["acq_total_ms"],
