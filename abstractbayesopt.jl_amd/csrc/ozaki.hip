@@ -595,20 +595,25 @@ constexpr int OZ_SLOT = 2 * OZ_T * OZ_HS;       // 32 768 bytes: A tile + B tile
 typedef __attribute__((address_space(3))) void* oz_lds_ptr;
 
 struct OzDmaCtx {
-    const int8_t* ab; const int8_t* bb;         // tile bases (uniform)
-    unsigned ao[2], bo[2];                      // per-lane source offsets of the wave's two pieces per operand
+    const int8_t* ab; const int8_t* bb;         // the wave's first piece of each operand (uniform)
+    int64_t astep, bstep;                       // 128 rows further down each operand: the wave's second piece (uniform)
+    unsigned ao, bo;                            // per-lane source offset inside a piece's 16 rows: (L/4)·ld + 16·chunk
     int wave;
 };
 
 template <int SLOT>
 __device__ __forceinline__ void oz_dma_issue(char* lds, const OzDmaCtx& c, int h) {
+#ifdef OZ_EXP_SAMEK
+    const int k = 0 * h;
+#else
     const int k = h * OZ_HS;
+#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         char* da = lds + SLOT * OZ_SLOT + (c.wave + 8 * q) * 1024;
         char* db = da + OZ_T * OZ_HS;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.ab + k + c.ao[q]), (oz_lds_ptr)da, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.bb + k + c.bo[q]), (oz_lds_ptr)db, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.ab + k + q * c.astep + c.ao), (oz_lds_ptr)da, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.bb + k + q * c.bstep + c.bo), (oz_lds_ptr)db, 16, 0, 0);
     }
 }
 
@@ -626,7 +631,9 @@ __device__ __forceinline__ void oz16d_read_b(const char* p, int half, OzFragB& f
 template <int SLOT>
 __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, int hmax, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
                                            OzFragB& By, v4i_t (&acc)[4][8]) {
+#ifndef OZ_EXP_NODMA
     oz_dma_issue<(SLOT + 3) & 3>(lds, c, h + 3 < hmax ? h + 3 : hmax);
+#endif
     const char* slot = lds + SLOT * OZ_SLOT;
     oz16d_read_a(slot + ra, A[SLOT & 1]);
     oz16d_read_b(slot + rb, 0, Bx);
@@ -640,9 +647,13 @@ __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, 
     for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
     OZ_SGB(0x008, 12);
     __builtin_amdgcn_sched_barrier(0);
+#if !defined(OZ_EXP_NOVMWAIT) && !defined(OZ_EXP_NODMA)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef OZ_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -657,13 +668,14 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
     c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
     c.wave = __builtin_amdgcn_readfirstlane(wave);
     {
+        // piece P = wave + 8q covers rows 16P … 16P+15; lane L fills row 16P + L/4, position L%4 with chunk (L%4) ^ ((row>>1)&3)
         const int chunk = (lane & 3) ^ ((lane >> 3) & 3);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int row = 16 * (wave + 8 * q) + (lane >> 2);
-            c.ao[q] = (unsigned)(row * (int)a.ldk + 16 * chunk);
-            c.bo[q] = (unsigned)(row * (int)a.ldw + 16 * chunk);
-        }
+        c.ab += (int64_t)(16 * c.wave) * a.ldk;
+        c.bb += (int64_t)(16 * c.wave) * a.ldw;
+        c.astep = 128 * a.ldk;
+        c.bstep = 128 * a.ldw;
+        c.ao = (unsigned)((lane >> 2) * (int)a.ldk + 16 * chunk);
+        c.bo = (unsigned)((lane >> 2) * (int)a.ldw + 16 * chunk);
     }
     const int nh = 4 * (ti + 1);                     // half-stages of this tile
 
@@ -729,6 +741,7 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
         dst[1] = hi;
     }
 }
+
 
 // ---- reconstruction + squares + column sums ------------------------------------------------------------------------------------------
 // partial[tb][j] = Σ_{i in row block tb (128 rows), i < nvalid} V[i][j]²,  V = CRT(U[·][i][j])·2^−(s_i + sK).
