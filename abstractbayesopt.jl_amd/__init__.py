@@ -19,7 +19,7 @@ from . import surrogate as _s
 from .surrogate import (AbstractSurrogate, HipStandardGP, _get_minimum, _update_model_parameters,
                         get_factor, get_kernel_constructor, get_lengthscale, get_mean_std, get_scale, mean_and_var,
                         nlml, nlml_fitted, nlml_ls, posterior_mean, posterior_var, prep_input, prep_output,
-                        rescale_model, std_y, training_data, unstandardized_mean_and_var)
+                        rescale_model, set_default_contraction, std_y, training_data, unstandardized_mean_and_var)
 
 StandardGP = HipStandardGP   # drop-in aliases
 GradientGP = HipGradientGP

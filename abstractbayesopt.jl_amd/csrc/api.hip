@@ -258,6 +258,7 @@ struct abo_gp {
     OzPlan oz_plan{};
     uint64_t oz_gen = 0;
     int64_t oz_N = -1;
+    int64_t last_chunk = 0;          // candidates per chunk of the last posterior call (its events are read back with it)
     DevBuf oz_WR, oz_sexp, oz_badr, oz_KR, oz_U, oz_badc;
     abo_timings tm{};
 
@@ -532,9 +533,26 @@ double grad_prior_var(const abo_gp* g) {
 constexpr size_t EV_BASE = 10;        // 0-4 fit phases, 5-7 acquisition call, 8-9 residue planes of W
 constexpr size_t EV_PER_CHUNK = 8;   // kgen 0-1, contraction 2-3, epilogue 4-5, int8 pipeline: end of quantisation 6, end of GEMM 7
 
-int64_t pick_chunk(const abo_gp* g, int64_t M) {
+// which engine runs the contraction of a posterior call on this handle (int8 = true), and with how many moduli
+bool wants_int8(const abo_gp* g, bool want_var, int pc, int* nmod) {
+    if (!want_var || pc != 1 || g->p_out != 1) return false;
+    int eng = g->oz_engine, nm = g->oz_nmod, de, dn;
+    oz_defaults(&de, &dn);
+    if (eng == ABO_CONTRACT_AUTO) eng = de;
+    if (!nm) nm = dn;
+    *nmod = nm;
+    return eng == ABO_CONTRACT_INT8 || (eng == ABO_CONTRACT_AUTO && g->Np >= OZ_AUTO_MIN_NP);
+}
+
+int64_t pick_chunk(const abo_gp* g, int64_t M, bool int8) {
     int64_t mc = g->prm.chunk;
-    if (mc <= 0) {
+    if (mc <= 0 && int8) {
+        // int8 engine: 28 bytes of residue planes and residue products per (candidate, training point); measured at N = 8192:
+        // 8192 candidates per chunk 597 ms, 16384 572, 32768 565, 65536 560 per C3 step — 32768 (7.5 GB of scratch) taken
+        mc = ((int64_t)1 << 31) / (g->Np * (int64_t)sizeof(double));
+        if (mc < 2048) mc = 2048;
+        if (mc > 65536) mc = 65536;
+    } else if (mc <= 0) {
         // ~1 GiB of K_XZ per chunk (measured at N = 8192, tools/chunk_sweep.sh: 2048 candidates per chunk 1072 ms,
         // 4096 1011, 8192 997, 16384 992-995, 32768 998, 65536 996 — small chunks pay launch tails in every kernel,
         // larger ones lose a little L2/MALL reuse of the candidate panels), at least 2048 and at most 65536 candidates
@@ -559,21 +577,24 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     hipStream_t s = g->stream;
     const int64_t Np = g->Np;
     const int T = (int)(Np / TB);
-    const int64_t Mc = pick_chunk(g, M);
-    if (!kstore) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
+    const bool want_var = var_out || score_out;
+    int nm = 0;
+    bool oz = wants_int8(g, want_var, pc, &nm);
+    const int64_t Mc = pick_chunk(g, M, oz);
+    g->last_chunk = Mc;
+    {
+        KgenArgs probe{};
+        probe.pt = g->p_out; probe.dp = g->dp;
+        // the fp64 chunk of K_XZ is not materialised when the generator writes the residue planes itself
+        if (!kstore && !(oz && kgen_writes_residues(probe) && !getenv("ABO_OZ_UNFUSED"))) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
+    }
     HIPCHK(g->partial.ensure(sizeof(double) * T * Mc));
     HIPCHK(g->mu_c.ensure(sizeof(double) * Mc));
     const int64_t nchunk = (M + Mc - 1) / Mc;
     HIPCHK(g->events(EV_BASE + EV_PER_CHUNK * (size_t)nchunk));
     g->tm.var_gemm_launches = 0;
     // engine of the contraction: the int8-residue pipeline for a StandardGP large enough to fill the chip with 256×256 tiles
-    const bool want_var = var_out || score_out;
-    bool oz = false;
-    if (want_var && pc == 1 && g->p_out == 1) {
-        int eng = g->oz_engine, nm = g->oz_nmod;
-        if (eng == ABO_CONTRACT_AUTO) { int de, dn; oz_defaults(&de, &dn); eng = de; if (!nm) nm = dn; }
-        if (!nm) { int de, dn; oz_defaults(&de, &dn); nm = dn; }
-        oz = eng == ABO_CONTRACT_INT8 || (eng == ABO_CONTRACT_AUTO && Np >= OZ_AUTO_MIN_NP);
+    {
         if (oz) {
             if (g->oz_plan.n != nm && !oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
             if (g->oz_gen != g->st->gen || g->oz_N != g->N) {      // residue planes of this view's W, once per model
@@ -659,7 +680,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
 }
 
 void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
-    const int64_t Mc = pick_chunk(g, M);
+    const int64_t Mc = g->last_chunk;
     const int64_t nchunk = (M + Mc - 1) / Mc;
     double kx = 0, vg = 0, fi = 0, oq = 0, og = 0, oc = 0;
     const bool oz = with_var && g->tm.contraction_engine == ABO_CONTRACT_INT8;

@@ -58,6 +58,14 @@ function HipStandardGP(kernel::Kernel, noise_var; mean=nothing, devices=[0], jit
     s = StandardGP(kernel, noise_var; mean=mean)           # reuse the normal-form logic (StandardGP.jl:41-64)
     HipStandardGP(s.gp, noise_var, nothing, Int32.(devices), Float64(jitter), Int64(n_max))
 end
+# Engine of the N²·M variance contraction behind posterior_var (include/abo_hip.h: abo_set_contraction), process-wide for the
+# handles created from now on — :auto (int8-residue engine from 2048 training points, fp64 MFMA below), :fp64 or :int8;
+# `moduli` = 8 … 16 (0 = 14).  The environment variable ABO_CONTRACTION = auto | fp64 | int8 | int8:<moduli> seeds the same default.
+function set_contraction!(engine::Symbol=:auto; moduli::Integer=0)
+    e = Dict(:auto => Int32(0), :fp64 => Int32(1), :int8 => Int32(2))[engine]
+    _check(@ccall LIBABO.abo_set_contraction(C_NULL::Ptr{Cvoid}, e::Int32, Int32(moduli)::Int32)::Int32)
+end
+
 _with(m::HipStandardGP, gpx) = HipStandardGP(m.gp, m.noise_var, gpx, m.devices, m.jitter, m.n_max)
 _multi(m::HipStandardGP) = length(m.devices) > 1
 

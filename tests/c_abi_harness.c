@@ -205,6 +205,34 @@ int main(int argc, char** argv) {
     CHECK(same, "acq: top-%d differs from the oracle's sortperm(scores; rev=true)[1:%d]", K, K);
     printf("ok acq (N=%lld d=%d M=%lld top-%d, max|dscore| %.2e)\n", (long long)N, d, (long long)M, K, maxabs(s, sc_e->v, M));
 
+    /* --- the int8-residue contraction engine from this host: same scores (to fp64 rounding), same selection --------- */
+    {
+        abo_gp* g8 = NULL;
+        ok_or_die(abo_create(&p, &g8), "abo_create (int8 engine)");
+        ok_or_die(abo_set_contraction(g8, ABO_CONTRACT_INT8, 0), "abo_set_contraction");
+        CHECK(abo_set_contraction(g8, 7, 0) == ABO_EINVAL && abo_set_contraction(g8, ABO_CONTRACT_INT8, 3) == ABO_EINVAL,
+              "abo_set_contraction accepts an unknown engine / moduli count");
+        ok_or_die(abo_fit(g8, X->v, N, d, y->v, ABO_HOST, &info), "abo_fit (int8 engine)");
+        double* s8 = (double*)malloc(sizeof(double) * M);
+        double* tv8 = (double*)malloc(sizeof(double) * K);
+        int64_t* ti8 = (int64_t*)malloc(sizeof(int64_t) * K);
+        ok_or_die(abo_acq(g8, Z->v, M, d, ABO_HOST, (int32_t)a[0], a[1], a[2], 0, s8, K, tv8, ti8, ABO_HOST), "abo_acq (int8 engine)");
+        abo_timings tm;
+        ok_or_die(abo_get_timings(g8, &tm), "abo_get_timings");
+        CHECK(tm.contraction_engine == ABO_CONTRACT_INT8 && tm.oz_nmod == 14, "int8 engine: timings say engine %lld, %lld moduli",
+              (long long)tm.contraction_engine, (long long)tm.oz_nmod);
+        ok_or_die(abo_get_timings(g, &tm), "abo_get_timings");
+        CHECK(tm.contraction_engine == ABO_CONTRACT_FP64, "N = %lld ran on engine %lld by default", (long long)N, (long long)tm.contraction_engine);
+        CHECK(maxabs(s8, sc_e->v, M) <= 1e-10, "int8 engine: scores off the oracle by %.3e", maxabs(s8, sc_e->v, M));
+        CHECK(maxabs(s8, s, M) <= 1e-12, "int8 engine: scores off the fp64 engine by %.3e", maxabs(s8, s, M));
+        int same8 = 1;
+        for (int e = 0; e < K; ++e) same8 = same8 && ti8[e] == (int64_t)idx_e->v[e];
+        CHECK(same8, "int8 engine: top-%d differs from the oracle's", K);
+        printf("ok int8-residue contraction engine (max|dscore| vs oracle %.2e, vs fp64 engine %.2e)\n", maxabs(s8, sc_e->v, M), maxabs(s8, s, M));
+        free(s8); free(tv8); free(ti8);
+        ok_or_die(abo_destroy(g8), "abo_destroy (int8 engine)");
+    }
+
     /* --- copy = shared reference; append leaves the parent untouched (rollback); refit equals append ------------ */
     ok_or_die(abo_retain(g), "abo_retain");
     ok_or_die(abo_destroy(g), "abo_destroy (one of two references)");

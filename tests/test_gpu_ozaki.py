@@ -156,3 +156,29 @@ def test_auto_engine_switches_on_size():
     assert small.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
     with pytest.raises(ValueError):
         make_model(O.SE, 1.0, 1.0, 1e-3, contraction="fp32")
+
+
+def test_sharded_handle_on_the_int8_engine_equals_the_single_handle():
+    """the multi-device handle creates its shards inside the library: they take the process default engine, and — exact integer
+    products — scores and selection equal the single handle's bit for bit however the candidates are cut"""
+    from tests.test_gpu_multigpu import sharded
+    d, N, M = 4, 500, 3001
+    X, y = synth.standardized_problem(N, d)
+    Z = synth.points(2, M, d)
+    abo.set_default_contraction("int8")
+    try:
+        one = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3), X, y)
+        grp = abo.update(sharded(O.MATERN52, 0.8, 1.0, 1e-3, (0, 0, 0)), X, y)
+        acq = abo.ExpectedImprovement(0.01, float(y.min()))
+        s1, tv1, ti1 = abo.evaluate(acq, one, Z, k=64)
+        s2, tv2, ti2 = abo.evaluate(acq, grp, Z, k=64)
+        assert one.timings()["contraction_engine"] == abo._lib.CONTRACT_INT8
+    finally:
+        abo.set_default_contraction("auto")
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(tv1, tv2)
+    np.testing.assert_array_equal(ti1, ti2)
+    ref = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="fp64"), X, y)
+    s0, _, ti0 = abo.evaluate(acq, ref, Z, k=64)
+    np.testing.assert_allclose(s1, s0, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(ti1, ti0)

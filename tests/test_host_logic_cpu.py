@@ -210,7 +210,7 @@ def test_committed_bench_lines_keep_the_driver_contract():
         assert j["value"] == j["ms_per_step"] and j["value"] > 0
         assert isinstance(j["config"]["workload"], str) and "model" not in j["config"]
         r = j["roofline"]
-        assert r["bound"] == bound and r["unit"] in ("GB/s", "TFLOP/s") and 0 < r["frac"] <= 1
+        assert r["bound"] == bound and r["unit"] in ("GB/s", "TFLOP/s", "TOP/s") and 0 < r["frac"] <= 1
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     j = json.load(open(os.path.join(root, "profiles", "r02_bench_default.json")))
     c = j["cpu_baseline"]

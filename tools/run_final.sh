@@ -8,9 +8,13 @@ timeout -k 10 300 python __graft_entry__.py smoke > gpurun_out/final_smoke.txt 2
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/final_pytest_gpu.txt 2>&1 || { tail -30 gpurun_out/final_pytest_gpu.txt; exit 1; }
 tail -1 gpurun_out/final_pytest_gpu.txt
 timeout -k 10 900 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --contraction fp64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c3_fp64_engine.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c2 --steps 30 --warmup 5 --cpu-sample-m 65536 --cpu-reps 3 > gpurun_out/final_bench_c2.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c5 --steps 5 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 echo "bench done"
+rm -rf gpurun_out/prof_${TAG}_c3fp64
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c3fp64 -- python3 bench.py --config c3 --contraction fp64 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_prof_c3fp64.log 2>&1 || { tail -5 gpurun_out/bench_prof_c3fp64.log; exit 1; }
+cp $(find gpurun_out/prof_${TAG}_c3fp64 -name "*kernel_stats.csv" | head -1) gpurun_out/final_kernel_stats_c3_fp64_engine.csv
 for cfg in c3 c2 c5; do
   rm -rf gpurun_out/prof_${TAG}_$cfg
   steps=5; [ $cfg = c2 ] && steps=30
@@ -19,9 +23,15 @@ for cfg in c3 c2 c5; do
   grep '^{' gpurun_out/bench_prof_$cfg.log > gpurun_out/final_bench_under_rocprof_$cfg.json || true
 done
 echo "kernel traces done"
-bash tools/run_pmc.sh ${TAG}f c3 > gpurun_out/final_pmc_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_run.log; exit 1; }
+bash tools/run_pmc_int8.sh ${TAG}i > gpurun_out/final_pmc_int8_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_int8_run.log; exit 1; }
+cp gpurun_out/pmc_${TAG}i_summary.txt gpurun_out/final_pmc_int8_summary.txt
+MC=$(python3 -c "import json; d=json.load(open('gpurun_out/final_bench_default.json')); print(int(d['config']['M_per_gpu'] // d['roofline']['launches_per_step']))")
+python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_int8_summary.txt 8192 $MC int8 14 > gpurun_out/final_c3_int8_pmc_traffic.json
+echo "pmc c3 int8 done"
+ABO_CONTRACTION=fp64 bash tools/run_pmc.sh ${TAG}f c3 > gpurun_out/final_pmc_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_run.log; exit 1; }
 cp gpurun_out/pmc_${TAG}f_summary.txt gpurun_out/final_pmc_summary.txt
 python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_summary.txt 8192 16384 > gpurun_out/final_c3_pmc_traffic.json
-echo "pmc c3 done"
+echo "pmc c3 fp64 done"
+timeout -k 10 120 tools/mfma_i8_power_probe > gpurun_out/final_mfma_i8_power_probe.txt 2>&1 || true
 bash tools/run_pmc_c5.sh > gpurun_out/final_pmc_c5.log 2>&1 || { tail -5 gpurun_out/final_pmc_c5.log; exit 1; }
 echo "pmc c5 done"
