@@ -626,27 +626,81 @@ __device__ __forceinline__ void oz16d_read_b(const char* p, int half, OzFragB& f
     for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(p + (16 * (4 * half + nn)) * OZ_HS);
 }
 
+// one DMA piece: q = 0/1 the wave's first / second 16-row group, op = 0 candidates (A), 1 W rows (B)
+template <int SLOT>
+__device__ __forceinline__ void oz_dma_piece(char* lds, const OzDmaCtx& c, int k, int q, int op) {
+    char* d = lds + SLOT * OZ_SLOT + op * (OZ_T * OZ_HS) + (c.wave + 8 * q) * 1024;
+    const int8_t* g = op ? c.bb + k + q * c.bstep + c.bo : c.ab + k + q * c.astep + c.ao;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (oz_lds_ptr)d, 16, 0, 0);
+}
+
+__device__ __forceinline__ void oz16_mma_row(const OzFragA& fa, const OzFragB& fb, int half, int m, v4i_t (&acc)[4][8]) {
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn)
+        acc[m][4 * half + nn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.a[m], fb.b[nn], acc[m][4 * half + nn], 0, 0, 0);
+}
+
+#define OZ_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // every step issues (past the end of the tile: a harmless re-fetch of the last half-stage into a slot nobody reads any more), so
-// the in-flight count is the same in every iteration and one loop body serves the whole tile
+// the in-flight count is the same in every iteration and one loop body serves the whole tile.  The step is cut into groups of
+// four MFMAs with the memory instructions dealt out between them (scheduling fences pin the order): four DMA pieces back to back
+// hold the wave's issue for several hundred cycles with both waves of the SIMD at the same point of their streams.
 template <int SLOT>
 __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, int hmax, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
                                            OzFragB& By, v4i_t (&acc)[4][8]) {
-#ifndef OZ_EXP_NODMA
-    oz_dma_issue<(SLOT + 3) & 3>(lds, c, h + 3 < hmax ? h + 3 : hmax);
-#endif
     const char* slot = lds + SLOT * OZ_SLOT;
-    oz16d_read_a(slot + ra, A[SLOT & 1]);
-    oz16d_read_b(slot + rb, 0, Bx);
-    oz16_mma(A[(SLOT & 1) ^ 1], By, 1, acc);
-    oz16d_read_b(slot + rb, 1, By);
-    oz16_mma(A[SLOT & 1], Bx, 0, acc);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
-    OZ_SGB(0x008, 8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
-    OZ_SGB(0x008, 12);
-    __builtin_amdgcn_sched_barrier(0);
+    const char* pa = slot + ra;
+    const char* pb = slot + rb;
+    OzFragA& An = A[SLOT & 1];
+    const OzFragA& Ao = A[(SLOT & 1) ^ 1];
+#ifdef OZ_EXP_SAMEK
+    const int k = 0;
+#else
+    const int k = (h + 3 < hmax ? h + 3 : hmax) * OZ_HS;
+#endif
+    constexpr int NS = (SLOT + 3) & 3;
+    // the previous half-stage's held-back unit (Ao × By, columns 4-7) with this half-stage's A and B0-3 fragments arriving
+    An.a[0] = *reinterpret_cast<const v4i_t*>(pa);
+    An.a[1] = *reinterpret_cast<const v4i_t*>(pa + 16 * OZ_HS);
+    oz16_mma_row(Ao, By, 1, 0, acc);
+    OZ_FENCE();
+    An.a[2] = *reinterpret_cast<const v4i_t*>(pa + 32 * OZ_HS);
+    An.a[3] = *reinterpret_cast<const v4i_t*>(pa + 48 * OZ_HS);
+    oz16_mma_row(Ao, By, 1, 1, acc);
+    OZ_FENCE();
+#ifndef OZ_EXP_NODMA
+    oz_dma_piece<NS>(lds, c, k, 0, 0);
+#endif
+    Bx.b[0] = *reinterpret_cast<const v4i_t*>(pb);
+    Bx.b[1] = *reinterpret_cast<const v4i_t*>(pb + 16 * OZ_HS);
+    oz16_mma_row(Ao, By, 1, 2, acc);
+    OZ_FENCE();
+#ifndef OZ_EXP_NODMA
+    oz_dma_piece<NS>(lds, c, k, 0, 1);
+#endif
+    Bx.b[2] = *reinterpret_cast<const v4i_t*>(pb + 32 * OZ_HS);
+    Bx.b[3] = *reinterpret_cast<const v4i_t*>(pb + 48 * OZ_HS);
+    oz16_mma_row(Ao, By, 1, 3, acc);
+    OZ_FENCE();
+    // this half-stage's first unit (An × Bx, columns 0-3) with the B4-7 fragments arriving
+#ifndef OZ_EXP_NODMA
+    oz_dma_piece<NS>(lds, c, k, 1, 0);
+#endif
+    By.b[0] = *reinterpret_cast<const v4i_t*>(pb + 64 * OZ_HS);
+    By.b[1] = *reinterpret_cast<const v4i_t*>(pb + 80 * OZ_HS);
+    oz16_mma_row(An, Bx, 0, 0, acc);
+    OZ_FENCE();
+#ifndef OZ_EXP_NODMA
+    oz_dma_piece<NS>(lds, c, k, 1, 1);
+#endif
+    By.b[2] = *reinterpret_cast<const v4i_t*>(pb + 96 * OZ_HS);
+    By.b[3] = *reinterpret_cast<const v4i_t*>(pb + 112 * OZ_HS);
+    oz16_mma_row(An, Bx, 0, 1, acc);
+    OZ_FENCE();
+    oz16_mma_row(An, Bx, 0, 2, acc);
+    oz16_mma_row(An, Bx, 0, 3, acc);
+    OZ_FENCE();
 #if !defined(OZ_EXP_NOVMWAIT) && !defined(OZ_EXP_NODMA)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #endif
@@ -654,7 +708,7 @@ __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, 
 #ifndef OZ_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
-    __builtin_amdgcn_sched_barrier(0);
+    OZ_FENCE();
 }
 
 __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
@@ -720,9 +774,13 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
             int w = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
+#ifdef OZ_EXP_NOEPI
+                const int r = acc[m][nn][b];
+#else
                 const double x = (double)acc[m][nn][b];
                 const double q = __builtin_rint(x * invp);
                 const int r = (int)__builtin_fma(-q, pd, x);
+#endif
                 w |= (r & 0xff) << (8 * b);
             }
             const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);

@@ -182,3 +182,27 @@ def test_sharded_handle_on_the_int8_engine_equals_the_single_handle():
     s0, _, ti0 = abo.evaluate(acq, ref, Z, k=64)
     np.testing.assert_allclose(s1, s0, rtol=0, atol=1e-12)
     np.testing.assert_array_equal(ti1, ti0)
+
+
+@pytest.mark.parametrize("sf2,noise,ell", [(37.5, 1e-2, 0.8), (3e-4, 1e-9, 0.8), (1.0, 1e-10, 1.5), (1e6, 1.0, 0.6)])
+def test_int8_engine_scales_and_conditioning(sf2, noise, ell):
+    """kernel scales far from 1 (the fixed-point image of K_XZ is scaled by σ_f², that of W by its row norms) and a factor whose
+    inverse has entries of 1e4 and more (SE kernel, noise 1e-10·σ_f²): the int8 engine stays at the fp64 engine's error level
+    against the oracle — both lose the digits the conditioning takes, neither more than the other"""
+    N, d, M = 700, 3, 1500
+    X = synth.points(1, N, d)
+    Z = synth.points(2, M, d) * 1.1 - 0.05
+    y = synth.objective(X, 0.05) * np.sqrt(sf2)
+    st = O.fit(O.SE, ell, sf2, noise, 0.0, X, y)
+    _, var_o = O.predict(st, Z)
+    m64, m8 = _fit_pair(O.SE, ell, sf2, noise, X, y)
+    var64 = abo.posterior_var(m64, Z)
+    var8 = abo.posterior_var(m8, Z)
+    e64 = np.max(np.abs(var64 - var_o)) / sf2
+    e8 = np.max(np.abs(var8 - var_o)) / sf2
+    case = f"int8/scale_sf2_{sf2:g}_noise_{noise:g}"
+    check(case, "var", e8, 1e-6)
+    check(case, "var_fp64_engine", e64, 1e-6)
+    assert e8 <= 4 * e64 + 1e-13, (e8, e64)
+    _, linv = abo.get_factor(m8)[0], abo.get_factor(m8)[2]
+    check(case, "log10_max_abs_Linv", float(np.log10(np.max(np.abs(linv)) * np.sqrt(sf2))), 12.0)
