@@ -4,6 +4,20 @@
 
 namespace abo {
 
+// the moduli (the first n of them for an n-modulus plan: pairwise coprime, descending from 256) and the per-modulus constants
+// of the quantiser as compile-time tables — the generator's fused residue output unrolls over them (oz_make_plan checks that its
+// own search yields the same sequence)
+constexpr int oz_mod_p(int l) {
+    constexpr int P[16] = {256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193};
+    return P[l];
+}
+constexpr double oz_mod_c26(int l) {      // 2^26 mod p, symmetric
+    const int p = oz_mod_p(l);
+    int c = (int)((1u << 26) % (unsigned)p);
+    if (2 * c > p) c -= p;
+    return (double)c;
+}
+
 // symmetric residue of an integer-valued double |x| < 2^53 modulo p, from the split x = xh·2^26 + xl (|xh| ≤ 2^27, |xl| ≤ 2^25):
 // t = xh·(2^26 mod p) + xl is exact and below 2^35, so rint(t/p) is the exact nearest quotient (t/p is at least 1/(2p) away from
 // a half-integer for odd p, the fp64 product errs by < 1e-7) and r = t − q·p lies in [−(p−1)/2, (p−1)/2]; for p = 256 the low

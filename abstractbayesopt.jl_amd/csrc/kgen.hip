@@ -439,10 +439,12 @@ hipError_t launch_kappa_test(int family, const double* d2, double* out, int64_t 
 }
 
 // the 16 candidate rows of a workgroup against this lane's two training points
-template <int FAM, int DP, bool FULL, bool RES>
+// RES: 0 = no residue output; −1 = residue planes for a run-time number of moduli (rolled loop, constants from the kernel
+// arguments); n > 0 = exactly n moduli, unrolled over the compile-time tables of abo_oz_dev.h (the default plan, n = 14)
+template <int FAM, int DP, bool FULL, int RES>
 __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[DP], const double (&x0)[DP], const double (&x1)[DP],
                                           double s0, double s1, double a0, double a1, int jb, int k, double (&mu)[JT]) {
-    const double rsc = RES ? __builtin_ldexp(1.0, p.res_sK) : 0.0;
+    const double rsc = RES != 0 ? __builtin_ldexp(1.0, p.res_sK) : 0.0;
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
         // rows past the last candidate are written as zeros (K_XX relies on it for its identity padding; for K_XZ
@@ -465,24 +467,34 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
             v1 = s1 * kappa_eval<FAM>(r1);
         }
         if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
-        if constexpr (RES) {
+        if constexpr (RES != 0) {
             // the int8-residue engine's image of the pair: two bytes per modulus (a wave writes one 128-byte line per row and plane)
             if (!(__builtin_fabs(v0) < 1.0e300) || !(__builtin_fabs(v1) < 1.0e300)) p.res_bad[jb + jj] = 1;
             double h0, l0, h1, l1;
             oz_split(v0, rsc, h0, l0);
             oz_split(v1, rsc, h1, l1);
-            int8_t* rp = p.res + (int64_t)(jb + jj) * p.res_ld + k;
-            for (int l = 0; l < p.res_n; ++l) {
-                const double c26 = p.res_c26[l], invp = p.res_invp[l], pd = p.res_p[l];
-                const int r0 = sym_residue(h0, l0, c26, invp, pd), r1 = sym_residue(h1, l1, c26, invp, pd);
-                *reinterpret_cast<short*>(rp + (int64_t)l * p.res_plane) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
+            const unsigned voff = (unsigned)((jb + jj) * (int)p.res_ld + k);        // < 2^31: a chunk's plane is at most 65536 × 32768 B
+            if constexpr (RES > 0) {
+#pragma unroll
+                for (int l = 0; l < RES; ++l) {
+                    const double pd = (double)oz_mod_p(l), invp = 1.0 / (double)oz_mod_p(l), c26 = oz_mod_c26(l);
+                    const int r0 = sym_residue(h0, l0, c26, invp, pd), r1 = sym_residue(h1, l1, c26, invp, pd);
+                    int8_t* plane = p.res + (int64_t)l * p.res_plane;                 // uniform
+                    *reinterpret_cast<short*>(plane + voff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
+                }
+            } else {
+                for (int l = 0; l < p.res_n; ++l) {
+                    const double c26 = p.res_c26[l], invp = p.res_invp[l], pd = p.res_p[l];
+                    const int r0 = sym_residue(h0, l0, c26, invp, pd), r1 = sym_residue(h1, l1, c26, invp, pd);
+                    *reinterpret_cast<short*>(p.res + (int64_t)l * p.res_plane + voff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
+                }
             }
         }
         mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
     }
 }
 
-template <int FAM, int DP, bool RES>
+template <int FAM, int DP, int RES>
 __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
     __shared__ double zs[JT][DP];
     __shared__ double red[4][JT];
@@ -632,24 +644,36 @@ static hipError_t launch_fam(const KgenArgs& a, hipStream_t s) {
     if (a.res) {
         hipError_t e = hipMemsetAsync(a.res_bad, 0, sizeof(int) * a.Mc, s);
         if (e != hipSuccess) return e;
+        if (a.res_n == 14) {
+            switch (a.dp) {
+                case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1, 14>), grid, block, 0, s, a); break;
+                case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2, 14>), grid, block, 0, s, a); break;
+                case 4: hipLaunchKernelGGL((kgen_kernel<FAM, 4, 14>), grid, block, 0, s, a); break;
+                case 8: hipLaunchKernelGGL((kgen_kernel<FAM, 8, 14>), grid, block, 0, s, a); break;
+                case 16: hipLaunchKernelGGL((kgen_kernel<FAM, 16, 14>), grid, block, 0, s, a); break;
+                case 32: hipLaunchKernelGGL((kgen_kernel<FAM, 32, 14>), grid, block, 0, s, a); break;
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
         switch (a.dp) {
-            case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1, true>), grid, block, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2, true>), grid, block, 0, s, a); break;
-            case 4: hipLaunchKernelGGL((kgen_kernel<FAM, 4, true>), grid, block, 0, s, a); break;
-            case 8: hipLaunchKernelGGL((kgen_kernel<FAM, 8, true>), grid, block, 0, s, a); break;
-            case 16: hipLaunchKernelGGL((kgen_kernel<FAM, 16, true>), grid, block, 0, s, a); break;
-            case 32: hipLaunchKernelGGL((kgen_kernel<FAM, 32, true>), grid, block, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1, -1>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2, -1>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((kgen_kernel<FAM, 4, -1>), grid, block, 0, s, a); break;
+            case 8: hipLaunchKernelGGL((kgen_kernel<FAM, 8, -1>), grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((kgen_kernel<FAM, 16, -1>), grid, block, 0, s, a); break;
+            case 32: hipLaunchKernelGGL((kgen_kernel<FAM, 32, -1>), grid, block, 0, s, a); break;
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     switch (a.dp) {
-        case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1, false>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2, false>), grid, block, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((kgen_kernel<FAM, 4, false>), grid, block, 0, s, a); break;
-        case 8: hipLaunchKernelGGL((kgen_kernel<FAM, 8, false>), grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((kgen_kernel<FAM, 16, false>), grid, block, 0, s, a); break;
-        case 32: hipLaunchKernelGGL((kgen_kernel<FAM, 32, false>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((kgen_kernel<FAM, 1, 0>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((kgen_kernel<FAM, 2, 0>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((kgen_kernel<FAM, 4, 0>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((kgen_kernel<FAM, 8, 0>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((kgen_kernel<FAM, 16, 0>), grid, block, 0, s, a); break;
+        case 32: hipLaunchKernelGGL((kgen_kernel<FAM, 32, 0>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -57,6 +57,8 @@ bool oz_make_plan(int n, OzPlan* out) {
         if (ok) pl.p[m++] = c;
         --c;
     }
+    for (int l = 0; l < n; ++l)
+        if (pl.p[l] != oz_mod_p(l)) return false;     // the compile-time table of abo_oz_dev.h is this very sequence
     u128 P = 1;
     for (int l = 0; l < n; ++l) P *= (u128)pl.p[l];   // < 2^125.4 for n = 16
     const int t = bitlen(P) - 41;                     // grid of the high parts: 41 significant bits
