@@ -12,7 +12,7 @@ HOST, DEVICE = 0, 1
 EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_append_grad", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_data", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
-           "abo_test_gemm_nt", "abo_test_kappa",
+           "abo_test_gemm_nt", "abo_test_kappa", "abo_test_oz_plan", "abo_test_oz_contract",
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
@@ -111,6 +111,8 @@ def lib():
     L.abo_abi_version.argtypes = []
     L.abo_pool_trim.argtypes = [i32]
     L.abo_test_kappa.argtypes = [i32, i32, vp, vp, i64]
+    L.abo_test_oz_plan.argtypes = [i32, vp, vp, vp, vp]
+    L.abo_test_oz_contract.argtypes = [i32, vp, i64, i32, i32, vp, i64, i32, f64, i32, vp, i64]
     L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
     L.abo_mgpu_create.argtypes = [C.POINTER(AboParams), i32, C.POINTER(i32), C.POINTER(vp)]
     L.abo_mgpu_clone.argtypes = [vp, C.POINTER(vp)]

@@ -47,7 +47,7 @@ hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s);
 // residues modulo n coprime moduli ≤ 256, Chinese-remainder reconstruction in fp64
 constexpr int OZ_MAXMOD = 16;
 struct OzPlan {
-    int n;                       // number of moduli (2 … 16)
+    int n;                       // number of moduli (8 … 16)
     int p[OZ_MAXMOD];            // 256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193
     double invp[OZ_MAXMOD];
     double c26[OZ_MAXMOD];       // 2^26 mod p (symmetric): the quantiser reduces x = xh·2^26 + xl as xh·c26 + xl

@@ -1722,6 +1722,47 @@ int32_t abo_score(int32_t device, const double* mu, const double* var, int64_t M
     return ABO_OK;
 }
 
+int32_t abo_test_oz_plan(int32_t n, int32_t* p, double* tables, double* scal, int32_t* eP) {
+    if (!p || !tables || !scal || !eP) return fail(ABO_EINVAL, "abo_test_oz_plan: null argument");
+    OzPlan pl;
+    if (!oz_make_plan(n, &pl)) return fail(ABO_EINVAL, "abo_test_oz_plan: %d moduli not supported (8 … %d)", n, OZ_MAXMOD);
+    for (int l = 0; l < n; ++l) {
+        p[l] = pl.p[l];
+        tables[0 * OZ_MAXMOD + l] = pl.invp[l];
+        tables[1 * OZ_MAXMOD + l] = pl.c26[l];
+        tables[2 * OZ_MAXMOD + l] = pl.s1[l];
+        tables[3 * OZ_MAXMOD + l] = pl.s2[l];
+    }
+    scal[0] = pl.P1; scal[1] = pl.P2; scal[2] = pl.invP;
+    *eP = pl.eP;
+    return ABO_OK;
+}
+
+int32_t abo_test_oz_contract(int32_t device, const double* W, int64_t ldw, int32_t Np, int32_t nvalid, const double* Kxz, int64_t ldk,
+                             int32_t Mc, double kmax, int32_t nmod, double* partial, int64_t ldp) {
+    if (!W || !Kxz || !partial) return fail(ABO_EINVAL, "abo_test_oz_contract: null argument");
+    if (Np <= 0 || Np % TB || Mc <= 0 || Mc % TB || nvalid < 0 || nvalid > Np || ldw < Np || ldk < Np || ldp < Mc || !(kmax > 0.0))
+        return fail(ABO_EINVAL, "abo_test_oz_contract: Np and Mc multiples of 128, nvalid <= Np, leading dimensions >= Np / Mc, kmax > 0");
+    OzPlan pl;
+    if (!oz_make_plan(nmod, &pl)) return fail(ABO_EINVAL, "abo_test_oz_contract: %d moduli not supported", nmod);
+    HIPCHK(hipSetDevice(device));
+    const int64_t q = pad_up(Np, 256), mq = pad_up(Mc, 256);
+    ScratchBuf wr(device, nullptr), kr(device, nullptr), u(device, nullptr), ints(device, nullptr);
+    HIPCHK(wr.b.ensure(oz_w_bytes(nmod, Np)));
+    HIPCHK(kr.b.ensure(oz_k_bytes(nmod, Np, Mc)));
+    HIPCHK(u.b.ensure(oz_k_bytes(nmod, Np, Mc)));
+    HIPCHK(ints.b.ensure(sizeof(int) * (2 * q + mq)));
+    int* sexp = ints.b.as<int>();
+    HIPCHK(oz_prepare_w(pl, W, ldw, Np, nvalid, wr.b.as<int8_t>(), sexp, sexp + q, nullptr));
+    OzVarArgs oa{};
+    oa.plan = &pl; oa.Kxz = Kxz; oa.ldk = ldk; oa.WR = wr.b.as<int8_t>(); oa.sexp = sexp; oa.bad_row = sexp + q;
+    oa.KR = kr.b.as<int8_t>(); oa.U = u.b.as<int8_t>(); oa.bad_col = sexp + 2 * q; oa.partial = partial; oa.ldp = ldp;
+    oa.Np = Np; oa.Mc = Mc; oa.nvalid = nvalid; oa.sK = oz_k_scale(kmax);
+    HIPCHK(launch_var_ozaki(oa, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ABO_OK;
+}
+
 int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n) {
     if (!d2 || !out || n < 0) return fail(ABO_EINVAL, "abo_test_kappa: bad argument");
     if (family < ABO_KERNEL_SE || family > ABO_KERNEL_MATERN32) return fail(ABO_EINVAL, "abo_test_kappa: unknown family");

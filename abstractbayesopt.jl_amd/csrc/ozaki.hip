@@ -47,7 +47,7 @@ double u128_to_double(u128 x) {          // correctly rounded for x < 2^64·2^53
 }  // namespace
 
 bool oz_make_plan(int n, OzPlan* out) {
-    if (n < 2 || n > OZ_MAXMOD) return false;
+    if (n < 8 || n > OZ_MAXMOD) return false;       // below 8 moduli P has fewer than the 41 bits the split heads take
     OzPlan pl{};
     pl.n = n;
     int c = 256, m = 0;

@@ -321,6 +321,14 @@ int32_t abo_abi_version(void);
 /* --- building blocks exposed for tests and profiling (all buffers DEVICE memory) ------------------
  * C[i][j] = alpha·Σ_k A[i][k]·B[j][k] + beta·C[i][j]; M, N multiples of 128, K multiple of 16,
  * leading dimensions even.  Exercises the fp64 MFMA tile core every solver stage is built on. */
+/* The int8-residue engine's host constants for n moduli (no GPU needed): p[16] moduli, tables[4][16] = {1/p, 2^26 mod p
+ * (symmetric), head and tail of (P/p)·((P/p)⁻¹ mod p)}, scal[3] = {head of P, tail of P, 1/P}, *eP with 2^eP ≤ P/4. */
+int32_t abo_test_oz_plan(int32_t n, int32_t* p, double* tables, double* scal, int32_t* eP);
+/* partial[tb][j] = Σ_{i in 128-row block tb, i < nvalid} (Σ_{k ≤ i} W[i][k]·Kxz[j][k])² through the int8-residue engine's own
+ * quantisers, GEMM and reconstruction, for ANY lower-triangular W [Np][ldw] and any Kxz [Mc][ldk] with |Kxz| ≤ kmax (device
+ * buffers; Np, Mc multiples of 128; partial [Np/128][ldp]). */
+int32_t abo_test_oz_contract(int32_t device, const double* W, int64_t ldw, int32_t Np, int32_t nvalid, const double* Kxz, int64_t ldk,
+                             int32_t Mc, double kmax, int32_t nmod, double* partial, int64_t ldp);
 /* out[i] = kappa(family, d2[i]) evaluated with the device math of the kernel-matrix generator */
 int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n);
 int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M,

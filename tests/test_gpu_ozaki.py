@@ -206,3 +206,38 @@ def test_int8_engine_scales_and_conditioning(sf2, noise, ell):
     assert e8 <= 4 * e64 + 1e-13, (e8, e64)
     _, linv = abo.get_factor(m8)[0], abo.get_factor(m8)[2]
     check(case, "log10_max_abs_Linv", float(np.log10(np.max(np.abs(linv)) * np.sqrt(sf2))), 12.0)
+
+
+@pytest.mark.parametrize("Np,Mc,nvalid,n", [(128, 128, 100, 14), (640, 384, 600, 14), (1280, 896, 1280, 12), (384, 256, 384, 16)])
+def test_engine_on_arbitrary_operands_against_its_cpu_restatement(Np, Mc, nvalid, n):
+    """the quantisers, the residue GEMM and the reconstruction on operands that are NOT a GP's: a lower-triangular W with rows of
+    very different norms and entries over twelve orders of magnitude, K_XZ of both signs — against oracle/ozaki_oracle.py (same
+    fixed-point images, products in exact integer arithmetic) and against a long-double product of the fp64 operands"""
+    import torch
+    from oracle import ozaki_oracle as Zo
+    rng = np.random.default_rng(Np + Mc)
+    W = np.tril(rng.standard_normal((Np, Np)) * 10.0 ** rng.uniform(-6, 6, (Np, 1)) * 10.0 ** rng.uniform(-3, 0, (Np, Np)))
+    W[nvalid:] = 0.0
+    W[:, nvalid:] = 0.0
+    W[np.arange(nvalid, Np), np.arange(nvalid, Np)] = 1.0          # identity padding, as the library keeps it
+    kmax = 3.7
+    K = rng.uniform(-kmax, kmax, (Mc, Np)) * (rng.random((Mc, Np)) < 0.7)
+    K[:, nvalid:] = 0.0
+    Wd, Kd = torch.from_numpy(W).cuda(), torch.from_numpy(K).cuda()
+    part = torch.full((Np // 128, Mc), -1.0, dtype=torch.float64).cuda()
+    torch.cuda.synchronize()
+    abo._lib.check(abo._lib.lib().abo_test_oz_contract(0, Wd.data_ptr(), Np, Np, nvalid, Kd.data_ptr(), Np, Mc, kmax, n,
+                                                       part.data_ptr(), Mc))
+    got = part.cpu().numpy()
+    V, _ = Zo.contract(W[:nvalid, :nvalid], K[:, :nvalid].T.copy(), kmax, n)
+    Vp = np.zeros((Np, Mc))
+    Vp[:nvalid] = V
+    want = (Vp.reshape(Np // 128, 128, Mc) ** 2).sum(1)
+    scale = np.maximum(want, 1e-300)
+    assert np.max(np.abs(got - want) / scale) < 1e-13          # same images, exact products: only the order of the 128 squares differs
+    Vld = W[:nvalid, :nvalid].astype(np.longdouble) @ K[:, :nvalid].T.astype(np.longdouble)
+    wld = np.zeros((Np, Mc), dtype=np.longdouble)
+    wld[:nvalid] = Vld
+    wld = (wld.reshape(Np // 128, 128, Mc) ** 2).sum(1)
+    err = float(np.max(np.abs(got - wld) / np.maximum(wld, 1e-300)))
+    check(f"int8/arbitrary_Np{Np}_n{n}", "sumsq_rel_vs_long_double", err, {12: 1e-7, 14: 1e-11, 16: 1e-11}[n])
