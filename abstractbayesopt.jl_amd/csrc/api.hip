@@ -541,6 +541,9 @@ bool wants_int8(const abo_gp* g, bool want_var, int pc, int* nmod) {
     if (eng == ABO_CONTRACT_AUTO) eng = de;
     if (!nm) nm = dn;
     *nmod = nm;
+    // int32 accumulation of the residue GEMMs is exact for k·2^14 < 2^31: beyond 65536 padded training points the engine is not
+    // offered (the fp64 kernels take over, whatever was asked for)
+    if (g->Np > 65536) return false;
     return eng == ABO_CONTRACT_INT8 || (eng == ABO_CONTRACT_AUTO && g->Np >= OZ_AUTO_MIN_NP);
 }
 
@@ -548,8 +551,9 @@ int64_t pick_chunk(const abo_gp* g, int64_t M, bool int8) {
     int64_t mc = g->prm.chunk;
     if (mc <= 0 && int8) {
         // int8 engine: 28 bytes of residue planes and residue products per (candidate, training point); measured at N = 8192:
-        // 8192 candidates per chunk 597 ms, 16384 572, 32768 565, 65536 560 per C3 step — 32768 (7.5 GB of scratch) taken
-        mc = ((int64_t)1 << 31) / (g->Np * (int64_t)sizeof(double));
+        // 8192 candidates per chunk 597 ms, 16384 572, 32768 565, 65536 560 per C3 step — 65536 at N = 8192 (15 GB of scratch of the
+        // 288), 32768 at N = 16384
+        mc = ((int64_t)1 << 32) / (g->Np * (int64_t)sizeof(double));
         if (mc < 2048) mc = 2048;
         if (mc > 65536) mc = 65536;
     } else if (mc <= 0) {
@@ -561,6 +565,10 @@ int64_t pick_chunk(const abo_gp* g, int64_t M, bool int8) {
         if (mc > 65536) mc = 65536;
     }
     mc = pad_up(mc, TB);
+    if (int8) {        // byte offsets inside one residue plane of a chunk stay below 2^31 (32-bit lane offsets in the generator and the DMA)
+        const int64_t cap = (((int64_t)1 << 31) / pad_up(g->Np, 256)) / 256 * 256 - 256;
+        if (mc > cap) mc = cap;
+    }
     const int64_t mp = pad_up(M, TB);
     return mc < mp ? mc : mp;
 }
