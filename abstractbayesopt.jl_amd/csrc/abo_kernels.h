@@ -61,7 +61,8 @@ size_t oz_k_bytes(int n, int Np, int Mc);    // residue planes of a candidate ch
 int oz_k_scale(double kmax);                 // sK with rint(K·2^sK) < 2^53 for 0 ≤ K ≤ kmax
 // W (lower-triangular, [Np][ldw]) → WR [n][Np256][Np256] int8, sexp[Np256] (row scales s_i), bad_row[Np256] (non-finite rows)
 // rows ≥ nvalid (identity padding, or the remains of a discarded appended branch) become zero planes
-hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s);
+hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s,
+                        int kper = 1, int ktg = 0);
 struct OzVarArgs {
     const OzPlan* plan;
     const double* Kxz;     // [Mc][ldk] candidate-major chunk (fp64, as launch_var_gemm takes it)
@@ -73,6 +74,7 @@ struct OzVarArgs {
     double* partial;       // [Np/128][ldp]
     int64_t ldp;
     int Np, Mc, nvalid, sK;
+    int kper = 1, ktg = 0; // gradient-enhanced model: training rows k with k % kper != 0 are scaled by 2^−ktg in the chunk's image
     int planes_ready = 0;  // 1: KR / bad_col were written by the generator (KgenArgs::res), skip the quantisation pass
     hipEvent_t ev_quant = nullptr, ev_gemm = nullptr;   // optional: recorded after the quantisation / after the GEMM
 };

@@ -533,9 +533,15 @@ double grad_prior_var(const abo_gp* g) {
 constexpr size_t EV_BASE = 10;        // 0-4 fit phases, 5-7 acquisition call, 8-9 residue planes of W
 constexpr size_t EV_PER_CHUNK = 8;   // kgen 0-1, contraction 2-3, epilogue 4-5, int8 pipeline: end of quantisation 6, end of GEMM 7
 
+// exponent of the row scaling of a gradient-enhanced model's derivative outputs: 2^t ≈ √(prior variance of a derivative output / σ_f²)
+int oz_grad_exp(const abo_gp* g) {
+    if (g->p_out <= 1) return 0;
+    return (int)std::lrint(0.5 * std::log2(grad_prior_var(g) / g->prm.sigma_f2));
+}
+
 // which engine runs the contraction of a posterior call on this handle (int8 = true), and with how many moduli
 bool wants_int8(const abo_gp* g, bool want_var, int pc, int* nmod) {
-    if (!want_var || pc != 1 || g->p_out != 1) return false;
+    if (!want_var || pc != 1) return false;         // all outputs of a gradient-enhanced model's candidates (pc > 1): fp64 kernels
     int eng = g->oz_engine, nm = g->oz_nmod, de, dn;
     oz_defaults(&de, &dn);
     if (eng == ABO_CONTRACT_AUTO) eng = de;
@@ -612,7 +618,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
                 HIPCHK(g->oz_badr.ensure(sizeof(int) * q));
                 HIPCHK(hipEventRecord(g->evs()[8], s));
                 HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
-                                    g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s));
+                                    g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
                 HIPCHK(hipEventRecord(g->evs()[9], s));
                 g->oz_gen = g->st->gen; g->oz_N = g->N;
                 g->tm.oz_prepare_ms = -1.0;                        // collected with the posterior timings
@@ -658,7 +664,9 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             oa.plan = &g->oz_plan; oa.Kxz = kchunk; oa.ldk = ldk; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
             oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
             oa.bad_col = g->oz_badc.as<int>(); oa.partial = g->partial.as<double>(); oa.ldp = Mc; oa.Np = (int)Np; oa.Mc = mcp;
-            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->prm.sigma_f2);
+            // a gradient-enhanced model's scaled chunk is bounded by σ_f²·√2 (oz_prepare_w), a StandardGP's by σ_f²
+            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->p_out > 1 ? 1.5 * g->prm.sigma_f2 : g->prm.sigma_f2);
+            oa.kper = g->p_out; oa.ktg = oz_grad_exp(g);
             oa.ev_quant = e[6]; oa.ev_gemm = e[7]; oa.planes_ready = fused ? 1 : 0;
             HIPCHK(hipEventRecord(e[2], s));
             HIPCHK(launch_var_ozaki(oa, s));

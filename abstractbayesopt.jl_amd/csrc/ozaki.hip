@@ -89,15 +89,18 @@ bool oz_make_plan(int n, OzPlan* out) {
 // ---- row scales of W ---------------------------------------------------------------------------------------------------------------
 // one wave per row i < Np: L1 = Σ_{k≤i} |W[i][k]|, mx = max; s_i = min(eP − 53 − e(L1), 51 − e(mx)) with e(x) the frexp exponent
 // (x < 2^e), so that 2^s_i·L1·2^53 ≤ P/4 and |W'| < 2^52.  sexp[i] = s_i; rows ≥ Np (padding to 256) get 0.
+// kper / ktg: columns k with k % kper != 0 carry an extra factor 2^ktg (the gradient outputs of a gradient-enhanced model, see
+// oz_prepare_w); kper = 1 → none.
 __global__ void __launch_bounds__(256) oz_rowscale_kernel(const double* __restrict__ W, int64_t ldw, int Np, int Np256, int eP,
-                                                          int* __restrict__ sexp) {
+                                                          int* __restrict__ sexp, int kper, int ktg) {
+    const double cw = __builtin_ldexp(1.0, ktg);
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= Np256) return;
     double l1 = 0.0, mx = 0.0;
     if (row < Np) {
         const double* w = W + (int64_t)row * ldw;
         for (int k = lane; k <= row; k += 64) {
-            const double a = __builtin_fabs(w[k]);
+            const double a = __builtin_fabs(w[k]) * ((kper > 1 && k % kper) ? cw : 1.0);
             l1 += a;
             mx = a > mx ? a : mx;
         }
@@ -131,6 +134,7 @@ struct OzQuantArgs {
     int lower;                 // 1: entries with k > r are zero (W = L⁻¹; the stored zeros are not even read)
     const int* srow;
     int sconst;
+    int kper, ktg;             // columns k with k % kper != 0 get 2^ktg on top (kper ≤ 1: none)
     int8_t* out;
     int64_t ld, plane;
     int* bad;                  // [rows_out] or nullptr
@@ -147,13 +151,14 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
     bool bad = false;
     if (live) {
         const double sc = __builtin_ldexp(1.0, a.srow ? a.srow[r] : a.sconst);
+        const double cw = __builtin_ldexp(1.0, a.ktg);
         const double* src = a.in + (int64_t)r * a.ldin + kc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const bool in = kc + q < a.cols_in && !(a.lower && kc + q > r);
             const double v = in ? src[q] : 0.0;
             bad = bad || !(__builtin_fabs(v) < 1.0e300);
-            oz_split(v, sc, xh[q], xl[q]);
+            oz_split(v, (a.kper > 1 && (kc + q) % a.kper) ? sc * cw : sc, xh[q], xl[q]);
         }
     }
     if (bad && a.bad) a.bad[r] = 1;
@@ -896,14 +901,19 @@ __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
 size_t oz_w_bytes(int n, int Np) { const int64_t q = pad_up(Np, OZ_T); return (size_t)n * q * q; }
 size_t oz_k_bytes(int n, int Np, int Mc) { return (size_t)n * pad_up(Mc, OZ_T) * pad_up(Np, OZ_T); }
 
-hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s) {
+// Gradient-enhanced models (kper = outputs per point, rows point-major: k % kper = 0 is the function value, the rest its partial
+// derivatives): the derivative rows of K_XZ are larger than the function rows by about √c/ℓ, so the product is taken as
+// (W·D⁻¹)(D·K_XZ) with D = diag(1 on function rows, 2^−ktg on derivative rows), 2^ktg ≈ √c/ℓ — exact scalings that make every entry
+// of D·K_XZ at most ≈ σ_f²√2 (Cauchy–Schwarz on the prior covariance), so that one fixed-point scale serves the whole chunk.
+hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s,
+                        int kper, int ktg) {
     const int Np256 = (int)pad_up(Np, OZ_T);
     hipError_t e = hipMemsetAsync(bad_row, 0, sizeof(int) * Np256, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(oz_rowscale_kernel, dim3((Np256 + 3) / 4), dim3(256), 0, s, W, ldw, nvalid, Np256, pl.eP, sexp);
+    hipLaunchKernelGGL(oz_rowscale_kernel, dim3((Np256 + 3) / 4), dim3(256), 0, s, W, ldw, nvalid, Np256, pl.eP, sexp, kper, ktg);
     OzQuantArgs q{};
     q.in = W; q.ldin = ldw; q.rows_in = nvalid; q.cols_in = Np; q.rows_out = Np256; q.cols_out = Np256; q.lower = 1;
-    q.srow = sexp; q.sconst = 0; q.out = WR; q.ld = Np256; q.plane = (int64_t)Np256 * Np256; q.bad = bad_row; q.pl = pl;
+    q.srow = sexp; q.sconst = 0; q.kper = kper; q.ktg = ktg; q.out = WR; q.ld = Np256; q.plane = (int64_t)Np256 * Np256; q.bad = bad_row; q.pl = pl;
     const int64_t threads = (int64_t)Np256 * (Np256 / 16);
     hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
     return hipGetLastError();
@@ -924,7 +934,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     if (!v.planes_ready) {       // the generator did not write the residue planes itself (d > 32, or a caller-made K_XZ)
         OzQuantArgs q{};
         q.in = v.Kxz; q.ldin = v.ldk; q.rows_in = v.Mc; q.cols_in = v.Np; q.rows_out = Mc256; q.cols_out = Np256; q.lower = 0;
-        q.srow = nullptr; q.sconst = v.sK; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
+        q.srow = nullptr; q.sconst = v.sK; q.kper = v.kper; q.ktg = -v.ktg; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
         const int64_t threads = (int64_t)Mc256 * (Np256 / 16);
         hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
     }

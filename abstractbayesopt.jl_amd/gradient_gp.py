@@ -36,8 +36,9 @@ class HipGradientGP(HipStandardGP):
     """GradientGP(kernel, p, noise_var; mean=gradConstMean(zeros(p))) (GradientGP.jl:617-639)."""
 
     def __init__(self, kernel: Kernel, p: int, noise_var: float, mean=None, device: int | None = None, jitter: float = 0.0,
-                 chunk: int = 0, n_max: int = 0):
-        super().__init__(kernel, noise_var, mean=None, device=device, jitter=jitter, chunk=chunk, n_max=n_max)
+                 chunk: int = 0, n_max: int = 0, contraction: str | None = None):
+        super().__init__(kernel, noise_var, mean=None, device=device, jitter=jitter, chunk=chunk, n_max=n_max,
+                         contraction=contraction)
         self.p = int(p)
         self.mean = gradConstMean(np.zeros(self.p)) if mean is None else mean
         if len(self.mean.c) != self.p:
@@ -82,6 +83,9 @@ def update(model: HipGradientGP, xs, ys) -> HipGradientGP:
     mean = np.ascontiguousarray(model.mean.c)
     _lib.check(L.abo_create_grad(C.byref(prm), model.p, mean.ctypes.data, C.byref(hp)))
     h = _Handle(hp.value)
+    if getattr(model, "contraction", None) is not None:
+        from .surrogate import parse_contraction
+        _lib.check(L.abo_set_contraction(h.ptr, *parse_contraction(model.contraction)))
     info = C.c_int64(0)
     _lib.check(L.abo_fit(h.ptr, xp, n, d, y.ctypes.data, HOST, C.byref(info)), info.value)
     return model._clone(h)

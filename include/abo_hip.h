@@ -61,8 +61,10 @@ enum { ABO_HOST = 0, ABO_DEVICE = 1 };
  *   ABO_CONTRACT_INT8  exact products of 52/53-bit fixed-point images of the two fp64 operands on v_mfma_i32_32x32x32_i8,
  *                      through residues modulo `nmod` coprime moduli ≤ 256 and a Chinese-remainder reconstruction in fp64
  *                      (14 moduli: errors of the size of the fp64 kernels' own rounding; each modulus less ≈ 14× more error,
- *                      7 % less time).  StandardGP handles only; a gradient-enhanced model stays on the fp64 kernels.
- *   ABO_CONTRACT_AUTO  INT8 for a StandardGP with ≥ 2048 (padded) training points, FP64 otherwise */
+ *                      7 % less time).  Serves function-value posteriors (abo_predict, abo_acq, resident grids) of StandardGP and
+ *                      gradient-enhanced handles up to 65536 factor rows; all-output posteriors of a gradient-enhanced model
+ *                      (abo_predict_grad*) stay on the fp64 kernels.
+ *   ABO_CONTRACT_AUTO  INT8 from 2048 (padded) factor rows on, FP64 below */
 enum { ABO_CONTRACT_AUTO = 0, ABO_CONTRACT_FP64 = 1, ABO_CONTRACT_INT8 = 2 };
 
 typedef struct abo_gp abo_gp;     /* opaque, reference-counted: one (immutable) conditioned model */

@@ -241,3 +241,36 @@ def test_engine_on_arbitrary_operands_against_its_cpu_restatement(Np, Mc, nvalid
     wld = (wld.reshape(Np // 128, 128, Mc) ** 2).sum(1)
     err = float(np.max(np.abs(got - wld) / np.maximum(wld, 1e-300)))
     check(f"int8/arbitrary_Np{Np}_n{n}", "sumsq_rel_vs_long_double", err, {12: 1e-7, 14: 1e-11, 16: 1e-11}[n])
+
+
+@pytest.mark.parametrize("family,d,N,ell", [(O.MATERN52, 3, 150, 0.25), (O.SE, 2, 200, 3.0), (O.MATERN72, 5, 120, 1.0)])
+def test_gradient_enhanced_model_on_the_int8_engine(family, d, N, ell):
+    """function-value posterior of a gradient-enhanced model (the rows of its K_XZ mix function and derivative covariances, apart by
+    √c/ℓ): the engine takes the product as (W·D⁻¹)(D·K_XZ) with an exact power-of-two D — short and long lengthscales alike stay at
+    the fp64 engine's error against oracle/grad_oracle.py"""
+    from oracle import grad_oracle as G
+    from tests.test_gpu_gradient_gp import make_grad
+    p = d + 1
+    X = synth.points(1, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    gF = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    Ys = np.column_stack([f, gF])
+    Zc = synth.points(2, 700, d)
+    st = G.fit(family, ell, 1.3, 1e-3, np.zeros(p), X, Ys)
+    _, vf = G.predict(st, Zc)
+    out = {}
+    for eng in ("fp64", "int8"):
+        m = abo.update(make_grad(family, ell, 1.3, 1e-3, p, contraction=eng), X, Ys)
+        mu, var = abo.mean_and_var(m, Zc)
+        assert m.timings()["contraction_engine"] == (abo._lib.CONTRACT_INT8 if eng == "int8" else abo._lib.CONTRACT_FP64)
+        out[eng] = (mu, var)
+        # all outputs of the candidates (posterior_grad_var) stay on the fp64 kernels whatever the engine
+        abo.posterior_grad_var(m, Zc[:8])
+        assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    np.testing.assert_array_equal(out["int8"][0], out["fp64"][0])
+    e8 = np.max(np.abs(out["int8"][1] - vf)) / 1.3
+    e64 = np.max(np.abs(out["fp64"][1] - vf)) / 1.3
+    case = f"int8/grad_fam{family}_d{d}_ell{ell:g}"
+    check(case, "var", e8, 1e-8)
+    check(case, "var_fp64_engine", e64, 1e-8)
+    assert e8 <= 4 * e64 + 1e-13, (e8, e64)

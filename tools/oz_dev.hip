@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dW, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(dK, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         CK(hipMemset(U, 0x55, oz_k_bytes(nmod, Np, Mc)));
-        CK(oz_prepare_w(pl, dW, Np, Np, nvalid, WR, sexp, badr, s));
+        CK(oz_prepare_w(pl, dW, Np, Np, nvalid, WR, sexp, badr, s, 1, 0));
         OzVarArgs v{};
         v.plan = &pl; v.Kxz = dK; v.ldk = Np; v.WR = WR; v.sexp = sexp; v.bad_row = badr; v.KR = KR; v.U = U; v.bad_col = badc;
         v.partial = dP; v.ldp = Mc; v.Np = Np; v.Mc = Mc; v.nvalid = nvalid; v.sK = oz_k_scale(1.0);
@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dK, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         CK(hipEventRecord(e0, s));
-        CK(oz_prepare_w(pl, dW, Np, Np, Np, WR, sexp, badr, s));
+        CK(oz_prepare_w(pl, dW, Np, Np, Np, WR, sexp, badr, s, 1, 0));
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("prepare_w N=%d: %.3f ms\n", Np, ms);
