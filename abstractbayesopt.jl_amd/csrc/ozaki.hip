@@ -779,6 +779,7 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
     oz16d_step<2, true>(oz_lds, c, hb + 2, nh - 1, ra, rb, A, Bx, By, acc, 2, wi);
     oz16d_step<3, true>(oz_lds, c, hb + 3, nh - 1, ra, rb, A, Bx, By, acc, 3, wi);
     if (wi != 0) oz16_mma(A[1], By, 1, acc);          // the held-back unit of the last half-stage (slot 3 → A[1]); zeros for wave row 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's re-fetches have landed before the epilogue reuses the ring as Ut
     __syncthreads();
 
     // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS (rows of U leave as 256-byte segments)
