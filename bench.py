@@ -34,7 +34,20 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak: 256 CU × 4 SIMD × 20
 # BF16 ≈ 2.5 PFLOP/s dense).  On random operands the chip holds 1.7 – 2.1 GHz under this load: tools/mfma_i8_power_probe.hip
 # sustains 3.1 (32×32×32) / 3.4 POP/s (16×16×64) from registers — quoted beside the peak, never instead of it.
 PEAK_INT8_MFMA_TOPS = 5033.0
-SUSTAINED_INT8_MFMA_TOPS = 3409.0
+
+
+def sustained_int8_tops():
+    """what v_mfma_i32_16x16x64_i8 sustains on random operands from registers (tools/mfma_i8_power_probe.hip), read from the
+    committed probe output; None when the file is missing"""
+    import re
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_mfma_i8_power_probe.txt")) as f:
+            for line in f:
+                if line.startswith("random operands") and "16x16x64" in line:
+                    return float(re.search(r"([0-9.]+) TOP/s", line).group(1))
+    except OSError:
+        pass
+    return None
                                # (v_mfma_f64_16x16x4_f64 measured at 64 clk/SIMD: profiles/r01_mfma_f64_probe.txt)
 
 CONFIGS = {
@@ -533,8 +546,8 @@ def main():
                 "algorithmic_bytes_per_launch": float(nmod) * (np256 * np256 / 2 + 2 * mc * np256),
                 "ops_per_launch": med["oz_gemm_ops"] / max(launches, 1), "launches_per_step": launches,
                 "avg_launch_ms": med["oz_gemm_ms"] / max(launches, 1),
-                "sustained_peak_random_operands": SUSTAINED_INT8_MFMA_TOPS,
-                "frac_of_sustained": tops / SUSTAINED_INT8_MFMA_TOPS,
+                "sustained_peak_random_operands": sustained_int8_tops(),
+                "frac_of_sustained": (tops / sustained_int8_tops()) if sustained_int8_tops() else None,
                 "engine": {"name": "int8-residue (ABO_CONTRACT_INT8)", "moduli": nmod,
                            "pipeline_ms_per_chunk": {"quantise_K_XZ": med["oz_quant_ms"] / max(launches, 1),
                                                      "residue_gemm": med["oz_gemm_ms"] / max(launches, 1),
