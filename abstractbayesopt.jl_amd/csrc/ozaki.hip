@@ -212,8 +212,14 @@ __device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj,
     const int per_group = 4 * a.tjg;
     const int grp = blockIdx.x / per_group, s = blockIdx.x % per_group;
     const int ngj = (a.Tj + a.tjg - 1) / a.tjg;
-    const int gh = grp % ngj, gl = (grp / ngj) % a.n, gg = grp / (ngj * a.n);
     const int ngi = (a.Ti + 3) / 4;
+#ifdef OZ_EXP_ROWGROUP_OUTER
+    const int gh = grp % ngj, gl = (grp / ngj) % a.n, gg = grp / (ngj * a.n);
+#else
+    // row groups innermost: the residue planes of one modulus for 64 column blocks (128 MB at N = 8192) are swept by all row groups
+    // back to back and stay in the Infinity Cache meanwhile — with the row groups outermost every sweep streamed them from HBM again
+    const int gg = grp % ngi, gl = (grp / ngi) % a.n, gh = grp / (ngi * a.n);
+#endif
     const int xcd = s & 7, c = s >> 3;
     const int cols_x = a.tjg >> 3;                     // column blocks per XCD patch
     const int ro = c / cols_x;
