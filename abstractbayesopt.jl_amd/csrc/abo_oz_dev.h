@@ -18,6 +18,13 @@ constexpr double oz_mod_c26(int l) {      // 2^26 mod p, symmetric
     return (double)c;
 }
 
+// Layout of a residue plane ([rows][cols] bytes, rows a multiple of 256, cols a multiple of 64): blocks of 256 rows × 64 k-bytes,
+// row-major inside a block, block (R, H) at ((R·nhs) + H)·16384 with nhs = cols / 64.  A DMA piece of the GEMM (16 rows × 64 bytes of
+// one half-stage) is then 1 KiB of contiguous memory — eight whole cache lines instead of sixteen half lines.
+__host__ __device__ inline long long oz_plane_off(int row, int k, int nhs) {
+    return ((long long)(row >> 8) * nhs + (k >> 6)) * 16384 + (row & 255) * 64 + (k & 63);
+}
+
 // symmetric residue of an integer-valued double |x| < 2^53 modulo p, from the split x = xh·2^26 + xl (|xh| ≤ 2^27, |xl| ≤ 2^25):
 // t = xh·(2^26 mod p) + xl is exact and below 2^35, so rint(t/p) is the exact nearest quotient (t/p is at least 1/(2p) away from
 // a half-integer for odd p, the fp64 product errs by < 1e-7) and r = t − q·p lies in [−(p−1)/2, (p−1)/2]; for p = 256 the low

@@ -473,7 +473,7 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
             double h0, l0, h1, l1;
             oz_split(v0, rsc, h0, l0);
             oz_split(v1, rsc, h1, l1);
-            const unsigned voff = (unsigned)((jb + jj) * (int)p.res_ld + k);        // < 2^31: a chunk's plane is at most 65536 × 32768 B
+            const unsigned voff = (unsigned)oz_plane_off(jb + jj, k, (int)(p.res_ld >> 6));   // < 2^31 (pick_chunk caps the chunk); k is even
             if constexpr (RES > 0) {
 #pragma unroll
                 for (int l = 0; l < RES; ++l) {

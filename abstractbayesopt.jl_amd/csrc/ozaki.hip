@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
         }
     }
     if (bad && a.bad) a.bad[r] = 1;
-    int8_t* dst = a.out + (int64_t)r * a.ld + kc;
+    int8_t* dst = a.out + oz_plane_off(r, kc, (int)(a.ld >> 6));      // 16 consecutive k never cross a 64-byte block row
     for (int l = 0; l < a.pl.n; ++l) {
         v4i_t w = {0, 0, 0, 0};
         if (live) {
@@ -196,7 +196,8 @@ struct OzGemmArgs {
     const int8_t* KR;      // [n][Mc256][ldk]
     const int8_t* WR;      // [n][Np256][ldw]
     int8_t* U;             // [n][Np256][ldu]
-    int64_t ldk, ldw, ldu, sK, sW, sU;
+    int64_t ldu, sK, sW, sU;
+    int nhs;               // 64-byte half-stages per row of a residue plane (Np256 / 64): plane block (R, H) at (R·nhs + H)·16 KB
     int Ti, Tj, n;
     int tjg;               // column blocks per group (multiple of 8; 64 unless Tj is smaller)
     double invp[OZ_MAXMOD];
@@ -248,12 +249,14 @@ __device__ __forceinline__ void oz_frag_mma(const OzFrag& f, v16i_t (&acc)[2][4]
 
 struct OzStage { v4i_t a[4], b[4]; };      // one thread's share of a stage: 4 × 16 B of each operand
 
+// k = first k-byte of the stage (a multiple of 128): two 16 KB plane blocks further per stage
 __device__ __forceinline__ void oz_gload(const int8_t* __restrict__ ab, const int8_t* __restrict__ bb, const unsigned (&ao)[4],
                                          const unsigned (&bo)[4], int k, OzStage& r) {
+    const int koff = (k >> 7) << 15;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        r.a[q] = *reinterpret_cast<const v4i_t*>(ab + k + ao[q]);
-        r.b[q] = *reinterpret_cast<const v4i_t*>(bb + k + bo[q]);
+        r.a[q] = *reinterpret_cast<const v4i_t*>(ab + koff + ao[q]);
+        r.b[q] = *reinterpret_cast<const v4i_t*>(bb + koff + bo[q]);
     }
 }
 
@@ -282,13 +285,13 @@ __global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
     const int wj = wave & 3, wi = wave >> 2;
     // LDS: stage buffer b = [A tile | B tile], each [256][144]
     const int lr = tid >> 3, lc = (tid & 7) * 16;
-    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T) * a.ldk;
-    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
+    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384;       // the tile's row block of plane blocks
+    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384;
     unsigned ao[4], bo[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        ao[q] = (unsigned)((lr + 64 * q) * (int)a.ldk + lc);
-        bo[q] = (unsigned)((lr + 64 * q) * (int)a.ldw + lc);
+    for (int q = 0; q < 4; ++q) {     // this thread's 16 bytes: row lr + 64q, k-bytes lc … lc+15 of the stage's 128 (two 64-byte plane blocks)
+        ao[q] = (unsigned)((lc >> 6) * 16384 + (lr + 64 * q) * 64 + (lc & 63));
+        bo[q] = ao[q];
     }
     const int nst = 2 * (ti + 1);
 
@@ -468,13 +471,13 @@ __global__ void __launch_bounds__(512) oz_gemm16_kernel(OzGemmArgs a) {
     const int wj = wave & 3, wi = wave >> 2;
     const int lr = tid >> 3, lc = (tid & 7) * 16;
     const int wpos = ((tid & 7) ^ ((lr >> 1) & 7)) * 16;         // swizzled position of this thread's chunk in its rows
-    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T) * a.ldk;
-    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
+    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384;       // the tile's row block of plane blocks
+    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384;
     unsigned ao[4], bo[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        ao[q] = (unsigned)((lr + 64 * q) * (int)a.ldk + lc);
-        bo[q] = (unsigned)((lr + 64 * q) * (int)a.ldw + lc);
+    for (int q = 0; q < 4; ++q) {     // this thread's 16 bytes: row lr + 64q, k-bytes lc … lc+15 of the stage's 128 (two 64-byte plane blocks)
+        ao[q] = (unsigned)((lc >> 6) * 16384 + (lr + 64 * q) * 64 + (lc & 63));
+        bo[q] = ao[q];
     }
     const int nst = 2 * (ti + 1);
 
@@ -619,7 +622,7 @@ __device__ __forceinline__ void oz_dma_issue(char* lds, const OzDmaCtx& c, int h
 #ifdef OZ_EXP_SAMEK
     const int k = 0 * h;
 #else
-    const int k = h * OZ_HS;
+    const int k = h * 16384;
 #endif
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -676,7 +679,7 @@ __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, 
 #ifdef OZ_EXP_SAMEK
     const int k = 0;
 #else
-    const int k = (h + 3 < hmax ? h + 3 : hmax) * OZ_HS;
+    const int k = (h + 3 < hmax ? h + 3 : hmax) * 16384;      // byte offset of the half-stage's plane block
 #endif
     constexpr int NS = (SLOT + 3) & 3;
     // the previous half-stage's held-back unit (Ao × By, columns 4-7) with this half-stage's A and B0-3 fragments arriving
@@ -737,18 +740,19 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wj = wave & 3, wi = wave >> 2;
     OzDmaCtx c;
-    c.ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * OZ_T) * a.ldk;
-    c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * OZ_T) * a.ldw;
+    c.ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384;
+    c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384;
     c.wave = __builtin_amdgcn_readfirstlane(wave);
     {
-        // piece P = wave + 8q covers rows 16P … 16P+15; lane L fills row 16P + L/4, position L%4 with chunk (L%4) ^ ((row>>1)&3)
+        // piece P = wave + 8q covers rows 16P … 16P+15 of the half-stage's 16 KB plane block — 1 KiB of contiguous memory; lane L
+        // fills LDS row 16P + L/4, position L%4 with chunk (L%4) ^ ((row>>1)&3) of that row
         const int chunk = (lane & 3) ^ ((lane >> 3) & 3);
-        c.ab += (int64_t)(16 * c.wave) * a.ldk;
-        c.bb += (int64_t)(16 * c.wave) * a.ldw;
-        c.astep = 128 * a.ldk;
-        c.bstep = 128 * a.ldw;
-        c.ao = (unsigned)((lane >> 2) * (int)a.ldk + 16 * chunk);
-        c.bo = (unsigned)((lane >> 2) * (int)a.ldw + 16 * chunk);
+        c.ab += 1024 * c.wave;
+        c.bb += 1024 * c.wave;
+        c.astep = 8192;
+        c.bstep = 8192;
+        c.ao = (unsigned)((lane >> 2) * 64 + 16 * chunk);
+        c.bo = c.ao;
     }
     const int nh = 4 * (ti + 1);                     // half-stages of this tile
 
@@ -949,7 +953,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
 
     OzGemmArgs g{};
     g.KR = v.KR; g.WR = v.WR; g.U = v.U;
-    g.ldk = Np256; g.ldw = Np256; g.ldu = Mc256;
+    g.nhs = Np256 / 64; g.ldu = Mc256;
     g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256; g.sU = (int64_t)Np256 * Mc256;
     g.Ti = Np256 / OZ_T; g.Tj = Mc256 / OZ_T; g.n = pl.n;
     g.tjg = g.Tj >= 64 ? 64 : (int)pad_up(g.Tj, 8);

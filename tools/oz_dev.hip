@@ -70,14 +70,14 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < Np256; ++k) {
                     int want = 0;
                     if (i < nvalid && k <= i) want = host_symres(rintl(ldexpl((long double)W[(size_t)i * Np + k], hs[i])), pl.p[l]);
-                    const int got = hWR[(size_t)l * Np256 * Np256 + (size_t)i * Np256 + k];
+                    const int got = hWR[(size_t)l * Np256 * Np256 + (size_t)oz_plane_off(i, k, Np256 / 64)];
                     if ((int8_t)want != (int8_t)got) { if (bad_w < 5) printf("WR mismatch l=%d i=%d k=%d want %d got %d\n", l, i, k, want, got); ++bad_w; }
                 }
             for (int j = 0; j < Mc256; ++j)
                 for (int k = 0; k < Np256; ++k) {
                     int want = 0;
                     if (j < Mc && k < Np) want = host_symres(rintl(ldexpl((long double)K[(size_t)j * Np + k], v.sK)), pl.p[l]);
-                    const int got = hKR[(size_t)l * Mc256 * Np256 + (size_t)j * Np256 + k];
+                    const int got = hKR[(size_t)l * Mc256 * Np256 + (size_t)oz_plane_off(j, k, Np256 / 64)];
                     if ((int8_t)want != (int8_t)got) { if (bad_k < 5) printf("KR mismatch l=%d j=%d k=%d want %d got %d\n", l, j, k, want, got); ++bad_k; }
                 }
         }
@@ -86,10 +86,10 @@ int main(int argc, char** argv) {
             for (int i = 0; i < Np256; ++i)
                 for (int j = 0; j < Mc256; ++j) {
                     long long acc = 0;
-                    const int8_t* wr = &hWR[(size_t)l * Np256 * Np256 + (size_t)i * Np256];
-                    const int8_t* kr = &hKR[(size_t)l * Mc256 * Np256 + (size_t)j * Np256];
+                    const int8_t* wr = &hWR[(size_t)l * Np256 * Np256];
+                    const int8_t* kr = &hKR[(size_t)l * Mc256 * Np256];
                     const int kend = 256 * (i / 256 + 1);
-                    for (int k = 0; k < kend; ++k) acc += (int)wr[k] * (int)kr[k];
+                    for (int k = 0; k < kend; ++k) acc += (int)wr[oz_plane_off(i, k, Np256 / 64)] * (int)kr[oz_plane_off(j, k, Np256 / 64)];
                     const int want = host_symres((long double)acc, pl.p[l]);
                     const int got = hU[(size_t)l * Np256 * Mc256 + (size_t)i * Mc256 + j];
                     if ((int8_t)want != (int8_t)got) { if (bad_u < 8) printf("U mismatch l=%d i=%d j=%d want %d got %d\n", l, i, j, want, got); ++bad_u; }
