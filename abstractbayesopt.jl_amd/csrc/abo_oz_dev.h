@@ -42,4 +42,34 @@ __device__ __forceinline__ void oz_split(double v, double sc, double& xh, double
     xl = __builtin_fma(-xh, 0x1p26, x);
 }
 
+// The same residue through four signed base-2^14 limbs in fp32 (the generator's fused output: fp32 VALU operations issue at twice the
+// fp64 rate): x = a3·2^42 + a2·2^28 + a1·2^14 + a0 with |a0|, |a1|, |a2| ≤ 2^13, |a3| ≤ 2^11; t = Σ a_i·(2^(14i) mod p) is an integer
+// below 2^22 — exact in fp32 at every partial sum —, t/p is at least 1/(2p) ≥ 1.9e-3 away from a half-integer for odd p while the
+// fp32 quotient errs by at most |t|/p·2^-23 ≤ 1.5e-3, so rndne gives the exact nearest quotient and r = t − q·p the symmetric residue.
+struct OzLimbs { float a0, a1, a2, a3; };
+
+__device__ __forceinline__ OzLimbs oz_limbs(double v, double sc) {
+    const double x = __builtin_rint(v * sc);
+    const double a3 = __builtin_rint(x * 0x1p-42);
+    const double r1 = __builtin_fma(-a3, 0x1p42, x);
+    const double a2 = __builtin_rint(r1 * 0x1p-28);
+    const double r2 = __builtin_fma(-a2, 0x1p28, r1);
+    const double a1 = __builtin_rint(r2 * 0x1p-14);
+    const double a0 = __builtin_fma(-a1, 0x1p14, r2);
+    return OzLimbs{(float)a0, (float)a1, (float)a2, (float)a3};
+}
+
+constexpr float oz_mod_c14(int l, int i) {      // 2^(14 i) mod p, symmetric
+    const long long p = oz_mod_p(l);
+    long long c = (1ll << (14 * i)) % p;
+    if (2 * c > p) c -= p;
+    return (float)c;
+}
+
+__device__ __forceinline__ int sym_residue_f32(const OzLimbs& x, float c1, float c2, float c3, float invp, float pf) {
+    const float t = __builtin_fmaf(x.a3, c3, __builtin_fmaf(x.a2, c2, __builtin_fmaf(x.a1, c1, x.a0)));
+    const float q = __builtin_rintf(t * invp);
+    return (int)__builtin_fmaf(-q, pf, t);
+}
+
 }  // namespace abo

@@ -774,7 +774,9 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
     oz_dma_issue<0>(oz_lds, c, 0);
     oz_dma_issue<1>(oz_lds, c, 1);
     oz_dma_issue<2>(oz_lds, c, 2);
+#ifndef OZ_EXP_NOPROLOGWAIT
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     int hb = 0;
