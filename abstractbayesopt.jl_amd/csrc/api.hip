@@ -173,7 +173,7 @@ std::atomic<uint64_t> g_storage_gen{1};
 // contraction engine of the posterior variance: process default (ABO_CONTRACTION = auto | fp64 | int8 | int8:<moduli>),
 // overridable per handle (abo_set_contraction)
 constexpr int OZ_DEFAULT_NMOD = 14;   // P ≈ 2^110: the fixed-point images keep 50+ bits of W per row and 52–53 bits of K_XZ
-constexpr int OZ_AUTO_MIN_NP = 2048;  // below this the contraction is launch-bound and the fp64 kernels win
+constexpr int OZ_AUTO_MIN_NP = 1536;  // below this the fp64 kernels win (tools/engine_crossover.py: 0.81 at 1024, 1.05 at 1536, 1.23 at 2048)
 std::atomic<int> g_oz_engine{-1}, g_oz_nmod{OZ_DEFAULT_NMOD};
 void oz_defaults(int* engine, int* nmod) {
     int e = g_oz_engine.load();

@@ -242,12 +242,17 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
     model = abo.update(gp, Xd, yd)
     cands = abo.ResidentCandidates(model, Zd)               # first creation: one-time allocations (17 GB of K_ZX), untimed
-    sync()
-    t0 = time.perf_counter()
-    model = abo.update(gp, Xd, yd)                          # the periodic full refresh: refit + grid re-evaluation
-    cands.refresh(model)
-    sync()
-    refresh_ms = (time.perf_counter() - t0) * 1e3
+    # the periodic full refresh: refit + grid re-evaluation.  One untimed repetition first (a BO loop refreshes every 16 steps with
+    # the buffer pool warm: the first refresh after a cold start also pays hipMalloc for a second model's 10+ GB), then the median of 3
+    refresh_all = []
+    for rep in range(4):
+        sync()
+        t0 = time.perf_counter()
+        model = abo.update(gp, Xd, yd)
+        cands.refresh(model)
+        sync()
+        refresh_all.append((time.perf_counter() - t0) * 1e3)
+    refresh_ms = float(np.median(refresh_all[1:]))
     fit_t = model.timings()
     best_y = float(y.min())
     ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "restore_ms": [], "downdate_pass_ms": [], "downdate_pass_bytes": []}
@@ -314,7 +319,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
                                    f"per pick) + 1 real bordered append per step",
                        "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "q": Q,
                        "sharding": f"grid x{world}, all_gather of (score, index, mu, x) per pick"},
-            "refresh_ms": refresh_ms, "value_amortized": ms + refresh_ms / 16.0,
+            "refresh_ms": refresh_ms, "refresh_ms_all": refresh_all, "value_amortized": ms + refresh_ms / 16.0,
             "refresh_phases_ms": {k: v for k, v in fit_t.items() if k.endswith("_ms")},
             "roofline": roof,
             "secondary_roofline": {"kernel": "trmv_kernel x2 (bordered append: l = L^-1 k, v = L^-T l)", "bound": "hbm",

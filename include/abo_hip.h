@@ -64,7 +64,7 @@ enum { ABO_HOST = 0, ABO_DEVICE = 1 };
  *                      7 % less time).  Serves function-value posteriors (abo_predict, abo_acq, resident grids) of StandardGP and
  *                      gradient-enhanced handles up to 65536 factor rows; all-output posteriors of a gradient-enhanced model
  *                      (abo_predict_grad*) stay on the fp64 kernels.
- *   ABO_CONTRACT_AUTO  INT8 from 2048 (padded) factor rows on, FP64 below */
+ *   ABO_CONTRACT_AUTO  INT8 from 1536 (padded) factor rows on, FP64 below */
 enum { ABO_CONTRACT_AUTO = 0, ABO_CONTRACT_FP64 = 1, ABO_CONTRACT_INT8 = 2 };
 
 typedef struct abo_gp abo_gp;     /* opaque, reference-counted: one (immutable) conditioned model */

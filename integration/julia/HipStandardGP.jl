@@ -59,7 +59,7 @@ function HipStandardGP(kernel::Kernel, noise_var; mean=nothing, devices=[0], jit
     HipStandardGP(s.gp, noise_var, nothing, Int32.(devices), Float64(jitter), Int64(n_max))
 end
 # Engine of the N²·M variance contraction behind posterior_var (include/abo_hip.h: abo_set_contraction), process-wide for the
-# handles created from now on — :auto (int8-residue engine from 2048 training points, fp64 MFMA below), :fp64 or :int8;
+# handles created from now on — :auto (int8-residue engine from 1536 factor rows, fp64 MFMA below), :fp64 or :int8;
 # `moduli` = 8 … 16 (0 = 14).  The environment variable ABO_CONTRACTION = auto | fp64 | int8 | int8:<moduli> seeds the same default.
 function set_contraction!(engine::Symbol=:auto; moduli::Integer=0)
     e = Dict(:auto => Int32(0), :fp64 => Int32(1), :int8 => Int32(2))[engine]
