@@ -610,7 +610,10 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     // engine of the contraction: the int8-residue pipeline for a StandardGP large enough to fill the chip with 256×256 tiles
     {
         if (oz) {
-            if (g->oz_plan.n != nm && !oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
+            if (g->oz_plan.n != nm) {                               // another moduli count: the cached planes of W belong to the old plan
+                if (!oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
+                g->oz_N = -1;
+            }
             if (g->oz_gen != g->st->gen || g->oz_N != g->N) {      // residue planes of this view's W, once per model
                 const int64_t q = pad_up(Np, 256);
                 HIPCHK(g->oz_WR.ensure(oz_w_bytes(nm, (int)Np)));
@@ -1080,7 +1083,7 @@ int32_t abo_set_contraction(abo_gp* gp, int32_t engine, int32_t nmod) {
         return ABO_OK;
     }
     gp->oz_engine = engine;
-    gp->oz_nmod = nmod ? nmod : OZ_DEFAULT_NMOD;
+    gp->oz_nmod = nmod;                                            // 0: whatever the process default is when the posterior runs
     return ABO_OK;
 }
 

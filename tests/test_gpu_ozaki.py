@@ -274,3 +274,23 @@ def test_gradient_enhanced_model_on_the_int8_engine(family, d, N, ell):
     check(case, "var", e8, 1e-8)
     check(case, "var_fp64_engine", e64, 1e-8)
     assert e8 <= 4 * e64 + 1e-13, (e8, e64)
+
+
+def test_engine_and_moduli_can_change_on_a_fitted_handle():
+    """abo_set_contraction on a handle that already answered posterior calls: the cached residue planes of W belong to the plan they
+    were made with and are rebuilt when the moduli count changes"""
+    X = synth.points(1, 500, 3)
+    y = synth.objective(X, 0.05)
+    Zc = synth.points(2, 800, 3)
+    m = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="int8"), X, y)
+    v14 = abo.posterior_var(m, Zc)
+    lib = abo._lib.lib()
+    abo._lib.check(lib.abo_set_contraction(m._require(), abo._lib.CONTRACT_INT8, 12))
+    v12 = abo.posterior_var(m, Zc)
+    assert m.timings()["oz_nmod"] == 12 and 1e-13 < np.max(np.abs(v12 - v14)) < 1e-7
+    abo._lib.check(lib.abo_set_contraction(m._require(), abo._lib.CONTRACT_FP64, 0))
+    v64 = abo.posterior_var(m, Zc)
+    assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    abo._lib.check(lib.abo_set_contraction(m._require(), abo._lib.CONTRACT_INT8, 14))
+    np.testing.assert_array_equal(abo.posterior_var(m, Zc), v14)
+    np.testing.assert_allclose(v64, v14, rtol=0, atol=1e-12)
