@@ -68,6 +68,11 @@ size_t pool_limit() {
     return lim;
 }
 
+size_t oz_scratch_limit() {
+    const char* e = getenv("ABO_OZ_SCRATCH_LIMIT_MB");
+    return e ? (size_t)atoll(e) << 20 : ~(size_t)0;
+}
+
 size_t round_size(size_t bytes) {
     const size_t g = bytes < ((size_t)1 << 20) ? 4096 : ((size_t)2 << 20);
     return (bytes + g - 1) / g * g;
@@ -594,7 +599,40 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     const bool want_var = var_out || score_out;
     int nm = 0;
     bool oz = wants_int8(g, want_var, pc, &nm);
-    const int64_t Mc = pick_chunk(g, M, oz);
+    int64_t Mc = pick_chunk(g, M, oz);
+    // the int8 engine's scratch — 2 × n bytes per (candidate, factor row) of a chunk, and the n residue planes of W: when the device
+    // cannot give it (a shared or nearly full GPU), the chunk is halved down to 4096 candidates, and below that the call runs on
+    // the fp64 kernels (8 bytes per pair of a chunk four times smaller) instead of failing
+    if (oz) {
+        if (g->oz_plan.n != nm) {                               // another moduli count: the cached planes of W belong to the old plan
+            if (!oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
+            g->oz_N = -1;
+        }
+        const int64_t q = pad_up(Np, 256);
+        hipError_t e = g->oz_WR.ensure(oz_w_bytes(nm, (int)Np));
+        if (e == hipSuccess) e = g->oz_sexp.ensure(sizeof(int) * q);
+        if (e == hipSuccess) e = g->oz_badr.ensure(sizeof(int) * q);
+        while (e == hipSuccess) {
+            // ABO_OZ_SCRATCH_LIMIT_MB caps what the two chunk buffers may take together (a knob for shared devices; the tests use it
+            // to walk this very path)
+            const size_t kb = oz_k_bytes(nm, (int)Np, (int)Mc);
+            e = 2 * kb > oz_scratch_limit() ? hipErrorOutOfMemory : g->oz_KR.ensure(kb);
+            if (e == hipSuccess) e = g->oz_U.ensure(kb);
+            if (e == hipSuccess) e = g->oz_badc.ensure(sizeof(int) * pad_up(Mc, 256));
+            if (e != hipErrorOutOfMemory || Mc <= 4096) break;
+            (void)hipGetLastError();
+            g->oz_KR.release(); g->oz_U.release();
+            Mc = pad_up(Mc / 2, 256);
+            e = hipSuccess;
+        }
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            g->oz_KR.release(); g->oz_U.release(); g->oz_WR.release();
+            g->oz_N = -1;
+            oz = false;
+            Mc = pick_chunk(g, M, false);
+        } else HIPCHK(e);
+    }
     g->last_chunk = Mc;
     {
         KgenArgs probe{};
@@ -607,29 +645,13 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     const int64_t nchunk = (M + Mc - 1) / Mc;
     HIPCHK(g->events(EV_BASE + EV_PER_CHUNK * (size_t)nchunk));
     g->tm.var_gemm_launches = 0;
-    // engine of the contraction: the int8-residue pipeline for a StandardGP large enough to fill the chip with 256×256 tiles
-    {
-        if (oz) {
-            if (g->oz_plan.n != nm) {                               // another moduli count: the cached planes of W belong to the old plan
-                if (!oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
-                g->oz_N = -1;
-            }
-            if (g->oz_gen != g->st->gen || g->oz_N != g->N) {      // residue planes of this view's W, once per model
-                const int64_t q = pad_up(Np, 256);
-                HIPCHK(g->oz_WR.ensure(oz_w_bytes(nm, (int)Np)));
-                HIPCHK(g->oz_sexp.ensure(sizeof(int) * q));
-                HIPCHK(g->oz_badr.ensure(sizeof(int) * q));
-                HIPCHK(hipEventRecord(g->evs()[8], s));
-                HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
-                                    g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
-                HIPCHK(hipEventRecord(g->evs()[9], s));
-                g->oz_gen = g->st->gen; g->oz_N = g->N;
-                g->tm.oz_prepare_ms = -1.0;                        // collected with the posterior timings
-            }
-            HIPCHK(g->oz_KR.ensure(oz_k_bytes(nm, (int)Np, (int)Mc)));
-            HIPCHK(g->oz_U.ensure(oz_k_bytes(nm, (int)Np, (int)Mc)));
-            HIPCHK(g->oz_badc.ensure(sizeof(int) * pad_up(Mc, 256)));
-        }
+    if (oz && (g->oz_gen != g->st->gen || g->oz_N != g->N)) {      // residue planes of this view's W, once per model
+        HIPCHK(hipEventRecord(g->evs()[8], s));
+        HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
+                            g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
+        HIPCHK(hipEventRecord(g->evs()[9], s));
+        g->oz_gen = g->st->gen; g->oz_N = g->N;
+        g->tm.oz_prepare_ms = -1.0;                                 // collected with the posterior timings
     }
     g->tm.contraction_engine = want_var ? (oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64) : 0;
     g->tm.oz_nmod = oz ? g->oz_plan.n : 0;

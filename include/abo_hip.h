@@ -64,6 +64,9 @@ enum { ABO_HOST = 0, ABO_DEVICE = 1 };
  *                      7 % less time).  Serves function-value posteriors (abo_predict, abo_acq, resident grids) of StandardGP and
  *                      gradient-enhanced handles up to 65536 factor rows; all-output posteriors of a gradient-enhanced model
  *                      (abo_predict_grad*) stay on the fp64 kernels.
+ *                      Its scratch is 2·nmod bytes per (candidate, factor row) of a chunk plus nmod·rows² bytes of planes; when the
+ *                      device cannot give that (or more than ABO_OZ_SCRATCH_LIMIT_MB allows) the chunk is halved down to 4096
+ *                      candidates, and below that the call runs on the fp64 kernels — never an error.
  *   ABO_CONTRACT_AUTO  INT8 from 1536 (padded) factor rows on, FP64 below */
 enum { ABO_CONTRACT_AUTO = 0, ABO_CONTRACT_FP64 = 1, ABO_CONTRACT_INT8 = 2 };
 

@@ -294,3 +294,24 @@ def test_engine_and_moduli_can_change_on_a_fitted_handle():
     abo._lib.check(lib.abo_set_contraction(m._require(), abo._lib.CONTRACT_INT8, 14))
     np.testing.assert_array_equal(abo.posterior_var(m, Zc), v14)
     np.testing.assert_allclose(v64, v14, rtol=0, atol=1e-12)
+
+
+def test_scratch_that_does_not_fit_halves_the_chunk_then_falls_back_to_fp64(monkeypatch):
+    """the engine's chunk buffers (2 x 14 bytes per candidate and factor row) not fitting the device is not an error: the chunk is
+    halved down to 4096 candidates, below that the call runs on the fp64 kernels — same results either way"""
+    N, d, M = 1800, 4, 20000
+    X = synth.points(1, N, d)
+    y = synth.objective(X, 0.05)
+    Zc = synth.points(2, M, d)
+    ref = abo.posterior_var(abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="int8"), X, y), Zc)
+    # 1792 factor rows pad to 2048: a 4096-candidate chunk takes 2·14·4096·2048 B = 224 MiB, the whole batch 1.1 GiB
+    monkeypatch.setenv("ABO_OZ_SCRATCH_LIMIT_MB", "300")
+    m = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="int8"), X, y)
+    v = abo.posterior_var(m, Zc)
+    assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_INT8 and m.timings()["var_gemm_launches"] >= 4
+    np.testing.assert_array_equal(v, ref)                   # exact products: the chunk size cannot show
+    monkeypatch.setenv("ABO_OZ_SCRATCH_LIMIT_MB", "100")
+    m = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="int8"), X, y)
+    v = abo.posterior_var(m, Zc)
+    assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    np.testing.assert_allclose(v, ref, rtol=0, atol=1e-12)
