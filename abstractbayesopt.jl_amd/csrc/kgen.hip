@@ -470,7 +470,9 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
         if constexpr (RES != 0) {
             // the int8-residue engine's image of the pair: two bytes per modulus (a wave writes one 128-byte line per row and plane)
             if (!(__builtin_fabs(v0) < 1.0e300) || !(__builtin_fabs(v1) < 1.0e300)) p.res_bad[jb + jj] = 1;
-            const unsigned voff = (unsigned)oz_plane_off(jb + jj, k, (int)(p.res_ld >> 6));   // < 2^31 (pick_chunk caps the chunk); k is even
+            // plane offset = (uniform) row part + (per-lane, row-independent) k part: the stores take a scalar base and a 32-bit lane offset
+            const unsigned koff = (unsigned)(((k >> 6) << 14) + (k & 63));
+            const int64_t rowoff = ((int64_t)((jb + jj) >> 8) * (p.res_ld >> 6)) * 16384 + ((jb + jj) & 255) * 64;
             if constexpr (RES > 0) {
                 const OzLimbs x0 = oz_limbs(v0, rsc), x1 = oz_limbs(v1, rsc);
 #pragma unroll
@@ -478,8 +480,8 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
                     const float pf = (float)oz_mod_p(l), invp = 1.0f / (float)oz_mod_p(l);
                     const int r0 = sym_residue_f32(x0, oz_mod_c14(l, 1), oz_mod_c14(l, 2), oz_mod_c14(l, 3), invp, pf);
                     const int r1 = sym_residue_f32(x1, oz_mod_c14(l, 1), oz_mod_c14(l, 2), oz_mod_c14(l, 3), invp, pf);
-                    int8_t* plane = p.res + (int64_t)l * p.res_plane;                 // uniform
-                    *reinterpret_cast<short*>(plane + voff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
+                    int8_t* plane = p.res + (int64_t)l * p.res_plane + rowoff;        // uniform
+                    *reinterpret_cast<short*>(plane + koff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
                 }
             } else {
                 double h0, l0, h1, l1;
@@ -488,7 +490,7 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
                 for (int l = 0; l < p.res_n; ++l) {
                     const double c26 = p.res_c26[l], invp = p.res_invp[l], pd = p.res_p[l];
                     const int r0 = sym_residue(h0, l0, c26, invp, pd), r1 = sym_residue(h1, l1, c26, invp, pd);
-                    *reinterpret_cast<short*>(p.res + (int64_t)l * p.res_plane + voff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
+                    *reinterpret_cast<short*>(p.res + (int64_t)l * p.res_plane + rowoff + koff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
                 }
             }
         }
