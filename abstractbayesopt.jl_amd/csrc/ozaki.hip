@@ -18,9 +18,13 @@
 // With n = 14 (P ≈ 2^110) the result differs from the exactly rounded product by about what the fp64 MFMA kernel's own
 // accumulation error is (tests/test_gpu_ozaki.py records both against a long-double product).
 //
-// Kernels: oz_rowscale_kernel (L1 / max per row of W → s_i), oz_quant_kernel (fp64 → n residue planes; W once per model,
-// K_XZ per chunk), oz_gemm_kernel (int8 NT GEMM, 256×256 tile per 8-wave workgroup, triangular k-range, epilogue = symmetric
-// mod + byte pack + LDS transpose), oz_crt_kernel (reconstruction + squares + per-row-block column sums).
+// Kernels: oz_rowscale_kernel (L1 / max per row of W → s_i), oz_quant_kernel (fp64 → n residue planes: W once per model; K_XZ per
+// chunk only when the generator cannot write the planes itself — kgen.hip does for a StandardGP with d ≤ 32), the residue GEMM
+// (256×256 tile per 8-wave workgroup, triangular k-range, epilogue = symmetric mod + byte pack + LDS transpose) in three variants
+// with identical results — oz_gemm16d_kernel (shipped: v_mfma_i32_16x16x64_i8 fed by an LDS-DMA ring), oz_gemm16_kernel and
+// oz_gemm_kernel (register-staged 16×16×64 / 32×32×32, kept as A/B references: ABO_OZ_REGSTAGE, ABO_OZ_MFMA32) —, and
+// oz_crt_kernel (reconstruction + squares + per-row-block column sums).  Residue planes are stored in 16 KB blocks of 256 rows ×
+// 64 k-bytes (abo_oz_dev.h: oz_plane_off).  What each step bought: profiles/r02_int8_ablation.txt.
 #include "abo_kernels.h"
 #include "abo_oz_dev.h"
 #include <cmath>
@@ -230,6 +234,58 @@ __device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj,
     return ti < a.Ti && tj < a.Tj;
 }
 
+// ---- epilogue pieces shared by the GEMM kernels -------------------------------------------------------------------------------------------
+// four accumulators (four consecutive candidates of one W row) → their symmetric residues mod p, one byte each.  The quotient is
+// exact: |x| < 2^31, so x/p in fp64 is far closer to the true quotient than 1/(2p), and r = x − q·p lands in [−p/2, p/2].
+__device__ __forceinline__ int oz_mod_pack4(int a0, int a1, int a2, int a3, double invp, double pd) {
+    const int v[4] = {a0, a1, a2, a3};
+    int w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#ifdef OZ_EXP_NOEPI
+        const int r = v[b];
+#else
+        const double x = (double)v[b];
+        const double q = __builtin_rint(x * invp);
+        const int r = (int)__builtin_fma(-q, pd, x);
+#endif
+        w |= (r & 0xff) << (8 * b);
+    }
+    return w;
+}
+
+// the tile's residues, transposed in LDS (Ut [256 rows i][OZ_UROW]), leave as 256-byte row segments of U[l][i][j]
+__device__ __forceinline__ void oz_store_tile(const OzGemmArgs& a, const char* Ut, int l, int ti, int tj) {
+    const int tid = threadIdx.x;
+    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
+    const int ur = tid >> 4, uc = (tid & 15) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = ur + 32 * q;
+        const char* src = Ut + i * OZ_UROW + uc;
+        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+}
+
+// epilogue of the 16×16×64 kernels: D layout lane → column (W row) lane % 16, register r → row (candidate) 4(lane/16) + r
+__device__ __forceinline__ void oz16_epilogue(const OzGemmArgs& a, char* Ut, const v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
+                                              int lane) {
+    const double invp = a.invp[l], pd = (double)a.p[l];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) {
+            const int il = 128 * wi + 16 * nn + (lane & 15);
+            const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
+            *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = oz_mod_pack4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pd);
+        }
+    __syncthreads();
+    oz_store_tile(a, Ut, l, ti, tj);
+}
+
 // fragments of one 32-byte k-group: two candidate row-groups (A operand), four W row-groups (B operand)
 struct OzFrag { v4i_t a[2], b[4]; };
 
@@ -394,30 +450,13 @@ __global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
             const int il = 128 * wi + 32 * nn + (lane & 31);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int w = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const double x = (double)acc[m][nn][4 * g + b];
-                    const double q = __builtin_rint(x * invp);
-                    const int r = (int)__builtin_fma(-q, pd, x);   // exact quotient: |x| < 2^31 ⇒ r in [−p/2, p/2]
-                    w |= (r & 0xff) << (8 * b);
-                }
                 const int jl = 64 * wj + 32 * m + 8 * g + 4 * (lane >> 5);
-                *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
+                *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) =
+                    oz_mod_pack4(acc[m][nn][4 * g], acc[m][nn][4 * g + 1], acc[m][nn][4 * g + 2], acc[m][nn][4 * g + 3], invp, pd);
             }
         }
     __syncthreads();
-    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
-    const int ur = tid >> 4, uc = (tid & 15) * 16;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int i = ur + 32 * q;
-        const char* src = Ut + i * OZ_UROW + uc;
-        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
-        dst[0] = lo;
-        dst[1] = hi;
-    }
+    oz_store_tile(a, Ut, l, ti, tj);
 }
 
 
@@ -558,37 +597,7 @@ __global__ void __launch_bounds__(512) oz_gemm16_kernel(OzGemmArgs a) {
     }
     __syncthreads();
 
-    // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS (rows of U leave as 256-byte segments)
-    const double invp = a.invp[l], pd = (double)a.p[l];
-    char* Ut = oz_lds;                                  // [256 i][264]
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 8; ++nn) {
-            const int il = 128 * wi + 16 * nn + (lane & 15);
-            int w = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const double x = (double)acc[m][nn][b];
-                const double q = __builtin_rint(x * invp);
-                const int r = (int)__builtin_fma(-q, pd, x);
-                w |= (r & 0xff) << (8 * b);
-            }
-            const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
-            *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
-        }
-    __syncthreads();
-    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
-    const int ur = tid >> 4, uc = (tid & 15) * 16;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int i = ur + 32 * q;
-        const char* src = Ut + i * OZ_UROW + uc;
-        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
-        dst[0] = lo;
-        dst[1] = hi;
-    }
+    oz16_epilogue(a, oz_lds, acc, l, ti, tj, wi, wj, lane);
 }
 
 
@@ -794,43 +803,8 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's re-fetches have landed before the epilogue reuses the ring as Ut
     __syncthreads();
 
-    // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS (rows of U leave as 256-byte segments)
-    const double invp = a.invp[l], pd = (double)a.p[l];
-    char* Ut = oz_lds;                                  // [256 i][264]
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 8; ++nn) {
-            const int il = 128 * wi + 16 * nn + (lane & 15);
-            int w = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-#ifdef OZ_EXP_NOEPI
-                const int r = acc[m][nn][b];
-#else
-                const double x = (double)acc[m][nn][b];
-                const double q = __builtin_rint(x * invp);
-                const int r = (int)__builtin_fma(-q, pd, x);
-#endif
-                w |= (r & 0xff) << (8 * b);
-            }
-            const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
-            *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = w;
-        }
-    __syncthreads();
-    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
-    const int ur = tid >> 4, uc = (tid & 15) * 16;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int i = ur + 32 * q;
-        const char* src = Ut + i * OZ_UROW + uc;
-        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
-        dst[0] = lo;
-        dst[1] = hi;
-    }
+    oz16_epilogue(a, oz_lds, acc, l, ti, tj, wi, wj, lane);
 }
-
 
 // ---- reconstruction + squares + column sums ------------------------------------------------------------------------------------------
 // partial[tb][j] = Σ_{i in row block tb (128 rows), i < nvalid} V[i][j]²,  V = CRT(U[·][i][j])·2^−(s_i + sK).
