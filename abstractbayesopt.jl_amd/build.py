@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libabo_hip.so")
-SOURCES = ["gemm.hip", "ozaki.hip", "kgen.hip", "chol.hip", "misc.hip", "api.hip", "mgpu.hip"]
+SOURCES = ["kgen.hip", "kgen_res.hip", "gemm.hip", "ozaki.hip", "chol.hip", "misc.hip", "api.hip", "mgpu.hip"]
 # -amdgpu-mfma-vgpr-form: keep fp64 MFMA accumulators in VGPRs; the AGPR form makes hipcc shuttle
 # every accumulator through v_accvgpr_read/write each k-step (2.2x slower, profiles/r01_mfma_f64_probe.txt)
 # -ldl / -pthread: the multi-device driver resolves RCCL with dlopen and runs one host thread per shard
@@ -22,11 +22,28 @@ def _stale():
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """One hipcc per translation unit, in parallel (kgen.hip with its per-family / per-dimension instantiations is the long pole),
+    then one link."""
     if not force and not _stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    objdir = os.path.join(os.path.dirname(LIB), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-pthread")]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -638,7 +638,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         KgenArgs probe{};
         probe.pt = g->p_out; probe.dp = g->dp;
         // the fp64 chunk of K_XZ is not materialised when the generator writes the residue planes itself
-        if (!kstore && !(oz && kgen_writes_residues(probe) && !getenv("ABO_OZ_UNFUSED"))) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
+        if (!kstore && !(oz && kgen_writes_residues(probe, nm) && !getenv("ABO_OZ_UNFUSED"))) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
     }
     HIPCHK(g->partial.ensure(sizeof(double) * T * Mc));
     HIPCHK(g->mu_c.ensure(sizeof(double) * Mc));
@@ -671,14 +671,11 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = g->prm.mean_c;
         // int8 engine: the generator writes the residue planes of the chunk itself (the fp64 K_XZ is then only materialised for a
         // caller that keeps it — the resident K_ZX of a candidate set)
-        const bool fused = oz && kgen_writes_residues(ka) && !getenv("ABO_OZ_UNFUSED");
+        const bool fused = oz && kgen_writes_residues(ka, g->oz_plan.n) && !getenv("ABO_OZ_UNFUSED");
         if (fused) {
             const int64_t q = pad_up(Np, 256);
             ka.res = g->oz_KR.as<int8_t>(); ka.res_ld = q; ka.res_plane = pad_up(mcp, 256) * q;
             ka.res_bad = g->oz_badc.as<int>(); ka.res_n = g->oz_plan.n; ka.res_sK = oz_k_scale(g->prm.sigma_f2);
-            for (int l = 0; l < g->oz_plan.n; ++l) {
-                ka.res_p[l] = (double)g->oz_plan.p[l]; ka.res_invp[l] = g->oz_plan.invp[l]; ka.res_c26[l] = g->oz_plan.c26[l];
-            }
             if (!kstore) ka.Kout = nullptr;
         }
         HIPCHK(hipEventRecord(e[0], s));
