@@ -33,8 +33,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f not in ("-shared", "-ldl", "-pthread")]
 
+    # an object is rebuilt when its own source, any header of csrc/ or the public header is newer (force: all of them)
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(PKG, "..", "include", "abo_hip.h")]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj
         cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -22,6 +22,18 @@ const double* cand_points(const abo_cand* c);      // device, [M][d]
 const double* cand_mu(const abo_cand* c);          // device, [M]
 int64_t cand_size(const abo_cand* c);
 
+// Process teardown.  `exiting()` turns true when the process has started to exit (an atexit hook registered behind the HIP
+// runtime's own, so it runs BEFORE the runtime tears down, and the library's static destructor): from then on no entry point
+// touches the device — a finaliser that runs late (a Julia / Python handle destroyed from an exit handler, a static
+// destructor of the host) must find abo_destroy / abo_cand_destroy / abo_mgpu_destroy / pool frees as quiet no-ops, never a
+// call into a runtime that is already gone.  `arm_exit_guard()` registers the hook (idempotent; called once a device exists);
+// `at_exit(f)` adds work to it (the multi-device driver parks and joins its idle worker threads there).
+bool exiting();
+void arm_exit_guard();
+void at_exit(void (*f)());
+// hipSuccess, or an error that only says "the runtime is shutting down" (hipErrorDeinitialized / hipErrorContextIsDestroyed …)
+bool gone(hipError_t e);
+
 // the calling thread's last-error slot (abo_last_error reads it)
 int32_t set_error(int32_t code, const char* text);
 const char* last_error_text();

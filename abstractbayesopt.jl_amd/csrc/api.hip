@@ -49,6 +49,20 @@ int32_t fail(int32_t code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                    \
     } while (0)
 
+// ---- process teardown guard (abo_internal.h) -------------------------------------------------------------------------------
+std::atomic<bool> g_exiting{false};
+std::atomic<bool> g_exit_armed{false};
+std::mutex g_exit_mu;
+std::vector<void (*)()> g_exit_hooks;
+void exit_hook() {
+    g_exiting.store(true);
+    std::vector<void (*)()> hooks;
+    { std::lock_guard<std::mutex> lk(g_exit_mu); hooks.swap(g_exit_hooks); }
+    for (auto f : hooks) f();
+}
+// the library's own unload (dlclose, or static destruction at exit if the atexit hook was never armed)
+__attribute__((destructor)) void lib_unload() { g_exiting.store(true); }
+
 // Device-memory pool.  `update` returns a NEW model every BO step (src/surrogates/StandardGP.jl:82)
 // and the previous one dies right after, so without a pool every step pays hipMalloc/hipFree for
 // ~4 GB of factor + workspace (and the implicit device synchronisations of hipFree).  Freed blocks
@@ -108,6 +122,7 @@ hipError_t pool_alloc(int dev, size_t bytes, void** p, size_t* cap) {
 }
 
 void pool_free(int dev, void* p, size_t cap) {
+    if (g_exiting.load()) return;        // the process is going away: the driver reclaims device memory, the runtime may be gone
     Pool& pl = g_pool[dev & 15];
     {
         std::lock_guard<std::mutex> lk(pl.mu);
@@ -121,6 +136,7 @@ void pool_free(int dev, void* p, size_t cap) {
 }
 
 void pool_trim(int dev) {
+    if (g_exiting.load()) return;
     Pool& pl = g_pool[dev & 15];
     std::vector<void*> drop;
     {
@@ -261,6 +277,7 @@ struct abo_gp {
     // oz_plan.n) and the per-chunk scratch
     int oz_engine = ABO_CONTRACT_AUTO, oz_nmod = 0;
     OzPlan oz_plan{};
+    bool oz_prepare_pending = false;  // events 8/9 of the current call bracket a rebuild of the residue planes of W (read with its timings)
     uint64_t oz_gen = 0;
     int64_t oz_N = -1;
     int64_t last_chunk = 0;          // candidates per chunk of the last posterior call (its events are read back with it)
@@ -645,13 +662,15 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     const int64_t nchunk = (M + Mc - 1) / Mc;
     HIPCHK(g->events(EV_BASE + EV_PER_CHUNK * (size_t)nchunk));
     g->tm.var_gemm_launches = 0;
+    g->oz_prepare_pending = false;
+    g->tm.oz_prepare_ms = 0.0;                                      // planes cached from an earlier call: nothing spent in this one
     if (oz && (g->oz_gen != g->st->gen || g->oz_N != g->N)) {      // residue planes of this view's W, once per model
         HIPCHK(hipEventRecord(g->evs()[8], s));
         HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
                             g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
         HIPCHK(hipEventRecord(g->evs()[9], s));
         g->oz_gen = g->st->gen; g->oz_N = g->N;
-        g->tm.oz_prepare_ms = -1.0;                                 // collected with the posterior timings
+        g->oz_prepare_pending = true;                               // both events recorded in THIS call: read with the posterior timings
     }
     g->tm.contraction_engine = want_var ? (oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64) : 0;
     g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
@@ -733,12 +752,11 @@ void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
     g->tm.acq_var_gemm_ms = vg;
     g->tm.acq_finalize_ms = fi;
     g->tm.oz_quant_ms = oq; g->tm.oz_gemm_ms = og; g->tm.oz_crt_ms = oc;
-    if (g->tm.oz_prepare_ms < 0.0) g->tm.oz_prepare_ms = ev_ms(g->evs()[8], g->evs()[9]);
-    // int8 operations the residue GEMMs performed: n moduli × M × 2·256²·Σ_{ti}(ti+1)·256 per 256-candidate block
-    if (oz) {
-        const double T = (double)(pad_up(g->Np, 256) / 256);
-        g->tm.oz_gemm_ops = 2.0 * g->tm.oz_nmod * (double)pad_up(M, 256) * 256.0 * 256.0 * T * (T + 1.0) / 2.0;
-    } else g->tm.oz_gemm_ops = 0.0;
+    if (g->oz_prepare_pending) { g->tm.oz_prepare_ms = ev_ms(g->evs()[8], g->evs()[9]); g->oz_prepare_pending = false; }
+    // ALGORITHMIC int8 operations of the residue GEMMs: n moduli × the triangular product N²·M (N(N+1)/2 multiply-adds per
+    // candidate, 2 operations each ≈ N²).  What the kernel issues beyond that — the upper halves of its 256-wide diagonal blocks
+    // (of which it skips 6 of 16 units), padding of N and M to 256 — is not credited.
+    g->tm.oz_gemm_ops = oz ? (double)g->tm.oz_nmod * (double)g->N * (double)g->N * (double)M : 0.0;
     // algorithmic (triangular) flop of the contraction: N²·M, N = true training size
     g->tm.var_gemm_flop = with_var ? (double)g->N * (double)g->N * (double)M : 0.0;
 }
@@ -1047,6 +1065,7 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
     if (params->device < 0 || params->device >= ndev)
         return fail(ABO_EINVAL, "abo_create: device %d not present (%d devices)", params->device, ndev);
     HIPCHK(hipSetDevice(params->device));
+    abo::arm_exit_guard();
     abo_gp* g = new (std::nothrow) abo_gp();
     if (!g) return fail(ABO_ENOMEM, "abo_create: host allocation failed");
     g->prm = *params;
@@ -1114,9 +1133,14 @@ int32_t abo_retain(abo_gp* gp) {
 
 int32_t abo_destroy(abo_gp* gp) {
     if (!gp) return ABO_OK;
+    // a finaliser that fires while the process exits (or after the runtime reported itself gone): the handle's device state
+    // is reclaimed with the process — nothing here may call into HIP any more, and nothing is worth freeing
+    if (g_exiting.load()) return ABO_OK;
     if (gp->refs.fetch_sub(1) == 1) {
-        (void)hipSetDevice(gp->prm.device);
-        if (gp->stream) (void)hipStreamSynchronize(gp->stream);
+        hipError_t e = hipSetDevice(gp->prm.device);
+        if (e == hipSuccess && gp->stream) e = hipStreamSynchronize(gp->stream);
+        if (abo::gone(e)) { g_exiting.store(true); return ABO_OK; }
+        (void)hipGetLastError();
         gp->free_all();
         delete gp;
     }
@@ -1164,6 +1188,7 @@ int32_t abo_append_grad(abo_gp* g, const double* x, int32_t d, const double* y, 
     rc = abo_create(&g->prm, &n);
     if (rc) return rc;
     n->p_out = g->p_out;
+    n->oz_engine = g->oz_engine; n->oz_nmod = g->oz_nmod;
     for (int q = 0; q < MAX_P; ++q) n->mean_vec[q] = g->mean_vec[q];
     rc = append_grad_impl(g, n, x, y, info);
     if (rc) { abo_destroy(n); return rc; }
@@ -1565,8 +1590,8 @@ int32_t abo_cand_create(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_
 }
 
 int32_t abo_cand_destroy(abo_cand* c) {
-    if (!c) return ABO_OK;
-    (void)hipSetDevice(c->device);
+    if (!c || g_exiting.load()) return ABO_OK;
+    if (abo::gone(hipSetDevice(c->device))) { g_exiting.store(true); return ABO_OK; }
     c->free_all();
     delete c;
     return ABO_OK;
@@ -1657,6 +1682,17 @@ int32_t abo::cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double
     return ABO_OK;
 }
 
+bool abo::exiting() { return g_exiting.load(); }
+void abo::arm_exit_guard() {
+    // registered AFTER the first successful device call: atexit handlers run in reverse order of registration, so this one
+    // runs before the HIP runtime's own teardown (registered when the runtime initialised)
+    if (!g_exit_armed.exchange(true)) std::atexit(exit_hook);
+}
+void abo::at_exit(void (*f)()) { std::lock_guard<std::mutex> lk(g_exit_mu); g_exit_hooks.push_back(f); }
+bool abo::gone(hipError_t e) {
+    return e == hipErrorDeinitialized || e == hipErrorContextIsDestroyed || e == hipErrorNotInitialized || e == hipErrorInvalidContext;
+}
+
 // internal accessors for the multi-device driver (mgpu.hip)
 hipStream_t abo::gp_stream(abo_gp* g) { return g->stream; }
 int abo::gp_device(const abo_gp* g) { return g->prm.device; }
@@ -1729,6 +1765,7 @@ int32_t abo_cand_exclude(abo_gp* g, abo_cand* c, int64_t idx) {
 
 int32_t abo_pool_trim(int32_t device) {
     if (device < 0 || device > 15) return fail(ABO_EINVAL, "abo_pool_trim: bad device %d", device);
+    if (g_exiting.load()) return ABO_OK;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipDeviceSynchronize());
     pool_trim(device);

@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>   // types and prototypes only: the functions are resolved with dlsym (no link-time dependency)
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -80,41 +81,72 @@ const Rccl& rccl() {
     return r;
 }
 
-// ---- one worker thread per shard slot, shared by all groups of the process --------------------------------------
+// ---- worker threads: one per shard of a device list, owned by that list's CommSet ---------------------------------------
+// Groups on the same device list (every `update` makes a new group) share the list's threads; groups on DIFFERENT lists share
+// nothing, so two models on disjoint device lists run their calls — collectives included — side by side.  A worker is parked
+// on its condition variable when idle.  At process exit (abo::at_exit, before the HIP runtime tears down) idle workers are
+// told to stop and joined; one that is still inside a job — the host is exiting in the middle of a call — is left alone.
 struct Worker {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::function<void()>> q;
+    bool stop = false, busy = false;
+    std::thread th;
     Worker() {
-        std::thread([this] {
+        th = std::thread([this] {
             for (;;) {
                 std::function<void()> job;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [this] { return !q.empty(); });
+                    cv.wait(lk, [this] { return stop || !q.empty(); });
+                    if (q.empty()) return;                 // stop requested and nothing left to run
                     job = std::move(q.front());
                     q.pop_front();
+                    busy = true;
                 }
                 job();
+                { std::lock_guard<std::mutex> lk(mu); busy = false; }
             }
-        }).detach();          // lives as long as the process; blocked on the condition variable when idle
+        });
     }
     void post(std::function<void()> f) {
         { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); }
         cv.notify_one();
     }
+    // exit path: returns true when the thread has been joined
+    bool stop_if_idle() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (busy || !q.empty()) return false;
+            stop = true;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+        return true;
+    }
 };
 
-Worker* worker(int slot) {
-    static std::mutex mu;
-    static Worker* w[MAXDEV] = {nullptr};
-    std::lock_guard<std::mutex> lk(mu);
-    if (!w[slot]) w[slot] = new Worker();   // never destroyed: a thread parked in it may outlive static destructors
-    return w[slot];
+std::mutex g_workers_mu;
+std::vector<Worker*> g_workers;          // every worker of the process (never freed: a busy one may outlive the exit hook)
+
+void stop_workers_at_exit() {
+    std::vector<Worker*> all;
+    { std::lock_guard<std::mutex> lk(g_workers_mu); all = g_workers; }
+    for (Worker* w : all)
+        if (!w->stop_if_idle()) w->th.detach();    // mid-call at exit: never join a thread that may be blocked in the runtime
 }
 
-// f(i) for every shard i concurrently; the first failure (lowest shard) becomes the caller's status and error text
-int32_t run_all(int n, const std::function<int32_t(int)>& f) {
+Worker* new_worker() {
+    Worker* w = new Worker();
+    std::lock_guard<std::mutex> lk(g_workers_mu);
+    if (g_workers.empty()) abo::at_exit(stop_workers_at_exit);
+    g_workers.push_back(w);
+    return w;
+}
+
+// f(i) for every shard i concurrently on the given workers; the first failure (lowest shard) becomes the caller's status
+// and error text
+int32_t run_all(Worker* const* wk, int n, const std::function<int32_t(int)>& f) {
     if (n == 1) return f(0);
     std::mutex mu;
     std::condition_variable cv;
@@ -122,7 +154,7 @@ int32_t run_all(int n, const std::function<int32_t(int)>& f) {
     std::vector<int32_t> rc(n, 0);
     std::vector<std::string> err(n);
     for (int i = 0; i < n; ++i) {
-        worker(i)->post([&, i] {
+        wk[i]->post([&, i] {
             rc[i] = f(i);
             if (rc[i]) err[i] = abo::last_error_text();
             std::lock_guard<std::mutex> lk(mu);
@@ -148,7 +180,14 @@ struct CommSet {
     void* gath[MAXDEV] = {nullptr};     // the gathered contributions of all shards
     size_t pack_cap[MAXDEV] = {0}, gath_cap[MAXDEV] = {0};
     std::mutex mu;                      // one exchange at a time per device list
+    Worker* wk[MAXDEV] = {nullptr};     // the list's worker threads, one per shard (more than one shard only)
+    // another device list of this process names one of these devices too: collectives of the two lists are then serialised
+    // process-wide (two communicators enqueueing on one device from different threads can wait for each other forever);
+    // disjoint lists never take that lock
+    std::atomic<bool> overlaps{false};
 };
+
+std::mutex g_overlap_mu;                // the process-wide collective lock of overlapping device lists
 
 CommSet* comm_set(const int* dev, int ndev) {
     static std::mutex mu;
@@ -175,6 +214,12 @@ CommSet* comm_set(const int* dev, int ndev) {
         if (r == ncclSuccess) cs->rccl_ok = true;
         else cs->why = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
         (void)hipGetLastError();
+    }
+    if (ndev > 1) for (int i = 0; i < ndev; ++i) cs->wk[i] = new_worker();
+    for (auto& kv : sets) {
+        bool shared = false;
+        for (int a : kv.second->dev) for (int b : cs->dev) shared = shared || a == b;
+        if (shared && kv.second->dev != cs->dev) { kv.second->overlaps.store(true); cs->overlaps.store(true); }
     }
     sets[key] = cs;
     return cs;
@@ -250,12 +295,12 @@ int32_t check_group(abo_mgpu* mg, const char* fn) {
 int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
     CommSet* cs = mg->cs;
     const int n = mg->ndev;
-    // one collective at a time in the whole process: two device lists that overlap share worker threads, and a shard
-    // parked in its stream synchronisation would otherwise keep the peer of the OTHER collective from ever enqueueing
-    static std::mutex xmu;
-    std::lock_guard<std::mutex> xlk(xmu);
+    // the caller holds cs->mu (one exchange at a time per device list); lists that share a device with another list
+    // additionally serialise process-wide, disjoint lists do not
+    std::unique_lock<std::mutex> xlk(g_overlap_mu, std::defer_lock);
+    if (cs->overlaps.load()) xlk.lock();
     if (cs->rccl_ok) {
-        int32_t rc = run_all(n, [&](int i) -> int32_t {
+        int32_t rc = run_all(cs->wk, n, [&](int i) -> int32_t {
             if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
             hipStream_t s = abo::gp_stream(mg->gp[i]);
             const ncclResult_t r = rccl().AllGather(cs->pack[i], cs->gath[i], words, ncclUint64, cs->comm[i], s);
@@ -267,7 +312,7 @@ int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
         });
         return rc;
     }
-    return run_all(n, [&](int i) -> int32_t {
+    return run_all(cs->wk, n, [&](int i) -> int32_t {
         if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
         hipStream_t s = abo::gp_stream(mg->gp[i]);
         if (hipMemcpyAsync(out + (size_t)i * words, cs->pack[i], words * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -330,7 +375,7 @@ int32_t abo_mgpu_clone(abo_mgpu* mg, abo_mgpu** out) {
 }
 
 int32_t abo_mgpu_destroy(abo_mgpu* mg) {
-    if (!mg) return ABO_OK;
+    if (!mg || abo::exiting()) return ABO_OK;          // late finaliser: the device state goes with the process (abo_internal.h)
     for (int i = 0; i < mg->ndev; ++i) abo_destroy(mg->gp[i]);
     delete mg;
     return ABO_OK;
@@ -363,7 +408,7 @@ int32_t abo_mgpu_fit(abo_mgpu* mg, const double* X, int64_t N, int32_t d, const 
     // which is what the driver's rollback restores anyway (src/bayesian_opt.jl:126-141)
     int64_t inf[MAXDEV] = {0};
     abo_gp* nw[MAXDEV] = {nullptr};
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         abo_params p = mg->prm;
         p.device = mg->dev[i];
         const int32_t r = abo_create(&p, &nw[i]);
@@ -383,7 +428,7 @@ int32_t abo_mgpu_predict(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, do
     int32_t rc = check_group(mg, "abo_mgpu_predict");
     if (rc) return rc;
     if (M < 0 || (M > 0 && !Z)) return failf(ABO_EINVAL, "abo_mgpu_predict: bad candidate buffer");
-    return run_all(mg->ndev, [&](int i) -> int32_t {
+    return run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         int64_t lo, hi;
         shard_range(M, i, mg->ndev, &lo, &hi);
         // an empty shard still checks the dimension (same status on every device)
@@ -401,7 +446,7 @@ int32_t abo_mgpu_acq(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, int32_
     CommSet* cs = mg->cs;
     std::lock_guard<std::mutex> lk(cs->mu);
     const size_t words = 2 * (size_t)k;
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         int64_t lo, hi;
         shard_range(M, i, mg->ndev, &lo, &hi);
         double* tv = nullptr;
@@ -437,7 +482,7 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
         for (int i = 0; i < mg->ndev; ++i)
             if (zdev[i]) { (void)hipSetDevice(mg->dev[i]); (void)hipFree(zdev[i]); zdev[i] = nullptr; }
     };
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         int64_t lo, hi;
         shard_range(n, i, mg->ndev, &lo, &hi);
         int32_t r = ensure_exchange_buffers(mg, i, words);
@@ -457,7 +502,7 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
     merge_blocks(blocks.data(), mg->ndev, k, top_val, top_idx);
     if (top_x) {
         // coordinates of the winners, fetched from the shard that generated them
-        rc = run_all(mg->ndev, [&](int i) -> int32_t {
+        rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
             int64_t lo, hi;
             shard_range(n, i, mg->ndev, &lo, &hi);
             if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
@@ -487,7 +532,7 @@ int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int6
     if (mc && mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_append: candidate set has %d shards, group %d", mc->ndev, mg->ndev);
     abo_gp* nw[MAXDEV] = {nullptr};
     int64_t inf[MAXDEV] = {0};
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         int32_t r = abo_append(mg->gp[i], x, d, y, &inf[i], &nw[i]);
         if (r) return r;
         if (mc) r = abo_cand_downdate(nw[i], mc->c[i]);
@@ -509,7 +554,7 @@ int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int6
 }
 
 int32_t abo_mgpu_cand_destroy(abo_mcand* mc) {
-    if (!mc) return ABO_OK;
+    if (!mc || abo::exiting()) return ABO_OK;
     for (int i = 0; i < mc->ndev; ++i) abo_cand_destroy(mc->c[i]);
     delete mc;
     return ABO_OK;
@@ -531,7 +576,7 @@ int32_t abo_mgpu_cand_create(abo_mgpu* mg, const double* Z, int64_t M, int32_t d
     abo_mcand* mc = nullptr;
     rc = mcand_new(mg, M, d, &mc);
     if (rc) return rc;
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         return abo_cand_create(mg->gp[i], Z + mc->lo[i] * d, mc->lo[i + 1] - mc->lo[i], d, ABO_HOST, &mc->c[i]);
     });
     if (rc) { const std::string keep = abo::last_error_text(); abo_mgpu_cand_destroy(mc); return abo::set_error(rc, keep.c_str()); }
@@ -547,7 +592,7 @@ int32_t abo_mgpu_cand_create_lhs(abo_mgpu* mg, int64_t n, int32_t d, const doubl
     abo_mcand* mc = nullptr;
     rc = mcand_new(mg, n, d, &mc);
     if (rc) return rc;
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         const int64_t m = mc->lo[i + 1] - mc->lo[i];
         double* z = nullptr;
         if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
@@ -567,7 +612,7 @@ int32_t abo_mgpu_cand_refresh(abo_mgpu* mg, abo_mcand* mc) {
     int32_t rc = check_group(mg, "abo_mgpu_cand_refresh");
     if (rc) return rc;
     if (!mc || mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_cand_refresh: candidate set does not belong to this group");
-    return run_all(mg->ndev, [&](int i) -> int32_t { return abo_cand_refresh(mg->gp[i], mc->c[i]); });
+    return run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t { return abo_cand_refresh(mg->gp[i], mc->c[i]); });
 }
 
 int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, double best_y, int32_t k, double* top_val,
@@ -579,7 +624,7 @@ int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, 
     CommSet* cs = mg->cs;
     std::lock_guard<std::mutex> lk(cs->mu);
     const size_t words = 2 * (size_t)k;
-    rc = run_all(mg->ndev, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         const int32_t r = ensure_exchange_buffers(mg, i, words);
         if (r) return r;
         return abo::cand_acq_ex(mg->gp[i], mc->c[i], kind, p0, best_y, mc->lo[i], nullptr, ABO_DEVICE, k,
@@ -605,7 +650,7 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
     // exchange block per shard: the pick record {score, index, μ, x[d]}; the (score, index) pair of the device top-1 is
     // parked behind it in the same buffer
     const size_t words = 3 + (size_t)d;
-    rc = run_all(n, [&](int i) -> int32_t {
+    rc = run_all(mg->cs->wk, n, [&](int i) -> int32_t {
         const int32_t r = ensure_exchange_buffers(mg, i, words + 2);
         if (r) return r;
         return abo_cand_save(mg->gp[i], mc->c[i]);
@@ -617,7 +662,7 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
     int32_t status = ABO_OK;
     std::string keep;
     for (int j = 0; j < q && !status; ++j) {
-        status = run_all(n, [&](int i) -> int32_t {
+        status = run_all(mg->cs->wk, n, [&](int i) -> int32_t {
             double* rec = static_cast<double*>(cs->pack[i]);
             double* tv = rec + words;
             int64_t* ti = reinterpret_cast<int64_t*>(rec + words + 1);
@@ -651,7 +696,7 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
         idx_out[j] = gidx;
         memcpy(x_out + (size_t)j * d, x, sizeof(double) * d);
         abo_gp* nw[MAXDEV] = {nullptr};
-        status = run_all(n, [&](int i) -> int32_t {
+        status = run_all(mg->cs->wk, n, [&](int i) -> int32_t {
             int64_t inf = 0;
             int32_t r = abo_append(cur[i], x, d, mu, &inf, &nw[i]);       // fantasy observation y = μ(x): β = 0
             if (r) return r;
@@ -670,7 +715,7 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
     if (status && keep.empty()) keep = abo::last_error_text();
     for (int i = 0; i < n; ++i)
         if (cur[i] != mg->gp[i]) abo_destroy(cur[i]);
-    rc = run_all(n, [&](int i) -> int32_t { return abo_cand_restore(mg->gp[i], mc->c[i]); });
+    rc = run_all(mg->cs->wk, n, [&](int i) -> int32_t { return abo_cand_restore(mg->gp[i], mc->c[i]); });
     if (status) return abo::set_error(status, keep.c_str());
     return rc;
 }

@@ -91,7 +91,7 @@ bool oz_make_plan(int n, OzPlan* out) {
 
 // ---- device helpers --------------------------------------------------------------------------------------------------------------
 // ---- row scales of W ---------------------------------------------------------------------------------------------------------------
-// one wave per row i < Np: L1 = Σ_{k≤i} |W[i][k]|, mx = max; s_i = min(eP − 53 − e(L1), 51 − e(mx)) with e(x) the frexp exponent
+// one wave per row i < Np: L1 = Σ_{k≤i} |W[i][k]|, mx = max; s_i = min(eP − 53 − e(L1), 52 − e(mx)) with e(x) the frexp exponent
 // (x < 2^e), so that 2^s_i·L1·2^53 ≤ P/4 and |W'| < 2^52.  sexp[i] = s_i; rows ≥ Np (padding to 256) get 0.
 // kper / ktg: columns k with k % kper != 0 carry an extra factor 2^ktg (the gradient outputs of a gradient-enhanced model, see
 // oz_prepare_w); kper = 1 → none.

@@ -172,12 +172,12 @@ def rescale_model(model: HipGradientGP, sigma):
     inner, scale, ell = extract_scale_and_lengthscale(model.kernel)
     k = (scale / s1 ** 2) * with_lengthscale(inner, ell)
     return HipGradientGP(k, model.p, model.noise_var / s1 ** 2, mean=gradConstMean(model.mean.c / s1), device=model.device,
-                         jitter=model.jitter, chunk=model.chunk, n_max=model.n_max)
+                         jitter=model.jitter, chunk=model.chunk, n_max=model.n_max, contraction=model.contraction)
 
 
 def _update_model_parameters(model: HipGradientGP, kernel: Kernel):
     return HipGradientGP(kernel, model.p, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter,
-                         chunk=model.chunk, n_max=model.n_max)
+                         chunk=model.chunk, n_max=model.n_max, contraction=model.contraction)
 
 
 def nlml(model: HipGradientGP, params, xs, ys) -> float:
@@ -185,6 +185,9 @@ def nlml(model: HipGradientGP, params, xs, ys) -> float:
     rebuilt with exp.(params), noise and prior mean are kept; −logpdf of the (d+1)N-row system."""
     from .surrogate import nlml_fitted
     log_ell, log_scale = params
+    if hasattr(log_ell, "partials") or hasattr(log_scale, "partials"):     # dual-number parameters: see surrogate.nlml
+        from .hyperparams import nlml_dual
+        return nlml_dual(model, (log_ell, log_scale), xs, ys, value_and_grad=nlml_and_grad)
     inner = extract_scale_and_lengthscale(model.kernel)[0]
     k = math.exp(log_scale) * with_lengthscale(inner, math.exp(log_ell))
     return nlml_fitted(update(_update_model_parameters(model, k), xs, ys))

@@ -23,11 +23,47 @@ def nlml_and_grad(model: HipStandardGP, params, xs, ys):
     """(nlml, [∂/∂log ℓ, ∂/∂log scale]) at params = [log ℓ, log scale] (value as StandardGP.jl:99-114)."""
     log_ell, log_scale = params
     k = math.exp(log_scale) * with_lengthscale(get_kernel_constructor(model), math.exp(log_ell))
-    g = HipStandardGP(k, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter)
+    g = HipStandardGP(k, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter, contraction=model.contraction)
     fitted = update(g, xs, ys)
     v, d1, d2 = C.c_double(), C.c_double(), C.c_double()
     _lib.check(_lib.lib().abo_nlml_grad(fitted._require(), C.byref(v), C.byref(d1), C.byref(d2)))
     return v.value, np.array([d1.value, d2.value])
+
+
+class Dual:
+    """value + partials — the shape of a ForwardDiff.Dual, which is what the reference's stock driver evaluates the objective
+    on (`autodiff=:forward`, bayesian_opt.jl:276-285).  Only what the chain rule of `nlml_dual` needs: the Julia shim
+    (integration/julia/HipStandardGP.jl) does the same with ForwardDiff.value / ForwardDiff.partials."""
+
+    def __init__(self, value, partials):
+        self.value = float(value)
+        self.partials = np.asarray(partials, dtype=np.float64)
+
+    def __add__(self, o):
+        return Dual(self.value + o.value, self.partials + o.partials) if isinstance(o, Dual) else Dual(self.value + o, self.partials)
+
+    __radd__ = __add__
+
+    def __mul__(self, o):
+        if isinstance(o, Dual):
+            return Dual(self.value * o.value, self.value * o.partials + o.value * self.partials)
+        return Dual(self.value * o, self.partials * o)
+
+    __rmul__ = __mul__
+
+
+def nlml_dual(model, params, xs, ys, value_and_grad=None):
+    """nlml on Dual parameters [log ℓ, log scale] (either may be a plain float: nlml_ls keeps the scale fixed): the
+    library evaluates value and analytic gradient at the VALUES (abo_nlml_grad, one refit) and the callers' partials go
+    through the chain rule — Dual(v, g₁·∂p₁ + g₂·∂p₂) — so no dual number crosses the C-ABI."""
+    value_and_grad = value_and_grad or nlml_and_grad
+    vals = [p.value if isinstance(p, Dual) else float(p) for p in params]
+    v, g = value_and_grad(model, vals, xs, ys)
+    part = None
+    for gi, p in zip(g, params):
+        if isinstance(p, Dual):
+            part = gi * p.partials if part is None else part + gi * p.partials
+    return Dual(v, part) if part is not None else v
 
 
 def monte_carlo_fill_distance(X_train, domain, n_samples: int = 10_000, rng=None) -> float:

@@ -281,8 +281,13 @@ def nlml(model: HipStandardGP, params, xs, ys) -> float:
     kernel with exp.(params), keeps noise and mean, returns −logpdf (value only — ForwardDiff duals
     cannot cross a C-ABI; SURVEY.md §8(f) rank 2 tracks the analytic gradient)."""
     log_ell, log_scale = params
+    if hasattr(log_ell, "partials") or hasattr(log_scale, "partials"):
+        # dual-number parameters (what Optim's autodiff=:forward feeds the objective, bayesian_opt.jl:276-285): value and
+        # analytic gradient at the values, partials through the chain rule
+        from .hyperparams import nlml_dual
+        return nlml_dual(model, (log_ell, log_scale), xs, ys)
     k = math.exp(log_scale) * with_lengthscale(get_kernel_constructor(model), math.exp(log_ell))
-    g = HipStandardGP(k, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter)
+    g = HipStandardGP(k, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter, contraction=model.contraction)
     return nlml_fitted(update(g, xs, ys))
 
 
@@ -314,12 +319,12 @@ def rescale_model(model: HipStandardGP, sigma):
     if not isinstance(mean, ZeroMean):
         mean = ConstMean(mean.c / sigma)
     return HipStandardGP(new_kernel, model.noise_var / sigma ** 2, mean=mean, device=model.device,
-                         jitter=model.jitter, chunk=model.chunk, n_max=model.n_max)
+                         jitter=model.jitter, chunk=model.chunk, n_max=model.n_max, contraction=model.contraction)
 
 
 def _update_model_parameters(model: HipStandardGP, kernel: Kernel):
     return HipStandardGP(kernel, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter,
-                         chunk=model.chunk, n_max=model.n_max)
+                         chunk=model.chunk, n_max=model.n_max, contraction=model.contraction)
 
 
 def get_lengthscale(model: HipStandardGP):

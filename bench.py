@@ -14,6 +14,8 @@ candidate batch is G·2²⁰ (C4 at G = 8) sharded contiguously, one process per
 redundantly, and the only collective is the all_gather of 100 (score, index) pairs per rank.
 
   python bench.py                       # 1 GPU, C3
+  python bench.py --gpus 8              # no launcher: one process drives the 8 devices through the library's own
+                                        # multi-device handle (abo_mgpu_*: worker thread per device, RCCL all-gather)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
          --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 2
 """
@@ -159,7 +161,9 @@ def source_sha(names):
     return h.hexdigest()[:16]
 
 
-PMC_SOURCES = {"c3": ["gemm.hip"], "c3_int8": ["ozaki.hip"], "c5": ["misc.hip"]}      # the translation unit of each config's dominant kernel
+# every file the dominant kernel of a config is compiled from (tools/pmc_traffic_json.py records the same hash)
+PMC_SOURCES = {"c3": ["gemm.hip", "abo_kernels.h"], "c3_int8": ["ozaki.hip", "abo_oz_dev.h", "abo_kernels.h"],
+               "c5": ["misc.hip", "abo_kernels.h", "abo_kappa.h"]}
 
 
 def pmc_traffic(config, mc_per_launch):
@@ -169,7 +173,7 @@ def pmc_traffic(config, mc_per_launch):
     traffic of that pass scaled to this run's candidates per launch.  The pass records the hash of the kernel's
     source file; when the file has changed since, the figure is STALE and `traffic` is reported as null."""
     key = config.replace("c4", "c3")                         # C4 = C3 per launch
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -183,6 +187,71 @@ def pmc_traffic(config, mc_per_launch):
         return None, d
     per = d.get("traffic_bytes_per_candidate")
     return (per * mc_per_launch if per is not None else d.get("traffic_bytes_per_launch")), d
+
+
+def contraction_label(abo, med):
+    """what `config.contraction` says about the engine that ran: the int8-residue engine's only approximation is the fixed-point
+    image of its operands, and the guarantee is stated per ROW of L^-1 (ozaki.hip: oz_rowscale_kernel), not per entry"""
+    if int(med["contraction_engine"]) != abo._lib.CONTRACT_INT8:
+        return "fp64 MFMA"
+    return (f"int8-residue, {int(med['oz_nmod'])} moduli: exact integer products and sums of fixed-point images of the fp64 operands "
+            "(K_XZ kept to 2^-52 of sigma_f2; each row of L^-1 kept to >= 50 bits below that row's L1 norm, i.e. an entry far below its "
+            "row's L1 norm keeps fewer of its own bits - at most log2(N) fewer than 53 for a dense equal-magnitude row); results fp64, "
+            "parity vs the oracle recorded in profiles/parity_r03.json")
+
+
+def dominant_kernel_roofline(abo, med, config, N, M_per):
+    """`roofline` object of the C2/C3/C4-shaped step from the median phase timings of one device (abo_get_timings)"""
+    launches = int(med["var_gemm_launches"])
+    flop = med["var_gemm_flop"]                       # N²·M_per (triangular credit), all launches of one step
+    t_kernel_ms = med["acq_var_gemm_ms"]
+    achieved = flop / (t_kernel_ms * 1e-3) / 1e12 if t_kernel_ms > 0 else 0.0
+    int8 = int(med["contraction_engine"]) == abo._lib.CONTRACT_INT8
+    traffic, pmc = pmc_traffic(config + ("_int8" if int8 else ""), M_per / max(launches, 1))
+    mc = M_per / max(launches, 1)
+    if int8:
+        # dominant kernel = the residue GEMM (one launch per chunk covers all moduli): ALGORITHMIC int8 operations —
+        # n moduli × N²·M (the triangular product, 2 operations per multiply-add; what the kernel issues beyond that on its
+        # diagonal blocks and on padding is not credited) ÷ its HIP-event duration
+        nmod = int(med["oz_nmod"])
+        tops = med["oz_gemm_ops"] / (med["oz_gemm_ms"] * 1e-3) / 1e12 if med["oz_gemm_ms"] > 0 else 0.0
+        np256 = -(-N // 256) * 256
+        return {
+            "kernel": f"oz_gemm16d_kernel (V = L^-1 K_XZ as {nmod} exact int8 residue GEMMs, v_mfma_i32_16x16x64_i8, "
+                      "triangular k-range, symmetric-mod epilogue)",
+            "bound": "mfma", "achieved": tops, "peak": PEAK_INT8_MFMA_TOPS, "unit": "TOP/s", "frac": tops / PEAK_INT8_MFMA_TOPS,
+            "traffic": traffic,
+            "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
+            "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
+            # residue planes read once + U written once: n·(Np²/2 + Mc·Np) + n·Np·Mc bytes
+            "algorithmic_bytes_per_launch": float(nmod) * (np256 * np256 / 2 + 2 * mc * np256),
+            "ops_per_launch": med["oz_gemm_ops"] / max(launches, 1), "launches_per_step": launches,
+            "avg_launch_ms": med["oz_gemm_ms"] / max(launches, 1),
+            "sustained_peak_random_operands": sustained_int8_tops(),
+            "frac_of_sustained": (tops / sustained_int8_tops()) if sustained_int8_tops() else None,
+            "engine": {"name": "int8-residue (ABO_CONTRACT_INT8)", "moduli": nmod,
+                       "pipeline_ms_per_chunk": {"quantise_K_XZ": med["oz_quant_ms"] / max(launches, 1),
+                                                 "residue_gemm": med["oz_gemm_ms"] / max(launches, 1),
+                                                 "reconstruct_and_square": med["oz_crt_ms"] / max(launches, 1)},
+                       "residue_planes_of_W_ms": med["oz_prepare_ms"],
+                       "fp64_equivalent_tflops": achieved, "fp64_equivalent_over_fp64_mfma_peak": achieved / PEAK_FP64_MFMA_TFLOPS},
+            "note": "achieved = algorithmic int8 operations (moduli x N^2 x M) of the residue GEMM launches / their HIP-event duration "
+                    "(library stream, median over timed steps); peak = dense int8 MFMA at 2.4 GHz; sustained_peak = the same "
+                    "instruction on random operands from registers, clock as the chip holds it "
+                    "(profiles/r02_mfma_i8_power_probe.txt); fp64_equivalent = N^2*M / time of the whole contraction pipeline",
+        }
+    return {
+        "kernel": "var_gemm256s_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
+        "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+        "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
+        "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
+        "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + mc * N + (N / 128) * mc),
+        "flop_per_launch": flop / max(launches, 1), "launches_per_step": launches,
+        "avg_launch_ms": t_kernel_ms / max(launches, 1),
+        "note": "algorithmic flop = N^2*M (triangular credit, SURVEY 8(d)); duration = HIP events on the "
+                "library stream around each launch, median over timed steps",
+    }
 
 
 def quick_config(abo, synth, torch, dev, local_rank, name, k_top, steps=20, warmup=3):
@@ -332,19 +401,51 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     return out
 
 
+def plan_launch(args, environ):
+    """Which host drives this invocation: 'ranks' (one process per GPU; the driver's torchrun launch, WORLD_SIZE set, or any
+    1-GPU run) or 'library' (a plain `python bench.py --gpus N`, N > 1: ONE process drives the N devices through the library's
+    multi-device handle abo_mgpu_* — the deployment north_star describes, a Julia host has no process launcher).  No GPU is
+    touched here, so the decision is testable on a CPU-only machine."""
+    world = int(environ.get("WORLD_SIZE", "1"))
+    if args.single_process:
+        if world != 1:
+            raise SystemExit("--single-process is for a plain `python bench.py --gpus N --single-process` launch, not torchrun")
+        return "library"
+    if world == 1 and args.gpus > 1 and "RANK" not in environ:
+        return "library"
+    if world != args.gpus:
+        raise SystemExit(f"torchrun started {world} rank(s) but --gpus says {args.gpus}")
+    return "ranks"
+
+
 def run_single_process(args):
-    """`--gpus N --single-process`: the C3/C4-shaped step driven through ONE multi-device handle (abo_mgpu_*), the shape
-    a Julia host uses.  The candidate grid is generated on the devices (Latin hypercube, shard by shard) and stays
+    """`python bench.py --gpus N` (no launcher) — the C3/C4-shaped step driven through ONE multi-device handle (abo_mgpu_*), the
+    shape a Julia host uses.  The candidate grid is generated on the devices (Latin hypercube, shard by shard) and stays
     resident; a step = replicated full refit on every device + posterior/EI over every shard + per-device top-100 +
-    ONE RCCL all-gather + merge.  --share-device puts all shards on GPU 0 (rehearsal on a one-GPU box: RCCL refuses a
-    device listed twice, the exchange then goes through the host)."""
-    import abstractbayesopt.jl_amd as abo
-    from abstractbayesopt.jl_amd import multigpu, synth
+    ONE RCCL all-gather of 100 x (score, index) per device + merge (acq_utils.jl:50-52 reproduced globally).  --share-device
+    puts all shards on GPU 0 (rehearsal on a one-GPU box: RCCL refuses a device listed twice, the exchange then goes through
+    the host, and the JSON line says so)."""
+    import torch                                        # device count only (does not initialise the GPU)
 
     fam_name, d, N, M_per, ell, sf2, noise, acq_name, p0 = CONFIGS[args.config]
     G = args.gpus
+    have = torch.cuda.device_count()
+    if not args.share_device and have < G:
+        raise SystemExit(f"bench.py --gpus {G}: this machine shows {have} GPU(s); --share-device rehearses {G} shards on GPU 0")
+    if args.config == "c5":
+        return run_single_process_c5(args)
+    # a resident grid would otherwise also keep its fp64 K_ZX (64 GiB per device at C3: the down-date path of config 5);
+    # this step re-evaluates the posterior from scratch, as abo_acq does
+    os.environ["ABO_CAND_KZX_GIB"] = "0"
+    if args.contraction:
+        os.environ["ABO_CONTRACTION"] = args.contraction
+
+    import abstractbayesopt.jl_amd as abo
+    from abstractbayesopt.jl_amd import synth
+
     strong = args.config == "c4"
     M_total = M_per if strong else M_per * G
+    M_per = M_total // G
     devices = [0] * G if args.share_device else list(range(G))
     X, y = synth.standardized_problem(N, d, 0.03)
     gp = abo.HipShardedGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, devices=devices, chunk=args.chunk)
@@ -352,29 +453,122 @@ def run_single_process(args):
     acq = abo.ExpectedImprovement(p0, best_y) if acq_name == "ei" else abo.UpperConfidenceBound(p0)
     model = abo.update(gp, X, y)
     cands = abo.ShardedCandidates(model, lhs=(M_total, np.zeros(d), np.ones(d), 2))
-    step_ms = []
+    L = abo._lib.lib()
+
+    def shard_timings(m):
+        out = []
+        for i in range(G):
+            t = abo._lib.AboTimings()
+            abo._lib.check(L.abo_get_timings(m.shard(i), t))
+            out.append(t.as_dict())
+        return out
+
+    step_ms, per_dev, phases = [], [], []
     for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            t_all = time.perf_counter()                   # every call below returns with all devices idle: no barrier needed
         t0 = time.perf_counter()
         model = abo.update(gp, X, y)                      # full refit on every device (X, y: 0.5 MiB of host data)
         cands.refresh(model)                              # posterior of every resident shard
         tv, ti = cands.evaluate(model, acq, 100)          # epilogue + per-device top-100 + all-gather + merge
         if step >= args.warmup:
             step_ms.append((time.perf_counter() - t0) * 1e3)
-    ms = float(np.mean(step_ms))
+            st = shard_timings(model)
+            per_dev.append([t["fit_total_ms"] + t["acq_total_ms"] for t in st])
+            phases.append(st[0])
+    ms = (time.perf_counter() - t_all) * 1e3 / args.steps
+    med = {k: float(np.median([p[k] for p in phases])) for k in phases[0]}
+    exchange, why = model.exchange(), model.exchange_note()
     out = {
         "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
         "value": ms, "unit": "ms", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": False, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.config.upper()} single-process: d={d} {fam_name} ell={ell} noise={noise}, N={N} train, "
-                               f"M={M_total} candidates over {G} shard(s) on devices {devices}, {acq_name.upper()} p0={p0}, "
-                               f"top-100, full refit every step, grid resident (device-generated LHS)",
-                   "N": N, "M_total": M_total, "d": d, "devices": devices, "exchange": model.exchange(),
-                   "exchange_note": model.exchange_note()},
+        "config": {"workload": f"{args.config.upper()}: d={d} {fam_name} ell={ell} sigma_f2={sf2} noise={noise}, N={N} train, "
+                               f"M={M_per} candidates per GPU ({M_total} total), {acq_name.upper()} p0={p0}, top-100, "
+                               f"full refit every step",
+                   "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "kernel": fam_name, "acq": acq_name,
+                   "host": "one process, library-owned worker thread per device (abo_mgpu_*); grid resident, device-generated "
+                           "Latin hypercube",
+                   "sharding": f"candidates x{G} contiguous, replicated refit, one all-gather of top-100 (score, index) per device",
+                   "devices": devices, "distinct_devices": len(set(devices)),
+                   "exchange": exchange, "exchange_note": why if exchange == "host" else "ncclAllGather over the devices' streams",
+                   "rccl_ranks": G if exchange == "rccl" else 0,
+                   "contraction": contraction_label(abo, med)},
         "candidates_per_s": M_total / (ms * 1e-3),
+        "roofline": dominant_kernel_roofline(abo, med, args.config, N, M_per),
+        "phases_ms_device0": {k: v for k, v in med.items() if k.endswith("_ms")},
+        "per_device_hip_event_ms_per_step": [float(v) for v in np.median(np.asarray(per_dev), axis=0)],
         "median_ms_per_step": float(np.median(step_ms)), "min_ms_per_step": float(np.min(step_ms)),
+        "max_ms_per_step": float(np.max(step_ms)),
         "top1": {"score": float(tv[0]), "index": int(ti[0])},
     }
+    if len(set(devices)) < G:
+        out["rehearsal"] = f"{G} shards share {len(set(devices))} physical device(s): NOT a scaling measurement"
+    print(json.dumps(out))
+
+
+def run_single_process_c5(args):
+    """BASELINE config 5 through the multi-device handle: a step = abo_mgpu_cand_qei (q = 8 greedy picks, each: EI + arg-max per
+    device, ONE all-gather of the devices' pick records, the same fantasy append + O(N·M) down-date on every device, rolled back at
+    the end) + abo_mgpu_append of the real observation with the grid's down-date in the same call."""
+    import abstractbayesopt.jl_amd as abo
+    from abstractbayesopt.jl_amd import multigpu, synth
+
+    fam_name, d, N, M_per, ell, sf2, noise, _, xi = CONFIGS["c5"]
+    G, Q = args.gpus, 8
+    M_total = M_per * G
+    devices = [0] * G if args.share_device else list(range(G))
+    X = synth.points(1, N, d)
+    y_raw = synth.objective(X, noise_std=float(np.sqrt(noise)))
+    y_mean, y_std = y_raw.mean(), y_raw.std(ddof=1)
+    y = (y_raw - y_mean) / y_std
+    gp = abo.HipShardedGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, devices=devices, chunk=args.chunk,
+                          n_max=N + 64)
+    model = abo.update(gp, X, y)
+    cands = abo.ShardedCandidates(model, lhs=(M_total, np.zeros(d), np.ones(d), 2))
+    refresh_all = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        model = abo.update(gp, X, y)
+        cands.refresh(model)
+        refresh_all.append((time.perf_counter() - t0) * 1e3)
+    best_y = float(y.min())
+    step_ms, picks = [], None
+    for step in range(args.warmup + args.steps):
+        if step == args.warmup:
+            t_all = time.perf_counter()
+        t0 = time.perf_counter()
+        pts, idxs, vals = cands.greedy_qei(model, Q, xi, best_y)
+        x_new = pts[0]
+        y_new = ((np.sin(2 * np.pi * x_new).sum() / np.sqrt(d)) - y_mean) / y_std
+        model = multigpu.append(model, x_new, float(y_new), cands)
+        best_y = min(best_y, float(y_new))
+        picks = (idxs, vals)
+        if step >= args.warmup:
+            step_ms.append((time.perf_counter() - t0) * 1e3)
+    ms = (time.perf_counter() - t_all) * 1e3 / args.steps
+    exchange, why = model.exchange(), model.exchange_note()
+    out = {
+        "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
+        "value": ms, "unit": "ms", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"C5: d={d} {fam_name} ell={ell} noise={noise}, N={N}(+1 per step) train, resident grid M={M_per} per "
+                               f"GPU ({M_total} total), greedy q-EI q={Q} (fantasy append + O(N*M) down-date per pick) + 1 real "
+                               f"bordered append per step",
+                   "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "q": Q,
+                   "host": "one process, library-owned worker thread per device (abo_mgpu_cand_qei / abo_mgpu_append)",
+                   "sharding": f"grid x{G}, one all-gather of (score, index, mu, x) per pick",
+                   "devices": devices, "distinct_devices": len(set(devices)), "exchange": exchange,
+                   "exchange_note": why if exchange == "host" else "ncclAllGather over the devices' streams",
+                   "rccl_ranks": G if exchange == "rccl" else 0},
+        "refresh_ms": float(np.median(refresh_all[1:])), "refresh_ms_all": refresh_all,
+        "median_ms_per_step": float(np.median(step_ms)), "min_ms_per_step": float(np.min(step_ms)),
+        "max_ms_per_step": float(np.max(step_ms)),
+        "last_batch": {"indices": [int(i) for i in picks[0]], "ei": [float(v) for v in picks[1]]},
+    }
+    if len(set(devices)) < G:
+        out["rehearsal"] = f"{G} shards share {len(set(devices))} physical device(s): NOT a scaling measurement"
     print(json.dumps(out))
 
 
@@ -392,7 +586,8 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3, help="repetitions of the CPU-baseline sample (median reported)")
     ap.add_argument("--single-process", action="store_true",
                     help="drive --gpus N devices from THIS process through the library's multi-device handle (abo_mgpu_*, "
-                         "RCCL all-gather inside the library) instead of one process per GPU under torchrun")
+                         "RCCL all-gather inside the library); the default for a plain `python bench.py --gpus N` with N > 1 — "
+                         "under torchrun (WORLD_SIZE set) every rank drives its own GPU instead")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
     ap.add_argument("--contraction", default=None,
                     help="engine of the N^2*M variance contraction: auto (library default), fp64, int8 or int8:<moduli>")
@@ -400,6 +595,9 @@ def main():
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     args = ap.parse_args()
+
+    if plan_launch(args, os.environ) == "library":
+        return run_single_process(args)
 
     import torch
     import torch.distributed as dist
@@ -411,13 +609,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.single_process:
-        if world != 1:
-            sys.exit("--single-process is for a plain `python bench.py --gpus N --single-process` launch, not torchrun")
-        return run_single_process(args)
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d" % (args.gpus, args.gpus))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -527,56 +718,8 @@ def main():
 
     if rank == 0:
         med = {k: float(np.median([p[k] for p in phases])) for k in phases[0]}
-        launches = int(med["var_gemm_launches"])
-        flop = med["var_gemm_flop"]                       # N²·M_per (triangular credit), all launches of one step
-        t_kernel_ms = med["acq_var_gemm_ms"]
-        achieved = flop / (t_kernel_ms * 1e-3) / 1e12 if t_kernel_ms > 0 else 0.0
         int8 = int(med["contraction_engine"]) == abo._lib.CONTRACT_INT8
-        traffic, pmc = pmc_traffic(args.config + ("_int8" if int8 else ""), M_per / max(launches, 1))
-        mc = M_per / max(launches, 1)
-        if int8:
-            # dominant kernel = the residue GEMM (one launch per chunk covers all moduli): int8 operations actually issued
-            # (n moduli × 2·256²·Σ(ti+1)·256 per 256-candidate block, diagonal blocks in full) ÷ its HIP-event duration
-            nmod = int(med["oz_nmod"])
-            tops = med["oz_gemm_ops"] / (med["oz_gemm_ms"] * 1e-3) / 1e12 if med["oz_gemm_ms"] > 0 else 0.0
-            np256 = -(-N // 256) * 256
-            roofline = {
-                "kernel": f"oz_gemm16d_kernel (V = L^-1 K_XZ as {nmod} exact int8 residue GEMMs, v_mfma_i32_16x16x64_i8, "
-                          "triangular k-range, symmetric-mod epilogue)",
-                "bound": "mfma", "achieved": tops, "peak": PEAK_INT8_MFMA_TOPS, "unit": "TOP/s", "frac": tops / PEAK_INT8_MFMA_TOPS,
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
-                "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
-                # residue planes read once + U written once: n·(Np²/2 + Mc·Np) + n·Np·Mc bytes
-                "algorithmic_bytes_per_launch": float(nmod) * (np256 * np256 / 2 + 2 * mc * np256),
-                "ops_per_launch": med["oz_gemm_ops"] / max(launches, 1), "launches_per_step": launches,
-                "avg_launch_ms": med["oz_gemm_ms"] / max(launches, 1),
-                "sustained_peak_random_operands": sustained_int8_tops(),
-                "frac_of_sustained": (tops / sustained_int8_tops()) if sustained_int8_tops() else None,
-                "engine": {"name": "int8-residue (ABO_CONTRACT_INT8)", "moduli": nmod,
-                           "pipeline_ms_per_chunk": {"quantise_K_XZ": med["oz_quant_ms"] / max(launches, 1),
-                                                     "residue_gemm": med["oz_gemm_ms"] / max(launches, 1),
-                                                     "reconstruct_and_square": med["oz_crt_ms"] / max(launches, 1)},
-                           "residue_planes_of_W_ms": med["oz_prepare_ms"],
-                           "fp64_equivalent_tflops": achieved, "fp64_equivalent_over_fp64_mfma_peak": achieved / PEAK_FP64_MFMA_TFLOPS},
-                "note": "achieved = int8 operations of the residue GEMM launches / their HIP-event duration (library stream, median "
-                        "over timed steps); peak = dense int8 MFMA at 2.4 GHz; sustained_peak = the same instruction on random "
-                        "operands from registers, clock as the chip holds it (profiles/r02_mfma_i8_power_probe.txt); "
-                        "fp64_equivalent = N^2*M / time of the whole contraction pipeline",
-            }
-        else:
-            roofline = {
-                "kernel": "var_gemm256s_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
-                "traffic_source": {k: pmc.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if pmc and k in pmc},
-                "algorithmic_bytes_per_launch": 8.0 * (N * N / 2 + mc * N + (N / 128) * mc),
-                "flop_per_launch": flop / max(launches, 1), "launches_per_step": launches,
-                "avg_launch_ms": t_kernel_ms / max(launches, 1),
-                "note": "algorithmic flop = N^2*M (triangular credit, SURVEY 8(d)); duration = HIP events on the "
-                        "library stream around each launch, median over timed steps",
-            }
+        roofline = dominant_kernel_roofline(abo, med, args.config, N, M_per)
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -587,8 +730,7 @@ def main():
                                    f"{acq_name.upper()} p0={p0}, top-{K_TOP}, full refit every step",
                        "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "kernel": fam_name, "acq": acq_name,
                        "sharding": f"candidates x{world}, all_gather top-{K_TOP}",
-                       "contraction": (f"int8-residue, {int(med['oz_nmod'])} moduli (exact products of 52/53-bit fixed-point images "
-                                       "of the fp64 operands; results fp64)") if int8 else "fp64 MFMA"},
+                       "contraction": contraction_label(abo, med)},
             "candidates_per_s": M_total / (ms_per_step * 1e-3),
             "roofline": roofline,
             "phases_ms": {k: v for k, v in med.items() if k.endswith("_ms")},

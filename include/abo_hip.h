@@ -58,7 +58,8 @@ enum { ABO_HOST = 0, ABO_DEVICE = 1 };
 
 /* engine of the N²·M contraction V = L⁻¹K_XZ behind posterior_var (src/surrogates/StandardGP.jl:377-379):
  *   ABO_CONTRACT_FP64  v_mfma_f64_16x16x4_f64 kernels (78.6 TFLOP/s pipe)
- *   ABO_CONTRACT_INT8  exact products of 52/53-bit fixed-point images of the two fp64 operands on v_mfma_i32_32x32x32_i8,
+ *   ABO_CONTRACT_INT8  exact products of fixed-point images of the two fp64 operands (K_XZ to 2^-52 of sigma_f2, each row of L⁻¹ to ≥ 50 bits
+ *                      below its L1 norm) on v_mfma_i32_16x16x64_i8,
  *                      through residues modulo `nmod` coprime moduli ≤ 256 and a Chinese-remainder reconstruction in fp64
  *                      (14 moduli: errors of the size of the fp64 kernels' own rounding; each modulus less ≈ 14× more error,
  *                      7 % less time).  Serves function-value posteriors (abo_predict, abo_acq, resident grids) of StandardGP and
@@ -97,7 +98,9 @@ typedef struct abo_timings {
     double downdate_bytes;       /* bytes of resident K_ZX that pass streamed (8·N·M); 0 when it re-evaluated the kernel */
     /* ABI 3: which engine ran the contraction of the last posterior call (ABO_CONTRACT_FP64 / _INT8; 0 = none), and for the
      * int8 engine its moduli count, its phases (acq_var_gemm_ms is their sum: quantisation of K_XZ, residue GEMMs,
-     * reconstruction) and the int8 operations the GEMM launches performed (one launch per chunk covers all moduli) */
+     * reconstruction) and the ALGORITHMIC int8 operations of the GEMM launches, moduli × N²·M (one launch per chunk covers all
+     * moduli; what the kernel issues beyond the triangular product is not credited).  oz_prepare_ms: residue planes of L⁻¹, spent in
+     * the last posterior call (0 when that call reused cached planes) */
     int64_t contraction_engine, oz_nmod;
     double oz_prepare_ms, oz_quant_ms, oz_gemm_ms, oz_crt_ms, oz_gemm_ops;
 } abo_timings;

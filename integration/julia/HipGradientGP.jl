@@ -1,4 +1,4 @@
-# HipGradientGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 2) for the gradient-enhanced surrogate of
+# HipGradientGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 4; checked by HipStandardGP.jl's _ensure_abi) for the gradient-enhanced surrogate of
 # AbstractBayesOpt.jl (`GradientGP`, src/surrogates/GradientGP.jl).  `include` it after HipStandardGP.jl (it uses that file's
 # AboParams, AboHandle, _check, _pack, _family, LIBABO) and export HipGradientGP.
 #
@@ -46,19 +46,14 @@ _get_minimum(::HipGradientGP, ys::Vector) = minimum(y[1] for y in ys)           
 _update_model_parameters(m::HipGradientGP, k::Kernel) =
     HipGradientGP(k, m.p, m.noise_var; mean=m.gp.mean, device=m.device, jitter=m.jitter, n_max=m.n_max)
 
-function get_mean_std(::HipGradientGP, y_train::AbstractVector, choice::String)   # :753 — only f is centred, one scale
-    Y = reduce(hcat, y_train)
-    μ = vec(mean(Y; dims=2)); μ[2:end] .= 0.0
-    σ = vec(std(Y; dims=2)); σ[2:end] .= σ[1]
-    choice == "scale_only" && (μ .= 0.0)
-    choice == "mean_only" && (σ .= 1.0)
-    μ, σ
-end
-std_y(::HipGradientGP, ys::AbstractVector, μ::AbstractVector, σ::AbstractVector) = [(y .- μ) ./ σ[1] for y in ys]
-function rescale_model(m::HipGradientGP, σ::AbstractVector)                       # :802
-    k = (get_scale(m)[1] / σ[1]^2) * with_lengthscale(get_kernel_constructor(m), get_lengthscale(m)[1])
-    mean = m.gp.mean isa gradConstMean ? gradConstMean(m.gp.mean.c ./ σ[1]) : m.gp.mean
-    HipGradientGP(k, m.p, m.noise_var / σ[1]^2; mean=mean, device=m.device, jitter=m.jitter, n_max=m.n_max)
+# standardisation helpers: host arithmetic only — forwarded to the reference's own methods (GradientGP.jl:753-820) on a prior-only
+# GradientGP holding the same gp / noise / p
+_ref(m::HipGradientGP) = GradientGP(m.gp, m.noise_var, m.p, nothing)
+get_mean_std(m::HipGradientGP, y_train::AbstractVector, choice::String) = get_mean_std(_ref(m), y_train, choice)
+std_y(m::HipGradientGP, ys::AbstractVector, μ::AbstractVector, σ::AbstractVector) = std_y(_ref(m), ys, μ, σ)
+function rescale_model(m::HipGradientGP, σ::AbstractVector)
+    r = rescale_model(_ref(m), σ)
+    HipGradientGP(r.gp, r.noise_var, m.p, nothing, m.device, m.jitter, m.n_max)
 end
 
 function Base.copy(m::HipGradientGP)                                              # :32
@@ -76,6 +71,7 @@ function _create(m::HipGradientGP)
 end
 
 function update(m::HipGradientGP, xs::AbstractVector, ys::AbstractVector)         # :659-668
+    _ensure_abi()
     X = _pack(xs); d, N = size(X)
     length(ys) == N || throw(DimensionMismatch("xs has $N points, ys $(length(ys)) observations"))
     all(y -> length(y) == m.p, ys) || throw(DimensionMismatch("each observation must hold p = $(m.p) values"))
@@ -149,4 +145,14 @@ function nlml_and_grad(m::HipGradientGP, params, xs::AbstractVector, ys::Abstrac
     v = Ref{Float64}(); g1 = Ref{Float64}(); g2 = Ref{Float64}(); f = _fitted_with(m, params[1], params[2], xs, ys)
     _check(@ccall LIBABO.abo_nlml_grad(f.gpx.ptr::Ptr{Cvoid}, v::Ptr{Float64}, g1::Ptr{Float64}, g2::Ptr{Float64})::Int32)
     v[], [g1[], g2[]]
+end
+# Dual-typed parameters (the stock driver's `autodiff=:forward`, bayesian_opt.jl:276-285): value + analytic gradient at the values,
+# the caller's partials pushed through the chain rule — see HipStandardGP.jl
+function nlml(m::HipGradientGP, params::AbstractVector{<:ForwardDiff.Dual{T}}, xs::AbstractVector, ys::AbstractVector) where {T}
+    v, g = nlml_and_grad(m, ForwardDiff.value.(params), xs, ys)
+    ForwardDiff.Dual{T}(v, g[1] * ForwardDiff.partials(params[1]) + g[2] * ForwardDiff.partials(params[2]))
+end
+function nlml_ls(m::HipGradientGP, log_ℓ::ForwardDiff.Dual{T}, log_scale::Real, xs::AbstractVector, ys::AbstractVector) where {T}
+    v, g = nlml_and_grad(m, [ForwardDiff.value(log_ℓ), Float64(log_scale)], xs, ys)
+    ForwardDiff.Dual{T}(v, g[1] * ForwardDiff.partials(log_ℓ))
 end

@@ -1,4 +1,4 @@
-# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 2) for AbstractBayesOpt.jl.
+# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 4) for AbstractBayesOpt.jl.
 #
 # Drop next to src/surrogates/StandardGP.jl, `include("surrogates/HipStandardGP.jl")` from src/AbstractBayesOpt.jl
 # (after StandardGP.jl and the acquisition functions) and export HipStandardGP.  Every method the BO driver calls on
@@ -22,6 +22,16 @@
 # abstractbayesopt.jl_amd/, which is this binding written with ctypes.
 
 const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
+const ABO_ABI = Int32(4)                 # ABO_ABI_VERSION of the header this file was written against
+const _abi_checked = Ref(false)
+# a stale libabo_hip.so on the load path would otherwise fail at the first missing symbol, somewhere inside a BO step
+function _ensure_abi()
+    _abi_checked[] && return
+    v = @ccall LIBABO.abo_abi_version()::Int32
+    v == ABO_ABI || error("libabo_hip.so reports ABI version $v, HipStandardGP.jl needs $ABO_ABI (rebuild the library: " *
+                          "python -c 'import __graft_entry__ as g; g.build()')")
+    _abi_checked[] = true
+end
 
 struct AboParams            # must match `struct abo_params` (include/abo_hip.h)
     family::Int32; device::Int32
@@ -101,19 +111,14 @@ _get_minimum(::HipStandardGP, ys::Vector) = minimum(ys)                         
 _update_model_parameters(m::HipStandardGP, k::Kernel) =
     HipStandardGP(k, m.noise_var; mean=m.gp.mean, devices=m.devices, jitter=m.jitter, n_max=m.n_max)
 
-# ---- standardisation helpers (host scalars; semantics of StandardGP.jl:164-232) -------------------------------------
-function get_mean_std(::HipStandardGP, y_train::Vector, choice::String)
-    flat = reduce(vcat, y_train)
-    μ, σ = mean(flat), std(flat)
-    choice == "scale_only" && (μ = zero(μ))
-    choice == "mean_only" && (σ = one(σ))
-    μ, σ
-end
-std_y(::HipStandardGP, ys::Vector, μ, σ) = [(y .- μ) ./ σ for y in ys]
+# ---- standardisation helpers: host scalars only, so they FORWARD to the reference's own methods (StandardGP.jl:164-232) on a
+# prior-only StandardGP holding the same gp / noise — nothing of their arithmetic is restated here -----------------------
+_ref(m::HipStandardGP) = StandardGP(m.gp, m.noise_var, nothing)
+get_mean_std(m::HipStandardGP, y_train::Vector, choice::String) = get_mean_std(_ref(m), y_train, choice)
+std_y(m::HipStandardGP, ys::Vector, μ, σ) = std_y(_ref(m), ys, μ, σ)
 function rescale_model(m::HipStandardGP, σ)
-    k = (get_scale(m)[1] / σ^2) * with_lengthscale(get_kernel_constructor(m), get_lengthscale(m)[1])
-    mean = m.gp.mean isa ZeroMean ? m.gp.mean : ConstMean(m.gp.mean.c / σ)      # a ConstMean moves with the data
-    HipStandardGP(k, m.noise_var / σ^2; mean=mean, devices=m.devices, jitter=m.jitter, n_max=m.n_max)
+    r = rescale_model(_ref(m), σ)                            # kernel scale / σ², noise / σ², a ConstMean moves with the data
+    HipStandardGP(r.gp, r.noise_var, nothing, m.devices, m.jitter, m.n_max)
 end
 function unstandardized_mean_and_var(m::HipStandardGP, xs::AbstractVector, params::Tuple)   # StandardGP.jl:395-404
     μ, σ = params[1], params[2]
@@ -137,6 +142,7 @@ _params(m::HipStandardGP) = AboParams(_family(get_kernel_constructor(m)), m.devi
                                       get_scale(m)[1], m.noise_var, _mean_c(m), m.jitter, m.n_max, 0)
 
 function update(m::HipStandardGP, xs::AbstractVector, ys::AbstractVector)          # StandardGP.jl:79-83
+    _ensure_abi()
     X = _pack(xs); d, N = size(X); length(ys) == N || throw(DimensionMismatch("xs has $N points, ys $(length(ys)) values"))
     p = Ref(_params(m)); h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0); y = collect(Float64, ys)
     if _multi(m)
@@ -238,11 +244,28 @@ function nlml(m::HipStandardGP, params, xs::AbstractVector, ys::AbstractVector)
     _check(@ccall LIBABO.abo_nlml(f.gpx.ptr::Ptr{Cvoid}, out::Ptr{Float64})::Int32); out[]
 end
 nlml_ls(m::HipStandardGP, log_ℓ, log_scale, xs::AbstractVector, ys::AbstractVector) = nlml(m, (log_ℓ, log_scale), xs, ys)
-# ForwardDiff duals (autodiff=:forward, bayesian_opt.jl:284) cannot cross a C-ABI: hand Optim `(f, g!)` built on this
+# value and analytic gradient w.r.t. (log ℓ, log σ_f²) from ONE refit (abo_nlml_grad)
 function nlml_and_grad(m::HipStandardGP, params, xs::AbstractVector, ys::AbstractVector)
     v = Ref{Float64}(); g1 = Ref{Float64}(); g2 = Ref{Float64}(); f = _fitted_with(m, params[1], params[2], xs, ys)
     _check(@ccall LIBABO.abo_nlml_grad(f.gpx.ptr::Ptr{Cvoid}, v::Ptr{Float64}, g1::Ptr{Float64}, g2::Ptr{Float64})::Int32)
     v[], [g1[], g2[]]
+end
+# The STOCK driver needs nothing else: optimize_hyperparameters (bayesian_opt.jl:253-285) hands `p -> nlml(model, p, xs, ys)` to
+# Optim with `autodiff=:forward`, i.e. it evaluates the objective on ForwardDiff.Dual parameters.  Duals cannot cross a C-ABI —
+# and need not: the library returns ∂NLML/∂(log ℓ, log σ_f²) analytically, so the Dual-typed methods evaluate at the VALUES and
+# push the caller's partials through the chain rule,
+#     nlml(p) = Dual(v, g₁·∂p₁ + g₂·∂p₂),
+# which is exactly what ForwardDiff would have produced by differentiating through kernel matrix, Cholesky and solve.  More
+# specific than the generic methods above, so dispatch picks them for Dual parameters only.  (A PosDefException of the refit
+# propagates, as `logpdf` would throw it; the driver's per-restart try/catch, :276-299, skips that restart.)
+function nlml(m::HipStandardGP, params::AbstractVector{<:ForwardDiff.Dual{T}}, xs::AbstractVector, ys::AbstractVector) where {T}
+    v, g = nlml_and_grad(m, ForwardDiff.value.(params), xs, ys)
+    ForwardDiff.Dual{T}(v, g[1] * ForwardDiff.partials(params[1]) + g[2] * ForwardDiff.partials(params[2]))
+end
+# length_scale_only = true (:253-256): only log ℓ is a Dual, the scale is the clamped start value (:247), a plain Float64
+function nlml_ls(m::HipStandardGP, log_ℓ::ForwardDiff.Dual{T}, log_scale::Real, xs::AbstractVector, ys::AbstractVector) where {T}
+    v, g = nlml_and_grad(m, [ForwardDiff.value(log_ℓ), Float64(log_scale)], xs, ys)
+    ForwardDiff.Dual{T}(v, g[1] * ForwardDiff.partials(log_ℓ))
 end
 
 # ---- incremental update (BASELINE config 5; the reference always refits) ---------------------------------------------

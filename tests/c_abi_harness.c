@@ -155,6 +155,49 @@ static void run_kat6(void) {
     printf("ok kat6 (ABO_ENOTPD, info=3)\n");
 }
 
+/* abo_nlml_grad against central differences of abo_nlml in (log ell, log sigma_f2): the arithmetic behind the Julia shim's
+ * Dual-typed nlml / nlml_ls (integration/julia/HipStandardGP.jl), which is what lets the STOCK optimize_hyperparameters
+ * (src/bayesian_opt.jl:253-285, autodiff = :forward) run unmodified.  Each evaluation is a refit, as in the reference. */
+static double nlml_at(const char* c, double log_ell, double log_sf2) {
+    abo_params p = params_of(c);
+    const rec_t *X = getf(c, "X"), *y = getf(c, "y");
+    p.ell = exp(log_ell); p.sigma_f2 = exp(log_sf2);
+    abo_gp* g = NULL;
+    int64_t info = 0;
+    double v = 0.0;
+    ok_or_die(abo_create(&p, &g), "abo_create (nlml_at)");
+    ok_or_die(abo_fit(g, X->v, y->n, (int32_t)(X->n / y->n), y->v, ABO_HOST, &info), "abo_fit (nlml_at)");
+    ok_or_die(abo_nlml(g, &v), "abo_nlml (nlml_at)");
+    ok_or_die(abo_destroy(g), "abo_destroy (nlml_at)");
+    return v;
+}
+
+static void run_nlml_grad(const char* c, double log_ell, double log_sf2) {
+    abo_params p = params_of(c);
+    const rec_t *X = getf(c, "X"), *y = getf(c, "y");
+    p.ell = exp(log_ell); p.sigma_f2 = exp(log_sf2);
+    abo_gp* g = NULL;
+    int64_t info = 0;
+    double v = 0.0, g1 = 0.0, g2 = 0.0;
+    ok_or_die(abo_create(&p, &g), "abo_create (nlml_grad)");
+    ok_or_die(abo_fit(g, X->v, y->n, (int32_t)(X->n / y->n), y->v, ABO_HOST, &info), "abo_fit (nlml_grad)");
+    ok_or_die(abo_nlml_grad(g, &v, &g1, &g2), "abo_nlml_grad");
+    ok_or_die(abo_destroy(g), "abo_destroy (nlml_grad)");
+    const double h = 1e-5;
+    const double f1 = (nlml_at(c, log_ell + h, log_sf2) - nlml_at(c, log_ell - h, log_sf2)) / (2 * h);
+    const double f2 = (nlml_at(c, log_ell, log_sf2 + h) - nlml_at(c, log_ell, log_sf2 - h)) / (2 * h);
+    const double scale = fabs(v) > 1.0 ? fabs(v) : 1.0;
+    CHECK(fabs(v - nlml_at(c, log_ell, log_sf2)) <= 1e-12 * scale, "%s: abo_nlml_grad value differs from abo_nlml", c);
+    CHECK(fabs(g1 - f1) <= 5e-6 * fabs(f1) + 1e-6 * scale, "%s: d/dlog(ell) %.12g vs central difference %.12g", c, g1, f1);
+    CHECK(fabs(g2 - f2) <= 5e-6 * fabs(f2) + 1e-6 * scale, "%s: d/dlog(sigma_f2) %.12g vs central difference %.12g", c, g2, f2);
+    /* the chain rule the shim applies for Dual parameters p = A t: d nlml / dt = A^T g */
+    const double A[2][2] = {{0.5, -1.0}, {3.0, 0.25}};
+    const double dt0 = A[0][0] * g1 + A[1][0] * g2;
+    const double fd0 = (nlml_at(c, log_ell + h * A[0][0], log_sf2 + h * A[1][0]) - nlml_at(c, log_ell - h * A[0][0], log_sf2 - h * A[1][0])) / (2 * h);
+    CHECK(fabs(dt0 - fd0) <= 5e-6 * fabs(fd0) + 1e-6 * scale, "%s: chain rule %.12g vs directional difference %.12g", c, dt0, fd0);
+    printf("ok nlml_grad %s (nlml %.10g, grad %.8g %.8g, central differences %.8g %.8g)\n", c, v, g1, g2, f1, f2);
+}
+
 /* which shared objects the process really mapped: the HIP runtime must be the system one, nothing of PyTorch or Python */
 static void report_runtime(void) {
     FILE* f = fopen("/proc/self/maps", "r");
@@ -173,15 +216,57 @@ static void report_runtime(void) {
     CHECK(hip[0] != 0, "no libamdhip64 mapped");
 }
 
+/* Leaves the process the way a host that never finalises its handles leaves it: a live model, a live multi-device group with
+ * an RCCL communicator, buffers parked in the library's pool, a worker thread parked in the multi-device driver — and returns
+ * from main.  Exit handlers, the library's static destructors and the HIP runtime's own teardown must get along: the child
+ * has to end with status 0 (a SIGSEGV under __cxa_finalize in an experimental build). */
+static int run_exit_live(void) {
+    const char* c = "acq";
+    abo_params p = params_of(c);
+    const rec_t *X = getf(c, "X"), *y = getf(c, "y"), *Z = getf(c, "Z");
+    const int64_t N = y->n;
+    const int32_t d = (int32_t)(X->n / N);
+    abo_gp *g = NULL, *tmp = NULL;
+    int64_t info = 0;
+    double mu[64], var[64], tv[8];
+    int64_t ti[8];
+    ok_or_die(abo_create(&p, &g), "abo_create");
+    ok_or_die(abo_fit(g, X->v, N, d, y->v, ABO_HOST, &info), "abo_fit");
+    ok_or_die(abo_predict(g, Z->v, 64, d, ABO_HOST, mu, var, ABO_HOST), "abo_predict");
+    ok_or_die(abo_create(&p, &tmp), "abo_create (pooled)");
+    ok_or_die(abo_fit(tmp, X->v, N, d, y->v, ABO_HOST, &info), "abo_fit (pooled)");
+    ok_or_die(abo_destroy(tmp), "abo_destroy (its buffers, stream and events go to the pool)");
+    int32_t devs[2] = {device, device};
+    abo_mgpu *mg2 = NULL, *mg1 = NULL;
+    ok_or_die(abo_mgpu_create(&p, 2, devs, &mg2), "abo_mgpu_create (2 shards: worker threads)");
+    ok_or_die(abo_mgpu_fit(mg2, X->v, N, d, y->v, &info), "abo_mgpu_fit");
+    ok_or_die(abo_mgpu_acq(mg2, Z->v, 4096, d, ABO_ACQ_EI, 0.01, 0.0, NULL, 8, tv, ti), "abo_mgpu_acq");
+    setenv("ABO_MGPU_EXCHANGE", "rccl", 1);
+    ok_or_die(abo_mgpu_create(&p, 1, devs, &mg1), "abo_mgpu_create (rccl)");
+    ok_or_die(abo_mgpu_fit(mg1, X->v, N, d, y->v, &info), "abo_mgpu_fit (rccl)");
+    ok_or_die(abo_mgpu_acq(mg1, Z->v, 4096, d, ABO_ACQ_EI, 0.01, 0.0, NULL, 8, tv, ti), "abo_mgpu_acq (rccl)");
+    int32_t nd = 0, ex = -1;
+    ok_or_die(abo_mgpu_info(mg1, &nd, NULL, &ex), "abo_mgpu_info");
+    printf("exit_live: leaving with a live model, a 2-shard group, a %s communicator and pooled buffers\n",
+           ex == ABO_XCHG_RCCL ? "live RCCL" : "host-exchange (RCCL unavailable)");
+    printf("exchange=%s\n", ex == ABO_XCHG_RCCL ? "rccl" : "host");
+    fflush(stdout);
+    return failures ? 1 : 0;                               /* nothing destroyed */
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s fixture.txt [device]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s fixture.txt [device] [exit_live]\n", argv[0]); return 2; }
     load(argv[1]);
     report_runtime();
     if (argc > 2) device = atoi(argv[2]);
+    if (argc > 3 && !strcmp(argv[3], "exit_live")) return run_exit_live();
     CHECK(abo_abi_version() == ABO_ABI_VERSION, "library ABI %d, header %d", abo_abi_version(), ABO_ABI_VERSION);
 
     run_kat("kat1"); run_kat("kat3"); run_kat("kat4"); run_kat("kat5");
     run_kat6();
+    run_nlml_grad("kat1", 0.0, 0.0);                       /* KAT-2's configuration (test_surrogates.jl:151-169) */
+    run_nlml_grad("kat1", log(0.4), log(2.5));
+    run_nlml_grad("acq", log(0.6), log(1.3));              /* N = 300, d = 4, Matern-5/2 */
 
     /* --- seeded problem: abo_acq with k = 100 against the CPU oracle's selection ------------------------------- */
     const char* c = "acq";

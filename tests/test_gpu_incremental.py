@@ -193,9 +193,17 @@ def test_full_size_parity_c5():
         m = abo.append(m, X[N + j], y[N + j])
         cands.downdate(m)
     mu_a, var_a = abo.mean_and_var(m, Z)
+    # the engine is PINNED: AUTO would fall back to the fp64 kernels silently if the int8 scratch did not fit the device
+    t = m.timings()
+    assert t["contraction_engine"] == abo._lib.CONTRACT_INT8 and t["oz_nmod"] == 14, t
     mu_c, var_c = cands.mean_and_var()
     nl_a = abo.nlml_fitted(m)
     L, alpha, _ = abo.get_factor(m)
+    # the fp64 engine on the same appended model (abo_set_contraction on the fitted handle: same factor, other contraction)
+    abo._lib.check(abo._lib.lib().abo_set_contraction(m._require(), abo._lib.CONTRACT_FP64, 0))
+    mu_64, var_64 = abo.mean_and_var(m, Z[:1024])
+    assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    np.testing.assert_array_equal(mu_64, mu_a[:1024])
     del cands, m
     ref = abo.update(make_model(O.MATERN52, ell, sf2, noise), X, y)
     mu_r, var_r = abo.mean_and_var(ref, Z)
@@ -215,6 +223,8 @@ def test_full_size_parity_c5():
     mu_o, var_o = O.predict(st, Z[:1024])
     check(case, "mu", np.max(np.abs(mu_a[:1024] - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
     check(case, "var", np.max(np.abs(var_a[:1024] - var_o)) / sf2, 1e-8)
+    check(case, "var_fp64_engine", np.max(np.abs(var_64 - var_o)) / sf2, 1e-8)
+    check(case, "var_between_engines", np.max(np.abs(var_64 - var_a[:1024])) / sf2, 1e-8)
     check(case, "mu_downdated_grid", np.max(np.abs(mu_c[:1024] - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
     check(case, "var_downdated_grid", np.max(np.abs(var_c[:1024] - var_o)) / sf2, 1e-8)
 

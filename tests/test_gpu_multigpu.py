@@ -206,3 +206,28 @@ def test_group_errors_are_statuses_and_leave_the_group_usable():
     np.testing.assert_array_equal(ti, ti1)
     ok = multigpu.append(grp, [2.0, 2.0], 0.5, cg)
     assert abs(abo.posterior_mean(ok, [[2.0, 2.0]])[0] - 0.5) < 1e-9
+
+
+@pytest.mark.parametrize("config", ["c2", "c5"])
+def test_bench_plain_multi_gpu_launch_runs_the_library_path(config):
+    """`python bench.py --gpus 2` exactly as the driver launches N = 1 (no torchrun): one process, two shards through
+    abo_mgpu_*.  On the one-GPU test box the shards share device 0 (--share-device), so the exchange is the host one
+    and the line must say so; on a multi-GPU node the same command without the flag runs RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", config,
+           "--share-device"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["devices"] == [0, 0] and cfg["exchange"] == "host" and "listed twice" in cfg["exchange_note"]
+    assert cfg["rccl_ranks"] == 0 and "rehearsal" in out
+    if config == "c2":
+        assert len(out["per_device_hip_event_ms_per_step"]) == 2 and out["roofline"]["frac"] > 0
+        assert cfg["M_total"] == 2 * cfg["M_per_gpu"]

@@ -315,3 +315,47 @@ def test_scratch_that_does_not_fit_halves_the_chunk_then_falls_back_to_fp64(monk
     v = abo.posterior_var(m, Zc)
     assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
     np.testing.assert_allclose(v, ref, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("Np", [4096])
+def test_adversarial_dense_equal_magnitude_rows_keep_their_guaranteed_bits(Np):
+    """The engine's guarantee is stated per ROW of W: its fixed-point image keeps what lies within ≈ 50 bits below the row's L1
+    norm (oz_rowscale_kernel: s_i = min(eP − 53 − e(L1), 52 − e(max))).  The worst case for an ENTRY is a dense row of equal
+    magnitudes, L1/max ≈ N: the largest entry then keeps only 53 − (53 + e(L1) − eP + …) ≈ 55 − log2(N) bits — 43 at N = 4096.  This
+    builds such rows (random signs, magnitudes within a factor 2, full rows k ≤ i at the bottom of the matrix), runs them through the
+    engine's own quantisers, GEMM and reconstruction, and records (a) the bits the largest entry of the worst row keeps and (b)
+    the error of Σ V² against a long-double product — which stays at the fp64 product's own level, because the lost digits lie
+    55 − log2(N) + log2(√N) bits below the sum they enter."""
+    import torch
+    from oracle import ozaki_oracle as Zo
+    rng = np.random.default_rng(7)
+    Mc, n, kmax = 256, 14, 1.0
+    W = np.tril(rng.choice([-1.0, 1.0], (Np, Np)) * rng.uniform(1.0, 2.0, (Np, Np)))
+    W *= 10.0 ** rng.uniform(-3, 3, (Np, 1))                   # row scales are per row: the scale of a row cannot matter
+    K = rng.uniform(-kmax, kmax, (Mc, Np))
+    pl = Zo.plan(n)
+    si = Zo.row_scales(W, pl["eP"])
+    mx = np.abs(W).max(1)
+    kept = si + np.frexp(mx)[1]                                  # bits of the row's largest entry above the rounding grid 2^-s_i
+    l1_over_max = np.abs(W).sum(1) / mx
+    worst = int(np.argmin(kept))
+    assert l1_over_max[worst] > 0.5 * Np / 2 and worst > Np // 2
+    assert 40 <= kept[worst] <= 46, kept[worst]                   # eP = 108: 108 − 53 − log2(L1/max) − (0…1) + …
+    Wd, Kd = torch.from_numpy(W).cuda(), torch.from_numpy(K).cuda()
+    part = torch.full((Np // 128, Mc), -1.0, dtype=torch.float64).cuda()
+    torch.cuda.synchronize()
+    abo._lib.check(abo._lib.lib().abo_test_oz_contract(0, Wd.data_ptr(), Np, Np, Np, Kd.data_ptr(), Np, Mc, kmax, n,
+                                                       part.data_ptr(), Mc))
+    got = part.cpu().numpy()
+    Vld = W.astype(np.longdouble) @ K.T.astype(np.longdouble)
+    want = (Vld.reshape(Np // 128, 128, Mc) ** 2).sum(1)
+    err = float(np.max(np.abs(got - want) / want))
+    # the same product in plain fp64 (what the fp64 engine's arithmetic does to these operands), for scale
+    V64 = W @ K.T
+    err64 = float(np.max(np.abs((V64.reshape(Np // 128, 128, Mc) ** 2).sum(1) - want) / want))
+    case = f"int8/adversarial_dense_rows_N{Np}"
+    check(case, "retained_bits_of_largest_entry_worst_row", float(kept[worst]), 53.0)
+    check(case, "l1_over_max_worst_row", float(l1_over_max[worst]), float(Np))
+    check(case, "sumsq_rel_vs_long_double", err, 1e-11)
+    check(case, "sumsq_rel_vs_long_double_plain_fp64_product", err64, 1e-11)
+    assert err <= 1e-12

@@ -345,12 +345,26 @@ def test_full_size_parity_c3():
     import torch
     Zd = torch.from_numpy(Z).cuda()
     s_d, tv, ti = abo.evaluate(acq, m, Zd, k=100)                     # the benchmarked call: all 2²⁰ candidates, top-100
+    # this test is the headline kernel's only full-size oracle check: the engine that ran the scored call is PINNED (AUTO falls
+    # back to the fp64 kernels without an error when the int8 scratch does not fit the device — that must fail here, not pass)
+    t = m.timings()
+    assert t["contraction_engine"] == abo._lib.CONTRACT_INT8 and t["oz_nmod"] == 14, t
     mu_d, var_d = abo.mean_and_var(m, Zd)
+    t = m.timings()
+    assert t["contraction_engine"] == abo._lib.CONTRACT_INT8 and t["oz_nmod"] == 14, t
     s, mu, var = s_d.cpu().numpy(), mu_d.cpu().numpy(), var_d.cpu().numpy()
     sl = np.concatenate([np.arange(0, 768), np.arange(M // 2 - 384, M // 2 + 384), np.arange(M - 768, M)])
     mu_o, var_o = O.predict(st, Z[sl])
     check(case, "mu", np.max(np.abs(mu[sl] - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
     check(case, "var", np.max(np.abs(var[sl] - var_o)) / sf2, 1e-8)
+    # the other engine on the same slice of the same model (same factor: only the contraction differs)
+    m64 = abo.update(make_model(O.MATERN52, ell, sf2, noise, contraction="fp64"), X, y)
+    mu64, var64 = abo.mean_and_var(m64, Z[sl])
+    assert m64.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+    np.testing.assert_array_equal(mu64, mu[sl])                       # the mean never goes through the contraction
+    check(case, "var_fp64_engine", np.max(np.abs(var64 - var_o)) / sf2, 1e-8)
+    check(case, "var_between_engines", np.max(np.abs(var64 - var[sl])) / sf2, 1e-8)
+    del m64
     ei_o = O.expected_improvement(mu_o, var_o, best, 0.01)
     check(case, "ei_abs", np.max(np.abs(s[sl] - ei_o)), 1e-9)
     # the selection is the stable reverse sort of the device's own scores, bit for bit, over the full 2²⁰
@@ -458,6 +472,47 @@ def test_nlml_gradient_against_oracle_finite_differences(family, d, N):
     h = 1e-5
     fd = np.array([(f(p + h * e) - f(p - h * e)) / (2 * h) for e in np.eye(2)])
     np.testing.assert_allclose(g, fd, rtol=2e-6, atol=1e-6 * max(1.0, abs(v)))
+
+
+@pytest.mark.parametrize("which", ["standard", "gradient"])
+def test_nlml_on_dual_parameters_is_the_chain_rule_of_the_analytic_gradient(which):
+    """The stock driver's `autodiff=:forward` (bayesian_opt.jl:276-285) evaluates nlml / nlml_ls on ForwardDiff.Dual
+    parameters; the Julia shim (integration/julia/HipStandardGP.jl) answers with Dual(v, g₁·∂p₁ + g₂·∂p₂) from
+    abo_nlml_grad.  Julia is not in this image, so the same arithmetic runs here on a dual-number stand-in
+    (hyperparams.Dual): seeded with the unit partials it must return the gradient — checked against central differences of
+    the value-only nlml —, through a linear reparametrisation p = A·t it must return Aᵀg, and with a plain-float scale
+    (nlml_ls: only log ℓ is a Dual) only the first component."""
+    from abstractbayesopt.jl_amd.hyperparams import Dual
+    if which == "standard":
+        X = synth.points(1, 300, 3)
+        y = synth.objective(X, 0.05)
+        gp = make_model(O.MATERN52, 1.0, 1.0, 1e-3)
+        nl, nl_ls = abo.nlml, abo.nlml_ls
+    else:
+        from tests.test_gpu_gradient_gp import make_grad
+        X = synth.points(1, 60, 2)
+        f = np.sin(2 * np.pi * X).sum(axis=1)
+        y = np.column_stack([f, 2 * np.pi * np.cos(2 * np.pi * X)])
+        gp = make_grad(O.MATERN52, 1.0, 1.0, 1e-3, 3)
+        nl, nl_ls = abo.nlml, abo.nlml_ls
+    p = np.array([np.log(0.7), np.log(1.4)])
+    out = nl(gp, [Dual(p[0], [1.0, 0.0]), Dual(p[1], [0.0, 1.0])], X, y)
+    v = nl(gp, p, X, y)
+    assert isinstance(out, Dual) and out.value == v
+    h = 1e-5
+    fd = np.array([(nl(gp, p + h * e, X, y) - nl(gp, p - h * e, X, y)) / (2 * h) for e in np.eye(2)])
+    np.testing.assert_allclose(out.partials, fd, rtol=5e-6, atol=1e-6 * max(1.0, abs(v)))
+    g = out.partials
+    # chain rule through p = A t, three seeds
+    A = np.array([[0.5, -1.0, 2.0], [3.0, 0.25, -0.5]])
+    t = [Dual(0.0, e) for e in np.eye(3)]
+    pd = [p[i] + A[i, 0] * t[0] + A[i, 1] * t[1] + A[i, 2] * t[2] for i in range(2)]
+    out2 = nl(gp, pd, X, y)
+    assert out2.value == v
+    np.testing.assert_allclose(out2.partials, A.T @ g, rtol=1e-14, atol=1e-14 * np.abs(g).max())
+    # nlml_ls: the scale is the clamped start value, a plain float (bayesian_opt.jl:247, :255)
+    out3 = nl_ls(gp, Dual(p[0], [1.0]), float(p[1]), X, y)
+    assert out3.value == v and out3.partials.shape == (1,) and out3.partials[0] == g[0]
 
 
 def test_optimize_hyperparameters_improves_nlml():

@@ -9,6 +9,8 @@ path, N, Mc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 INT8 = len(sys.argv) > 4 and sys.argv[4] == "int8"
 NMOD = int(sys.argv[5]) if INT8 else 0
 PREFIX, SRC = ("abo::oz_gemm16d", "ozaki.hip") if INT8 else ("abo::var_gemm", "gemm.hip")
+# every file the kernel is compiled from — the same lists as bench.py's PMC_SOURCES (its staleness guard compares the hash)
+SRCS = ["ozaki.hip", "abo_oz_dev.h", "abo_kernels.h"] if INT8 else ["gemm.hip", "abo_kernels.h"]
 blocks, cur = {}, None
 for line in open(path):
     if line.startswith("== "):
@@ -34,13 +36,16 @@ for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         extra[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
 durs = [v for (p, k), v in blocks.get("_dur", {}).items() if k == kern]
 dur_us = sum(durs) / len(durs) if durs else None
-def _sha(name):
+def _sha(names):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return hashlib.sha256(open(os.path.join(root, "abstractbayesopt.jl_amd", "csrc", name), "rb").read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in names:
+        h.update(open(os.path.join(root, "abstractbayesopt.jl_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 out = {
-    "kernel_source": "abstractbayesopt.jl_amd/csrc/" + SRC, "kernel_source_sha": _sha(SRC),   # bench.py drops the figure when the file changes
+    "kernel_source": "abstractbayesopt.jl_amd/csrc/" + SRC, "kernel_sources": SRCS, "kernel_source_sha": _sha(SRCS),   # bench.py drops the figure when the file changes
     "source": f"{path} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ / GRBM, separate passes, tools/run_pmc.sh)",
     "kernel": kern.replace("abo::", ""), "N": N, "Mc_per_launch": Mc,
     "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb,

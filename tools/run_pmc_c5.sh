@@ -27,7 +27,8 @@ if k in acc:
     kb = sum(acc[k]) / len(acc[k]); d = sum(dur[k]) / len(dur[k]) / 1e6
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE, tools/run_pmc_c5.sh", "kernel": "cand_gemv_kernel", "N": 16384, "M": 131072,
                "kernel_source": "abstractbayesopt.jl_amd/csrc/misc.hip",
-               "kernel_source_sha": hashlib.sha256(open("abstractbayesopt.jl_amd/csrc/misc.hip", "rb").read()).hexdigest()[:16],
+               "kernel_sources": ["misc.hip", "abo_kernels.h", "abo_kappa.h"],     # = bench.py PMC_SOURCES["c5"]
+               "kernel_source_sha": hashlib.sha256(b"".join(open("abstractbayesopt.jl_amd/csrc/" + n, "rb").read() for n in ("misc.hip", "abo_kernels.h", "abo_kappa.h"))).hexdigest()[:16],
                "FETCH_SIZE_KB_mean": kb, "correction": "gfx950: x2 (64 B counted per 128-B request of a 16-B/lane stream)",
                "traffic_bytes_per_launch": kb * 2048, "algorithmic_bytes_per_launch": 8.0 * 16384 * 131072,
                "avg_launch_ms_under_pmc": d}, open("gpurun_out/c5_pmc_traffic.json", "w"), indent=1)
