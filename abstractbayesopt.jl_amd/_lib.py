@@ -16,8 +16,8 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
-           "abo_mgpu_cand_qei"]
-ABI_VERSION = 3
+           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad"]
+ABI_VERSION = 4
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
 
@@ -33,10 +33,16 @@ class AboTimings(C.Structure):
                                           "acq_finalize_ms", "acq_topk_ms", "acq_total_ms")] + \
                [("var_gemm_launches", C.c_int64), ("var_gemm_flop", C.c_double), ("downdate_ms", C.c_double),
                 ("downdate_bytes", C.c_double), ("contraction_engine", C.c_int64), ("oz_nmod", C.c_int64)] + \
-               [(n, C.c_double) for n in ("oz_prepare_ms", "oz_quant_ms", "oz_gemm_ms", "oz_crt_ms", "oz_gemm_ops")]
+               [(n, C.c_double) for n in ("oz_prepare_ms", "oz_quant_ms", "oz_gemm_ms", "oz_crt_ms", "oz_gemm_ops", "refine_ms")] + \
+               [("refine_starts", C.c_int64), ("refine_evals", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class AboRefineOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("linesearch_max", C.c_int32), ("history", C.c_int32), ("reserved", C.c_int32),
+                ("g_tol", C.c_double), ("f_abstol", C.c_double), ("x_abstol", C.c_double)]
 
 
 class PosDefException(Exception):
@@ -130,6 +136,11 @@ def lib():
     L.abo_mgpu_cand_destroy.argtypes = [vp]
     L.abo_mgpu_cand_acq.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp]
     L.abo_mgpu_cand_qei.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp, vp]
+    L.abo_refine.argtypes = [vp, i32, f64, f64, vp, vp, i32, vp, i32, C.POINTER(AboRefineOpts), vp, vp, vp]
+    L.abo_optimize_acquisition.argtypes = [vp, i32, f64, f64, vp, vp, i32, i64, i32, C.c_uint64, C.POINTER(AboRefineOpts),
+                                           vp, C.POINTER(f64), vp, vp, vp, vp]
+    L.abo_mgpu_optimize_acquisition.argtypes = L.abo_optimize_acquisition.argtypes
+    L.abo_test_acq_grad.argtypes = [vp, i32, f64, f64, vp, i64, i32, vp, vp]
     for name in EXPORTS:
         getattr(L, name).restype = i32
     _lib = L

@@ -195,16 +195,80 @@ def device_latin_hypercube(n: int, lower, upper, seed: int, device: int = 0, fir
     return Z
 
 
-def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, lower, upper, max_iter: int = 100,
-                  g_tol: float = 1e-5, f_abstol: float = 2.2e-9, x_abstol: float = 1e-4, history: int = 10):
-    """Local refinement stage of optimize_acquisition (acq_utils.jl:55-71), batched for the GPU.
+def _library_refinable(acqf, surrogate) -> bool:
+    """the on-device refinement serves EI / UCB / PI on a StandardGP handle (single device or sharded group)"""
+    return (not isinstance(acqf, EnsembleAcquisition) and getattr(acqf, "kind", None) in (ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN)
+            and not hasattr(surrogate, "p"))
 
-    The reference runs one box-constrained L-BFGS per start (Fminbox(LBFGS(HagerZhang)), central finite
-    differences, g_tol=1e-5, f_abstol=2.2e-9, x_abstol=1e-4), i.e. thousands of sequential M = 1 posterior
-    calls.  Here all S starts advance in lockstep: one fused acquisition call evaluates the whole
-    central-difference stencil (2d·S points), one more per line-search trial (S points) — a projected
-    L-BFGS with Armijo backtracking, the same stopping rules, every posterior/acquisition value from the
-    HIP path.  Returns (points (S, d), values (S,))."""
+
+def _refine_opts(max_iter, g_tol, f_abstol, x_abstol, history):
+    return _lib.AboRefineOpts(max_iter=int(max_iter), linesearch_max=20, history=int(history), reserved=0, g_tol=float(g_tol),
+                              f_abstol=float(f_abstol), x_abstol=float(x_abstol))
+
+
+def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, lower, upper, max_iter: int = 100,
+                  g_tol: float = 1e-5, f_abstol: float = 2.2e-9, x_abstol: float = 1e-4, history: int = 10, return_iters: bool = False):
+    """Local refinement stage of optimize_acquisition (acq_utils.jl:55-71): one box-constrained L-BFGS run per start in the
+    reference (Fminbox(LBFGS(HagerZhang(linesearchmax=20))), g_tol=1e-5, f_abstol=2.2e-9, x_abstol=1e-4, central finite
+    differences of M = 1 posterior calls).  Here a thin caller of `abo_refine` (include/abo_hip.h): ONE launch, one workgroup per
+    start running that start's whole projected L-BFGS on the device with the analytic gradient of the acquisition function.
+    Returns (points (S, d), values (S,)).  Ensemble acquisitions and gradient-enhanced models take the host loop below
+    (`_refine_starts_fd`: the same algorithm on batched finite-difference stencils)."""
+    if not _library_refinable(acqf, surrogate):
+        return _refine_starts_fd(acqf, surrogate, starts, lower, upper, max_iter, g_tol, f_abstol, x_abstol, history)
+    lower = np.ascontiguousarray(np.asarray(lower, dtype=np.float64))
+    upper = np.ascontiguousarray(np.asarray(upper, dtype=np.float64))
+    st = np.ascontiguousarray(np.asarray(starts, dtype=np.float64))
+    S, d = st.shape
+    x, f, it = np.empty((S, d)), np.empty(S), np.zeros((S, 2), dtype=np.int32)
+    opts = _refine_opts(max_iter, g_tol, f_abstol, x_abstol, history)
+    h = surrogate.shard(0) if hasattr(surrogate, "devices") else surrogate._require()
+    _lib.check(_lib.lib().abo_refine(h, acqf.kind, acqf._p0(), acqf._best(), lower.ctypes.data, upper.ctypes.data, d,
+                                     st.ctypes.data, S, C.byref(opts), x.ctypes.data, f.ctypes.data, it.ctypes.data))
+    return (x, f, it) if return_iters else (x, f)
+
+
+def acquisition_value_and_grad(acqf: AbstractAcquisition, surrogate: HipStandardGP, x):
+    """(f (M,), ∇f (M, d)) of EI / UCB / PI at the points x: the evaluation the on-device refinement is built on
+    (abo_test_acq_grad) — analytic ∇μ, ∇σ² and the closed-form partials of the acquisition function."""
+    z = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    if z.ndim == 1:
+        z = z[:, None]
+    f, g = np.empty(z.shape[0]), np.empty(z.shape)
+    _lib.check(_lib.lib().abo_test_acq_grad(surrogate._require(), acqf.kind, acqf._p0(), acqf._best(), z.ctypes.data, z.shape[0],
+                                            z.shape[1], f.ctypes.data, g.ctypes.data))
+    return f, g
+
+
+def optimize_acquisition_device(acqf: AbstractAcquisition, surrogate: HipStandardGP, domain, n_grid: int = 10_000,
+                                n_local: int = 100, seed: int = 0, return_all: bool = False, **opts):
+    """optimize_acquisition (acq_utils.jl:33-73) in ONE C-ABI call: Latin-hypercube grid generated on the device(s), scored,
+    reduced to the n_local best, every start refined by its own workgroup, the best point returned.  Works on a HipStandardGP
+    (abo_optimize_acquisition) and on a HipShardedGP (abo_mgpu_optimize_acquisition: grid and starts sharded over the group)."""
+    lower = np.ascontiguousarray(np.asarray(domain.lower, dtype=np.float64))
+    upper = np.ascontiguousarray(np.asarray(domain.upper, dtype=np.float64))
+    d, k = lower.shape[0], min(int(n_local), int(n_grid))
+    best, val = np.empty(d), C.c_double()
+    sx, sv, rx, rv = np.empty((k, d)), np.empty(k), np.empty((k, d)), np.empty(k)
+    o = _refine_opts(opts.get("max_iter", 0), opts.get("g_tol", 0), opts.get("f_abstol", 0), opts.get("x_abstol", 0), opts.get("history", 0))
+    L = _lib.lib()
+    if hasattr(surrogate, "devices"):
+        fn, h = L.abo_mgpu_optimize_acquisition, surrogate._require_group()
+    else:
+        fn, h = L.abo_optimize_acquisition, surrogate._require()
+    _lib.check(fn(h, acqf.kind, acqf._p0(), acqf._best(), lower.ctypes.data, upper.ctypes.data, d, int(n_grid), int(n_local),
+                  int(seed) & (2 ** 64 - 1), C.byref(o), best.ctypes.data, C.byref(val), sx.ctypes.data, sv.ctypes.data,
+                  rx.ctypes.data, rv.ctypes.data))
+    if return_all:
+        return best, val.value, sx, sv, rx, rv
+    return best
+
+
+def _refine_starts_fd(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, lower, upper, max_iter: int = 100,
+                      g_tol: float = 1e-5, f_abstol: float = 2.2e-9, x_abstol: float = 1e-4, history: int = 10):
+    """The host-driven variant of the refinement (ensemble acquisitions, gradient-enhanced models): all S starts advance in
+    lockstep, one fused acquisition call evaluates the whole central-difference stencil (2d·S points), one more per
+    line-search trial (S points) — projected L-BFGS with Armijo backtracking, the same stopping rules."""
     lower = np.asarray(lower, dtype=np.float64)
     upper = np.asarray(upper, dtype=np.float64)
     x = np.clip(np.asarray(starts, dtype=np.float64).copy(), lower, upper)
@@ -272,7 +336,9 @@ def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, l
         # Armijo backtracking on the projected step, all unfinished starts per trial in one fused call
         t = np.ones(S)
         if not Sh:                                             # first step: a tenth of the box at most
-            t = np.minimum(1.0, 0.1 * np.min(upper - lower) / np.maximum(np.max(np.abs(p), axis=1), 1e-300))
+            width = upper - lower                                # (a degenerate side pins its coordinate, it does not limit the others)
+            wmin = float(np.min(width[width > 0])) if np.any(width > 0) else 0.0
+            t = np.minimum(1.0, 0.1 * wmin / np.maximum(np.max(np.abs(p), axis=1), 1e-300))
         x_new, f_new = x.copy(), f.copy()
         todo = active.copy()
         for _ls in range(20):                                  # HagerZhang(linesearchmax = 20) in the reference
@@ -302,6 +368,11 @@ def optimize_acquisition(acqf: AbstractAcquisition, surrogate: HipStandardGP, do
     the (n_local, d) start points and their grid scores."""
     rng = np.random.default_rng() if rng is None else rng
     k = min(n_local, n_grid)
+    if device_grid and refine and _library_refinable(acqf, surrogate):
+        # grid, selection, refinement and arg-max in one C-ABI call: nothing but the result crosses PCIe
+        best, _, sx, sv, _, _ = optimize_acquisition_device(acqf, surrogate, domain, n_grid, n_local,
+                                                            seed=int(rng.integers(0, 2 ** 63)), return_all=True)
+        return (best, sx, sv) if return_starts else best
     if device_grid and not isinstance(acqf, EnsembleAcquisition):
         # the grid is generated, scored and reduced on the GPU; only the k starts come back
         grid = device_latin_hypercube(n_grid, domain.lower, domain.upper, int(rng.integers(0, 2 ** 63)), surrogate.device)

@@ -14,6 +14,11 @@ int32_t acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space
 int32_t cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores,
                     int32_t scores_space, int32_t k, double* top_val, int64_t* top_idx, int32_t top_space);
 
+// optimize_acquisition's last step on the host (acq_utils.jl:66-72): the refined point with the largest finite value (first on
+// ties), or the best grid point when no refined value reaches its score
+void pick_best_point(const double* starts_x, const double* starts_val, const double* rx, const double* rf, int k, int d,
+                     double* best_x, double* best_val);
+
 hipStream_t gp_stream(abo_gp* g);
 int gp_device(const abo_gp* g);
 const abo_params& gp_params(const abo_gp* g);

@@ -243,6 +243,34 @@ hipError_t launch_pick_record(const double* tv, const int64_t* ti, int64_t idx_b
 hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                       int64_t count, hipStream_t s);
 
+// ---- local refinement of optimize_acquisition on the device (refine.hip) ---------------------------------------
+struct RefineArgs {
+    const double* Xs;      // [Np][dp] scaled training points
+    const double* W;       // L⁻¹ (lower), WT = its transpose (upper); leading dimension ld
+    const double* WT;
+    const double* alpha;   // [Np]
+    int64_t ld;
+    int N, Np, d, dp, family;
+    double s, sigma_f2, mean_c;            // 1/ℓ, σ_f², prior mean
+    int kind;                              // ABO_ACQ_*
+    double p0, best_y;
+    const double* lower;   // device [d]
+    const double* upper;   // device [d]
+    const double* starts;  // device [S][d]
+    double* x_out;         // device [S][d]   (grad_only: the gradient)
+    double* f_out;         // device [S]
+    int* iters_out;        // device [S][2] = {iterations, evaluations} or nullptr
+    double* scratch;       // device [S][4][Np]
+    int max_iter, ls_max, history;
+    double g_tol, f_abstol, x_abstol;
+};
+size_t refine_lds_bytes(int d, int dp, int history);
+// one workgroup per start: the whole projected L-BFGS of that start in one launch (grad_only = 1: one evaluation per point,
+// x_out receives the gradient)
+hipError_t launch_refine(const RefineArgs& a, int S, int grad_only, hipStream_t s);
+// out[j][0..d) = Z[idx[j] − idx_base][0..d) for j < k (zeros for idx[j] < 0): the coordinates of selected candidates
+hipError_t launch_gather_points(const double* Z, const int64_t* idx, int64_t idx_base, int k, int d, double* out, hipStream_t s);
+
 struct TopkWork {            // scratch sized by topk_workspace_entries()
     uint64_t* keys[2];
     int64_t* idx[2];

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <set>
@@ -1681,6 +1682,201 @@ int32_t abo::cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double
     HIPCHK(hipStreamSynchronize(s));
     return ABO_OK;
 }
+
+// ---- optimize_acquisition on the device (acq_utils.jl:33-73): refinement launch + the one-call driver -----------------
+namespace {
+
+struct RefineOpts { int max_iter, ls_max, history; double g_tol, f_abstol, x_abstol; };
+
+RefineOpts refine_defaults(const abo_refine_opts* o) {
+    RefineOpts r{100, 20, 10, 1e-5, 2.2e-9, 1e-4};        // acq_utils.jl:10, :62; Optim's LBFGS keeps m = 10 pairs
+    if (o) {
+        if (o->max_iter > 0) r.max_iter = o->max_iter;
+        if (o->linesearch_max > 0) r.ls_max = o->linesearch_max;
+        if (o->history > 0) r.history = o->history;
+        if (o->g_tol > 0.0) r.g_tol = o->g_tol;
+        if (o->f_abstol > 0.0) r.f_abstol = o->f_abstol;
+        if (o->x_abstol > 0.0) r.x_abstol = o->x_abstol;
+    }
+    return r;
+}
+
+int32_t check_refinable(abo_gp* g, int32_t d, int32_t kind, const char* fn) {
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (g->p_out > 1) return fail(ABO_EINVAL, "%s: gradient-enhanced handles are not served (function-value acquisitions of a StandardGP only)", fn);
+    if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "%s: unknown acquisition kind %d", fn, kind);
+    return ABO_OK;
+}
+
+// bounds (2·d doubles: lower, upper), starts (S·d) and the outputs all in DEVICE memory; asynchronous on the handle's stream
+// between events 5 and 6
+int32_t refine_device(abo_gp* g, int32_t kind, double p0, double best_y, const double* bounds_d, const double* starts_d, int S,
+                      RefineOpts o, double* x_out_d, double* f_out_d, int* iters_d, int grad_only) {
+    hipStream_t s = g->stream;
+    RefineArgs ra{};
+    ra.Xs = g->st->Xs.as<double>(); ra.W = g->st->W.as<double>(); ra.WT = g->st->WT.as<double>(); ra.alpha = g->alpha.as<double>();
+    ra.ld = g->st->cap; ra.N = (int)g->N; ra.Np = (int)g->Np; ra.d = g->d; ra.dp = g->dp; ra.family = g->prm.family;
+    ra.s = 1.0 / g->prm.ell; ra.sigma_f2 = g->prm.sigma_f2; ra.mean_c = g->prm.mean_c;
+    ra.kind = kind; ra.p0 = p0; ra.best_y = best_y;
+    ra.lower = bounds_d; ra.upper = bounds_d ? bounds_d + g->d : nullptr; ra.starts = starts_d;
+    ra.x_out = x_out_d; ra.f_out = f_out_d; ra.iters_out = iters_d;
+    // the L-BFGS state of a start lives in its workgroup's LDS (64 KiB without opting into more): fewer pairs for very wide inputs
+    int m = o.history;
+    while (m > 0 && refine_lds_bytes(g->d, g->dp, m) > 65536) --m;
+    if (refine_lds_bytes(g->d, g->dp, m) > 65536)
+        return fail(ABO_EINVAL, "abo_refine: input dimension %d too large for the on-device refinement (library limit: %d)", g->d, 700);
+    ra.max_iter = o.max_iter; ra.ls_max = o.ls_max; ra.history = m; ra.g_tol = o.g_tol; ra.f_abstol = o.f_abstol; ra.x_abstol = o.x_abstol;
+    HIPCHK(g->T.ensure(sizeof(double) * 4 * (size_t)g->Np * (size_t)S));      // per-start scratch (k, κ', v, u); T is free after the fit
+    ra.scratch = g->T.as<double>();
+    HIPCHK(launch_refine(ra, S, grad_only, s));
+    return ABO_OK;
+}
+
+// the best refined point, the reference's way (acq_utils.jl:66-72: strict `>` keeps the first maximum); the best grid point if no
+// refined value reaches its score
+void pick_best(const double* starts_x, const double* starts_val, const double* rx, const double* rf, int k, int d, double* best_x,
+               double* best_val) {
+    int j = -1;
+    for (int e = 0; e < k; ++e) {
+        const double v = rf[e];
+        if (!(v == v) || std::fabs(v) > 1.0e300) continue;
+        if (j < 0 || v > rf[j]) j = e;
+    }
+    const double* src = starts_x;
+    double val = k > 0 ? starts_val[0] : std::numeric_limits<double>::quiet_NaN();
+    if (j >= 0 && (rf[j] >= val || !(val == val))) { src = rx + (size_t)j * d; val = rf[j]; }
+    if (best_x) for (int c = 0; c < d; ++c) best_x[c] = k > 0 ? src[c] : std::numeric_limits<double>::quiet_NaN();
+    if (best_val) *best_val = val;
+}
+
+}  // namespace
+
+void abo::pick_best_point(const double* starts_x, const double* starts_val, const double* rx, const double* rf, int k, int d,
+                          double* best_x, double* best_val) {
+    pick_best(starts_x, starts_val, rx, rf, k, d, best_x, best_val);
+}
+
+extern "C" {
+
+int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const double* lower, const double* upper, int32_t d,
+                   const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out, int32_t* iters_out) {
+    if (!g) return fail(ABO_EINVAL, "abo_refine: null handle");
+    int32_t rc = check_refinable(g, d, kind, "abo_refine");
+    if (rc) return rc;
+    if (S < 0 || (S > 0 && (!starts || !x_out || !f_out)) || !lower || !upper) return fail(ABO_EINVAL, "abo_refine: bad argument");
+    for (int c = 0; c < d; ++c)
+        if (!(lower[c] <= upper[c])) return fail(ABO_EINVAL, "abo_refine: lower[%d] > upper[%d]", c, c);
+    if (S == 0) return ABO_OK;
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const size_t nb = 2 * (size_t)d, ns = (size_t)S * d;
+    // one staging block: bounds | starts | x_out | f_out | iters
+    HIPCHK(g->Zdev.ensure(sizeof(double) * (nb + 2 * ns + S) + sizeof(int) * 2 * S));
+    double* base = g->Zdev.as<double>();
+    double *bd = base, *sd = base + nb, *xd = sd + ns, *fd = xd + ns;
+    int* id = reinterpret_cast<int*>(fd + S);
+    HIPCHK(hipMemcpyAsync(bd, lower, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(bd + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(sd, starts, sizeof(double) * ns, hipMemcpyHostToDevice, s));
+    HIPCHK(g->events(8));
+    HIPCHK(hipEventRecord(g->evs()[5], s));
+    rc = refine_device(g, kind, p0, best_y, bd, sd, S, refine_defaults(opts), xd, fd, id, 0);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(g->evs()[6], s));
+    std::vector<int> it(2 * (size_t)S);
+    HIPCHK(hipMemcpyAsync(x_out, xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(f_out, fd, sizeof(double) * S, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(it.data(), id, sizeof(int) * 2 * S, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    g->tm.refine_ms = ev_ms(g->evs()[5], g->evs()[6]);
+    g->tm.refine_starts = S;
+    g->tm.refine_evals = 0;
+    for (int e = 0; e < S; ++e) g->tm.refine_evals += it[2 * e + 1];
+    if (iters_out) for (int e = 0; e < 2 * S; ++e) iters_out[e] = it[e];
+    return ABO_OK;
+}
+
+int32_t abo_test_acq_grad(abo_gp* g, int32_t kind, double p0, double best_y, const double* Z, int64_t M, int32_t d, double* f,
+                          double* grad) {
+    if (!g) return fail(ABO_EINVAL, "abo_test_acq_grad: null handle");
+    int32_t rc = check_refinable(g, d, kind, "abo_test_acq_grad");
+    if (rc) return rc;
+    if (M < 0 || M > 65535 || (M > 0 && (!Z || !f || !grad))) return fail(ABO_EINVAL, "abo_test_acq_grad: bad argument (M ≤ 65535)");
+    if (M == 0) return ABO_OK;
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const size_t ns = (size_t)M * d;
+    HIPCHK(g->Zdev.ensure(sizeof(double) * (2 * ns + M)));
+    double *sd = g->Zdev.as<double>(), *xd = sd + ns, *fd = xd + ns;
+    HIPCHK(hipMemcpyAsync(sd, Z, sizeof(double) * ns, hipMemcpyHostToDevice, s));
+    rc = refine_device(g, kind, p0, best_y, nullptr, sd, (int)M, refine_defaults(nullptr), xd, fd, nullptr, 1);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(grad, xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(f, fd, sizeof(double) * M, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ABO_OK;
+}
+
+int32_t abo_optimize_acquisition(abo_gp* g, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
+                                 int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                 double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                 double* refined_val) {
+    if (!g) return fail(ABO_EINVAL, "abo_optimize_acquisition: null handle");
+    int32_t rc = check_refinable(g, d, kind, "abo_optimize_acquisition");
+    if (rc) return rc;
+    if (!lower || !upper || !best_x) return fail(ABO_EINVAL, "abo_optimize_acquisition: null argument");
+    if (n_grid < 1 || n_local < 1) return fail(ABO_EINVAL, "abo_optimize_acquisition: n_grid and n_local must be positive");
+    for (int c = 0; c < d; ++c)
+        if (!(lower[c] <= upper[c])) return fail(ABO_EINVAL, "abo_optimize_acquisition: lower[%d] > upper[%d]", c, c);
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const int k = (int)(n_local < n_grid ? n_local : n_grid);
+    const size_t nb = 2 * (size_t)d, ns = (size_t)k * d;
+    // device block of this call: bounds | starts | refined x | refined f | start scores | start indices | iteration counts
+    ScratchBuf blk(g->prm.device, s), grid(g->prm.device, s);
+    HIPCHK(blk.b.ensure(sizeof(double) * (nb + 2 * ns + 2 * (size_t)k) + sizeof(int64_t) * k + sizeof(int) * 2 * k));
+    HIPCHK(grid.b.ensure(sizeof(double) * (size_t)n_grid * d));
+    double* bd = blk.b.as<double>();
+    double *sd = bd + nb, *xd = sd + ns, *fd = xd + ns, *tv = fd + k;
+    int64_t* ti = reinterpret_cast<int64_t*>(tv + k);
+    int* id = reinterpret_cast<int*>(ti + k);
+    HIPCHK(hipMemcpyAsync(bd, lower, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(bd + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    // grid stage (acq_utils.jl:44-52): Latin hypercube on the device, fused scores, stable reverse sort's first k
+    HIPCHK(launch_lhs(grid.b.as<double>(), n_grid, d, bd, bd + d, seed, 0, n_grid, s));
+    rc = abo::acq_ex(g, grid.b.as<double>(), n_grid, d, ABO_DEVICE, kind, p0, best_y, 0, nullptr, ABO_DEVICE, k, tv, ti, ABO_DEVICE);
+    if (rc) return rc;
+    const double grid_ms = g->tm.acq_total_ms;
+    HIPCHK(launch_gather_points(grid.b.as<double>(), ti, 0, k, d, sd, s));
+    // refinement stage (:55-71): one launch
+    HIPCHK(g->events(10));
+    HIPCHK(hipEventRecord(g->evs()[8], s));
+    rc = refine_device(g, kind, p0, best_y, bd, sd, k, refine_defaults(opts), xd, fd, id, 0);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(g->evs()[9], s));
+    std::vector<double> hs(ns), hv(k), hx(ns), hf(k);
+    std::vector<int> it(2 * (size_t)k);
+    HIPCHK(hipMemcpyAsync(hs.data(), sd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hv.data(), tv, sizeof(double) * k, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hx.data(), xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hf.data(), fd, sizeof(double) * k, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(it.data(), id, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    g->tm.acq_total_ms = grid_ms;
+    g->tm.refine_ms = ev_ms(g->evs()[8], g->evs()[9]);
+    g->tm.refine_starts = k;
+    g->tm.refine_evals = 0;
+    for (int e = 0; e < k; ++e) g->tm.refine_evals += it[2 * e + 1];
+    pick_best(hs.data(), hv.data(), hx.data(), hf.data(), k, d, best_x, best_val);
+    if (starts_x) memcpy(starts_x, hs.data(), sizeof(double) * ns);
+    if (starts_val) memcpy(starts_val, hv.data(), sizeof(double) * k);
+    if (refined_x) memcpy(refined_x, hx.data(), sizeof(double) * ns);
+    if (refined_val) memcpy(refined_val, hf.data(), sizeof(double) * k);
+    return ABO_OK;
+}
+
+}  // extern "C"
 
 bool abo::exiting() { return g_exiting.load(); }
 void abo::arm_exit_guard() {

@@ -524,6 +524,38 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
     return rc;
 }
 
+// optimize_acquisition (acq_utils.jl:33-73) across the group: grid stage sharded (abo_mgpu_acq_lhs), the selected starts dealt
+// out contiguously, every device refines its share in one launch (abo_refine), the host keeps the best
+int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
+                                      int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                      double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                      double* refined_val) {
+    int32_t rc = check_group(mg, "abo_mgpu_optimize_acquisition");
+    if (rc) return rc;
+    if (!lower || !upper || !best_x) return failf(ABO_EINVAL, "abo_mgpu_optimize_acquisition: null argument");
+    if (n_grid < 1 || n_local < 1) return failf(ABO_EINVAL, "abo_mgpu_optimize_acquisition: n_grid and n_local must be positive");
+    const int k = (int)(n_local < n_grid ? n_local : n_grid);
+    std::vector<double> tv(k), tx((size_t)k * d), rx((size_t)k * d), rf(k);
+    std::vector<int64_t> ti(k);
+    rc = abo_mgpu_acq_lhs(mg, n_grid, d, lower, upper, seed, kind, p0, best_y, k, tv.data(), ti.data(), tx.data());
+    if (rc) return rc;
+    // a selection shorter than k cannot happen (k ≤ n_grid), but a NaN score can: such a start is returned unchanged by abo_refine
+    rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
+        int64_t lo, hi;
+        shard_range(k, i, mg->ndev, &lo, &hi);
+        if (hi == lo) return ABO_OK;
+        return abo_refine(mg->gp[i], kind, p0, best_y, lower, upper, d, tx.data() + lo * d, (int32_t)(hi - lo), opts,
+                          rx.data() + lo * d, rf.data() + lo, nullptr);
+    });
+    if (rc) return rc;
+    abo::pick_best_point(tx.data(), tv.data(), rx.data(), rf.data(), k, d, best_x, best_val);
+    if (starts_x) memcpy(starts_x, tx.data(), sizeof(double) * k * d);
+    if (starts_val) memcpy(starts_val, tv.data(), sizeof(double) * k);
+    if (refined_x) memcpy(refined_x, rx.data(), sizeof(double) * k * d);
+    if (refined_val) memcpy(refined_val, rf.data(), sizeof(double) * k);
+    return ABO_OK;
+}
+
 // ---- config 5 across devices -----------------------------------------------------------------------------------
 int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* mc) {
     if (info) *info = 0;

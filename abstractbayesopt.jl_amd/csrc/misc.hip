@@ -404,4 +404,18 @@ hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base,
     return hipGetLastError();
 }
 
+__global__ void gather_points_kernel(const double* Z, const int64_t* idx, int64_t idx_base, int k, int d, double* out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= k * d) return;
+    const int j = e / d, c = e % d;
+    const int64_t gi = idx[j];
+    out[e] = gi >= 0 ? Z[(gi - idx_base) * d + c] : 0.0;
+}
+
+hipError_t launch_gather_points(const double* Z, const int64_t* idx, int64_t idx_base, int k, int d, double* out, hipStream_t s) {
+    if (k <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_points_kernel, dim3((unsigned)((k * d + 255) / 256)), dim3(256), 0, s, Z, idx, idx_base, k, d, out);
+    return hipGetLastError();
+}
+
 }  // namespace abo

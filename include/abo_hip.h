@@ -27,8 +27,10 @@
 extern "C" {
 #endif
 
-#define ABO_ABI_VERSION 3   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
-                               3: abo_set_contraction, abo_timings grew (contraction engine and its phases) */
+#define ABO_ABI_VERSION 4   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
+                               3: abo_set_contraction, abo_timings grew (contraction engine and its phases)
+                               4: abo_refine, abo_optimize_acquisition, abo_mgpu_optimize_acquisition, abo_fit_acq; abo_timings
+                                  grew (refinement stage) */
 
 /* status codes */
 enum {
@@ -103,6 +105,10 @@ typedef struct abo_timings {
      * the last posterior call (0 when that call reused cached planes) */
     int64_t contraction_engine, oz_nmod;
     double oz_prepare_ms, oz_quant_ms, oz_gemm_ms, oz_crt_ms, oz_gemm_ops;
+    /* ABI 4: the last abo_refine / abo_optimize_acquisition on this handle: duration of its ONE refinement launch, the starts it
+     * refined and the acquisition evaluations (value + analytic gradient each) all starts took together */
+    double refine_ms;
+    int64_t refine_starts, refine_evals;
 } abo_timings;
 
 /* --- lifetime -------------------------------------------------------------------------------
@@ -186,6 +192,36 @@ int32_t abo_predict_grad_cov(abo_gp* gp, const double* Z, int64_t M, int32_t d, 
 int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind,
                 double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
                 double* top_val, int64_t* top_idx, int32_t out_space);
+
+/* --- optimize_acquisition (src/acquisition_functions/acq_utils.jl:33-73) on the device -------------------------------
+ * The reference: Latin-hypercube grid of n_grid points → scores → the n_local best as starts (:44-52) → for EVERY start one
+ * box-constrained L-BFGS run, Fminbox(LBFGS(HagerZhang(linesearchmax = 20))) with Optim.Options(g_tol = 1e-5, f_abstol = 2.2e-9,
+ * x_abstol = 1e-4), each objective value an M = 1 posterior call and each gradient a finite-difference stencil of them
+ * (:55-71) → the best refined point (:66-72).
+ * abo_refine is the second stage for S given starts: ONE launch, one workgroup per start running that start's whole projected
+ * L-BFGS on the device — analytic ∇μ, ∇σ² from the kernel's derivative (∂k/∂x, L⁻¹, L⁻ᵀ), closed-form ∂EI/∂(μ,σ²) (UCB, PI
+ * likewise), Armijo backtracking with at most linesearch_max trials, the reference's three stopping rules.  Maximises the
+ * acquisition function inside the box [lower, upper].  x_out S × d, f_out S (the acquisition value at x_out: what abo_acq returns
+ * for that point up to the rounding of a differently ordered sum), iters_out (optional) S × 2 = {iterations, evaluations}.  A start whose value is not finite
+ * is returned unchanged.  All buffers HOST memory.  StandardGP handles only (a gradient-enhanced handle: ABO_EINVAL).
+ * abo_optimize_acquisition is the whole function in ONE call: grid generated on the device (abo_lhs, `seed`), scored and
+ * reduced to the min(n_local, n_grid) best (abo_acq), those refined, the best point returned: best_x (d), best_val; optional
+ * starts_x (k × d) / starts_val (k): the selected grid points and their scores in selection order; refined_x / refined_val: what
+ * each became.  The result is the refined point with the largest value (first one on ties, the reference keeps the first under
+ * its strict `>`), or the best grid point if no refined value reaches its score. */
+typedef struct abo_refine_opts {   /* NULL or zero fields = the reference's settings */
+    int32_t max_iter;        /* L-BFGS iterations per start, 0 = 100 */
+    int32_t linesearch_max;  /* trials per line search, 0 = 20 (acq_utils.jl:10) */
+    int32_t history;         /* L-BFGS pairs kept, 0 = 10 (Optim's LBFGS default) */
+    int32_t reserved;
+    double g_tol, f_abstol, x_abstol;   /* 0 = 1e-5, 2.2e-9, 1e-4 (acq_utils.jl:62) */
+} abo_refine_opts;
+int32_t abo_refine(abo_gp* gp, int32_t kind, double p0, double best_y, const double* lower, const double* upper, int32_t d,
+                   const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out, int32_t* iters_out);
+int32_t abo_optimize_acquisition(abo_gp* gp, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
+                                 int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                 double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                 double* refined_val);
 
 /* --- resident candidate sets (BASELINE config 5: greedy q-EI over a fixed grid) --------------------
  * abo_cand_create copies M candidates to the device and evaluates their posterior with `gp`
@@ -304,6 +340,14 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
  * posterior is rolled back and the fantasy models are dropped: on return model and set are as before.  x_out q × d,
  * idx_out / ei_out q.  distinct != 0 excludes every picked candidate for the rest of the call. */
 int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* cands);
+/* abo_optimize_acquisition across the group's devices: the grid stage as abo_mgpu_acq_lhs (shards generated, scored and reduced
+ * on their devices, ONE all-gather of the selections), then the selected starts are dealt out contiguously and every device
+ * refines its share with abo_refine's launch; a start's refinement does not depend on which device runs it, so the result equals
+ * the single-device call with the same seed bit for bit. */
+int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
+                                      int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                      double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                      double* refined_val);
 int32_t abo_mgpu_cand_create(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, abo_mcand** out);
 int32_t abo_mgpu_cand_create_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
                                  abo_mcand** out);
@@ -337,6 +381,10 @@ int32_t abo_test_oz_plan(int32_t n, int32_t* p, double* tables, double* scal, in
  * buffers; Np, Mc multiples of 128; partial [Np/128][ldp]). */
 int32_t abo_test_oz_contract(int32_t device, const double* W, int64_t ldw, int32_t Np, int32_t nvalid, const double* Kxz, int64_t ldk,
                              int32_t Mc, double kmax, int32_t nmod, double* partial, int64_t ldp);
+/* f[j], grad[j][0..d) = value and analytic gradient of the acquisition function at Z[j] (host buffers, M × d): the evaluation
+ * the refinement stage is built on, one workgroup per point */
+int32_t abo_test_acq_grad(abo_gp* gp, int32_t kind, double p0, double best_y, const double* Z, int64_t M, int32_t d, double* f,
+                          double* grad);
 /* out[i] = kappa(family, d2[i]) evaluated with the device math of the kernel-matrix generator */
 int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n);
 int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M,

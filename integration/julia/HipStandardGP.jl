@@ -15,6 +15,7 @@
 #   bayesian_opt.jl:428; ExpectedImprovement.jl:82  _get_minimum
 #   BO_utils.jl:48,:55,:59    get_mean_std, rescale_model, std_y
 #   StandardGP.jl:395-404     unstandardized_mean_and_var
+#   bayesian_opt.jl:430       optimize_acquisition(acqf, model, domain)   optimize_acquisition (one ccall: grid + refinement)
 #
 # NOTE: no Julia toolchain exists in the build image, so this file has not been executed there.  What HAS been
 # executed is the same sequence of C-ABI calls from a host with neither Python nor PyTorch in the process
@@ -218,6 +219,37 @@ function grid_stage(acqf::Union{ExpectedImprovement,UpperConfidenceBound,Probabi
         d::Int32, lower::Ptr{Float64}, upper::Ptr{Float64}, seed::UInt64, kind::Int32, p0::Float64, best::Float64, k::Int32,
         tv::Ptr{Float64}, ti::Ptr{Int64}, tx::Ptr{Float64})::Int32)
     [tx[:, j] for j in 1:k], tv
+end
+# optimize_acquisition (acq_utils.jl:33-73) in ONE ccall — more specific than the generic method (concrete acquisition and surrogate
+# types), so `optimize(BO)` picks it without any change to the driver (bayesian_opt.jl:430).  The Latin-hypercube grid is generated
+# on the device(s), scored, reduced to the n_local best (:44-52); every start is then refined by its own workgroup in one launch:
+# the whole projected L-BFGS on the device with the analytic gradient of the acquisition function, the reference's tolerances
+# (:62) and linesearchmax (:10); the best refined point comes back (:66-72).  The stock path would run up to n_local serial Optim
+# runs of M = 1 ccalls with finite-difference gradients.
+struct AboRefineOpts        # must match `struct abo_refine_opts`; zeros = the reference's settings
+    max_iter::Int32; linesearch_max::Int32; history::Int32; reserved::Int32
+    g_tol::Float64; f_abstol::Float64; x_abstol::Float64
+end
+function optimize_acquisition(acqf::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityImprovement}, m::HipStandardGP,
+                              domain::ContinuousDomain; n_grid::Int=10_000, n_local::Int=100, seed::UInt64=rand(UInt64))
+    m.gpx === nothing && throw(ArgumentError("surrogate is not conditioned on data yet (gpx === nothing)"))
+    kind, p0, best = _acq_args(acqf)
+    lower = collect(Float64, domain.lower); upper = collect(Float64, domain.upper); d = length(lower)
+    bx = Vector{Float64}(undef, d); bv = Ref{Float64}(); opts = Ref(AboRefineOpts(0, 0, 0, 0, 0.0, 0.0, 0.0))
+    GC.@preserve lower upper bx begin
+        if m.gpx.multi
+            _check(@ccall gc_safe=true LIBABO.abo_mgpu_optimize_acquisition(m.gpx.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
+                best::Float64, lower::Ptr{Float64}, upper::Ptr{Float64}, d::Int32, n_grid::Int64, n_local::Int32, seed::UInt64,
+                opts::Ptr{AboRefineOpts}, bx::Ptr{Float64}, bv::Ptr{Float64}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64},
+                C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
+        else
+            _check(@ccall gc_safe=true LIBABO.abo_optimize_acquisition(m.gpx.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
+                best::Float64, lower::Ptr{Float64}, upper::Ptr{Float64}, d::Int32, n_grid::Int64, n_local::Int32, seed::UInt64,
+                opts::Ptr{AboRefineOpts}, bx::Ptr{Float64}, bv::Ptr{Float64}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64},
+                C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
+        end
+    end
+    bx
 end
 # a single-device model joins the multi-device entry points as a one-shard group on its data
 function _group_of(m::HipStandardGP)

@@ -290,6 +290,42 @@ int main(int argc, char** argv) {
     CHECK(same, "acq: top-%d differs from the oracle's sortperm(scores; rev=true)[1:%d]", K, K);
     printf("ok acq (N=%lld d=%d M=%lld top-%d, max|dscore| %.2e)\n", (long long)N, d, (long long)M, K, maxabs(s, sc_e->v, M));
 
+    /* --- optimize_acquisition in one call (acq_utils.jl:33-73): device grid, top-k, on-device refinement, arg-max -------- */
+    {
+        enum { KL = 20 };
+        double lower[8], upper[8], bx[8], bval = 0.0, sx[KL * 8], sv[KL], rx[KL * 8], rv[KL];
+        for (int cdim = 0; cdim < d; ++cdim) { lower[cdim] = 0.0; upper[cdim] = 1.0; }
+        ok_or_die(abo_optimize_acquisition(g, (int32_t)a[0], a[1], a[2], lower, upper, d, 4000, KL, 3u, NULL, bx, &bval, sx, sv, rx, rv),
+                  "abo_optimize_acquisition");
+        int inbox = 1, noloss = 1;
+        for (int cdim = 0; cdim < d; ++cdim) inbox = inbox && bx[cdim] >= 0.0 && bx[cdim] <= 1.0;
+        for (int e = 0; e < KL; ++e) noloss = noloss && rv[e] >= sv[e] - 1e-15 && (e == 0 || sv[e] <= sv[e - 1]);
+        CHECK(inbox, "optimize_acquisition: result outside the box");
+        CHECK(noloss, "optimize_acquisition: a refined start lost against its start, or the starts are not sorted");
+        CHECK(bval >= sv[0], "optimize_acquisition: best value %.17g below the best grid score %.17g", bval, sv[0]);
+        double sb = 0.0;
+        ok_or_die(abo_acq(g, bx, 1, d, ABO_HOST, (int32_t)a[0], a[1], a[2], 0, &sb, 0, NULL, NULL, ABO_HOST), "abo_acq (best point)");
+        CHECK(fabs(sb - bval) <= 1e-9 * fmax(1.0, fabs(bval)), "optimize_acquisition: value %.17g, score of the returned point %.17g", bval, sb);
+        abo_timings tm;
+        ok_or_die(abo_get_timings(g, &tm), "abo_get_timings");
+        CHECK(tm.refine_starts == KL && tm.refine_evals >= KL && tm.refine_ms > 0.0, "optimize_acquisition: timings not filled");
+        /* the sharded group: same grid (counter-based generator), same selection, same refinement → same bits */
+        int32_t devs2[2] = {device, device};
+        abo_mgpu* mg = NULL;
+        double bx2[8], bval2 = 0.0, rv2[KL];
+        ok_or_die(abo_mgpu_create(&p, 2, devs2, &mg), "abo_mgpu_create");
+        ok_or_die(abo_mgpu_fit(mg, X->v, N, d, y->v, &info), "abo_mgpu_fit");
+        ok_or_die(abo_mgpu_optimize_acquisition(mg, (int32_t)a[0], a[1], a[2], lower, upper, d, 4000, KL, 3u, NULL, bx2, &bval2, NULL, NULL, NULL, rv2),
+                  "abo_mgpu_optimize_acquisition");
+        CHECK(bval2 == bval && memcmp(bx, bx2, sizeof(double) * d) == 0 && memcmp(rv, rv2, sizeof rv) == 0,
+              "mgpu optimize_acquisition differs from the single-device call");
+        ok_or_die(abo_mgpu_destroy(mg), "abo_mgpu_destroy");
+        CHECK(abo_refine(g, 9, 0.0, 0.0, lower, upper, d, sx, 1, NULL, rx, rv, NULL) == ABO_EINVAL, "abo_refine accepts an unknown acquisition");
+        CHECK(abo_refine(g, 0, 0.0, 0.0, lower, upper, d + 1, sx, 1, NULL, rx, rv, NULL) == ABO_EDIM, "abo_refine accepts a wrong dimension");
+        printf("ok optimize_acquisition (n_grid=4000 n_local=%d: best %.6g vs best grid score %.6g, %lld evaluations, refinement %.3f ms)\n",
+               KL, bval, sv[0], (long long)tm.refine_evals, tm.refine_ms);
+    }
+
     /* --- the int8-residue contraction engine from this host: same scores (to fp64 rounding), same selection --------- */
     {
         abo_gp* g8 = NULL;

@@ -1,0 +1,193 @@
+"""GPU tests (-m gpu) of the on-device refinement stage of optimize_acquisition (csrc/refine.hip; C-ABI abo_refine,
+abo_optimize_acquisition, abo_mgpu_optimize_acquisition) — reference: src/acquisition_functions/acq_utils.jl:33-73.
+
+The reference differentiates the acquisition function by finite differences of M = 1 posterior calls; the library evaluates
+the analytic gradient (∇μ, ∇σ² through ∂k/∂x, L⁻¹, L⁻ᵀ and the closed-form partials of EI / UCB / PI).  Checked here:
+the gradient against central differences of the library's own scores AND of the CPU oracle's, the refinement against SciPy's
+L-BFGS-B on the oracle's acquisition and against the host-driven finite-difference loop, the one-call entry against its parts,
+the sharded group against the single handle (bit for bit)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import abstractbayesopt.jl_amd as abo
+from abstractbayesopt.jl_amd import synth
+from abstractbayesopt.jl_amd.acquisition import _refine_starts_fd, acquisition_value_and_grad, refine_starts
+from oracle import gp_oracle as O
+
+from tests.parity_record import check
+from tests.test_gpu_parity import make_model
+
+
+def _oracle_acq(acq, st):
+    if isinstance(acq, abo.UpperConfidenceBound):
+        return lambda z: O.upper_confidence_bound(*O.predict(st, z), acq.beta)
+    kind = O.ACQ_EI if isinstance(acq, abo.ExpectedImprovement) else O.ACQ_PI
+    return lambda z: O.acquisition(kind, *O.predict(st, z), acq.xi, acq.best_y)
+
+
+@pytest.mark.parametrize("family,d,N", [(O.SE, 1, 30), (O.MATERN52, 3, 200), (O.MATERN72, 8, 500), (O.MATERN32, 2, 64),
+                                        (O.MATERN52, 40, 150), (O.SE, 5, 1100)])
+def test_analytic_acquisition_gradient_against_central_differences(family, d, N):
+    X, y = synth.standardized_problem(N, d, 0.03)
+    ell, sf2, noise = 0.7 * np.sqrt(d), 1.3, 1e-3
+    m = abo.update(make_model(family, ell, sf2, noise), X, y)
+    st = O.fit(family, ell, sf2, noise, 0.0, X, y)
+    Z = synth.points(5, 24, d) * 0.9 + 0.05
+    best = float(y.min())
+    h = 1e-6
+    for acq in (abo.ExpectedImprovement(0.01, best), abo.UpperConfidenceBound(2.0), abo.ProbabilityImprovement(0.01, best)):
+        f, g = acquisition_value_and_grad(acq, m, Z)
+        np.testing.assert_allclose(f, acq(m, Z), rtol=1e-9, atol=1e-10)   # the scored path's value (another summation order)
+        oracle = _oracle_acq(acq, st)
+        np.testing.assert_allclose(f, oracle(Z), rtol=1e-8, atol=1e-11)
+        # central differences of the ORACLE's acquisition (independent arithmetic), all coordinates in one batch
+        pts = np.repeat(Z[:, None, :], 2 * d, axis=1)
+        for c in range(d):
+            pts[:, 2 * c, c] += h
+            pts[:, 2 * c + 1, c] -= h
+        vals = oracle(pts.reshape(-1, d)).reshape(len(Z), 2 * d)
+        fd = (vals[:, 0::2] - vals[:, 1::2]) / (2 * h)
+        scale = np.maximum(np.max(np.abs(fd), axis=1, keepdims=True), 1e-8)
+        err = float(np.max(np.abs(g - fd) / scale))
+        check(f"refine/grad_fam{family}_d{d}_N{N}", f"{type(acq).__name__}_rel_vs_oracle_central_differences", err, 2e-5)
+
+
+def test_gradient_on_the_small_variance_branch_and_at_training_points():
+    """σ² ≤ 1e-12 → EI = PI = max(Δ, 0) (ExpectedImprovement.jl:44-46, ProbabilityImprovement.jl:42-44): the gradient there is
+    −∇μ where Δ > 0 and 0 elsewhere; UCB's σ term drops at σ² ≤ 0"""
+    X = np.array([[0.2], [0.5], [0.8]])
+    y = np.array([0.3, -1.0, 0.4])
+    m = abo.update(make_model(O.SE, 0.3, 1.0, 0.0), X, y)             # noise-free: σ² = 1e-18 at the data
+    acq = abo.ExpectedImprovement(0.0, 0.0)
+    f, g = acquisition_value_and_grad(acq, m, X)
+    var = abo.posterior_var(m, X)
+    assert np.all(var <= 1e-12)
+    np.testing.assert_allclose(f, np.maximum(0.0 - y, 0.0), atol=1e-10)
+    assert g[0, 0] == 0.0 and g[2, 0] == 0.0 and np.isfinite(g[1, 0])          # Δ ≤ 0 at the outer points, Δ = 1 in the middle
+    fp, gp_ = acquisition_value_and_grad(abo.ProbabilityImprovement(0.0, 0.0), m, X)
+    np.testing.assert_array_equal(fp, f)                                       # the same branch value for PI
+    np.testing.assert_array_equal(gp_, g)
+
+
+@pytest.mark.parametrize("family,d,N", [(O.MATERN52, 3, 60), (O.SE, 2, 100), (O.MATERN72, 6, 400)])
+def test_refinement_against_scipy_on_the_oracle_and_against_the_finite_difference_loop(family, d, N):
+    from scipy.optimize import minimize
+    X, y = synth.standardized_problem(N, d, 0.02)
+    ell, sf2, noise = 0.5, 1.0, 1e-3
+    m = abo.update(make_model(family, ell, sf2, noise), X, y)
+    st = O.fit(family, ell, sf2, noise, 0.0, X, y)
+    lower, upper = np.zeros(d), np.ones(d)
+    best = float(y.min())
+    for acq in (abo.UpperConfidenceBound(2.0), abo.ExpectedImprovement(0.01, best), abo.ProbabilityImprovement(0.01, best)):
+        starts = synth.points(7, 16, d)
+        f0 = acq(m, starts)
+        xr, fr, it = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+        assert np.all(fr >= f0 - 1e-15), "a refined start lost against its start"
+        assert np.all(xr >= lower) and np.all(xr <= upper)
+        np.testing.assert_allclose(acq(m, xr), fr, rtol=1e-9, atol=1e-10)       # the reported value is the score of the reported point
+        assert np.all(it[:, 0] <= 100) and np.all(it[:, 1] <= 1 + 100 * 20)
+        if isinstance(acq, abo.UpperConfidenceBound):          # (EI / PI can be flat zero at every start: nothing to climb)
+            assert it[:, 1].sum() > 3 * len(starts) and np.median(fr - f0) > 1e-3
+        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)
+        oracle = _oracle_acq(acq, st)
+        worse = 0
+        for i in range(len(starts)):
+            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
+                           options={"ftol": 1e-14, "gtol": 1e-8})
+            tol = 1e-5 * max(1.0, abs(res.fun))
+            # the same basin is not guaranteed for every start: count the starts that end below SciPy's optimum AND below the
+            # finite-difference loop's
+            if fr[i] < -res.fun - tol and fr[i] < ff[i] - tol:
+                worse += 1
+        assert worse <= 1, (type(acq).__name__, worse)
+        # the analytic-gradient run is at least as good as the finite-difference one on (nearly) every start
+        assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
+
+
+def test_refine_edge_cases():
+    d = 2
+    X, y = synth.standardized_problem(40, d, 0.02)
+    m = abo.update(make_model(O.MATERN52, 0.4, 1.0, 1e-3), X, y)
+    acq = abo.UpperConfidenceBound(2.0)
+    # a degenerate box side (lower == upper), starts outside the box (clipped), a start on a corner
+    lower, upper = np.array([0.3, 0.0]), np.array([0.3, 1.0])
+    starts = np.array([[0.9, 0.5], [0.3, 0.0], [-4.0, 7.0]])
+    xr, fr = refine_starts(acq, m, starts, lower, upper)
+    assert np.all(xr[:, 0] == 0.3) and np.all(xr[:, 1] >= 0.0) and np.all(xr[:, 1] <= 1.0)
+    np.testing.assert_allclose(acq(m, xr), fr, rtol=1e-9, atol=1e-10)
+    clipped = np.clip(starts, lower, upper)
+    assert np.all(fr >= acq(m, clipped) - 1e-10) and np.any(fr > acq(m, clipped) + 1e-3)    # the free coordinate does move
+    # a non-finite start value is handed back as it came
+    xn, fn = refine_starts(acq, m, np.array([[np.nan, 0.5]]), np.zeros(2), np.ones(2))
+    assert np.isnan(fn[0])
+    # wrong dimension / reversed bounds are refused, never a crash
+    with pytest.raises(abo.DimensionMismatch):
+        refine_starts(acq, m, np.zeros((2, 3)), np.zeros(3), np.ones(3))
+    with pytest.raises(ValueError):
+        refine_starts(acq, m, np.zeros((2, 2)), np.ones(2), np.zeros(2))
+    # determinism: one workgroup per start, fixed-order reductions
+    a = refine_starts(acq, m, synth.points(3, 50, d), np.zeros(2), np.ones(2))
+    b = refine_starts(acq, m, synth.points(3, 50, d), np.zeros(2), np.ones(2))
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_one_call_optimize_acquisition_equals_its_parts_and_the_sharded_group():
+    """abo_optimize_acquisition = device LHS → abo_acq top-k → abo_refine → arg-max; the group version shards grid and starts
+    and must return the same bits"""
+    from tests.test_gpu_multigpu import sharded
+    d, N = 3, 120
+    X, y = synth.standardized_problem(N, d, 0.02)
+    dom = abo.ContinuousDomain(np.zeros(d), np.ones(d))
+    m = abo.update(make_model(O.MATERN52, 0.5, 1.0, 1e-3), X, y)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    best, val, sx, sv, rx, rv = abo.optimize_acquisition_device(acq, m, dom, n_grid=5000, n_local=40, seed=11, return_all=True)
+    t = m.timings()
+    assert t["refine_starts"] == 40 and t["refine_evals"] >= 40 and t["refine_ms"] > 0
+    # parts: the same grid (same counter-based generator and seed), the same selection, the same refinement
+    grid = abo.device_latin_hypercube(5000, dom.lower, dom.upper, 11)
+    _, tv, ti = abo.evaluate(acq, m, grid, k=40, return_scores=False)
+    np.testing.assert_array_equal(sv, tv.cpu().numpy())
+    np.testing.assert_array_equal(sx, grid[ti].cpu().numpy())
+    xr, fr = refine_starts(acq, m, sx, dom.lower, dom.upper)
+    np.testing.assert_array_equal(rx, xr)
+    np.testing.assert_array_equal(rv, fr)
+    j = int(np.argmax(np.where(np.isfinite(rv), rv, -np.inf)))
+    assert val == max(rv[j], sv[0]) and np.array_equal(best, rx[j] if rv[j] >= sv[0] else sx[0])
+    assert val >= sv[0] and np.all(best >= 0) and np.all(best <= 1)
+    np.testing.assert_allclose(acq(m, [best])[0], val, rtol=1e-9, atol=1e-10)
+    # host API: optimize_acquisition(device_grid=True) is that one call
+    rng = np.random.default_rng(5)
+    seed = int(np.random.default_rng(5).integers(0, 2 ** 63))
+    b2 = abo.optimize_acquisition(acq, m, dom, n_grid=5000, n_local=40, rng=rng, device_grid=True)
+    np.testing.assert_array_equal(b2, abo.optimize_acquisition_device(acq, m, dom, 5000, 40, seed=seed))
+    # two and three shards on this device
+    for devs in ((0, 0), (0, 0, 0)):
+        g = abo.update(sharded(O.MATERN52, 0.5, 1.0, 1e-3, devs), X, y)
+        gb, gval, gsx, gsv, grx, grv = abo.optimize_acquisition_device(acq, g, dom, n_grid=5000, n_local=40, seed=11, return_all=True)
+        np.testing.assert_array_equal(gsx, sx)
+        np.testing.assert_array_equal(gsv, sv)
+        np.testing.assert_array_equal(grx, rx)
+        np.testing.assert_array_equal(grv, rv)
+        np.testing.assert_array_equal(gb, best)
+        assert gval == val
+
+
+def test_refinement_on_an_appended_model_ignores_stale_rows():
+    """rows / columns ≥ N of the shared factor storage may hold a discarded fantasy branch: the evaluation masks by the view's N"""
+    d, N = 2, 126
+    X, y = synth.standardized_problem(N + 4, d, 0.02)
+    gp = make_model(O.MATERN52, 0.4, 1.0, 1e-3, n_max=N + 8)
+    base = abo.update(gp, X[:N], y[:N])
+    fant = abo.append(abo.append(abo.append(base, X[N], 3.0), X[N + 1], -2.0), X[N + 2], 1.0)   # crosses the 128-row block border
+    del fant
+    acq = abo.UpperConfidenceBound(2.0)
+    starts = synth.points(9, 10, d)
+    # (the same capacity: an N ≤ 128 model without spare capacity takes the one-launch fit, whose factor differs in the last bits)
+    ref = abo.update(make_model(O.MATERN52, 0.4, 1.0, 1e-3, n_max=N + 8), X[:N], y[:N])
+    xa, fa = refine_starts(acq, base, starts, np.zeros(d), np.ones(d))
+    xb, fb = refine_starts(acq, ref, starts, np.zeros(d), np.ones(d))
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(fa, fb)

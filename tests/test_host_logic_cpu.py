@@ -233,9 +233,11 @@ def test_pmc_traffic_is_dropped_when_the_kernel_source_changed(tmp_path, monkeyp
     spec = importlib.util.spec_from_file_location("_bench", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    rec = json.load(open(os.path.join(root, "profiles", "r02_c3_pmc_traffic.json")))
     traffic, src = b.pmc_traffic("c3", 16384)
-    if rec["kernel_source_sha"] == b.source_sha(["gemm.hip"]):
+    rec = json.load(open(os.path.join(root, src["file"])))                     # the newest committed pass (r03, r02, r01)
+    # the guard hashes EVERY file the kernel is compiled from (bench.PMC_SOURCES), not just its translation unit
+    assert b.PMC_SOURCES["c3"] == ["gemm.hip", "abo_kernels.h"] and "abo_oz_dev.h" in b.PMC_SOURCES["c3_int8"]
+    if rec["kernel_source_sha"] == b.source_sha(b.PMC_SOURCES["c3"]):
         assert traffic == pytest.approx(rec["traffic_bytes_per_candidate"] * 16384) and not src.get("stale")
     else:
         assert traffic is None and src["stale"] is True
