@@ -5,7 +5,8 @@ from . import _lib, acquisition, distributed, incremental, multigpu, synth
 from ._lib import AboError, DimensionMismatch, PosDefException
 from .acquisition import (AbstractAcquisition, EnsembleAcquisition, ExpectedImprovement, ProbabilityImprovement,
                           UpperConfidenceBound, device_latin_hypercube, evaluate, latin_hypercube,
-                          optimize_acquisition, optimize_acquisition_device, acquisition_value_and_grad, refine_starts)
+                          optimize_acquisition, optimize_acquisition_device, acquisition_value_and_grad, refine_starts,
+                          update_and_evaluate)
 from .domains import ContinuousDomain
 from . import gradient_gp as _g
 from .gradient_gp import (GradientNormUCB, HipGradientGP, gradConstMean, posterior_grad_cov, posterior_grad_mean,

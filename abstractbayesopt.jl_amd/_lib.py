@@ -16,7 +16,7 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
-           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad"]
+           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq"]
 ABI_VERSION = 4
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
@@ -141,6 +141,7 @@ def lib():
                                            vp, C.POINTER(f64), vp, vp, vp, vp]
     L.abo_mgpu_optimize_acquisition.argtypes = L.abo_optimize_acquisition.argtypes
     L.abo_test_acq_grad.argtypes = [vp, i32, f64, f64, vp, i64, i32, vp, vp]
+    L.abo_fit_acq.argtypes = [vp, vp, i64, i32, vp, i32, C.POINTER(i64), vp, i64, i32, i32, f64, f64, i64, vp, i32, vp, vp, i32]
     for name in EXPORTS:
         getattr(L, name).restype = i32
     _lib = L

@@ -163,6 +163,63 @@ def evaluate(acq: AbstractAcquisition, surrogate: HipStandardGP, x, k: int = 0, 
     return scores, tv, ti
 
 
+def update_and_evaluate(acq: AbstractAcquisition, model: HipStandardGP, xs, ys, x, k: int = 0, return_scores: bool = True,
+                        idx_base: int = 0, best_y: float | None = None):
+    """`update(model, xs, ys)` followed by `evaluate(acq, new_model, x, k)` in ONE C-ABI call with one host synchronisation
+    (abo_fit_acq): the acquisition's launches are queued right behind the fit's.  EI / PI take best_y = min(ys), as
+    `update(acq, ys, surrogate)` would (ExpectedImprovement.jl:81-83) — pass `best_y` when the caller already has it (for device-resident ys the minimum otherwise
+    costs a device reduction and a synchronisation of its own).  Returns (new_model, scores, top_vals, top_idx).  At the
+    reference's own sizes (tens of points, 10 000 grid points) the host round trip between the two calls is a third of a step."""
+    from .surrogate import _Handle, _is_torch, parse_contraction
+    if isinstance(acq, EnsembleAcquisition) or hasattr(model, "devices") or hasattr(model, "p"):
+        from . import update as _update                      # not fused for these: the two calls
+        new = _update(model, xs, ys)
+        return (new,) + tuple(evaluate(update(acq, ys, new), new, x, k=k, return_scores=return_scores, idx_base=idx_base))
+    L = _lib.lib()
+    xp, n, d, xspace, xkeep = as_points(xs)
+    if _is_torch(ys):
+        yt = ys.reshape(-1).contiguous()
+        yspace, yp, ny, ykeep = (DEVICE if yt.is_cuda else HOST), yt.data_ptr(), yt.shape[0], yt
+        needs_min = best_y is None and isinstance(acq, (ExpectedImprovement, ProbabilityImprovement))
+        ymin = float(yt.min().item()) if needs_min else best_y
+    else:
+        ya = np.ascontiguousarray(np.asarray(ys, dtype=np.float64).reshape(-1))
+        yspace, yp, ny, ykeep = HOST, ya.ctypes.data, ya.shape[0], ya
+        ymin = best_y if best_y is not None else (float(ya.min()) if ya.size else 0.0)
+    if ny != n:
+        raise _lib.DimensionMismatch(f"xs has {n} points but ys has {ny} values")
+    if xspace != yspace:
+        raise ValueError("xs and ys must both be host arrays or both be tensors on the model's GPU")
+    if isinstance(acq, (ExpectedImprovement, ProbabilityImprovement)):
+        acq = replace(acq, best_y=ymin)
+    zp, m, dz, zspace, zkeep = as_points(x)
+    if zspace == DEVICE:
+        import torch
+        dev = zkeep.device
+        scores = torch.empty(m, dtype=torch.float64, device=dev) if return_scores else None
+        tv = torch.empty(k, dtype=torch.float64, device=dev) if k > 0 else None
+        ti = torch.empty(k, dtype=torch.int64, device=dev) if k > 0 else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+    else:
+        scores = np.empty(m) if return_scores else None
+        tv = np.empty(k) if k > 0 else None
+        ti = np.empty(k, dtype=np.int64) if k > 0 else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+    if dz != d:
+        raise _lib.DimensionMismatch(f"candidate dimension {dz}, training dimension {d}")
+    hp = C.c_void_p()
+    prm = model._params()
+    _lib.check(L.abo_create(C.byref(prm), C.byref(hp)))
+    h = _Handle(hp.value)
+    if getattr(model, "contraction", None) is not None:
+        _lib.check(L.abo_set_contraction(h.ptr, *parse_contraction(model.contraction)))
+    info = C.c_int64(0)
+    st = L.abo_fit_acq(h.ptr, xp, n, d, yp, xspace, C.byref(info), zp, m, zspace, acq.kind, acq._p0(), acq._best(), idx_base,
+                       ptr(scores), k, ptr(tv), ptr(ti), zspace)
+    _lib.check(st, info.value)
+    return model._clone(h), scores, tv, ti
+
+
 def torch_index(idx, like):
     import torch
     return torch.as_tensor(idx, dtype=torch.int64, device=like.device)

@@ -272,6 +272,12 @@ struct abo_gp {
     double ap_s2 = 0.0, ap_beta = 0.0; // Schur complement l_nn² and (y* − μ(x*))/l_nn²
     double ap_s2v[MAX_P] = {0}, ap_betav[MAX_P] = {0};   // gradient-enhanced append: the same per appended row (p_out of them)
     DevBuf alpha, vext, tvec, T, info, scal;
+    // host landing zone of the fit's scalars ({log det, δᵀα} and the LAPACK-style info): read back by one asynchronous copy at
+    // the end of the fit's launches and looked at after the NEXT stream synchronisation — the fit's own (abo_fit) or, for
+    // abo_fit_acq, the one behind the acquisition launches that were queued right behind the fit
+    double h_sc[2] = {0.0, 0.0};
+    int64_t h_info = 0;
+    bool fit_small_path = false;
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
     // int8-residue contraction (ozaki.hip): engine choice, the residue planes of this view's W (valid for oz_gen / oz_N /
@@ -363,14 +369,49 @@ int32_t copy_out(void* dst, const void* src, size_t bytes, int32_t space, hipStr
 
 int32_t factorise(abo_gp* g, double noise, int64_t* info_host);
 int32_t fit_small(abo_gp* g, double noise, int64_t* info_host);
+void fit_collect(abo_gp* g);
 
 float ev_ms(hipEvent_t a, hipEvent_t b) {
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, a, b);
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }   // (an event that was never recorded)
     return ms;
 }
 
+// Phase events.  Every call is bracketed by two events (its total); the events INSIDE a call — fit phases, per-chunk kernel
+// brackets of the posterior — are profiling instrumentation: each costs a host call and a marker packet between two kernels,
+// ≈ 40 of them per BO step, which at the reference's own sizes (a step of 0.2 ms) is a fifth of the step.  ABO_PHASE_EVENTS=0
+// leaves them out (the phase fields of abo_timings then read 0, the totals stay); default on.
+bool phase_events() {
+    static const bool on = [] { const char* e = getenv("ABO_PHASE_EVENTS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+#define PHASE_EVENT(ev, s) do { if (phase_events()) HIPCHK(hipEventRecord((ev), (s))); } while (0)
+
+// the scalars and phase timings of a finished fit (h_sc / h_info have landed: the stream has been synchronised since)
+void fit_collect(abo_gp* g) {
+    g->logdet = g->h_sc[0];
+    g->quad = g->h_sc[1];
+    g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
+    if (!phase_events()) {
+        g->tm.fit_kernel_matrix_ms = g->tm.fit_cholesky_ms = g->tm.fit_inverse_ms = g->tm.fit_alpha_ms = 0.0;
+        return;
+    }
+    if (g->fit_small_path) {
+        g->tm.fit_kernel_matrix_ms = 0.0;
+        g->tm.fit_cholesky_ms = ev_ms(g->evs()[1], g->evs()[2]);      // the one launch
+        g->tm.fit_inverse_ms = 0.0;
+        g->tm.fit_alpha_ms = 0.0;
+    } else {
+        g->tm.fit_kernel_matrix_ms = ev_ms(g->evs()[0], g->evs()[1]);
+        g->tm.fit_cholesky_ms = ev_ms(g->evs()[1], g->evs()[2]);
+        g->tm.fit_inverse_ms = ev_ms(g->evs()[2], g->evs()[3]);
+        g->tm.fit_alpha_ms = ev_ms(g->evs()[3], g->evs()[4]);
+    }
+    g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
+}
+
 // Right-looking blocked Cholesky, 128-wide panels, then L⁻¹ by recursive doubling.
+// info_host == nullptr: launches only — the caller synchronises later and then looks at g->h_info / calls fit_collect().
 int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     hipStream_t s = g->stream;
     Storage* st = g->st;
@@ -398,7 +439,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
         HIPCHK(launch_set_diag(W, ld, Np, (int)ld, 1.0, s));
         HIPCHK(launch_set_diag(WT, ld, Np, (int)ld, 1.0, s));
     }
-    HIPCHK(hipEventRecord(g->evs()[1], s));
+    PHASE_EVENT(g->evs()[1], s);
 
     // Two-level blocking: inside a strip of SW columns the 128-wide panels update only the rest of the strip
     // (K = 128 products on a tall, narrow block); the matrix behind the strip is updated once per strip with
@@ -457,7 +498,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
         }
     }
     if (split) HIPCHK(launch_trtri_diag_batched(K, W, WT, ld, Np / TB, info, s));
-    HIPCHK(hipEventRecord(g->evs()[2], s));
+    PHASE_EVENT(g->evs()[2], s);
     // no host round trip here: after a failed pivot every later kernel of the fit either exits on `info` (the GEMMs) or
     // works on finite leftovers whose results are discarded; `info` is read once, with the scalars, at the end
 
@@ -494,24 +535,19 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             HIPCHK(launch_gemm_nt(b, s));
         }
     }
-    HIPCHK(hipEventRecord(g->evs()[3], s));
+    PHASE_EVENT(g->evs()[3], s);
     // alpha = Wᵀ(W·delta)
     HIPCHK(launch_trmv(W, ld, st->delta.as<double>(), g->tvec.as<double>(), Np, 1, s));
     HIPCHK(launch_trmv(WT, ld, g->tvec.as<double>(), g->alpha.as<double>(), Np, 0, s));
     HIPCHK(launch_nlml_terms(K, ld, st->delta.as<double>(), g->alpha.as<double>(), N, g->scal.as<double>(), s));
     HIPCHK(hipEventRecord(g->evs()[4], s));
-    double sc[2];
-    HIPCHK(hipMemcpyAsync(sc, g->scal.as<double>(), sizeof sc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(info_host, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    g->fit_small_path = false;
+    HIPCHK(hipMemcpyAsync(g->h_sc, g->scal.as<double>(), sizeof g->h_sc, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&g->h_info, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (!info_host) return ABO_OK;        // deferred: fit_collect() after the caller's synchronisation
     HIPCHK(hipStreamSynchronize(s));
-    if (*info_host != 0) return ABO_OK;   // caller decides (retry with jitter or ENOTPD)
-    g->logdet = sc[0];
-    g->quad = sc[1];
-    g->tm.fit_kernel_matrix_ms = ev_ms(g->evs()[0], g->evs()[1]);
-    g->tm.fit_cholesky_ms = ev_ms(g->evs()[1], g->evs()[2]);
-    g->tm.fit_inverse_ms = ev_ms(g->evs()[2], g->evs()[3]);
-    g->tm.fit_alpha_ms = ev_ms(g->evs()[3], g->evs()[4]);
-    g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
+    *info_host = g->h_info;
+    if (g->h_info == 0) fit_collect(g);   // else the caller decides (retry with jitter or ENOTPD)
     return ABO_OK;
 }
 
@@ -522,28 +558,22 @@ int32_t fit_small(abo_gp* g, double noise, int64_t* info_host) {
     int64_t* info = g->info.as<int64_t>();
     HIPCHK(hipEventRecord(g->evs()[0], s));
     HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
-    HIPCHK(hipEventRecord(g->evs()[1], s));
+    PHASE_EVENT(g->evs()[1], s);
     FitSmallArgs fs{};
     fs.Xraw = st->Xraw.as<double>(); fs.y = st->ybuf.as<double>(); fs.Xs = st->Xs.as<double>(); fs.delta = st->delta.as<double>();
     fs.alpha = g->alpha.as<double>(); fs.scal = g->scal.as<double>();
     fs.N = (int)g->N; fs.d = g->d; fs.dp = g->dp; fs.family = g->prm.family;
     fs.s = 1.0 / g->prm.ell; fs.sigma_f2 = g->prm.sigma_f2; fs.noise = noise; fs.mean_c = g->prm.mean_c;
     HIPCHK(launch_fit_small(st->K.as<double>(), st->W.as<double>(), st->WT.as<double>(), info, fs, s));
-    HIPCHK(hipEventRecord(g->evs()[2], s));
-    HIPCHK(hipEventRecord(g->evs()[3], s));
+    PHASE_EVENT(g->evs()[2], s);
     HIPCHK(hipEventRecord(g->evs()[4], s));
-    double sc[2];
-    HIPCHK(hipMemcpyAsync(sc, g->scal.as<double>(), sizeof sc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(info_host, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    g->fit_small_path = true;
+    HIPCHK(hipMemcpyAsync(g->h_sc, g->scal.as<double>(), sizeof g->h_sc, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&g->h_info, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (!info_host) return ABO_OK;        // deferred: fit_collect() after the caller's synchronisation
     HIPCHK(hipStreamSynchronize(s));
-    if (*info_host != 0) return ABO_OK;
-    g->logdet = sc[0];
-    g->quad = sc[1];
-    g->tm.fit_kernel_matrix_ms = 0.0;
-    g->tm.fit_cholesky_ms = ev_ms(g->evs()[1], g->evs()[2]);      // the one launch
-    g->tm.fit_inverse_ms = 0.0;
-    g->tm.fit_alpha_ms = 0.0;
-    g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
+    *info_host = g->h_info;
+    if (g->h_info == 0) fit_collect(g);
     return ABO_OK;
 }
 
@@ -666,10 +696,10 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     g->oz_prepare_pending = false;
     g->tm.oz_prepare_ms = 0.0;                                      // planes cached from an earlier call: nothing spent in this one
     if (oz && (g->oz_gen != g->st->gen || g->oz_N != g->N)) {      // residue planes of this view's W, once per model
-        HIPCHK(hipEventRecord(g->evs()[8], s));
+        PHASE_EVENT(g->evs()[8], s);
         HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
                             g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
-        HIPCHK(hipEventRecord(g->evs()[9], s));
+        PHASE_EVENT(g->evs()[9], s);
         g->oz_gen = g->st->gen; g->oz_N = g->N;
         g->oz_prepare_pending = true;                               // both events recorded in THIS call: read with the posterior timings
     }
@@ -698,9 +728,9 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             ka.res_bad = g->oz_badc.as<int>(); ka.res_n = g->oz_plan.n; ka.res_sK = oz_k_scale(g->prm.sigma_f2);
             if (!kstore) ka.Kout = nullptr;
         }
-        HIPCHK(hipEventRecord(e[0], s));
+        PHASE_EVENT(e[0], s);
         HIPCHK(launch_kgen(ka, s));
-        HIPCHK(hipEventRecord(e[1], s));
+        PHASE_EVENT(e[1], s);
         if (oz) {
             OzVarArgs oa{};
             oa.plan = &g->oz_plan; oa.Kxz = kchunk; oa.ldk = ldk; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
@@ -709,19 +739,19 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             // a gradient-enhanced model's scaled chunk is bounded by σ_f²·√2 (oz_prepare_w), a StandardGP's by σ_f²
             oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->p_out > 1 ? 1.5 * g->prm.sigma_f2 : g->prm.sigma_f2);
             oa.kper = g->p_out; oa.ktg = oz_grad_exp(g);
-            oa.ev_quant = e[6]; oa.ev_gemm = e[7]; oa.planes_ready = fused ? 1 : 0;
-            HIPCHK(hipEventRecord(e[2], s));
+            oa.ev_quant = phase_events() ? e[6] : nullptr; oa.ev_gemm = phase_events() ? e[7] : nullptr; oa.planes_ready = fused ? 1 : 0;
+            PHASE_EVENT(e[2], s);
             HIPCHK(launch_var_ozaki(oa, s));
-            HIPCHK(hipEventRecord(e[3], s));
+            PHASE_EVENT(e[3], s);
             g->tm.var_gemm_launches += 1;
         } else if (want_var) {
             VarGemmArgs va{};
             va.W = g->st->W.as<double>(); va.Kxz = kchunk; va.partial = g->partial.as<double>();
             va.ldw = g->st->cap; va.ldk = ldk; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
             va.force128 = getenv("ABO_TILE128") ? 1 : 0;
-            HIPCHK(hipEventRecord(e[2], s));
+            PHASE_EVENT(e[2], s);
             HIPCHK(launch_var_gemm(va, s));
-            HIPCHK(hipEventRecord(e[3], s));
+            PHASE_EVENT(e[3], s);
             g->tm.var_gemm_launches += 1;
         }
         FinalizeArgs fa{};
@@ -730,9 +760,9 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         fa.T = (var_out || score_out) ? T : 0; fa.Mc = mcp; fa.kind = kind; fa.sigma_f2 = g->prm.sigma_f2;
         fa.p0 = p0; fa.best_y = best_y;
         fa.prior_grad = grad_prior_var(g); fa.pc = pc; fa.point_major = point_major; fa.Mpts = Mpts;
-        HIPCHK(hipEventRecord(e[4], s));
+        PHASE_EVENT(e[4], s);
         HIPCHK(launch_finalize(fa, s));
-        HIPCHK(hipEventRecord(e[5], s));
+        PHASE_EVENT(e[5], s);
     }
     return ABO_OK;
 }
@@ -742,7 +772,7 @@ void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
     const int64_t nchunk = (M + Mc - 1) / Mc;
     double kx = 0, vg = 0, fi = 0, oq = 0, og = 0, oc = 0;
     const bool oz = with_var && g->tm.contraction_engine == ABO_CONTRACT_INT8;
-    for (int64_t c = 0; c < nchunk; ++c) {
+    for (int64_t c = 0; phase_events() && c < nchunk; ++c) {
         hipEvent_t* e = &g->evs()[EV_BASE + EV_PER_CHUNK * c];
         kx += ev_ms(e[0], e[1]);
         if (with_var) vg += ev_ms(e[2], e[3]);
@@ -753,7 +783,7 @@ void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
     g->tm.acq_var_gemm_ms = vg;
     g->tm.acq_finalize_ms = fi;
     g->tm.oz_quant_ms = oq; g->tm.oz_gemm_ms = og; g->tm.oz_crt_ms = oc;
-    if (g->oz_prepare_pending) { g->tm.oz_prepare_ms = ev_ms(g->evs()[8], g->evs()[9]); g->oz_prepare_pending = false; }
+    if (g->oz_prepare_pending) { g->tm.oz_prepare_ms = phase_events() ? ev_ms(g->evs()[8], g->evs()[9]) : 0.0; g->oz_prepare_pending = false; }
     // ALGORITHMIC int8 operations of the residue GEMMs: n moduli × the triangular product N²·M (N(N+1)/2 multiply-adds per
     // candidate, 2 operations each ≈ N²).  What the kernel issues beyond that — the upper halves of its 256-wide diagonal blocks
     // (of which it skips 6 of 16 units), padding of N and M to 256 — is not credited.
@@ -780,8 +810,10 @@ int32_t stage_candidates(abo_gp* g, const double* Z, int64_t M, int32_t z_space,
 // Full refit into a fresh Storage of capacity max(N, n_max) points.  X/y: caller buffers (host or device).
 // Gradient-enhanced models (p_out > 1): y holds p_out values per point, by outputs at the ABI (y[q·N + i]) or — internal
 // callers, y_point_major — already in the factor's point-major order (y[i·p + q]).
+// defer: queue the fit's launches and return without waiting (no jitter retries then): the handle is provisionally marked
+// fitted so that posterior launches can be queued behind it; the caller synchronises and calls fit_finish().
 int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, int32_t space, int64_t* info,
-                 int y_point_major = 0) {
+                 int y_point_major = 0, bool defer = false) {
     hipStream_t s = g->stream;
     g->from_append = false;
     Storage* st = new (std::nothrow) Storage();
@@ -824,6 +856,19 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     HIPCHK(g->scal.ensure(sizeof(double) * 8));
     // N ≤ 128, d ≤ 16, no spare capacity: the whole fit is one launch (chol.hip, mode 3 of the diagonal-block kernel)
     const bool fused_small = P == 1 && cap == TB && st->dp <= 16 && !getenv("ABO_NO_FUSED_FIT");
+    if (defer) {
+        if (!fused_small) {
+            HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
+            HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
+            HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
+        }
+        rc = fused_small ? fit_small(g, g->prm.noise_var, nullptr) : factorise(g, g->prm.noise_var, nullptr);
+        if (rc) return rc;
+        st->noise_used = g->prm.noise_var;
+        st->add_view(R);
+        g->fitted = true;                 // provisional until fit_finish()
+        return ABO_OK;
+    }
     if (fused_small) {
         int64_t inf = 0;
         double noise = g->prm.noise_var;
@@ -1353,10 +1398,10 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
             HIPCHK(launch_finalize(fa, s));
         }
         if (rc) return rc;
-        HIPCHK(hipEventRecord(g->evs()[6], s));
+        PHASE_EVENT(g->evs()[6], s);
     } else {
         HIPCHK(hipEventRecord(g->evs()[5], s));
-        HIPCHK(hipEventRecord(g->evs()[6], s));
+        PHASE_EVENT(g->evs()[6], s);
     }
     if (k > 0) {
         const int64_t we = topk_workspace_entries(M, k);
@@ -1386,12 +1431,51 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
     }
     HIPCHK(hipStreamSynchronize(s));
     if (M > 0) collect_posterior_timings(g, M, kind != ABO_ACQ_MEAN);
-    g->tm.acq_topk_ms = ev_ms(g->evs()[6], g->evs()[7]);
+    g->tm.acq_topk_ms = phase_events() ? ev_ms(g->evs()[6], g->evs()[7]) : 0.0;
     g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[7]);
     return ABO_OK;
 }
 
+namespace {
+// after the synchronisation that followed a deferred fit: the verdict on the factorisation
+int32_t fit_finish(abo_gp* g, int64_t* info) {
+    if (g->h_info != 0) {
+        if (g->st && g->fitted) g->st->drop_view(g->N);
+        g->fitted = false;
+        if (info) *info = g->h_info;
+        return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
+                    (long long)g->h_info);
+    }
+    fit_collect(g);
+    return ABO_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int32_t abo_fit_acq(abo_gp* g, const double* X, int64_t N, int32_t d, const double* y, int32_t space, int64_t* info, const double* Z,
+                    int64_t M, int32_t z_space, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
+                    double* top_val, int64_t* top_idx, int32_t out_space) {
+    if (info) *info = 0;
+    if (!g || !X || !y) return fail(ABO_EINVAL, "abo_fit_acq: null argument");
+    // an opt-in jitter retry needs the verdict on the factorisation before anything else is queued, and a gradient-enhanced
+    // model's targets are reordered on the way in: both take the two calls this entry point otherwise fuses
+    if (g->prm.jitter > 0.0 || g->p_out > 1) {
+        const int32_t rc = abo_fit(g, X, N, d, y, space, info);
+        return rc ? rc : abo_acq(g, Z, M, d, z_space, kind, p0, best_y, idx_base, scores, k, top_val, top_idx, out_space);
+    }
+    if (N < 1) return fail(ABO_EINVAL, "abo_fit_acq: need at least one training point");
+    if (d < 1 || d > 65536) return fail(ABO_EINVAL, "abo_fit_acq: input dimension %d outside 1..65536", d);
+    if (N > (int64_t)1 << 20) return fail(ABO_EINVAL, "abo_fit_acq: N = %lld too large", (long long)N);
+    HIPCHK(hipSetDevice(g->prm.device));
+    int32_t rc = fit_impl(g, X, N, d, y, space, info, 0, /*defer=*/true);
+    if (rc) return rc;
+    // the acquisition's launches go straight behind the fit's: after a failed pivot they work on finite leftovers or exit on
+    // `info`, and their results are discarded below
+    rc = abo::acq_ex(g, Z, M, d, z_space, kind, p0, best_y, idx_base, scores, out_space, k, top_val, top_idx, out_space);
+    if (rc) { (void)hipStreamSynchronize(g->stream); (void)fit_finish(g, info); return rc; }
+    return fit_finish(g, info);           // acq_ex returned behind its stream synchronisation: the fit's scalars have landed
+}
 
 int32_t abo_nlml(abo_gp* g, double* out) {
     if (!g || !out) return fail(ABO_EINVAL, "abo_nlml: null argument");

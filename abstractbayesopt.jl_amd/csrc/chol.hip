@@ -116,6 +116,12 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     if (*info != 0) return;
     if (t == 0) fail = 0;
     if constexpr (MODE == 2) r0 = blockIdx.x * NB;
+    // mode 3 (the whole fit of an N ≤ 128 model): the block beyond the last sub-block that holds a training point is the identity —
+    // factor, inverse and every product with it are known in advance — so the sub-block loops stop at nsb = ⌈N/16⌉ (the
+    // reference's loops run 5 … 50 points: 1 … 4 of the 8 sub-blocks).  Same bits as the full sweep: the skipped steps only ever
+    // multiplied by exact zeros and ones.
+    const int nsb = MODE == 3 ? (fs.N + SB - 1) / SB : NSB;
+    const int NBe = SB * nsb;                              // rows / columns that take part
     PROBE(0);
     double* Kb = K + (int64_t)r0 * ld + r0;
     if constexpr (MODE == 3) {
@@ -163,9 +169,9 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     PROBE(1);
 
     // ---------------- phase 1: Cholesky ----------------
-    for (int p = 0; p < (MODE == 2 ? 0 : NSB); ++p) {
+    for (int p = 0; p < (MODE == 2 ? 0 : nsb); ++p) {
         const int o = SB * p;
-        const int below = NB - o - SB;                     // rows under the diagonal sub-block
+        const int below = NBe - o - SB;                    // rows under the diagonal sub-block
         // (1)+(2) fused, in registers: lanes 0-15 of a wave hold the 16 rows of the diagonal sub-block, lanes 16-63
         // hold 48 of the rows below it, one row (16 doubles) per lane.  Column j: the pivot and the scaled column
         // entries L[k][j] are wave-uniform v_readlane broadcasts from lanes 0-15, so factoring the diagonal block and
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         // synchronisation inside the 16 columns.
         if (wave * 48 < below || wave == 0) {
             const int row = lane < SB ? o + lane : o + SB + wave * 48 + (lane - SB);
-            const bool valid = row < NB;
+            const bool valid = row < NBe;
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
@@ -209,7 +215,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         if (p < 4) PROBE(6 + 2 * p);                       // probe build only: end of the register potf2 + row solve of sub-step p
         if (fail) return;                                  // uniform (LDS flag after the barrier)
         {                                                  // (3) trailing update on the lower sub-blocks
-            const int nb = NSB - 1 - p;                    // sub-block rows/cols left
+            const int nb = nsb - 1 - p;                    // sub-block rows/cols left
             const int total = nb * (nb + 1) / 2;
             for (int e = wave; e < total; e += DT / 64) {
                 int bi = 0, rem = e;                       // e -> (bi ≥ bj) in row-major lower order
@@ -231,8 +237,12 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     }
 
     PROBE(2);
+    if constexpr (MODE == 3) {
+        if (t >= NBe && t < NB) dinv[t] = 1.0;             // identity part: never factored above
+        __syncthreads();
+    }
     // ---------------- phase 2: X = L⁻¹, Xᵀ into the strict upper triangle ----------------
-    if (t < NB) {                                          // (a) diagonal sub-block inverses
+    if (t < NBe) {                                         // (a) diagonal sub-block inverses (identity sub-blocks: nothing to do)
         const int o = SB * (t >> 4), n = t & 15;
         double x[SB];
 #pragma unroll
@@ -264,8 +274,8 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         }
         return;
     }
-    for (int dl = 1; dl < NSB; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
-        for (int c = wave; c + dl < NSB; c += DT / 64) {
+    for (int dl = 1; dl < nsb; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
+        for (int c = wave; c + dl < nsb; c += DT / 64) {
             const int i = c + dl;
             const int oc = SB * c, oi = SB * i;
             d4_t tt = {0.0, 0.0, 0.0, 0.0};

@@ -143,6 +143,17 @@ int32_t abo_destroy(abo_gp* gp);
 int32_t abo_fit(abo_gp* gp, const double* X, int64_t N, int32_t d, const double* y, int32_t space,
                 int64_t* info);
 
+/* update(model, xs, ys) + scores = acqf(model, grid) + sortperm(scores; rev=true)[1:k] — abo_fit followed by abo_acq — in ONE call
+ * with ONE host synchronisation: the acquisition's launches are queued directly behind the fit's, the LAPACK-style `info` and the
+ * fit's scalars are read once, at the end (after a failed factorisation the acquisition's launches run on leftovers and their
+ * results are discarded: status ABO_ENOTPD, *info as abo_fit, outputs untouched in meaning).  What a BO loop at the reference's own
+ * sizes (5 … 100 points, 10 000 grid points, acq_utils.jl:37) spends most of its step on is the host round trip between the two
+ * calls.  The handle ends up exactly as after abo_fit.  best_y is the caller's (EI / PI take min(ys), ExpectedImprovement.jl:81-83).
+ * With an opt-in jitter (abo_params.jitter > 0) or a gradient-enhanced handle the two calls run one after the other. */
+int32_t abo_fit_acq(abo_gp* gp, const double* X, int64_t N, int32_t d, const double* y, int32_t space, int64_t* info, const double* Z,
+                    int64_t M, int32_t z_space, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
+                    double* top_val, int64_t* top_idx, int32_t out_space);
+
 /* --- incremental update (BASELINE config 5; no counterpart in the reference, which always refits —
  * nearest code: update(), src/surrogates/StandardGP.jl:79-83) -------------------------------------
  * Bordered ("rank-1 append") Cholesky update: returns in *out a NEW model conditioned on the N+1

@@ -153,3 +153,50 @@ def test_edge_and_random_shapes_against_oracle(N, d, M):
     mu2, var2 = abo.mean_and_var(m2, Z[:64])
     mo2, vo2 = O.predict(st2, Z[:64])
     assert np.max(np.abs(mu2 - mo2)) <= 1e-8 * max(1.0, np.max(np.abs(mo2))) and np.max(np.abs(var2 - vo2)) <= 1e-8 * sf2
+
+
+@pytest.mark.parametrize("N,d,M", [(25, 1, 10000), (100, 2, 10000), (129, 3, 3000), (700, 4, 5000), (1600, 4, 2000)])
+def test_fused_update_and_evaluate_equals_the_two_calls(N, d, M):
+    """abo_fit_acq = abo_fit + abo_acq with one host synchronisation: the same model and the same scores / selection, bit for
+    bit, on the one-launch small fit (N ≤ 128), the blocked fit and the int8 engine's sizes"""
+    X, y = synth.standardized_problem(N, d, 0.02)
+    Z = synth.points(2, M, d)
+    gp = make_model(O.MATERN52, 0.5, 1.0, 1e-4)
+    acq = abo.ExpectedImprovement(0.01, 123.0)                       # best_y is replaced by min(ys), as update(acq, ys, m) does
+    m1 = abo.update(gp, X, y)
+    s1, tv1, ti1 = abo.evaluate(abo.update(acq, y, m1), m1, Z, k=100)
+    m2, s2, tv2, ti2 = abo.update_and_evaluate(acq, gp, X, y, Z, k=100)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(tv1, tv2)
+    np.testing.assert_array_equal(ti1, ti2)
+    for a, b in zip(abo.get_factor(m1), abo.get_factor(m2)):
+        np.testing.assert_array_equal(a, b)
+    assert abo.nlml_fitted(m1) == abo.nlml_fitted(m2)
+    t = m2.timings()
+    assert t["fit_total_ms"] > 0 and t["acq_total_ms"] > 0
+    # the fused call's model is a normal model: appendable, copyable, refinable
+    np.testing.assert_array_equal(abo.posterior_mean(abo.copy(m2), Z[:50]), abo.posterior_mean(m1, Z[:50]))
+
+
+def test_fused_call_reports_a_failed_factorisation_and_leaves_the_handle_unfitted():
+    """test_bayesian_opt.jl:749-786 through the fused entry: PosDefException(3), nothing usable left behind, no crash in the
+    acquisition launches that were queued behind the failing fit"""
+    X = np.array([[-1.0, -1.0], [5.0, -5.0], [-1.0 + 1e-12, -1.0 + 1e-12]])
+    y = np.array([1.0, 2.0, 1.0])
+    Z = synth.points(2, 500, 2)
+    gp = abo.HipStandardGP(abo.SqExponentialKernel(), 0.0)
+    with pytest.raises(abo.PosDefException) as e:
+        abo.update_and_evaluate(abo.UpperConfidenceBound(2.0), gp, X, y, Z, k=10)
+    assert e.value.info == 3
+    # the same on the blocked path (N > 128): a duplicated point far down the matrix
+    X2 = synth.points(1, 300, 2)
+    X2[250] = X2[17]
+    gp2 = abo.HipStandardGP(abo.with_lengthscale(abo.SqExponentialKernel(), 0.01), 0.0)     # K ≈ I except for the duplicated point
+    with pytest.raises(abo.PosDefException) as e:
+        abo.update_and_evaluate(abo.UpperConfidenceBound(2.0), gp2, X2, np.zeros(300), Z, k=10)
+    assert e.value.info == 251
+    with pytest.raises(abo.PosDefException) as e2:
+        abo.update(gp2, X2, np.zeros(300))
+    assert e2.value.info == 251
+    with pytest.raises(abo.DimensionMismatch):
+        abo.update_and_evaluate(abo.UpperConfidenceBound(2.0), gp, X, y, synth.points(2, 10, 3), k=1)
