@@ -447,52 +447,77 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // per tile than a panel-by-panel SYRK.
     const char* swe = getenv("ABO_CHOL_STRIP");
     const int SW = swe ? atoi(swe) : 512;
+    // Optional third level (ABO_CHOL_SUPER = super-strip width; default off): strips grouped into super-strips, behind a strip only
+    // the rest of its super-strip is updated (K = SW), the matrix behind the super-strip once per super-strip with K = SS — a
+    // quarter of the passes over the trailing matrix.  Measured in round 3 and NOT adopted: Cholesky at N = 16384 38.2 → 36.6 ms
+    // at best (SS = 1024), N = 8192 8.67 → 8.76 … 9.03 (profiles/r03_chol_super_sweep.txt) — the trailing products are bound by
+    // the 128×128 tile's operand traffic from L2 (16 flop per byte), not by the passes over C.
+    const char* sse = getenv("ABO_CHOL_SUPER");
+    int SS = sse ? atoi(sse) : 0;
+    if (SS <= SW) SS = SW;
+    SS = SS / SW * SW;
     // Panel chain: potf2 of the diagonal block → triangular solve of the rows below it on L itself → in-strip update.  The
     // 128×128 inverses of the diagonal blocks (the seeds of the blocked L⁻¹ below) are not on that chain: all of them are
     // formed by ONE batched launch behind the factorisation.  ABO_CHOL_SPLIT=0 restores the round-1 chain (factor + inverse
     // in one kernel, panel solve as a product with the inverse) for A/B runs.
     const char* spe = getenv("ABO_CHOL_SPLIT");
     const bool split = (!spe || atoi(spe) != 0) && Np > TB;     // a single block has no chain: factor + inverse in one launch
-    for (int s0 = 0; s0 < Np; s0 += SW) {
-        const int sw = (Np - s0) < SW ? (Np - s0) : SW;
-        for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
-            const int rem = Np - r0 - TB;
-            if (split) {
-                HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s));
-                if (rem <= 0) break;
-                HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s));
-            } else {
-                HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
-                if (rem <= 0) break;
+    for (int S0 = 0; S0 < Np; S0 += SS) {
+        const int ss = (Np - S0) < SS ? (Np - S0) : SS;
+        for (int s0 = S0; s0 < S0 + ss; s0 += SW) {
+            const int sw = (S0 + ss - s0) < SW ? (S0 + ss - s0) : SW;
+            for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
+                const int rem = Np - r0 - TB;
+                if (split) {
+                    HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s));
+                    if (rem <= 0) break;
+                    HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s));
+                } else {
+                    HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
+                    if (rem <= 0) break;
+                }
+                GemmArgs a{};
+                // panel solve  L[r,p] = A[r,p] · Linv_ppᵀ   (in place; each workgroup owns its rows)
+                a.A = K + (int64_t)(r0 + TB) * ld + r0; a.lda = ld;
+                a.B = W + (int64_t)r0 * ld + r0; a.ldb = ld;
+                a.C = K + (int64_t)(r0 + TB) * ld + r0; a.ldc = ld;
+                a.M = rem; a.N = TB; a.K = TB; a.kmode = K_FULL; a.lower_only = 0; a.batch = 1;
+                a.alpha = 1.0; a.beta = 0.0; a.info = info;
+                if (!split) HIPCHK(launch_gemm_nt(a, s));
+                // in-strip update  A[r,c] −= L[r,p]·L[c,p]ᵀ  for the strip's remaining columns c, lower tiles only
+                const int ncol = s0 + sw - r0 - TB;
+                if (ncol > 0) {
+                    GemmArgs u{};
+                    u.A = K + (int64_t)(r0 + TB) * ld + r0; u.lda = ld;
+                    u.B = u.A; u.ldb = ld;
+                    u.C = K + (int64_t)(r0 + TB) * ld + (r0 + TB); u.ldc = ld;
+                    u.M = rem; u.N = ncol; u.K = TB; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+                    u.alpha = -1.0; u.beta = 1.0; u.info = info;
+                    HIPCHK(launch_gemm_nt(u, s));
+                }
             }
-            GemmArgs a{};
-            // panel solve  L[r,p] = A[r,p] · Linv_ppᵀ   (in place; each workgroup owns its rows)
-            a.A = K + (int64_t)(r0 + TB) * ld + r0; a.lda = ld;
-            a.B = W + (int64_t)r0 * ld + r0; a.ldb = ld;
-            a.C = K + (int64_t)(r0 + TB) * ld + r0; a.ldc = ld;
-            a.M = rem; a.N = TB; a.K = TB; a.kmode = K_FULL; a.lower_only = 0; a.batch = 1;
-            a.alpha = 1.0; a.beta = 0.0; a.info = info;
-            if (!split) HIPCHK(launch_gemm_nt(a, s));
-            // in-strip update  A[r,c] −= L[r,p]·L[c,p]ᵀ  for the strip's remaining columns c, lower tiles only
-            const int ncol = s0 + sw - r0 - TB;
-            if (ncol > 0) {
+            // update behind the strip, inside its super-strip:  A[r,c] −= L[r,strip]·L[c,strip]ᵀ  for all rows r below the strip and
+            // the super-strip's remaining columns c (lower tiles only), K = sw
+            const int rows = Np - s0 - sw;
+            const int cols = S0 + ss - s0 - sw;
+            if (rows > 0 && cols > 0) {
                 GemmArgs u{};
-                u.A = K + (int64_t)(r0 + TB) * ld + r0; u.lda = ld;
+                u.A = K + (int64_t)(s0 + sw) * ld + s0; u.lda = ld;
                 u.B = u.A; u.ldb = ld;
-                u.C = K + (int64_t)(r0 + TB) * ld + (r0 + TB); u.ldc = ld;
-                u.M = rem; u.N = ncol; u.K = TB; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+                u.C = K + (int64_t)(s0 + sw) * ld + (s0 + sw); u.ldc = ld;
+                u.M = rows; u.N = cols; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
                 u.alpha = -1.0; u.beta = 1.0; u.info = info;
                 HIPCHK(launch_gemm_nt(u, s));
             }
         }
-        const int rest = Np - s0 - sw;
+        const int rest = Np - S0 - ss;
         if (rest > 0) {
-            // trailing update behind the strip  A[r,c] −= L[r,strip]·L[c,strip]ᵀ  on the lower triangle, K = sw
+            // trailing update behind the super-strip  A[r,c] −= L[r,super]·L[c,super]ᵀ  on the lower triangle, K = ss
             GemmArgs u{};
-            u.A = K + (int64_t)(s0 + sw) * ld + s0; u.lda = ld;
+            u.A = K + (int64_t)(S0 + ss) * ld + S0; u.lda = ld;
             u.B = u.A; u.ldb = ld;
-            u.C = K + (int64_t)(s0 + sw) * ld + (s0 + sw); u.ldc = ld;
-            u.M = rest; u.N = rest; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+            u.C = K + (int64_t)(S0 + ss) * ld + (S0 + ss); u.ldc = ld;
+            u.M = rest; u.N = rest; u.K = ss; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
             u.alpha = -1.0; u.beta = 1.0; u.info = info;
             HIPCHK(launch_gemm_nt(u, s));
         }
