@@ -13,7 +13,7 @@ from .gradient_gp import (GradientNormUCB, HipGradientGP, gradConstMean, posteri
                           posterior_grad_var)
 from .hyperparams import lengthscale_bounds, monte_carlo_fill_distance, nlml_and_grad, optimize_hyperparameters
 from .incremental import ResidentCandidates, append, greedy_qei
-from .multigpu import HipShardedGP, ShardedCandidates
+from .multigpu import HipShardedGP, HipShardedGradientGP, ShardedCandidates
 from .kernels import (ApproxMatern52Kernel, ApproxMatern72Kernel, ConstMean, Kernel, Matern32Kernel, Matern52Kernel,
                       ScaledKernel, SqExponentialKernel, ZeroMean, with_lengthscale)
 from . import surrogate as _s
@@ -33,10 +33,10 @@ def update(obj, a, b):
         return obj                                              # gradNormUCB.jl:66-68
     if isinstance(obj, AbstractAcquisition):
         return acquisition.update(obj, a, b)
-    if isinstance(obj, HipGradientGP):
-        return _g.update(obj, a, b)
     if isinstance(obj, HipShardedGP):
         return multigpu.update(obj, a, b)
+    if isinstance(obj, HipGradientGP):
+        return _g.update(obj, a, b)
     return _s.update(obj, a, b)
 
 
@@ -56,7 +56,7 @@ def _dispatch(name):
     std, grd = getattr(_s, name), getattr(_g, name)
 
     def f(model, *args, **kw):
-        return (grd if isinstance(model, HipGradientGP) else std)(model, *args, **kw)
+        return (grd if hasattr(model, "p") else std)(model, *args, **kw)      # HipGradientGP and HipShardedGradientGP
 
     f.__name__ = name
     f.__doc__ = std.__doc__

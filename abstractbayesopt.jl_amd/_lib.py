@@ -16,7 +16,7 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
-           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq"]
+           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad"]
 ABI_VERSION = 4
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
@@ -121,6 +121,8 @@ def lib():
     L.abo_test_oz_contract.argtypes = [i32, vp, i64, i32, i32, vp, i64, i32, f64, i32, vp, i64]
     L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
     L.abo_mgpu_create.argtypes = [C.POINTER(AboParams), i32, C.POINTER(i32), C.POINTER(vp)]
+    L.abo_mgpu_create_grad.argtypes = [C.POINTER(AboParams), i32, vp, i32, C.POINTER(i32), C.POINTER(vp)]
+    L.abo_mgpu_append_grad.argtypes = [vp, vp, i32, vp, C.POINTER(i64), vp]
     L.abo_mgpu_clone.argtypes = [vp, C.POINTER(vp)]
     L.abo_mgpu_destroy.argtypes = [vp]
     L.abo_mgpu_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]

@@ -274,6 +274,9 @@ struct abo_mgpu {
     abo_gp* gp[MAXDEV] = {nullptr};
     abo_params prm{};
     CommSet* cs = nullptr;
+    // gradient-enhanced group (abo_mgpu_create_grad): p = d + 1 outputs per point and their prior means; p_out = 1: StandardGP
+    int p_out = 1;
+    double mean_vec[abo::MAX_P] = {0};
 };
 
 struct abo_mcand {
@@ -284,6 +287,13 @@ struct abo_mcand {
 };
 
 namespace {
+
+// a fresh un-conditioned handle of the group's kind on device dv
+int32_t new_shard_handle(const abo_mgpu* mg, int dv, abo_gp** out) {
+    abo_params p = mg->prm;
+    p.device = dv;
+    return mg->p_out > 1 ? abo_create_grad(&p, mg->p_out, mg->mean_vec, out) : abo_create(&p, out);
+}
 
 int32_t check_group(abo_mgpu* mg, const char* fn) {
     if (!mg) return failf(ABO_EINVAL, "%s: null group", fn);
@@ -346,23 +356,34 @@ void merge_blocks(const uint64_t* blocks, int ndev, int k, double* top_val, int6
 
 extern "C" {
 
-int32_t abo_mgpu_create(const abo_params* params, int32_t ndev, const int32_t* dev, abo_mgpu** out) {
-    if (!params || !dev || !out) return failf(ABO_EINVAL, "abo_mgpu_create: null argument");
-    if (ndev < 1 || ndev > MAXDEV) return failf(ABO_EINVAL, "abo_mgpu_create: ndev = %d outside 1..%d", ndev, MAXDEV);
+static int32_t mgpu_create_impl(const abo_params* params, int32_t p_out, const double* mean_c, int32_t ndev, const int32_t* dev,
+                                abo_mgpu** out, const char* fn) {
+    if (!params || !dev || !out) return failf(ABO_EINVAL, "%s: null argument", fn);
+    if (ndev < 1 || ndev > MAXDEV) return failf(ABO_EINVAL, "%s: ndev = %d outside 1..%d", fn, ndev, MAXDEV);
+    if (p_out > abo::MAX_P) return failf(ABO_EINVAL, "%s: p = %d outputs outside 2..%d", fn, p_out, abo::MAX_P);
     abo_mgpu* mg = new (std::nothrow) abo_mgpu();
-    if (!mg) return failf(ABO_ENOMEM, "abo_mgpu_create: host allocation failed");
+    if (!mg) return failf(ABO_ENOMEM, "%s: host allocation failed", fn);
     mg->ndev = ndev;
     mg->prm = *params;
+    mg->p_out = p_out;
+    for (int q = 0; q < p_out && p_out > 1; ++q) mg->mean_vec[q] = mean_c ? mean_c[q] : 0.0;
     for (int i = 0; i < ndev; ++i) {
         mg->dev[i] = dev[i];
-        abo_params p = *params;
-        p.device = dev[i];
-        const int32_t rc = abo_create(&p, &mg->gp[i]);
+        const int32_t rc = new_shard_handle(mg, dev[i], &mg->gp[i]);      // (validates the parameters once per device)
         if (rc) { abo_mgpu_destroy(mg); return rc; }
     }
     mg->cs = comm_set(mg->dev, ndev);
     *out = mg;
     return ABO_OK;
+}
+
+int32_t abo_mgpu_create(const abo_params* params, int32_t ndev, const int32_t* dev, abo_mgpu** out) {
+    return mgpu_create_impl(params, 1, nullptr, ndev, dev, out, "abo_mgpu_create");
+}
+
+int32_t abo_mgpu_create_grad(const abo_params* params, int32_t p, const double* mean_c, int32_t ndev, const int32_t* dev, abo_mgpu** out) {
+    if (p < 2) return failf(ABO_EINVAL, "abo_mgpu_create_grad: p = %d outputs (a gradient-enhanced model has p = d + 1 >= 2)", p);
+    return mgpu_create_impl(params, p, mean_c, ndev, dev, out, "abo_mgpu_create_grad");
 }
 
 int32_t abo_mgpu_clone(abo_mgpu* mg, abo_mgpu** out) {
@@ -409,10 +430,8 @@ int32_t abo_mgpu_fit(abo_mgpu* mg, const double* X, int64_t N, int32_t d, const 
     int64_t inf[MAXDEV] = {0};
     abo_gp* nw[MAXDEV] = {nullptr};
     rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
-        abo_params p = mg->prm;
-        p.device = mg->dev[i];
-        const int32_t r = abo_create(&p, &nw[i]);
-        return r ? r : abo_fit(nw[i], X, N, d, y, ABO_HOST, &inf[i]);
+        const int32_t r = new_shard_handle(mg, mg->dev[i], &nw[i]);
+        return r ? r : abo_fit(nw[i], X, N, d, y, ABO_HOST, &inf[i]);      // gradient-enhanced: y holds p·N values, by outputs
     });
     if (info) for (int i = 0; i < mg->ndev; ++i) if (inf[i]) { *info = inf[i]; break; }
     if (rc) {
@@ -557,15 +576,16 @@ int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, dou
 }
 
 // ---- config 5 across devices -----------------------------------------------------------------------------------
-int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* mc) {
+static int32_t mgpu_append_impl(abo_mgpu* mg, const double* x, int32_t d, double y, const double* yv, int64_t* info, abo_mcand* mc,
+                                const char* fn) {
     if (info) *info = 0;
-    int32_t rc = check_group(mg, "abo_mgpu_append");
+    int32_t rc = check_group(mg, fn);
     if (rc) return rc;
-    if (mc && mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_append: candidate set has %d shards, group %d", mc->ndev, mg->ndev);
+    if (mc && mc->ndev != mg->ndev) return failf(ABO_EINVAL, "%s: candidate set has %d shards, group %d", fn, mc->ndev, mg->ndev);
     abo_gp* nw[MAXDEV] = {nullptr};
     int64_t inf[MAXDEV] = {0};
     rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
-        int32_t r = abo_append(mg->gp[i], x, d, y, &inf[i], &nw[i]);
+        int32_t r = yv ? abo_append_grad(mg->gp[i], x, d, yv, &inf[i], &nw[i]) : abo_append(mg->gp[i], x, d, y, &inf[i], &nw[i]);
         if (r) return r;
         if (mc) r = abo_cand_downdate(nw[i], mc->c[i]);
         return r;
@@ -583,6 +603,17 @@ int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int6
     }
     for (int i = 0; i < mg->ndev; ++i) { abo_destroy(mg->gp[i]); mg->gp[i] = nw[i]; }
     return ABO_OK;
+}
+
+int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* mc) {
+    if (mg && mg->p_out > 1) return failf(ABO_EINVAL, "abo_mgpu_append: a gradient-enhanced group takes p values per observation (abo_mgpu_append_grad)");
+    return mgpu_append_impl(mg, x, d, y, nullptr, info, mc, "abo_mgpu_append");
+}
+
+int32_t abo_mgpu_append_grad(abo_mgpu* mg, const double* x, int32_t d, const double* y, int64_t* info, abo_mcand* mc) {
+    if (!y) return failf(ABO_EINVAL, "abo_mgpu_append_grad: null argument");
+    if (mg && mg->p_out < 2) return failf(ABO_EINVAL, "abo_mgpu_append_grad: the group's model has no gradient outputs (abo_mgpu_append)");
+    return mgpu_append_impl(mg, x, d, 0.0, y, info, mc, "abo_mgpu_append_grad");
 }
 
 int32_t abo_mgpu_cand_destroy(abo_mcand* mc) {
@@ -730,7 +761,16 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
         abo_gp* nw[MAXDEV] = {nullptr};
         status = run_all(mg->cs->wk, n, [&](int i) -> int32_t {
             int64_t inf = 0;
-            int32_t r = abo_append(cur[i], x, d, mu, &inf, &nw[i]);       // fantasy observation y = μ(x): β = 0
+            int32_t r;
+            if (mg->p_out > 1) {
+                // gradient-enhanced model: the fantasy observation is the posterior mean of ALL p outputs at x — evaluated on
+                // every device from its own (identical) model, so nothing more has to be exchanged
+                double yv[abo::MAX_P];
+                r = abo_predict_grad(cur[i], x, 1, d, ABO_HOST, yv, nullptr, ABO_HOST);
+                if (!r) r = abo_append_grad(cur[i], x, d, yv, &inf, &nw[i]);
+            } else {
+                r = abo_append(cur[i], x, d, mu, &inf, &nw[i]);          // fantasy observation y = μ(x): β = 0
+            }
             if (r) return r;
             r = abo_cand_downdate(nw[i], mc->c[i]);
             if (!r && distinct && gidx >= mc->lo[i] && gidx < mc->lo[i + 1]) r = abo_cand_exclude(nw[i], mc->c[i], gidx - mc->lo[i]);

@@ -171,11 +171,19 @@ def rescale_model(model: HipGradientGP, sigma):
     s1 = float(np.asarray(sigma).reshape(-1)[0])
     inner, scale, ell = extract_scale_and_lengthscale(model.kernel)
     k = (scale / s1 ** 2) * with_lengthscale(inner, ell)
+    if hasattr(model, "devices"):                        # a sharded group keeps its device list
+        from .multigpu import HipShardedGradientGP
+        return HipShardedGradientGP(k, model.p, model.noise_var / s1 ** 2, mean=gradConstMean(model.mean.c / s1),
+                                    devices=model.devices, jitter=model.jitter, chunk=model.chunk, n_max=model.n_max)
     return HipGradientGP(k, model.p, model.noise_var / s1 ** 2, mean=gradConstMean(model.mean.c / s1), device=model.device,
                          jitter=model.jitter, chunk=model.chunk, n_max=model.n_max, contraction=model.contraction)
 
 
 def _update_model_parameters(model: HipGradientGP, kernel: Kernel):
+    if hasattr(model, "devices"):
+        from .multigpu import HipShardedGradientGP
+        return HipShardedGradientGP(kernel, model.p, model.noise_var, mean=model.mean, devices=model.devices, jitter=model.jitter,
+                                    chunk=model.chunk, n_max=model.n_max)
     return HipGradientGP(kernel, model.p, model.noise_var, mean=model.mean, device=model.device, jitter=model.jitter,
                          chunk=model.chunk, n_max=model.n_max, contraction=model.contraction)
 

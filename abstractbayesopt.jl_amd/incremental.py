@@ -146,6 +146,11 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
         if dist is not None and dist.get_world_size(group) > 1:
             rec = _allgather_best(rec, dist, group)
         score, gidx, mu, x = rec[0], int(rec[1]), rec[2], rec[3:]
+        if hasattr(model, "p"):
+            # gradient-enhanced model: the fantasy observation is the posterior mean of all p outputs at x (every rank
+            # evaluates it on its own identical model; its first entry is the μ of the record)
+            from .gradient_gp import posterior_grad_mean
+            mu = np.asarray(posterior_grad_mean(model, x[None, :]), dtype=np.float64).reshape(-1)
         model = append(model, x, mu)           # fantasy observation y = μ(x): β = 0, only σ² changes
         cands.downdate(model)
         if distinct and idx_base <= gidx < idx_base + cands.M:

@@ -97,19 +97,57 @@ class HipShardedGP(HipStandardGP):
         raise TypeError("HipShardedGP is not picklable: rebuild it from (xs, ys, hyper-parameters)")
 
 
+class HipShardedGradientGP(HipShardedGP):
+    """GradientGP(kernel, p, noise_var; mean = gradConstMean(zeros(p))) (GradientGP.jl:617-639) replicated on `devices`:
+    the (d+1)N-row system is fitted on every device, candidates are sharded, acquisitions address the function output;
+    `append` takes one observation [f(x), ∇f(x)…] and greedy q-EI conditions on the posterior mean of all p outputs."""
+
+    def __init__(self, kernel, p: int, noise_var, mean=None, devices=(0,), jitter: float = 0.0, chunk: int = 0, n_max: int = 0):
+        from .gradient_gp import gradConstMean
+        super().__init__(kernel, noise_var, mean=None, devices=devices, jitter=jitter, chunk=chunk, n_max=n_max)
+        self.p = int(p)
+        self.mean = gradConstMean(np.zeros(self.p)) if mean is None else mean
+        if len(self.mean.c) != self.p:
+            raise _lib.DimensionMismatch(f"mean has {len(self.mean.c)} entries, the model p = {self.p} outputs")
+
+    def _params(self):
+        return _lib.AboParams(family=self.kernel.family, device=self.device, ell=float(self.kernel.lengthscale),
+                              sigma_f2=float(self.kernel.scale), noise_var=float(self.noise_var), mean_c=float(self.mean.c[0]),
+                              jitter=self.jitter, n_max=self.n_max, chunk=self.chunk)
+
+    def _clone_group(self, handle):
+        m = object.__new__(HipShardedGradientGP)
+        m.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_g", "_h")})
+        m._h = None
+        m._g = handle
+        return m
+
+
 def update(model: HipShardedGP, xs, ys) -> HipShardedGP:
-    """update(model, xs, ys) (StandardGP.jl:79-83) on every device of the group, concurrently; returns a new model."""
+    """update(model, xs, ys) (StandardGP.jl:79-83; GradientGP.jl:659-668 for a gradient-enhanced group) on every device of the
+    group, concurrently; returns a new model."""
     L = _lib.lib()
     xp, n, d, xspace, xkeep = as_points(xs)
     if xspace != _lib.HOST:
         raise TypeError("the multi-device handle takes host arrays")
-    ya = _host(ys).reshape(-1)
-    if ya.shape[0] != n:
-        raise _lib.DimensionMismatch(f"xs has {n} points but ys has {ya.shape[0]} values")
+    grad = isinstance(model, HipShardedGradientGP)
+    if grad:
+        from .gradient_gp import prep_output
+        ya = prep_output(model, ys)                                   # by outputs: all f values, then all ∂₁f, …
+        if ya.shape[0] != n * model.p:
+            raise _lib.DimensionMismatch(f"xs has {n} points but ys has {ya.shape[0] // model.p} observations")
+    else:
+        ya = _host(ys).reshape(-1)
+        if ya.shape[0] != n:
+            raise _lib.DimensionMismatch(f"xs has {n} points but ys has {ya.shape[0]} values")
     prm = model._params()
     devs = (C.c_int32 * len(model.devices))(*model.devices)
     gp = C.c_void_p()
-    _lib.check(L.abo_mgpu_create(C.byref(prm), len(model.devices), devs, C.byref(gp)))
+    if grad:
+        mean = np.ascontiguousarray(model.mean.c)
+        _lib.check(L.abo_mgpu_create_grad(C.byref(prm), model.p, mean.ctypes.data, len(model.devices), devs, C.byref(gp)))
+    else:
+        _lib.check(L.abo_mgpu_create(C.byref(prm), len(model.devices), devs, C.byref(gp)))
     h = _GroupHandle(gp.value)
     info = C.c_int64(0)
     st = L.abo_mgpu_fit(h.ptr, xp, n, d, ya.ctypes.data, C.byref(info))
@@ -202,13 +240,21 @@ class ShardedCandidates:
         return X, idx, ei
 
 
-def append(model: HipShardedGP, x, y: float, cands: ShardedCandidates | None = None) -> HipShardedGP:
+def append(model: HipShardedGP, x, y, cands: ShardedCandidates | None = None) -> HipShardedGP:
     """Bordered append of one observation on every device (returns a new model; `model` stays valid); a sharded
-    candidate set is down-dated in the same call."""
+    candidate set is down-dated in the same call.  A gradient-enhanced group takes y = [f(x), ∇f(x)…]."""
     L = _lib.lib()
     new = copy(model)
     xa = _host(x).reshape(-1)
     info = C.c_int64(0)
+    cp = cands._h.ptr if cands is not None else None
+    if isinstance(model, HipShardedGradientGP):
+        ya = _host(y).reshape(-1)
+        if ya.shape[0] != model.p:
+            raise _lib.DimensionMismatch(f"the observation must hold p = {model.p} values (f and its gradient)")
+        st = L.abo_mgpu_append_grad(new._g.ptr, xa.ctypes.data, xa.shape[0], ya.ctypes.data, C.byref(info), cp)
+        _lib.check(st, info.value)
+        return new
     st = L.abo_mgpu_append(new._g.ptr, xa.ctypes.data, xa.shape[0], float(y), C.byref(info),
                            cands._h.ptr if cands is not None else None)
     _lib.check(st, info.value)

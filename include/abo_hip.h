@@ -29,8 +29,8 @@ extern "C" {
 
 #define ABO_ABI_VERSION 4   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
                                3: abo_set_contraction, abo_timings grew (contraction engine and its phases)
-                               4: abo_refine, abo_optimize_acquisition, abo_mgpu_optimize_acquisition, abo_fit_acq; abo_timings
-                                  grew (refinement stage) */
+                               4: abo_refine, abo_optimize_acquisition, abo_mgpu_optimize_acquisition, abo_fit_acq, abo_mgpu_create_grad,
+                                  abo_mgpu_append_grad; abo_timings grew (refinement stage) */
 
 /* status codes */
 enum {
@@ -321,6 +321,12 @@ enum { ABO_XCHG_HOST = 0, ABO_XCHG_RCCL = 1 };
 /* HipStandardGP(kernel, noise_var; mean, devices = [...]) — params->device is ignored, dev[0..ndev) are the HIP ordinals,
  * 1 ≤ ndev ≤ 16 */
 int32_t abo_mgpu_create(const abo_params* params, int32_t ndev, const int32_t* dev, abo_mgpu** out);
+/* the same for the gradient-enhanced model (abo_create_grad on every device: GradientGP(kernel, p, noise_var; mean), GradientGP.jl:
+ * 617-639).  abo_mgpu_fit then takes y of length p·N ordered by outputs, abo_mgpu_predict / _acq / _acq_lhs / _cand_* address the
+ * function output, abo_mgpu_append_grad appends one observation {f, ∂f/∂x_1 …} on every device (abo_append_grad), and
+ * abo_mgpu_cand_qei conditions each pick on the posterior mean of all p outputs at the picked point (the Kriging-believer fantasy of a
+ * model that observes gradients).  abo_mgpu_optimize_acquisition is not offered for it (abo_refine serves StandardGP handles). */
+int32_t abo_mgpu_create_grad(const abo_params* params, int32_t p, const double* mean_c, int32_t ndev, const int32_t* dev, abo_mgpu** out);
 /* Base.copy (StandardGP.jl:26): a new group sharing every per-device state (abo_retain) */
 int32_t abo_mgpu_clone(abo_mgpu* mg, abo_mgpu** out);
 int32_t abo_mgpu_destroy(abo_mgpu* mg);
@@ -351,6 +357,7 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
  * posterior is rolled back and the fantasy models are dropped: on return model and set are as before.  x_out q × d,
  * idx_out / ei_out q.  distinct != 0 excludes every picked candidate for the rest of the call. */
 int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* cands);
+int32_t abo_mgpu_append_grad(abo_mgpu* mg, const double* x, int32_t d, const double* y, int64_t* info, abo_mcand* cands);
 /* abo_optimize_acquisition across the group's devices: the grid stage as abo_mgpu_acq_lhs (shards generated, scored and reduced
  * on their devices, ONE all-gather of the selections), then the selected starts are dealt out contiguously and every device
  * refines its share with abo_refine's launch; a start's refinement does not depend on which device runs it, so the result equals

@@ -28,13 +28,16 @@ struct HipGradientGP{T,G<:AbstractGPs.GP} <: AbstractSurrogate
     p::Int
     gpx::Union{Nothing,AboHandle}
     device::Int32; jitter::Float64; n_max::Int64
+    devices::Vector{Int32}               # more than one entry: abo_mgpu_create_grad (the model replicated, candidates sharded)
 end
 
-function HipGradientGP(kernel::Kernel, p::Int, noise_var; mean=gradConstMean(zeros(p)), device=0, jitter=0.0, n_max=0)
+function HipGradientGP(kernel::Kernel, p::Int, noise_var; mean=gradConstMean(zeros(p)), device=0, devices=[device], jitter=0.0, n_max=0)
     s = GradientGP(kernel, p, noise_var; mean=mean)           # reuse the normal-form + gradKernel logic (:622-643)
-    HipGradientGP(s.gp, noise_var, p, nothing, Int32(device), Float64(jitter), Int64(n_max))
+    HipGradientGP(s.gp, noise_var, p, nothing, Int32(devices[1]), Float64(jitter), Int64(n_max), Int32.(devices))
 end
-_with(m::HipGradientGP, gpx) = HipGradientGP(m.gp, m.noise_var, m.p, gpx, m.device, m.jitter, m.n_max)
+HipGradientGP(gp, noise_var, p, gpx, device, jitter, n_max) = HipGradientGP(gp, noise_var, p, gpx, device, jitter, n_max, Int32[device])
+_with(m::HipGradientGP, gpx) = HipGradientGP(m.gp, m.noise_var, m.p, gpx, m.device, m.jitter, m.n_max, m.devices)
+_multi(m::HipGradientGP) = length(m.devices) > 1
 
 get_lengthscale(m::HipGradientGP) = 1 ./ m.gp.kernel.base_kernel.kernel.transform.s
 get_scale(m::HipGradientGP) = m.gp.kernel.base_kernel.σ²
@@ -44,7 +47,7 @@ prep_input(m::HipGradientGP, xs) = xs                          # the library add
 prep_output(::HipGradientGP, y::Vector) = vec(permutedims(reduce(hcat, y)))      # by outputs, :919
 _get_minimum(::HipGradientGP, ys::Vector) = minimum(y[1] for y in ys)            # function values only, :1044
 _update_model_parameters(m::HipGradientGP, k::Kernel) =
-    HipGradientGP(k, m.p, m.noise_var; mean=m.gp.mean, device=m.device, jitter=m.jitter, n_max=m.n_max)
+    HipGradientGP(k, m.p, m.noise_var; mean=m.gp.mean, devices=m.devices, jitter=m.jitter, n_max=m.n_max)
 
 # standardisation helpers: host arithmetic only — forwarded to the reference's own methods (GradientGP.jl:753-820) on a prior-only
 # GradientGP holding the same gp / noise / p
@@ -53,11 +56,16 @@ get_mean_std(m::HipGradientGP, y_train::AbstractVector, choice::String) = get_me
 std_y(m::HipGradientGP, ys::AbstractVector, μ::AbstractVector, σ::AbstractVector) = std_y(_ref(m), ys, μ, σ)
 function rescale_model(m::HipGradientGP, σ::AbstractVector)
     r = rescale_model(_ref(m), σ)
-    HipGradientGP(r.gp, r.noise_var, m.p, nothing, m.device, m.jitter, m.n_max)
+    HipGradientGP(r.gp, r.noise_var, m.p, nothing, m.device, m.jitter, m.n_max, m.devices)
 end
 
 function Base.copy(m::HipGradientGP)                                              # :32
     m.gpx === nothing && return m
+    if m.gpx.multi
+        h = Ref{Ptr{Cvoid}}()
+        _check(@ccall LIBABO.abo_mgpu_clone(m.gpx.ptr::Ptr{Cvoid}, h::Ptr{Ptr{Cvoid}})::Int32)
+        return _with(m, AboHandle(h[], true))
+    end
     _check(@ccall LIBABO.abo_retain(m.gpx.ptr::Ptr{Cvoid})::Int32)
     _with(m, AboHandle(m.gpx.ptr))
 end
@@ -75,7 +83,19 @@ function update(m::HipGradientGP, xs::AbstractVector, ys::AbstractVector)       
     X = _pack(xs); d, N = size(X)
     length(ys) == N || throw(DimensionMismatch("xs has $N points, ys $(length(ys)) observations"))
     all(y -> length(y) == m.p, ys) || throw(DimensionMismatch("each observation must hold p = $(m.p) values"))
-    y = collect(Float64, prep_output(m, ys)); hd = _create(m); info = Ref{Int64}(0)
+    y = collect(Float64, prep_output(m, ys)); info = Ref{Int64}(0)
+    if _multi(m)                                           # replicated on every listed device (abo_mgpu_create_grad + abo_mgpu_fit)
+        prm = Ref(AboParams(_family(get_kernel_constructor(m)), m.device, get_lengthscale(m)[1], get_scale(m)[1], m.noise_var,
+                            _mean_vec(m)[1], m.jitter, m.n_max, 0))
+        h = Ref{Ptr{Cvoid}}(); mv = _mean_vec(m); devs = m.devices
+        GC.@preserve mv devs _check(@ccall LIBABO.abo_mgpu_create_grad(prm::Ptr{AboParams}, m.p::Int32, mv::Ptr{Float64},
+                                                                        length(devs)::Int32, devs::Ptr{Int32}, h::Ptr{Ptr{Cvoid}})::Int32)
+        g = AboHandle(h[], true)
+        GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_mgpu_fit(g.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64, d::Int32,
+            y::Ptr{Float64}, info::Ptr{Int64})::Int32), info[])
+        return _with(m, g)
+    end
+    hd = _create(m)
     GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64, d::Int32,
         y::Ptr{Float64}, 0::Int32, info::Ptr{Int64})::Int32), info[])
     _with(m, hd)
@@ -84,6 +104,12 @@ end
 function append(m::HipGradientGP, x::AbstractVector{Float64}, y::AbstractVector{Float64})   # one observation = p rows
     length(y) == m.p || throw(DimensionMismatch("the observation must hold p = $(m.p) values"))
     h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0)
+    if m.gpx.multi
+        n = copy(m)
+        GC.@preserve x y _check(@ccall(LIBABO.abo_mgpu_append_grad(n.gpx.ptr::Ptr{Cvoid}, x::Ptr{Float64}, length(x)::Int32,
+            y::Ptr{Float64}, info::Ptr{Int64}, C_NULL::Ptr{Cvoid})::Int32), info[])
+        return n
+    end
     GC.@preserve x y _check(@ccall(LIBABO.abo_append_grad(m.gpx.ptr::Ptr{Cvoid}, x::Ptr{Float64}, length(x)::Int32, y::Ptr{Float64},
                                                            info::Ptr{Int64}, h::Ptr{Ptr{Cvoid}})::Int32), info[])
     _with(m, AboHandle(h[]))
@@ -93,9 +119,23 @@ function _predict_f(m::HipGradientGP, x, want_mu, want_var)                     
     Z = _pack(x); d, M = size(Z)
     mu = want_mu ? Vector{Float64}(undef, M) : Float64[]; var = want_var ? Vector{Float64}(undef, M) : Float64[]
     pm = want_mu ? pointer(mu) : Ptr{Float64}(C_NULL); pv = want_var ? pointer(var) : Ptr{Float64}(C_NULL)
-    GC.@preserve Z mu var _check(@ccall gc_safe=true LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
-        0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
+    GC.@preserve Z mu var begin
+        if m.gpx.multi                                       # function output, candidates sharded over the group's devices
+            _check(@ccall gc_safe=true LIBABO.abo_mgpu_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+                                                                 pm::Ptr{Float64}, pv::Ptr{Float64})::Int32)
+        else
+            _check(@ccall gc_safe=true LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+                                                            0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
+        end
+    end
     mu, var
+end
+# all-output posteriors and NLML of a replicated model are answered by shard 0's handle (every shard holds the same factor)
+function _shard0(m::HipGradientGP)
+    m.gpx.multi || return m.gpx.ptr
+    h = Ref{Ptr{Cvoid}}()
+    _check(@ccall LIBABO.abo_mgpu_get(m.gpx.ptr::Ptr{Cvoid}, 0::Int32, h::Ptr{Ptr{Cvoid}})::Int32)
+    h[]
 end
 posterior_mean(m::HipGradientGP, x::AbstractVector) = _predict_f(m, x, true, false)[1]    # :985
 posterior_var(m::HipGradientGP, x::AbstractVector)  = _predict_f(m, x, false, true)[2]    # :1001
@@ -106,7 +146,7 @@ function _predict_all(m::HipGradientGP, x, want_mu, want_var)                   
     Z = _pack(x); d, M = size(Z)
     mu = want_mu ? Vector{Float64}(undef, M * m.p) : Float64[]; var = want_var ? Vector{Float64}(undef, M * m.p) : Float64[]
     pm = want_mu ? pointer(mu) : Ptr{Float64}(C_NULL); pv = want_var ? pointer(var) : Ptr{Float64}(C_NULL)
-    GC.@preserve Z mu var _check(@ccall gc_safe=true LIBABO.abo_predict_grad(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64,
+    GC.@preserve Z mu var _check(@ccall gc_safe=true LIBABO.abo_predict_grad(_shard0(m)::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64,
         d::Int32, 0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
     mu, var
 end
@@ -117,7 +157,7 @@ posterior_grad_var(m::HipGradientGP, x)  = _predict_all(m, x isa Real ? [x] : x,
 function _grad_cov(m::HipGradientGP, x, β)
     Z = _pack(x); d, M = size(Z); p = m.p
     mu = Matrix{Float64}(undef, p, M); cov = Array{Float64}(undef, p, p, M); sc = Vector{Float64}(undef, M)
-    GC.@preserve Z mu cov sc _check(@ccall gc_safe=true LIBABO.abo_predict_grad_cov(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64},
+    GC.@preserve Z mu cov sc _check(@ccall gc_safe=true LIBABO.abo_predict_grad_cov(_shard0(m)::Ptr{Cvoid}, Z::Ptr{Float64},
         M::Int64, d::Int32, 0::Int32, Float64(β)::Float64, mu::Ptr{Float64}, cov::Ptr{Float64}, sc::Ptr{Float64}, 0::Int32)::Int32)
     mu, cov, sc
 end

@@ -231,3 +231,73 @@ def test_bench_plain_multi_gpu_launch_runs_the_library_path(config):
     if config == "c2":
         assert len(out["per_device_hip_event_ms_per_step"]) == 2 and out["roofline"]["frac"] > 0
         assert cfg["M_total"] == 2 * cfg["M_per_gpu"]
+
+
+def _grad_problem(N, d, seed=1):
+    X = synth.points(seed, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    g = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    return X, np.column_stack([f, g])
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0, 0, 0)])
+def test_gradient_enhanced_group_equals_the_single_device_model(devices):
+    """abo_mgpu_create_grad / abo_mgpu_append_grad / abo_mgpu_cand_qei on a gradient-enhanced model (GradientGP.jl:617-668):
+    fit, function-value posterior, acquisition + merged top-k, an appended observation with its grid down-date and the greedy
+    q-EI picks (fantasy = posterior mean of all p outputs) equal the single-device HipGradientGP bit for bit; the q-EI model
+    equals a from-scratch refit on the picked points with those fantasy observations (oracle/grad_oracle.py)."""
+    from oracle import grad_oracle as G
+    from tests.test_gpu_gradient_gp import make_grad
+    d, N, M, q = 2, 60, 1500, 3
+    p = d + 1
+    X, Y = _grad_problem(N + 1, d)
+    Z = synth.points(2, M, d)
+    fam, ell, sf2, noise = O.MATERN52, 0.45, 1.2, 1e-3
+    one = abo.update(make_grad(fam, ell, sf2, noise, p, n_max=N + 8), X[:N], Y[:N])
+    grp = abo.update(abo.HipShardedGradientGP(sf2 * abo.with_lengthscale(FAMS[fam](), ell), p, noise, devices=devices, n_max=N + 8),
+                     X[:N], Y[:N])
+    mu1, var1 = abo.mean_and_var(one, Z)
+    mu2, var2 = abo.mean_and_var(grp, Z)
+    np.testing.assert_array_equal(mu1, mu2)
+    np.testing.assert_array_equal(var1, var2)
+    st = G.fit(fam, ell, sf2, noise, np.zeros(p), X[:N], Y[:N])
+    mo, vo = G.predict(st, Z[:200])
+    assert np.max(np.abs(mu2[:200] - mo)) < 1e-8 and np.max(np.abs(var2[:200] - vo)) < 1e-8
+    best = float(Y[:N, 0].min())
+    acq = abo.ExpectedImprovement(0.01, best)
+    s1, tv1, ti1 = abo.evaluate(acq, one, Z, k=32)
+    s2, tv2, ti2 = abo.evaluate(acq, grp, Z, k=32)
+    np.testing.assert_array_equal(s1, s2)
+    np.testing.assert_array_equal(ti1, ti2)
+    # one real observation appended on every device, the sharded grid down-dated in the same call
+    c1 = abo.ResidentCandidates(one, Z)
+    c2 = abo.ShardedCandidates(grp, Z)
+    one2 = abo.append(one, X[N], Y[N])
+    c1.downdate(one2)
+    grp2 = multigpu.append(grp, X[N], Y[N], c2)
+    np.testing.assert_array_equal(abo.mean_and_var(one2, Z[:300])[1], abo.mean_and_var(grp2, Z[:300])[1])
+    tvc1 = c1.evaluate(acq, k=8)
+    tvc2 = c2.evaluate(grp2, acq, 8)
+    np.testing.assert_array_equal(tvc1[1], tvc2[0])
+    np.testing.assert_array_equal(tvc1[2], tvc2[1])
+    with pytest.raises(ValueError):                       # the scalar append is refused for a gradient-enhanced group
+        abo._lib.check(abo._lib.lib().abo_mgpu_append(grp2._g.ptr, X[N].ctypes.data, d, 0.5, None, None))
+    # greedy q-EI: the library's sharded loop against the host loop on the single-device model
+    c1.save()
+    pts1, idx1, val1, mq = abo.greedy_qei(one2, c1, q, 0.01, best)
+    pts2, idx2, val2 = c2.greedy_qei(grp2, q, 0.01, best)
+    np.testing.assert_array_equal(idx1, idx2)
+    np.testing.assert_array_equal(pts1, pts2)
+    np.testing.assert_allclose(val1, val2, rtol=0, atol=1e-15)
+    # … and against a from-scratch refit that conditions on the fantasy observations one after the other
+    Xf, Yf = X.copy(), Y.copy()
+    cur = abo.update(make_grad(fam, ell, sf2, noise, p), Xf, Yf)
+    for j in range(q):
+        yj = np.asarray(abo.posterior_grad_mean(cur, pts1[j][None, :])).reshape(-1)
+        Xf, Yf = np.vstack([Xf, pts1[j]]), np.vstack([Yf, yj])
+        cur = abo.update(make_grad(fam, ell, sf2, noise, p), Xf, Yf)
+    mq_mu, mq_var = abo.mean_and_var(mq, Z[:300])
+    rf_mu, rf_var = abo.mean_and_var(cur, Z[:300])
+    assert np.max(np.abs(mq_mu - rf_mu)) < 1e-8 and np.max(np.abs(mq_var - rf_var)) < 1e-8
+    # the group's model and grid are as before the q-EI call
+    np.testing.assert_array_equal(c2.evaluate(grp2, acq, 8)[1], tvc2[1])
