@@ -824,6 +824,10 @@ struct OzCrtArgs {
 
 // A workgroup = 4 waves × 64 lanes × 16 candidates over one 128-row block: each wave reconstructs 32 of the rows (one 16-byte load
 // per residue plane and row), the four partial column sums meet in LDS in a fixed order.
+// NM > 0: the moduli count is the compile-time NM (the default plan): the residues of a row's NM planes are fetched by NM loads
+// issued back to back — each wave keeps NM × 1 KiB in flight instead of one load per loop trip, which is what a kernel that reads
+// 7.5 GB once needs to approach the HBM rate — and read past the caches (non-temporal: nothing here is touched twice).
+template <int NM>
 __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
     __shared__ double red[3][64][17];
     const int tb = blockIdx.y;
@@ -844,14 +848,30 @@ __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
             double c1[16], c2[16];
 #pragma unroll
             for (int b = 0; b < 16; ++b) { c1[b] = 0.0; c2[b] = 0.0; }
-            for (int l = 0; l < n; ++l) {
-                const v4i_t w = *reinterpret_cast<const v4i_t*>(u + (int64_t)l * a.sU);
-                const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+            if constexpr (NM > 0) {
+                v4i_t wl[NM];
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const double ud = (double)((w[b >> 2] << (24 - 8 * (b & 3))) >> 24);
-                    c1[b] = __builtin_fma(ud, s1, c1[b]);
-                    c2[b] = __builtin_fma(ud, s2, c2[b]);
+                for (int l = 0; l < NM; ++l) wl[l] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(u + (int64_t)l * a.sU));
+#pragma unroll
+                for (int l = 0; l < NM; ++l) {
+                    const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) {
+                        const double ud = (double)((wl[l][b >> 2] << (24 - 8 * (b & 3))) >> 24);
+                        c1[b] = __builtin_fma(ud, s1, c1[b]);
+                        c2[b] = __builtin_fma(ud, s2, c2[b]);
+                    }
+                }
+            } else {
+                for (int l = 0; l < n; ++l) {
+                    const v4i_t w = *reinterpret_cast<const v4i_t*>(u + (int64_t)l * a.sU);
+                    const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) {
+                        const double ud = (double)((w[b >> 2] << (24 - 8 * (b & 3))) >> 24);
+                        c1[b] = __builtin_fma(ud, s1, c1[b]);
+                        c2[b] = __builtin_fma(ud, s2, c2[b]);
+                    }
                 }
             }
             const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
@@ -946,7 +966,9 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     OzCrtArgs c{};
     c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
     c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
-    hipLaunchKernelGGL(oz_crt_kernel, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
+    static const int crt_generic = getenv("ABO_OZ_CRT_GENERIC") ? 1 : 0;          // A/B: the run-time-n loop for every plan
+    if (pl.n == 14 && !crt_generic) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
+    else hipLaunchKernelGGL(oz_crt_kernel<0>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
     return hipGetLastError();
 }
 
