@@ -275,6 +275,55 @@ def quick_config(abo, synth, torch, dev, local_rank, name, k_top, steps=20, warm
             "value": ms, "unit": "ms", "steps": steps, "warmup": warmup}
 
 
+def quick_c1_shape(abo, synth, torch, dev, local_rank, k_top=100, steps=200, warmup=20):
+    """The reference's own loop size (BASELINE config 1's shape: tens of points, acq_utils.jl:37's 10 000 grid points): a step =
+    refit + EI over the grid + top-100, through the two C-ABI calls and through the fused one (abo_fit_acq); and one whole
+    `optimize_acquisition` (device LHS grid → scores → top-100 → on-device L-BFGS refinement of every start → best point) in one
+    call (abo_optimize_acquisition) at N = 100, d = 2."""
+    N, d, M = 25, 1, 10_000
+    X = synth.points(1, N, d)
+    y = np.sin(10.0 * X[:, 0])
+    Xd, yd, Zd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(synth.points(2, M, d)).to(dev)
+    gp = abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.3), 1e-6, device=local_rank)
+    acq = abo.ExpectedImprovement(0.0, float(y.min()))
+    out = {"workload": f"C1 shape: d={d} Matern52Kernel, N={N}, M={M} grid, EI, top-{k_top}, full refit every step", "unit": "ms",
+           "steps": steps, "warmup": warmup}
+    for name, fused in (("value", False), ("fused_call_ms", True)):
+        for step in range(warmup + steps):
+            if step == warmup:
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+            if fused:
+                abo.update_and_evaluate(acq, gp, Xd, yd, Zd, k=k_top, return_scores=False, best_y=acq.best_y)
+            else:
+                model = abo.update(gp, Xd, yd)
+                abo.evaluate(acq, model, Zd, k=k_top, return_scores=False)
+        torch.cuda.synchronize(dev)
+        out[name] = (time.perf_counter() - t0) * 1e3 / steps
+    t = model.timings()
+    out["device_ms"] = {"fit": t["fit_total_ms"], "acq": t["acq_total_ms"]}
+    out["phase_events"] = os.environ.get("ABO_PHASE_EVENTS", "1") != "0"
+    # optimize_acquisition in one call at the reference's stock sizes (n_grid = 10 000, n_local = 100)
+    N2, d2 = 100, 2
+    X2 = synth.points(1, N2, d2)
+    y2 = np.sin(3 * X2).sum(axis=1)
+    y2 = (y2 - y2.mean()) / y2.std(ddof=1)
+    m2 = abo.update(abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 0.4), 1e-4, device=local_rank), X2, y2)
+    dom = abo.ContinuousDomain(np.zeros(d2), np.ones(d2))
+    ucb = abo.UpperConfidenceBound(2.0)
+    wall = []
+    for r in range(25):
+        t0 = time.perf_counter()
+        abo.optimize_acquisition_device(ucb, m2, dom, 10_000, 100, seed=r)
+        wall.append((time.perf_counter() - t0) * 1e3)
+    t2 = m2.timings()
+    out["optimize_acquisition"] = {"workload": f"N={N2}, d={d2}, UCB(2), n_grid=10000, n_local=100: grid + top-100 + on-device L-BFGS of "
+                                               "every start + arg-max in ONE C-ABI call (abo_optimize_acquisition)",
+                                   "value": float(np.median(wall[5:])), "unit": "ms", "device_grid_ms": t2["acq_total_ms"],
+                                   "device_refine_ms": t2["refine_ms"], "acquisition_evaluations": int(t2["refine_evals"])}
+    return out
+
+
 def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, warmup=None):
     """BASELINE config 5.  A step = greedy q-EI over the resident grid (q = 8 picks, each: EI + arg-max,
     fantasy bordered append, O(N·M) down-date), roll the grid posterior back, append the real (noisy)
@@ -751,11 +800,12 @@ def main():
             del model, Zd
             abo._lib.lib().abo_pool_trim(local_rank)
             c2 = quick_config(abo, synth, torch, dev, local_rank, "c2", K_TOP)
+            c1 = quick_c1_shape(abo, synth, torch, dev, local_rank, K_TOP)
             c5 = run_c5(args, CONFIGS["c5"], 1, 0, local_rank, dev, False, steps=5, warmup=2)
             c5_keep = {k: c5[k] for k in ("value", "unit", "steps", "warmup", "roofline", "secondary_roofline", "refresh_ms",
                                           "value_amortized", "phases_ms", "refresh_phases_ms")}
             c5_keep["workload"] = c5["config"]["workload"]
-            out["secondary"] = [c2, c5_keep]
+            out["secondary"] = [c2, c5_keep, c1]
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

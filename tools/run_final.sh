@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 timeout -k 10 300 python __graft_entry__.py smoke > gpurun_out/final_smoke.txt 2>&1 || { tail -5 gpurun_out/final_smoke.txt; exit 1; }
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/final_pytest_gpu.txt 2>&1 || { tail -30 gpurun_out/final_pytest_gpu.txt; exit 1; }
 tail -1 gpurun_out/final_pytest_gpu.txt
@@ -17,7 +17,13 @@ timeout -k 10 900 python bench.py > gpurun_out/final_bench_default.json 2> gpuru
 timeout -k 10 300 python bench.py --contraction fp64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c3_fp64_engine.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c2 --steps 30 --warmup 5 --cpu-sample-m 65536 --cpu-reps 3 > gpurun_out/final_bench_c2.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c5 --steps 5 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 600 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 > gpurun_out/final_bench_c3_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 --config c5 > gpurun_out/final_bench_c5_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 echo "bench done"
+(echo "tools/small_n_latency.py: refit + EI over M + top-100 at the sizes the reference's own loops live at"; echo "--- default (phase events on)"; timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N="; echo "--- ABO_PHASE_EVENTS=0"; ABO_PHASE_EVENTS=0 timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N=") > gpurun_out/final_small_n_latency.txt
+timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/final_optimize_acquisition_latency.txt
+timeout -k 10 300 bash tools/fit_times.sh > gpurun_out/final_fit_times.txt 2>&1 || true
+echo "latency tools done"
 rm -rf gpurun_out/prof_${TAG}_c3fp64
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c3fp64 -- python3 bench.py --config c3 --contraction fp64 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_prof_c3fp64.log 2>&1 || { tail -5 gpurun_out/bench_prof_c3fp64.log; exit 1; }
 cp $(find gpurun_out/prof_${TAG}_c3fp64 -name "*kernel_stats.csv" | head -1) gpurun_out/final_kernel_stats_c3_fp64_engine.csv
