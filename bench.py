@@ -42,13 +42,14 @@ def sustained_int8_tops():
     """what v_mfma_i32_16x16x64_i8 sustains on random operands from registers (tools/mfma_i8_power_probe.hip), read from the
     committed probe output; None when the file is missing"""
     import re
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_mfma_i8_power_probe.txt")) as f:
-            for line in f:
-                if line.startswith("random operands") and "16x16x64" in line:
-                    return float(re.search(r"([0-9.]+) TOP/s", line).group(1))
-    except OSError:
-        pass
+    for tag in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_mfma_i8_power_probe.txt")) as f:
+                for line in f:
+                    if line.startswith("random operands") and "16x16x64" in line:
+                        return float(re.search(r"([0-9.]+) TOP/s", line).group(1))
+        except OSError:
+            pass
     return None
                                # (v_mfma_f64_16x16x4_f64 measured at 64 clk/SIMD: profiles/r01_mfma_f64_probe.txt)
 

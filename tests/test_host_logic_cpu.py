@@ -200,8 +200,8 @@ def test_committed_bench_lines_keep_the_driver_contract():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name, bound in (("r02_bench_default.json", "mfma"), ("r02_c2_bench.json", "mfma"), ("r02_c5_bench.json", "hbm"),
-                        ("r01_bench_default.json", "mfma")):
+    for name, bound in (("r03_bench_default.json", "mfma"), ("r03_c2_bench.json", "mfma"), ("r03_c5_bench.json", "hbm"),
+                        ("r02_bench_default.json", "mfma"), ("r01_bench_default.json", "mfma")):
         j = json.load(open(os.path.join(root, "profiles", name)))
         assert j["metric"].startswith("GP-update+acq-eval ms per BO step") and j["unit"] == "ms"
         assert j["higher_is_better"] is False and j["scaling"] in ("weak", "strong") and j["vs_baseline"] is None
@@ -212,15 +212,17 @@ def test_committed_bench_lines_keep_the_driver_contract():
         r = j["roofline"]
         assert r["bound"] == bound and r["unit"] in ("GB/s", "TFLOP/s", "TOP/s") and 0 < r["frac"] <= 1
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
-    j = json.load(open(os.path.join(root, "profiles", "r02_bench_default.json")))
+    j = json.load(open(os.path.join(root, "profiles", "r03_bench_default.json")))
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and "unit" in c
     assert c["repetitions"] >= 3 and len(c["all_values"]) == c["repetitions"]
     # the default line times all three single-GPU configurations: C3 (headline) + C2 and C5 as secondary entries, C5 with
     # its own roofline
     sec = j["secondary"]
-    assert len(sec) == 2 and sec[0]["workload"].startswith("C2") and sec[1]["workload"].startswith("C5")
+    assert len(sec) == 3 and sec[0]["workload"].startswith("C2") and sec[1]["workload"].startswith("C5")
     assert sec[1]["roofline"]["bound"] == "hbm" and 0 < sec[1]["roofline"]["frac"] <= 1
+    # round 3: the reference's own loop size and one whole optimize_acquisition in one call
+    assert sec[2]["workload"].startswith("C1 shape") and 0 < sec[2]["fused_call_ms"] and sec[2]["optimize_acquisition"]["value"] > 0
 
 
 def test_pmc_traffic_is_dropped_when_the_kernel_source_changed(tmp_path, monkeypatch):
