@@ -8,6 +8,12 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "parity_r03.json")
 rec = json.load(open(src))
-json.dump(rec, open(os.path.join(ROOT, "tests", "golden", "parity_bounds.json"), "w"), indent=1, sort_keys=True)
-shutil.copy(src, os.path.join(ROOT, "profiles", "parity_r03.json"))
-print(f"{len(rec)} cases")
+# MERGE: a gpurun call starts with an empty gpurun_out/, so a partial test run records only its own cases
+for dst in (os.path.join(ROOT, "tests", "golden", "parity_bounds.json"), os.path.join(ROOT, "profiles", "parity_r03.json")):
+    try:
+        old = json.load(open(dst))
+    except (OSError, ValueError):
+        old = {}
+    old.update(rec)
+    json.dump(old, open(dst, "w"), indent=1, sort_keys=True)
+    print(f"{dst}: {len(rec)} cases merged, {len(old)} in all")
