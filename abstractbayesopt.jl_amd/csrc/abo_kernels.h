@@ -268,6 +268,10 @@ size_t refine_lds_bytes(int d, int dp, int history);
 // one workgroup per start: the whole projected L-BFGS of that start in one launch (grad_only = 1: one evaluation per point,
 // x_out receives the gradient)
 hipError_t launch_refine(const RefineArgs& a, int S, int grad_only, hipStream_t s);
+// the same refinement in lockstep rounds with the evaluations of a round batched on the fp64 MFMA tile core (large N: L⁻¹ is read
+// once per round instead of once per start); work = refine_lockstep_bytes(S, Np, d, history) of device memory
+size_t refine_lockstep_bytes(int S, int Np, int d, int history);
+hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStream_t s);
 // out[j][0..d) = Z[idx[j] − idx_base][0..d) for j < k (zeros for idx[j] < 0): the coordinates of selected candidates
 hipError_t launch_gather_points(const double* Z, const int64_t* idx, int64_t idx_base, int k, int d, double* out, hipStream_t s);
 

@@ -1836,6 +1836,16 @@ int32_t refine_device(abo_gp* g, int32_t kind, double p0, double best_y, const d
     if (refine_lds_bytes(g->d, g->dp, m) > 65536)
         return fail(ABO_EINVAL, "abo_refine: input dimension %d too large for the on-device refinement (library limit: %d)", g->d, 700);
     ra.max_iter = o.max_iter; ra.ls_max = o.ls_max; ra.history = m; ra.g_tol = o.g_tol; ra.f_abstol = o.f_abstol; ra.x_abstol = o.x_abstol;
+    // from 1024 factor rows on the starts advance in lockstep rounds whose evaluations are batched on the MFMA tile core (L⁻¹ read once
+    // per round instead of once per start and evaluation; measured crossover, profiles/r03_optimize_acquisition_latency.txt: N = 500
+    // 2.56 ms one launch / 2.96 lockstep, N = 1024 6.98 / 4.16); ABO_REFINE_LOCKSTEP_NP moves the switch (0 = never)
+    const char* lke = getenv("ABO_REFINE_LOCKSTEP_NP");
+    const long lock_np = lke ? atol(lke) : 1024L;
+    if (!grad_only && lock_np > 0 && g->Np >= lock_np) {
+        HIPCHK(g->T.ensure(refine_lockstep_bytes(S, (int)g->Np, g->d, m)));
+        HIPCHK(launch_refine_lockstep(ra, S, g->T.p, s));
+        return ABO_OK;
+    }
     HIPCHK(g->T.ensure(sizeof(double) * 4 * (size_t)g->Np * (size_t)S));      // per-start scratch (k, κ', v, u); T is free after the fit
     ra.scratch = g->T.as<double>();
     HIPCHK(launch_refine(ra, S, grad_only, s));

@@ -21,8 +21,8 @@
 // of the library's own acquisition values in tests/test_gpu_refine.py.
 //
 // Cost per evaluation and start: N² flop and 8·N² bytes of L⁻¹ (both triangles once), served from L2 / Infinity Cache when the
-// starts walk in step: microseconds at the sizes the reference's loop lives at (N ≤ 10³), ≈ 10 ms at N = 8192 where 100 starts
-// re-stream 512 MB each (a batched-GEMM evaluation would amortise that; not built — DESIGN.md §7).
+// starts walk in step: microseconds at the sizes the reference's loop lives at (N < 10³).  From 1024 factor rows on the lockstep
+// variant at the end of this file takes over (a round's evaluations batched on the MFMA tile core: L⁻¹ read once per round).
 #include "abo_kappa.h"
 #include "abo_kernels.h"
 #include "../../include/abo_hip.h"
@@ -248,6 +248,64 @@ __device__ void eval_point(const RefineArgs& a, const double* x, double* xs, dou
     __syncthreads();
 }
 
+// One iteration's head of the projected L-BFGS at the iterate x with gradient g (thread-serial: O(m·d)): projected gradient pg, the
+// curvature pair of the step just accepted (have_prev), the stop test, the two-loop ascent direction p and the first step length.
+// Returns 1 to stop (projected gradient within g_tol, or not a number).  Used by the one-launch kernel (state in LDS) and by the
+// lockstep variant (state in global memory): the same arithmetic in the same order.
+__device__ __forceinline__ int lbfgs_direction(int d, int m, const double* x, const double* g, double* pg, double* p, const double* xprev,
+                                               const double* pgprev, const double* lo, const double* up, double* Sh, double* Yh, double* rho,
+                                               double* al, bool have_prev, int& nh, double g_tol, double& tstep) {
+    // projected gradient: components that push against an active bound are dropped (maximisation)
+    double gmax = 0.0;
+    bool bad = false;
+    for (int c = 0; c < d; ++c) {
+        double v = g[c];
+        if ((x[c] <= lo[c] && v < 0.0) || (x[c] >= up[c] && v > 0.0)) v = 0.0;
+        bad = bad || !(v == v);
+        gmax = fmax(gmax, fabs(v));
+        if (have_prev && m > 0 && nh == m && c == 0) {                   // make room for the new pair before pg is overwritten
+            for (int h = 1; h < m; ++h)
+                for (int cc = 0; cc < d; ++cc) { Sh[(h - 1) * d + cc] = Sh[h * d + cc]; Yh[(h - 1) * d + cc] = Yh[h * d + cc]; }
+            nh = m - 1;
+        }
+        if (have_prev && m > 0) { Sh[nh * d + c] = x[c] - xprev[c]; Yh[nh * d + c] = pgprev[c] - v; }   // s = Δx, y = −Δ(pg)
+        pg[c] = v;
+    }
+    if (have_prev && m > 0) ++nh;
+    if (bad || gmax <= g_tol) return 1;
+    // two-loop recursion for an ascent direction; pairs with s·y ≤ 0 are skipped
+    for (int c = 0; c < d; ++c) p[c] = pg[c];
+    for (int h = nh - 1; h >= 0; --h) {
+        double sy = 0.0, sq = 0.0;
+        for (int c = 0; c < d; ++c) { sy = fma(Sh[h * d + c], Yh[h * d + c], sy); sq = fma(Sh[h * d + c], p[c], sq); }
+        rho[h] = sy > 1e-300 ? 1.0 / sy : 0.0;
+        al[h] = rho[h] * sq;
+        for (int c = 0; c < d; ++c) p[c] = fma(-al[h], Yh[h * d + c], p[c]);
+    }
+    if (nh > 0) {
+        double sy = 0.0, yy = 0.0;
+        for (int c = 0; c < d; ++c) { sy = fma(Sh[(nh - 1) * d + c], Yh[(nh - 1) * d + c], sy); yy = fma(Yh[(nh - 1) * d + c], Yh[(nh - 1) * d + c], yy); }
+        const double sc = (sy > 1e-300 && yy > 0.0) ? sy / yy : 1.0;
+        for (int c = 0; c < d; ++c) p[c] *= sc;
+    }
+    for (int h = 0; h < nh; ++h) {
+        double yq = 0.0;
+        for (int c = 0; c < d; ++c) yq = fma(Yh[h * d + c], p[c], yq);
+        const double b = rho[h] * yq;
+        for (int c = 0; c < d; ++c) p[c] = fma(al[h] - b, Sh[h * d + c], p[c]);
+    }
+    double ppg = 0.0, pmax = 0.0, wmin = 1.0e300;
+    for (int c = 0; c < d; ++c) ppg = fma(p[c], pg[c], ppg);
+    if (!(ppg > 0.0)) for (int c = 0; c < d; ++c) p[c] = pg[c];      // not an ascent direction: steepest ascent
+    for (int c = 0; c < d; ++c) {
+        pmax = fmax(pmax, fabs(p[c]));
+        if (up[c] > lo[c]) wmin = fmin(wmin, up[c] - lo[c]);            // a degenerate side (lower == upper) pins its coordinate, it does not limit the others
+    }
+    // first step: a tenth of the narrowest (non-degenerate) box side at most
+    tstep = nh == 0 ? fmin(1.0, 0.1 * wmin / fmax(pmax, 1e-300)) : 1.0;
+    return 0;
+}
+
 // LDS layout (doubles): x, g, pg, p, xprev, pgprev, cand, gc, lo, up [d each]; xs [dp]; Sh, Yh [m·d each]; rho, al [m each];
 // red [RW·2·RCH]; out [2·RCH]; fres [4]; ctrl [4 ints → 2 doubles]
 size_t refine_lds_bytes(int d, int dp, int m) {
@@ -294,58 +352,7 @@ __global__ void __launch_bounds__(RT) refine_kernel(RefineArgs a) {
     if (f == f && fabs(f) < 1.0e300) {                                   // a non-finite start value: nothing to refine
         for (it = 0; it < a.max_iter; ++it) {
             if (t == 0) {
-                // projected gradient: components that push against an active bound are dropped (maximisation)
-                double gmax = 0.0;
-                bool bad = false;
-                for (int c = 0; c < d; ++c) {
-                    double v = g[c];
-                    if ((x[c] <= lo[c] && v < 0.0) || (x[c] >= up[c] && v > 0.0)) v = 0.0;
-                    pg[c] = v;
-                    bad = bad || !(v == v);
-                    gmax = fmax(gmax, fabs(v));
-                }
-                if (have_prev && m > 0) {                                // curvature pair of the accepted step: s = Δx, y = −Δ(pg)
-                    if (nh == m) {
-                        for (int h = 1; h < m; ++h)
-                            for (int c = 0; c < d; ++c) { Sh[(h - 1) * d + c] = Sh[h * d + c]; Yh[(h - 1) * d + c] = Yh[h * d + c]; }
-                        nh = m - 1;
-                    }
-                    for (int c = 0; c < d; ++c) { Sh[nh * d + c] = x[c] - xprev[c]; Yh[nh * d + c] = pgprev[c] - pg[c]; }
-                    ++nh;
-                }
-                const int stop = (bad || gmax <= a.g_tol) ? 1 : 0;
-                if (!stop) {
-                    // two-loop recursion for an ascent direction; pairs with s·y ≤ 0 are skipped
-                    for (int c = 0; c < d; ++c) p[c] = pg[c];
-                    for (int h = nh - 1; h >= 0; --h) {
-                        double sy = 0.0, sq = 0.0;
-                        for (int c = 0; c < d; ++c) { sy = fma(Sh[h * d + c], Yh[h * d + c], sy); sq = fma(Sh[h * d + c], p[c], sq); }
-                        rho[h] = sy > 1e-300 ? 1.0 / sy : 0.0;
-                        al[h] = rho[h] * sq;
-                        for (int c = 0; c < d; ++c) p[c] = fma(-al[h], Yh[h * d + c], p[c]);
-                    }
-                    if (nh > 0) {
-                        double sy = 0.0, yy = 0.0;
-                        for (int c = 0; c < d; ++c) { sy = fma(Sh[(nh - 1) * d + c], Yh[(nh - 1) * d + c], sy); yy = fma(Yh[(nh - 1) * d + c], Yh[(nh - 1) * d + c], yy); }
-                        const double sc = (sy > 1e-300 && yy > 0.0) ? sy / yy : 1.0;
-                        for (int c = 0; c < d; ++c) p[c] *= sc;
-                    }
-                    for (int h = 0; h < nh; ++h) {
-                        double yq = 0.0;
-                        for (int c = 0; c < d; ++c) yq = fma(Yh[h * d + c], p[c], yq);
-                        const double b = rho[h] * yq;
-                        for (int c = 0; c < d; ++c) p[c] = fma(al[h] - b, Sh[h * d + c], p[c]);
-                    }
-                    double ppg = 0.0, pmax = 0.0, wmin = 1.0e300;
-                    for (int c = 0; c < d; ++c) ppg = fma(p[c], pg[c], ppg);
-                    if (!(ppg > 0.0)) for (int c = 0; c < d; ++c) p[c] = pg[c];      // not an ascent direction: steepest ascent
-                    for (int c = 0; c < d; ++c) {
-                        pmax = fmax(pmax, fabs(p[c]));
-                        if (up[c] > lo[c]) wmin = fmin(wmin, up[c] - lo[c]);            // a degenerate side (lower == upper) pins its coordinate, it does not limit the others
-                    }
-                    // first step: a tenth of the narrowest (non-degenerate) box side at most
-                    fres[3] = nh == 0 ? fmin(1.0, 0.1 * wmin / fmax(pmax, 1e-300)) : 1.0;
-                }
+                const int stop = lbfgs_direction(d, m, x, g, pg, p, xprev, pgprev, lo, up, Sh, Yh, rho, al, have_prev, nh, a.g_tol, fres[3]);
                 ctrl[0] = stop;
             }
             __syncthreads();
@@ -405,6 +412,241 @@ __global__ void __launch_bounds__(RT) acq_grad_kernel(RefineArgs a) {
     eval_point<FAM>(a, x, xs, a.scratch + (int64_t)sidx * 4 * a.Np, red, out, fres, g);
     for (int c = t; c < d; c += RT) a.x_out[(int64_t)sidx * d + c] = g[c];
     if (t == 0) a.f_out[sidx] = fres[0];
+}
+
+// ---- lockstep variant for large N ----------------------------------------------------------------------------------------------------------
+// One workgroup per start re-streams L⁻¹ (8·N² bytes) per evaluation at what ONE CU can pull (≈ 150 GB/s): microseconds up to N ≈ 10³,
+// milliseconds at N = 8192.  Every active start owes exactly one evaluation per round (its start, or its current line-search trial), so
+// from 1024 factor rows on the starts advance in LOCKSTEP ROUNDS and a round's evaluations are batched:
+//     rl_kgen_kernel      k and κ' of every pending point against the training set                         [Sp][Np] each
+//     gemm_nt (fp64 MFMA) V = K·L⁻ᵀ  (A = W lower-triangular k-range, B = the pending points' k rows; transposed copy)  L⁻¹ read ONCE per round
+//     rl_zero_tail        V[:, N … Np) = 0 (rows ≥ N of a shared factor may hold a discarded appended branch)
+//     gemm_nt             U = V·L⁻¹  (A = WT upper-triangular k-range)
+//     rl_reduce_kernel    μ, σ², ∇μ, ∇σ² → f, ∇f per point (the tail of eval_point)
+//     rl_step_kernel      one thread per start: consume (f, ∇f), advance the start's L-BFGS state machine (the same lbfgs_direction, the
+//                         same Armijo rule and stopping tests as refine_kernel), write its next pending point
+// all on the handle's stream, no host round trip inside a batch of rounds; the host looks at a device counter every 8 rounds and stops
+// when no start is active.  Same algorithm as refine_kernel; v and u come out of the MFMA tile core in another summation order, so the
+// two variants agree to rounding, not bit for bit (tests/test_gpu_refine.py).
+struct RlState {                 // per-start scalars
+    double f, tstep;
+    int phase, it, ls, nh, nev, have_prev;      // phase 0 = waiting for the start's value, 1 = in a line search, 2 = finished
+};
+
+// doubles of vector state per start: x, g, pg, p, xprev, pgprev [6·d], Sh, Yh [2·m·d], rho, al [2·m]
+__host__ __device__ inline size_t rl_vec_doubles(int d, int m) { return (size_t)6 * d + (size_t)2 * m * d + 2 * m; }
+
+template <int FAM>
+__global__ void __launch_bounds__(256) rl_kgen_kernel(RefineArgs a, const double* __restrict__ P, const int* __restrict__ active,
+                                                      double* __restrict__ KX, double* __restrict__ GV) {
+    __shared__ double xs[1024];
+    const int j = blockIdx.y, t = threadIdx.x;
+    const int i = blockIdx.x * 256 + t;
+    const bool on = active[j] != 0;
+    for (int c = t; c < a.dp; c += 256) xs[c] = (on && c < a.d) ? P[(int64_t)j * a.d + c] * a.s : 0.0;
+    __syncthreads();
+    if (i >= a.Np) return;
+    double k = 0.0, dk = 0.0;
+    if (on && i < a.N) {
+        const double* xi = a.Xs + (int64_t)i * a.dp;
+        double u = 0.0;
+        for (int c = 0; c < a.dp; ++c) { const double e = xi[c] - xs[c]; u = fma(e, e, u); }
+        kappa_and_deriv<FAM>(u, k, dk);
+        k *= a.sigma_f2; dk *= a.sigma_f2;
+    }
+    KX[(int64_t)j * a.Np + i] = k;
+    GV[(int64_t)j * a.Np + i] = dk;
+}
+
+__global__ void rl_zero_tail_kernel(double* V, int Np, int N, int Sp) {
+    const int w = Np - N;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < w * Sp) V[(int64_t)(e / w) * Np + N + e % w] = 0.0;
+}
+
+// EV[j] = {f, ∇f[0..d)} of pending point j
+__global__ void __launch_bounds__(RT) rl_reduce_kernel(RefineArgs a, const double* __restrict__ P, const int* __restrict__ active,
+                                                       const double* __restrict__ KX, const double* __restrict__ GV,
+                                                       const double* __restrict__ V, const double* __restrict__ U, double* __restrict__ EV) {
+    extern __shared__ double sm[];
+    double* xs = sm;                         // [dp]
+    double* red = xs + a.dp;                 // [RW·2·RCH]
+    double* out = red + RW * 2 * RCH;        // [2·RCH]
+    const int j = blockIdx.x, t = threadIdx.x, N = a.N, d = a.d, dp = a.dp;
+    if (!active[j]) return;                  // uniform
+    const double* kv = KX + (int64_t)j * a.Np;
+    const double* gv = GV + (int64_t)j * a.Np;
+    const double* vv = V + (int64_t)j * a.Np;
+    const double* uv = U + (int64_t)j * a.Np;
+    for (int c = t; c < dp; c += RT) xs[c] = c < d ? P[(int64_t)j * d + c] * a.s : 0.0;
+    __syncthreads();
+    double acc[2 * RCH];
+    acc[0] = 0.0; acc[1] = 0.0;
+    for (int i = t; i < N; i += RT) {
+        acc[0] = fma(kv[i], a.alpha[i], acc[0]);
+        acc[1] = fma(vv[i], vv[i], acc[1]);
+    }
+    block_sum(acc, 2, red, out);
+    const double mu = a.mean_c + out[0];
+    const double var = a.sigma_f2 - out[1] + 1e-18;
+    __syncthreads();
+    double dmu, dvar;
+    const double f = acq_value_and_partials(a.kind, mu, var, a.p0, a.best_y, dmu, dvar);
+    double* ev = EV + (int64_t)j * (d + 1);
+    for (int c0 = 0; c0 < d; c0 += RCH) {
+        const int nc = (d - c0) < RCH ? (d - c0) : RCH;
+#pragma unroll
+        for (int q = 0; q < 2 * RCH; ++q) acc[q] = 0.0;
+        for (int i = t; i < N; i += RT) {
+            const double* xi = a.Xs + (int64_t)i * dp;
+            const double gi = 2.0 * a.s * gv[i], ai = a.alpha[i] * gi, ui = uv[i] * gi;
+#pragma unroll
+            for (int q = 0; q < RCH; ++q) {
+                if (q < nc) {
+                    const double e = xs[c0 + q] - xi[c0 + q];
+                    acc[q] = fma(ai, e, acc[q]);
+                    acc[RCH + q] = fma(ui, e, acc[RCH + q]);
+                }
+            }
+        }
+        block_sum(acc, 2 * RCH, red, out);
+        if (t < nc) ev[1 + c0 + t] = dmu * out[t] + dvar * (-2.0 * out[RCH + t]);
+        __syncthreads();
+    }
+    if (t == 0) ev[0] = f;
+}
+
+// one thread per start: phase −1 (first call) sets the pending point to the clipped start; afterwards consume EV, advance, publish the
+// next pending point.  counters[0] = number of active starts after this round (int64: the GEMMs' early-exit word is counters[1] = 1 when 0).
+__global__ void rl_step_kernel(RefineArgs a, int S, int first, double* __restrict__ P, int* __restrict__ active, const double* __restrict__ EV,
+                               double* __restrict__ vec, RlState* __restrict__ st, long long* __restrict__ counters) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S) return;
+    const int d = a.d, m = a.history;
+    double* x = vec + (size_t)j * rl_vec_doubles(d, m);
+    double* g = x + d;
+    double* pg = g + d;
+    double* p = pg + d;
+    double* xprev = p + d;
+    double* pgprev = xprev + d;
+    double* Sh = pgprev + d;
+    double* Yh = Sh + (size_t)m * d;
+    double* rho = Yh + (size_t)m * d;
+    double* al = rho + m;
+    double* cand = P + (size_t)j * d;              // the pending point doubles as the line search's trial point
+    RlState& s = st[j];
+    if (first) {
+        for (int c = 0; c < d; ++c) {
+            const double v = a.starts[(size_t)j * d + c];
+            x[c] = v == v ? fmin(fmax(v, a.lower[c]), a.upper[c]) : v;
+            cand[c] = x[c];
+        }
+        s.f = 0.0; s.tstep = 1.0; s.phase = 0; s.it = 0; s.ls = 0; s.nh = 0; s.nev = 0; s.have_prev = 0;
+        active[j] = 1;
+        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), 1ull);
+        return;
+    }
+    if (!active[j]) return;
+    const double* ev = EV + (size_t)j * (d + 1);
+    const double fc = ev[0];
+    ++s.nev;
+    bool begin_iteration = false, finished = false;
+    if (s.phase == 0) {                              // the start's own value and gradient
+        s.f = fc;
+        for (int c = 0; c < d; ++c) g[c] = ev[1 + c];
+        if (!(fc == fc && fabs(fc) < 1.0e300)) finished = true;      // a non-finite start value: nothing to refine
+        else begin_iteration = true;
+    } else {                                         // a line-search trial came back
+        double lin = 0.0;
+        for (int c = 0; c < d; ++c) lin = fma(pg[c], cand[c] - x[c], lin);
+        const bool ok = fc == fc && fabs(fc) < 1.0e300 && fc >= s.f + 1e-4 * lin;
+        if (ok) {
+            double dx = 0.0;
+            for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(cand[c] - x[c]));
+            const bool done = dx <= a.x_abstol || fabs(fc - s.f) <= a.f_abstol;
+            for (int c = 0; c < d; ++c) { xprev[c] = x[c]; pgprev[c] = pg[c]; x[c] = cand[c]; g[c] = ev[1 + c]; }
+            s.f = fc; s.have_prev = 1; ++s.it;
+            if (done || s.it >= a.max_iter) finished = true;
+            else begin_iteration = true;
+        } else {
+            s.tstep *= 0.5;
+            if (++s.ls >= a.ls_max) finished = true;                 // no acceptable step: keep x
+        }
+    }
+    if (begin_iteration) {
+        double t0 = 1.0;
+        if (lbfgs_direction(d, m, x, g, pg, p, xprev, pgprev, a.lower, a.upper, Sh, Yh, rho, al, s.have_prev != 0, s.nh, a.g_tol, t0)) finished = true;
+        else { s.tstep = t0; s.ls = 0; s.phase = 1; }
+    }
+    if (finished) {
+        active[j] = 0;
+        s.phase = 2;
+        for (int c = 0; c < d; ++c) a.x_out[(size_t)j * d + c] = x[c];
+        a.f_out[j] = s.f;
+        if (a.iters_out) { a.iters_out[2 * j] = s.it; a.iters_out[2 * j + 1] = s.nev; }
+        const unsigned long long left = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), ~0ull) - 1ull;
+        if (left == 0) counters[1] = 1;              // the GEMMs of later rounds exit on this word
+        return;
+    }
+    for (int c = 0; c < d; ++c) cand[c] = fmin(fmax(fma(s.tstep, p[c], x[c]), a.lower[c]), a.upper[c]);
+}
+
+size_t refine_lockstep_bytes(int S, int Np, int d, int history) {
+    const size_t Sp = (size_t)pad_up(S, 128);
+    return sizeof(double) * (Sp * d + 5 * Sp * (size_t)Np + Sp * (d + 1) + (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S +
+           sizeof(int) * Sp + 64;
+}
+
+// work: refine_lockstep_bytes(…) of device memory.  Synchronous with respect to the stream only at the round-counter reads.
+hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStream_t s) {
+    if (S <= 0) return hipSuccess;
+    const int Sp = (int)pad_up(S, 128), Np = a.Np, d = a.d, m = a.history;
+    char* w = static_cast<char*>(work);
+    long long* counters = reinterpret_cast<long long*>(w); w += 64;
+    double* P = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * d;
+    double* KX = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
+    double* GV = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
+    double* V = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
+    double* U = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
+    double* Ct = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;      // the GEMMs' untransposed outputs (unused)
+    double* EV = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * (d + 1);
+    double* vec = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)S * rl_vec_doubles(d, m);
+    RlState* st = reinterpret_cast<RlState*>(w); w += sizeof(RlState) * S;
+    int* active = reinterpret_cast<int*>(w);
+    hipError_t e;
+    if ((e = hipMemsetAsync(counters, 0, 64, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(active, 0, sizeof(int) * Sp, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(P, 0, sizeof(double) * (size_t)Sp * d, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 1, P, active, EV, vec, st, counters);
+    const int max_rounds = 1 + a.max_iter * a.ls_max;      // every loop of the one-launch kernel is bounded by the same product
+    const size_t lds = sizeof(double) * ((size_t)a.dp + RW * 2 * RCH + 2 * RCH);
+    for (int r = 0; r < max_rounds; ++r) {
+        dim3 kg((Np + 255) / 256, Sp);
+        switch (a.family) {
+            case ABO_KERNEL_SE: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_SE>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
+            case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN52>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
+            case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN72>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
+            default: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN32>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
+        }
+        GemmArgs g1{};       // Ct1[i][j] = Σ_{k ≤ i} W[i][k]·KX[j][k]; transposed copy V[j][i]
+        g1.A = a.W; g1.lda = a.ld; g1.B = KX; g1.ldb = Np; g1.C = Ct; g1.ldc = Sp; g1.Ct = V; g1.ldct = Np;
+        g1.M = Np; g1.N = Sp; g1.K = Np; g1.kmode = K_A_LOWER; g1.lower_only = 0; g1.batch = 1; g1.alpha = 1.0; g1.beta = 0.0;
+        g1.info = reinterpret_cast<const int64_t*>(&counters[1]);
+        if ((e = launch_gemm_nt(g1, s)) != hipSuccess) return e;
+        if (Np > a.N) hipLaunchKernelGGL(rl_zero_tail_kernel, dim3(((Np - a.N) * Sp + 255) / 256), dim3(256), 0, s, V, Np, a.N, Sp);
+        GemmArgs g2 = g1;    // U[j][i] = Σ_{k ≥ i} WT[i][k]·V[j][k]
+        g2.A = a.WT; g2.B = V; g2.Ct = U; g2.kmode = K_A_UPPER;
+        if ((e = launch_gemm_nt(g2, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(rl_reduce_kernel, dim3(S), dim3(RT), lds, s, a, P, active, KX, GV, V, U, EV);
+        hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 0, P, active, EV, vec, st, counters);
+        if ((r & 7) == 7 || r + 1 == max_rounds) {
+            long long left = 0;
+            if ((e = hipMemcpyAsync(&left, counters, sizeof left, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+            if (left == 0) break;
+        }
+    }
+    return hipGetLastError();
 }
 
 template <int FAM>

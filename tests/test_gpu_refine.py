@@ -200,3 +200,43 @@ def test_refinement_on_an_appended_model_ignores_stale_rows():
     xb, fb = refine_starts(acq, ref, starts, np.zeros(d), np.ones(d))
     np.testing.assert_array_equal(xa, xb)
     np.testing.assert_array_equal(fa, fb)
+
+
+@pytest.mark.parametrize("family,d,N,S", [(O.MATERN52, 3, 300, 40), (O.SE, 2, 200, 130), (O.MATERN72, 8, 900, 17)])
+def test_lockstep_variant_equals_the_one_launch_kernel_to_rounding(family, d, N, S, monkeypatch):
+    """From 1024 factor rows on `abo_refine` advances the starts in lockstep rounds and batches a round's evaluations on the fp64
+    MFMA tile core (L⁻¹ read once per round instead of once per start).  Same algorithm, another summation order in v and u:
+    forced here at small N (ABO_REFINE_LOCKSTEP_NP), both variants must land on the same optimum value for every start (their
+    iterates may differ in the last bits, and with them an occasional line-search decision), stay in the box, never lose."""
+    X, y = synth.standardized_problem(N, d, 0.02)
+    m = abo.update(make_model(family, 0.5, 1.0, 0.05, n_max=N + 8), X, y)
+    lower, upper = np.full(d, -0.5), np.full(d, 1.5)
+    best = float(np.median(y))
+    for acq in (abo.UpperConfidenceBound(2.0), abo.ExpectedImprovement(0.01, best)):
+        starts = synth.points(11, S, d) * 2.0 - 0.5
+        starts[0, 0] = np.nan                                   # a non-finite start is handed back unchanged by both
+        f0 = acq(m, starts)
+        monkeypatch.setenv("ABO_REFINE_LOCKSTEP_NP", "0")
+        xa, fa, ita = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+        monkeypatch.setenv("ABO_REFINE_LOCKSTEP_NP", "128")
+        xb, fb, itb = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+        xb2, fb2 = refine_starts(acq, m, starts, lower, upper)
+        np.testing.assert_array_equal(fb, fb2)                   # deterministic
+        np.testing.assert_array_equal(xb, xb2)
+        assert np.isnan(fa[0]) and np.isnan(fb[0])
+        ok = np.isfinite(fa)
+        assert np.all(fb[ok] >= f0[ok] - 1e-10) and np.all(xb[ok] >= lower) and np.all(xb[ok] <= upper)
+        np.testing.assert_allclose(acq(m, xb[ok]), fb[ok], rtol=1e-9, atol=1e-10)
+        close = np.abs(fa[ok] - fb[ok]) <= 1e-6 * np.maximum(1.0, np.abs(fa[ok]))
+        assert close.mean() >= 0.9, (type(acq).__name__, close.mean())
+        assert itb[ok, 1].sum() > 2 * ok.sum() and np.all(itb[:, 0] <= 100)
+    # an appended view with a discarded fantasy branch behind it (stale rows ≥ N of the shared factor)
+    Xn = synth.points(5, 3, d)
+    fant = abo.append(abo.append(m, Xn[0], 2.0), Xn[1], -3.0)
+    del fant
+    acq = abo.UpperConfidenceBound(2.0)
+    starts = synth.points(12, 9, d)
+    xc, fc = refine_starts(acq, m, starts, lower, upper)
+    monkeypatch.setenv("ABO_REFINE_LOCKSTEP_NP", "0")
+    xd, fd = refine_starts(acq, m, starts, lower, upper)
+    np.testing.assert_allclose(fc, fd, rtol=1e-6, atol=1e-8)

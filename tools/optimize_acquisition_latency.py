@@ -13,6 +13,7 @@ from abstractbayesopt.jl_amd.acquisition import _refine_starts_fd
 
 print("optimize_acquisition in one C-ABI call (abo_optimize_acquisition), n_grid = 10000, n_local = 100, UCB(beta = 2), Matern-5/2,")
 print("objective sum_c sin(3 x_c) + noise on N seeded points (a mid-run BO state: the acquisition surface has interior maxima to climb);")
+print("refinement: one launch (one workgroup per start) below 1024 factor rows, lockstep rounds batched on the MFMA tile core from there on;")
 print("median of 20 calls after 3 warm-ups; device = HIP events of the library stream (grid stage | refinement launch)")
 for N, d in [(25, 1), (100, 2), (500, 4), (1024, 4), (2048, 8), (8192, 8)]:
     X = synth.points(1, N, d)
