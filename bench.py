@@ -645,6 +645,9 @@ def main():
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     args = ap.parse_args()
+    # the roofline figures of this line come from the library's per-kernel HIP events: they stay on here whatever the caller's
+    # environment says (ABO_PHASE_EVENTS=0 is the production setting of a small-N loop, tools/small_n_latency.py measures both)
+    os.environ["ABO_PHASE_EVENTS"] = "1"
 
     if plan_launch(args, os.environ) == "library":
         return run_single_process(args)
