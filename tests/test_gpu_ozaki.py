@@ -360,3 +360,41 @@ def test_adversarial_dense_equal_magnitude_rows_keep_their_guaranteed_bits(Np):
     check(case, "sumsq_rel_vs_long_double", err, 1e-11)
     check(case, "sumsq_rel_vs_long_double_plain_fp64_product", err64, 1e-11)
     assert err <= 1e-12
+
+
+def test_requested_engine_survives_append_rescale_and_hyperparameter_rebuilds():
+    """A handle's explicit contraction engine must follow the model through every path that builds a new handle from it: a
+    bordered append (also of a gradient-enhanced model: abo_append_grad), rescale_model, _update_model_parameters (what
+    optimize_hyperparameters returns) — at a size where AUTO would pick the other engine, so a dropped choice shows."""
+    from tests.test_gpu_gradient_gp import make_grad
+    N, d = 1600, 3                                             # 1664 padded factor rows: AUTO → int8, requested: fp64
+    X = synth.points(1, N + 1, d)
+    y = synth.objective(X, 0.05)
+    Zc = synth.points(2, 300, d)
+
+    def engine(model):
+        abo.posterior_var(model, Zc)
+        return model.timings()["contraction_engine"]
+
+    gp = make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="fp64", n_max=N + 8)
+    m = abo.update(gp, X[:N], y[:N])
+    assert engine(m) == abo._lib.CONTRACT_FP64
+    assert engine(abo.append(m, X[N], y[N])) == abo._lib.CONTRACT_FP64
+    r = abo.rescale_model(gp, 2.0)
+    assert r.contraction == "fp64" and engine(abo.update(r, X[:N], y[:N] / 2.0)) == abo._lib.CONTRACT_FP64
+    u = abo._update_model_parameters(gp, 1.5 * abo.with_lengthscale(abo.Matern52Kernel(), 0.6))
+    assert u.contraction == "fp64" and engine(abo.update(u, X[:N], y[:N])) == abo._lib.CONTRACT_FP64
+    # and the other way round below the AUTO threshold: int8 requested at a size where AUTO takes fp64
+    gs = make_model(O.MATERN52, 0.8, 1.0, 1e-3, contraction="int8", n_max=408)
+    ms = abo.update(gs, X[:400], y[:400])
+    assert engine(ms) == abo._lib.CONTRACT_INT8 and engine(abo.append(ms, X[400], y[400])) == abo._lib.CONTRACT_INT8
+    # gradient-enhanced model: p·N = 4·420 = 1680 factor rows
+    Ng = 420
+    f = np.sin(2 * np.pi * X[:Ng + 1]).sum(axis=1)
+    Y = np.column_stack([f, 2 * np.pi * np.cos(2 * np.pi * X[:Ng + 1])])
+    gg = make_grad(O.MATERN52, 0.5, 1.0, 1e-2, d + 1, contraction="fp64", n_max=Ng + 4)
+    mg = abo.update(gg, X[:Ng], Y[:Ng])
+    assert engine(mg) == abo._lib.CONTRACT_FP64
+    assert engine(abo.append(mg, X[Ng], Y[Ng])) == abo._lib.CONTRACT_FP64          # abo_append_grad copies the choice
+    assert abo.rescale_model(gg, [2.0] * (d + 1)).contraction == "fp64"
+    assert abo._update_model_parameters(gg, 1.5 * abo.with_lengthscale(abo.Matern52Kernel(), 0.6)).contraction == "fp64"
