@@ -10,8 +10,9 @@
  *
  * Fixture format: whitespace-separated tokens; a record is  <name> <count> <count numbers>  (%.17g doubles).
  */
-#define _POSIX_C_SOURCE 200112L   /* setenv */
+#define _POSIX_C_SOURCE 200112L   /* setenv, clock_gettime */
 #include <math.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -254,12 +255,55 @@ static int run_exit_live(void) {
     return failures ? 1 : 0;                               /* nothing destroyed */
 }
 
+/* Per-step latency of the path from a host with no interpreter in the way (what a Julia `ccall` host pays): the reference's own
+ * loop size — N = 25 points, d = 1, 10 000 grid points, EI, top-100 — as abo_create + abo_fit + abo_acq + abo_destroy per step (the
+ * two calls of the stock driver) and as abo_create + abo_fit_acq + abo_destroy; host arrays in, top-100 out. */
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static int run_latency(void) {
+    enum { N = 25, M = 10000, K = 100, STEPS = 300, WARM = 30 };
+    static double X[N], y[N], Z[M], tv[K];
+    static int64_t ti[K];
+    for (int i = 0; i < N; ++i) { X[i] = (i + 0.37) / N; y[i] = sin(10.0 * X[i]); }
+    for (int j = 0; j < M; ++j) Z[j] = (j + 0.5) / M;
+    abo_params p;
+    memset(&p, 0, sizeof p);
+    p.family = ABO_KERNEL_MATERN52; p.device = device; p.ell = 0.3; p.sigma_f2 = 1.0; p.noise_var = 1e-6;
+    double best = y[0];
+    for (int i = 1; i < N; ++i) if (y[i] < best) best = y[i];
+    for (int fused = 0; fused < 2; ++fused) {
+        double t0 = 0.0;
+        for (int s = 0; s < WARM + STEPS; ++s) {
+            if (s == WARM) t0 = now_ms();
+            abo_gp* g = NULL;
+            int64_t info = 0;
+            ok_or_die(abo_create(&p, &g), "abo_create");
+            if (fused) {
+                ok_or_die(abo_fit_acq(g, X, N, 1, y, ABO_HOST, &info, Z, M, ABO_HOST, ABO_ACQ_EI, 0.0, best, 0, NULL, K, tv, ti, ABO_HOST), "abo_fit_acq");
+            } else {
+                ok_or_die(abo_fit(g, X, N, 1, y, ABO_HOST, &info), "abo_fit");
+                ok_or_die(abo_acq(g, Z, M, 1, ABO_HOST, ABO_ACQ_EI, 0.0, best, 0, NULL, K, tv, ti, ABO_HOST), "abo_acq");
+            }
+            ok_or_die(abo_destroy(g), "abo_destroy");
+        }
+        printf("latency %s: %.4f ms per step (N=%d, d=1, M=%d, EI, top-%d; host arrays, %d steps; ABO_PHASE_EVENTS=%s)\n",
+               fused ? "abo_fit_acq" : "abo_fit + abo_acq", (now_ms() - t0) / STEPS, N, M, K, STEPS,
+               getenv("ABO_PHASE_EVENTS") ? getenv("ABO_PHASE_EVENTS") : "1");
+    }
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s fixture.txt [device] [exit_live]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s fixture.txt [device] [exit_live | latency]\n", argv[0]); return 2; }
     load(argv[1]);
     report_runtime();
     if (argc > 2) device = atoi(argv[2]);
     if (argc > 3 && !strcmp(argv[3], "exit_live")) return run_exit_live();
+    if (argc > 3 && !strcmp(argv[3], "latency")) return run_latency();
     CHECK(abo_abi_version() == ABO_ABI_VERSION, "library ABI %d, header %d", abo_abi_version(), ABO_ABI_VERSION);
 
     run_kat("kat1"); run_kat("kat3"); run_kat("kat4"); run_kat("kat5");
