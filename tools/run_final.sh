@@ -1,5 +1,6 @@
-# Round artefacts: tests, bench (default line = C3 headline + C2 / C5 secondaries; C2 and C5 on their own), rocprofv3
-# kernel stats per configuration, PMC passes of the two dominant kernels -> gpurun_out/final_*
+# Round artefacts: tests, PMC passes of the dominant kernels (first: the bench lines below read their traffic figures), bench (default
+# line = C3 headline + C2 / C5 / C1-shape secondaries; C2 and C5 on their own; two shards on one device through the plain launch),
+# latency tools, rocprofv3 kernel stats per configuration -> gpurun_out/final_*
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -11,8 +12,16 @@ bash tools/run_pmc_int8.sh ${TAG}i > gpurun_out/final_pmc_int8_run.log 2>&1 || {
 cp gpurun_out/pmc_${TAG}i_summary.txt gpurun_out/final_pmc_int8_summary.txt
 MC=$(grep '^{' gpurun_out/pmc_${TAG}i_fetch.log | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(int(d['config']['M_per_gpu'] // d['roofline']['launches_per_step']))")
 python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_int8_summary.txt 8192 $MC int8 14 > gpurun_out/final_c3_int8_pmc_traffic.json
-echo "pmc c3 int8 done"
 cp gpurun_out/final_c3_int8_pmc_traffic.json profiles/${TAG}_c3_int8_pmc_traffic.json    # the bench lines below read it (same source hash)
+echo "pmc c3 int8 done"
+ABO_CONTRACTION=fp64 bash tools/run_pmc.sh ${TAG}f c3 > gpurun_out/final_pmc_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_run.log; exit 1; }
+cp gpurun_out/pmc_${TAG}f_summary.txt gpurun_out/final_pmc_summary.txt
+python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_summary.txt 8192 16384 > gpurun_out/final_c3_pmc_traffic.json
+cp gpurun_out/final_c3_pmc_traffic.json profiles/${TAG}_c3_pmc_traffic.json
+echo "pmc c3 fp64 done"
+bash tools/run_pmc_c5.sh > gpurun_out/final_pmc_c5.log 2>&1 || { tail -5 gpurun_out/final_pmc_c5.log; exit 1; }
+cp gpurun_out/c5_pmc_traffic.json profiles/${TAG}_c5_pmc_traffic.json
+echo "pmc c5 done"
 timeout -k 10 900 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --contraction fp64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c3_fp64_engine.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c2 --steps 30 --warmup 5 --cpu-sample-m 65536 --cpu-reps 3 > gpurun_out/final_bench_c2.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
@@ -21,8 +30,10 @@ timeout -k 10 600 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 >
 timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 --config c5 > gpurun_out/final_bench_c5_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 echo "bench done"
 (echo "tools/small_n_latency.py: refit + EI over M + top-100 at the sizes the reference's own loops live at"; echo "--- default (phase events on)"; timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N="; echo "--- ABO_PHASE_EVENTS=0"; ABO_PHASE_EVENTS=0 timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N=") > gpurun_out/final_small_n_latency.txt
-timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/final_optimize_acquisition_latency.txt
+(timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep -v amdgpu.ids; echo; echo "--- the one-launch kernel at every size (ABO_REFINE_LOCKSTEP_NP=0)"; ABO_REFINE_LOCKSTEP_NP=0 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N="; echo "--- lockstep rounds at every size (ABO_REFINE_LOCKSTEP_NP=128)"; ABO_REFINE_LOCKSTEP_NP=128 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N=") > gpurun_out/final_optimize_acquisition_latency.txt
+(echo "tools/c_host_latency.sh: per-step latency from the plain-C host (tests/c_abi_harness.c latency; system HIP runtime, no interpreter, host arrays in, top-100 out)"; bash tools/c_host_latency.sh 2>&1 | grep "^latency") > gpurun_out/final_c_host_latency.txt
 timeout -k 10 300 bash tools/fit_times.sh > gpurun_out/final_fit_times.txt 2>&1 || true
+timeout -k 10 600 python tools/soak.py > gpurun_out/final_soak.txt 2>&1 || { tail -5 gpurun_out/final_soak.txt; exit 1; }
 echo "latency tools done"
 rm -rf gpurun_out/prof_${TAG}_c3fp64
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c3fp64 -- python3 bench.py --config c3 --contraction fp64 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_prof_c3fp64.log 2>&1 || { tail -5 gpurun_out/bench_prof_c3fp64.log; exit 1; }
@@ -35,10 +46,4 @@ for cfg in c3 c2 c5; do
   grep '^{' gpurun_out/bench_prof_$cfg.log > gpurun_out/final_bench_under_rocprof_$cfg.json || true
 done
 echo "kernel traces done"
-ABO_CONTRACTION=fp64 bash tools/run_pmc.sh ${TAG}f c3 > gpurun_out/final_pmc_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_run.log; exit 1; }
-cp gpurun_out/pmc_${TAG}f_summary.txt gpurun_out/final_pmc_summary.txt
-python3 tools/pmc_traffic_json.py gpurun_out/final_pmc_summary.txt 8192 16384 > gpurun_out/final_c3_pmc_traffic.json
-echo "pmc c3 fp64 done"
 timeout -k 10 120 tools/mfma_i8_power_probe > gpurun_out/final_mfma_i8_power_probe.txt 2>&1 || true
-bash tools/run_pmc_c5.sh > gpurun_out/final_pmc_c5.log 2>&1 || { tail -5 gpurun_out/final_pmc_c5.log; exit 1; }
-echo "pmc c5 done"

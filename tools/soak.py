@@ -40,6 +40,19 @@ for it in range(300):
         abo.multigpu.append(grp, Zh[it % 3000], 0.2, cg)
         small = abo.update(abo.HipStandardGP(abo.Matern52Kernel(), 1e-6), synth.points(7, 30, 2), np.arange(30.0))   # fused small fit
         abo.posterior_var(small, Zh[:100, :2])
+        # round 3: one-call optimize_acquisition (one-launch and lockstep refinement), the sharded one, the fused update + acquisition,
+        # a gradient-enhanced group
+        dom = abo.ContinuousDomain(np.zeros(4), np.ones(4))
+        ucb = abo.UpperConfidenceBound(2.0)
+        b1 = abo.optimize_acquisition_device(ucb, m, dom, 5000, 30, seed=it)
+        os.environ["ABO_REFINE_LOCKSTEP_NP"] = "128"
+        b2 = abo.optimize_acquisition_device(ucb, m, dom, 5000, 30, seed=it)
+        del os.environ["ABO_REFINE_LOCKSTEP_NP"]
+        b3 = abo.optimize_acquisition_device(ucb, grp, dom, 5000, 30, seed=it)
+        assert np.array_equal(b1, b3) and np.all(np.isfinite(b2))
+        abo.update_and_evaluate(acq, gp, X, y, Zh, k=10)
+        gg = abo.update(abo.HipShardedGradientGP(abo.SqExponentialKernel(), 3, 0.1, devices=(0, 0), n_max=64), synth.points(5, 40, 2), np.ones((40, 3)))
+        abo.multigpu.append(gg, [0.3, 0.7], [1.0, 0.0, 0.0])
     if it % 50 == 0:
         torch.cuda.synchronize()
         marks.append(used_mb())
