@@ -9,6 +9,7 @@
 //   top-k  sortperm(scores; rev=true)[1:k]   src/acquisition_functions/acq_utils.jl:51-52
 // All of it is O(M) byte-moving work: one coalesced pass, no atomics, fixed summation order.
 #include "abo_kernels.h"
+#include <cstdlib>
 #include "../../include/abo_hip.h"
 
 namespace abo {
@@ -359,6 +360,119 @@ __global__ void topk_fill_kernel(double* top_val, int64_t* top_idx, int lo, int 
     if (e < hi) { top_val[e] = __longlong_as_double(0x7ff8000000000000ll); top_idx[e] = -1; }
 }
 
+// ---- top-k of a small batch in ONE launch ------------------------------------------------------------------------------------------
+// The reference's own grid (acq_utils.jl:37: 10 000 points) is a small batch: the block-sort path above takes three launches and two
+// full bitonic sorts of 2048 entries for it (50 µs — a third of a whole BO step at those sizes).  One workgroup instead, M ≤ 16384,
+// k ≤ 1024:
+//   1. keys (the order-preserving u64 image of the scores) into LDS, coalesced;
+//   2. radix select of the k-th largest key, most significant byte first: per pass a 256-bin histogram of the entries that still
+//      match the prefix (LDS integer atomics: counts are exact whatever the order), a descending scan of the bins by one wave, the
+//      pass stops the search as soon as the k-th key is pinned down;
+//   3. every entry above the threshold is selected; of the entries EQUAL to it the first `need` in index order (each thread owns a
+//      contiguous index range, one block-wide exclusive scan of the per-thread tie counts gives the order) — Julia's stable reverse
+//      sort keeps ties in index order;
+//   4. the ≤ k selected (key, index) pairs are bitonic-sorted (descending key, ascending index) and written out.
+// Same total order as the block-sort path (NaN first, +Inf … −Inf, 0.0 before −0.0, ties → lowest index): bit-identical results.
+constexpr int TKS_T = 1024;
+constexpr int TKS_MAXM = 16384;
+
+__global__ void __launch_bounds__(TKS_T) topk_small_kernel(const double* __restrict__ scores, int M, int k, int kp, int64_t idx_base,
+                                                           double* __restrict__ top_val, int64_t* __restrict__ top_idx) {
+    __shared__ uint64_t keys[TKS_MAXM];          // 128 KB
+    __shared__ uint64_t sk[1024];
+    __shared__ int si[1024];
+    __shared__ int hist[256];
+    __shared__ int wsum[TKS_T / 64];
+    __shared__ uint64_t s_prefix;
+    __shared__ int s_need, s_ngt, s_done;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int e = t; e < M; e += TKS_T) keys[e] = score_key(scores[e]);
+    if (t == 0) { s_prefix = 0; s_need = k; s_ngt = 0; s_done = 0; }
+    __syncthreads();
+    // contiguous index range of this thread
+    const int per = (M + TKS_T - 1) / TKS_T;
+    const int e0 = t * per, e1 = min(M, e0 + per);
+    // ---- 2. radix select: after the loop T = s_prefix is the k-th largest key, s_ngt = #keys > T, s_need = k − s_ngt ties to take
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        for (int b = t; b < 256; b += TKS_T) hist[b] = 0;
+        __syncthreads();
+        const uint64_t prefix = s_prefix;
+        const uint64_t mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        for (int e = e0; e < e1; ++e) {
+            const uint64_t key = keys[e];
+            if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 0xff)], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {                           // descending scan of the 256 bins: four bins per lane, lane 0 owns the top ones
+            int c[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = hist[255 - (4 * lane + q)]; tot += c[q]; }
+            int incl = tot;                        // inclusive prefix over lanes (counts of bins above and including this lane's)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            int above = incl - tot;                // entries in bins strictly above this lane's four
+            const int need = s_need;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (above < need && above + c[q] >= need) {      // the k-th largest lies in this bin (exactly one lane and q)
+                    s_prefix = prefix | ((uint64_t)(255 - (4 * lane + q)) << shift);
+                    s_ngt += above;
+                    s_need = need - above;
+                }
+                above += c[q];
+            }
+        }
+        __syncthreads();
+    }
+    const uint64_t T = s_prefix;
+    const int need = s_need, ngt = s_ngt;
+    // ---- 3. selection: slots [0, ngt) for keys > T (any order: they are sorted below), slots [ngt, ngt + need) for the first ties
+    int my_gt = 0, my_eq = 0;
+    for (int e = e0; e < e1; ++e) { const uint64_t key = keys[e]; my_gt += key > T; my_eq += key == T; }
+    // block-wide exclusive scans of (my_gt, my_eq): lanes, then waves
+    int ig = my_gt, ie = my_eq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int vg = __shfl_up(ig, o), ve = __shfl_up(ie, o);
+        if (lane >= o) { ig += vg; ie += ve; }
+    }
+    if (lane == 63) { wsum[wave] = ig; hist[wave] = ie; }        // (hist is free again)
+    __syncthreads();
+    int og = 0, oe = 0;
+    for (int w = 0; w < wave; ++w) { og += wsum[w]; oe += hist[w]; }
+    int pg = og + ig - my_gt, pe = oe + ie - my_eq;               // exclusive positions of this thread's first entries
+    for (int e = t; e < kp; e += TKS_T) { sk[e] = KEY_PAD; si[e] = 0x7fffffff; }
+    __syncthreads();
+    for (int e = e0; e < e1; ++e) {
+        const uint64_t key = keys[e];
+        if (key > T) { sk[pg] = key; si[pg] = e; ++pg; }
+        else if (key == T) { if (pe < need) { sk[ngt + pe] = key; si[ngt + pe] = e; } ++pe; }
+    }
+    __syncthreads();
+    // ---- 4. bitonic sort of kp ≤ 1024 (key, index) pairs: "before" = larger key, then smaller index
+    for (int size = 2; size <= kp; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (t < kp / 2) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t k0 = sk[lo], k1 = sk[hi];
+                const int i0 = si[lo], i1 = si[hi];
+                const bool b10 = (k1 > k0) || (k1 == k0 && i1 < i0);
+                const bool b01 = (k0 > k1) || (k0 == k1 && i0 < i1);
+                if (up ? b10 : b01) { sk[lo] = k1; si[lo] = i1; sk[hi] = k0; si[hi] = i0; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = t; e < k; e += TKS_T) {
+        const int i = si[e];
+        if (i == 0x7fffffff) { top_val[e] = __longlong_as_double(0x7ff8000000000000ll); top_idx[e] = -1; }
+        else { top_val[e] = scores[i]; top_idx[e] = (int64_t)i + idx_base; }
+    }
+}
+
 static int pow2_at_least(int k) { int p = 1; while (p < k) p <<= 1; return p; }
 
 constexpr int TK_KMAX = TK_E / 2;   // entries one round can select
@@ -381,6 +495,13 @@ hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base,
     const int kreal = (int64_t)k < M ? k : (int)(M < 1 ? 1 : M);
     if (kreal < k) hipLaunchKernelGGL(topk_fill_kernel, dim3((k - kreal + 255) / 256), dim3(256), 0, s, top_val, top_idx, kreal, k);
     k = kreal;
+    static const int small_off = getenv("ABO_TOPK_BLOCKSORT") ? 1 : 0;       // A/B: always the block-sort path
+    if (!small_off && M >= 1 && M <= TKS_MAXM && k <= 1024) {
+        int kp = pow2_at_least(k);
+        if (kp < 2) kp = 2;
+        hipLaunchKernelGGL(topk_small_kernel, dim3(1), dim3(TKS_T), 0, s, scores, (int)M, k, kp, idx_base, top_val, top_idx);
+        return hipGetLastError();
+    }
     for (int e0 = 0; e0 < k; e0 += TK_KMAX) {
         const int kc = (k - e0) < TK_KMAX ? (k - e0) : TK_KMAX;
         const int kp = pow2_at_least(kc);

@@ -200,3 +200,25 @@ def test_fused_call_reports_a_failed_factorisation_and_leaves_the_handle_unfitte
     assert e2.value.info == 251
     with pytest.raises(abo.DimensionMismatch):
         abo.update_and_evaluate(abo.UpperConfidenceBound(2.0), gp, X, y, synth.points(2, 10, 3), k=1)
+
+
+def test_small_batch_topk_single_launch_radix_select():
+    """M ≤ 16384, k ≤ 1024 take the one-launch selection (misc.hip: topk_small_kernel: radix select of the k-th key, ties in index
+    order, bitonic sort of the ≤ k selected); beyond that the block-sort passes.  Both must reproduce sortperm(scores; rev=true)[1:k]
+    (acq_utils.jl:51-52) bit for bit — here on scores with thousands of exact ties (candidates far from the data all score the prior),
+    a NaN, and sizes on both sides of every boundary."""
+    rng = np.random.default_rng(0)
+    m = abo.update(abo.HipStandardGP(abo.SqExponentialKernel(), 0.1), np.array([[0.0], [1.0]]), np.array([0.0, 1.0]))
+    acq = abo.UpperConfidenceBound(2.0)
+    for M in (1, 2, 63, 65, 1000, 1025, 4097, 10000, 16383, 16384, 16385, 20000):
+        Z = np.concatenate([rng.uniform(0, 1, M // 2), np.full(M - M // 2, 50.0) + np.arange(M - M // 2)])
+        rng.shuffle(Z)
+        if M > 10:
+            Z[3] = np.nan
+        for k in (1, 7, 100, 128, 129, 1024):
+            s, tv, ti = abo.evaluate(acq, m, Z, k=k)
+            ov, oi = O.top_k(s, k)
+            kk = min(k, M)
+            np.testing.assert_array_equal(ti[:kk], oi[:kk])
+            np.testing.assert_array_equal(tv[:kk], ov[:kk])
+            assert np.all(ti[kk:] == -1) and np.all(np.isnan(tv[kk:]))
