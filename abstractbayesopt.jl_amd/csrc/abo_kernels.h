@@ -76,6 +76,13 @@ struct OzVarArgs {
     int Np, Mc, nvalid, sK;
     int kper = 1, ktg = 0; // gradient-enhanced model: training rows k with k % kper != 0 are scaled by 2^−ktg in the chunk's image
     int planes_ready = 0;  // 1: KR / bad_col were written by the generator (KgenArgs::res), skip the quantisation pass
+    // all outputs of a gradient-enhanced model's candidates: chunk row r is output (r0 + r) % rper of its point (rmode 1, point-major
+    // rows) or output (r0 + r) / rpts (rmode 2, rows by outputs); derivative rows (output != 0) are scaled by 2^-ktg in the chunk's
+    // image as well, and their column sums by 2^(2 ktg) on the way out.  rmode 0: every row is a function value.
+    int rmode = 0, rper = 1;
+    int64_t r0 = 0, rpts = 1;
+    double* Vout = nullptr;     // when given: V = W.K_XZ itself, [Mc][ldv] fp64 (candidate-major), instead of the column sums of squares
+    int64_t ldv = 0;
     hipEvent_t ev_quant = nullptr, ev_gemm = nullptr;   // optional: recorded after the quantisation / after the GEMM
 };
 hipError_t launch_var_ozaki(const OzVarArgs& a, hipStream_t s);

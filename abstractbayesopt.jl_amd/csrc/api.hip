@@ -619,7 +619,7 @@ int oz_grad_exp(const abo_gp* g) {
 
 // which engine runs the contraction of a posterior call on this handle (int8 = true), and with how many moduli
 bool wants_int8(const abo_gp* g, bool want_var, int pc, int* nmod) {
-    if (!want_var || pc != 1) return false;         // all outputs of a gradient-enhanced model's candidates (pc > 1): fp64 kernels
+    if (!want_var || (pc != 1 && pc != g->p_out)) return false;
     int eng = g->oz_engine, nm = g->oz_nmod, de, dn;
     oz_defaults(&de, &dn);
     if (eng == ABO_CONTRACT_AUTO) eng = de;
@@ -657,25 +657,13 @@ int64_t pick_chunk(const abo_gp* g, int64_t M, bool int8) {
     return mc < mp ? mc : mp;
 }
 
-// mu / var / score for M candidates into device arrays (any may be null)
-// pc outputs per candidate (1 = function value; p_out = all outputs of a gradient-enhanced GP), rows by outputs
-// unless point_major; mu/var/score arrays then have pc·M entries.
-// kstore / ldstore: write K_XZ into a caller-owned candidate-major matrix (pad_up(M,128) rows of ldstore ≥ Np doubles)
-// instead of the per-chunk scratch — the resident K_ZX of a candidate set.
-int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0, double best_y, double* mu_out,
-                  double* var_out, double* score_out, int pc = 1, int point_major = 0, double* kstore = nullptr,
-                  int64_t ldstore = 0) {
-    const int64_t M = Mpts * pc;                         // candidate rows
-    hipStream_t s = g->stream;
+// The int8 engine's scratch — 2 × n bytes per (candidate, factor row) of a chunk, and the n residue planes of W: when the device
+// cannot give it (a shared or nearly full GPU), the chunk *Mc is halved down to 4096 candidates, and below that *oz comes back false:
+// the call then runs on the fp64 kernels (8 bytes per pair of a chunk four times smaller) instead of failing.
+int32_t oz_acquire(abo_gp* g, int nm, int64_t M, int64_t* Mc_io, bool* oz_io) {
     const int64_t Np = g->Np;
-    const int T = (int)(Np / TB);
-    const bool want_var = var_out || score_out;
-    int nm = 0;
-    bool oz = wants_int8(g, want_var, pc, &nm);
-    int64_t Mc = pick_chunk(g, M, oz);
-    // the int8 engine's scratch — 2 × n bytes per (candidate, factor row) of a chunk, and the n residue planes of W: when the device
-    // cannot give it (a shared or nearly full GPU), the chunk is halved down to 4096 candidates, and below that the call runs on
-    // the fp64 kernels (8 bytes per pair of a chunk four times smaller) instead of failing
+    int64_t Mc = *Mc_io;
+    bool oz = *oz_io;
     if (oz) {
         if (g->oz_plan.n != nm) {                               // another moduli count: the cached planes of W belong to the old plan
             if (!oz_make_plan(nm, &g->oz_plan)) return fail(ABO_EINVAL, "contraction: %d moduli not supported", nm);
@@ -706,6 +694,42 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             Mc = pick_chunk(g, M, false);
         } else HIPCHK(e);
     }
+    *Mc_io = Mc;
+    *oz_io = oz;
+    return ABO_OK;
+}
+
+// residue planes of this view's W, once per model (cached on the handle until the storage generation or the view changes)
+int32_t oz_planes_of_w(abo_gp* g) {
+    hipStream_t s = g->stream;
+    if (g->oz_gen != g->st->gen || g->oz_N != g->N) {
+        PHASE_EVENT(g->evs()[8], s);
+        HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)g->Np, (int)g->N, g->oz_WR.as<int8_t>(),
+                            g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
+        PHASE_EVENT(g->evs()[9], s);
+        g->oz_gen = g->st->gen; g->oz_N = g->N;
+        g->oz_prepare_pending = true;                               // both events recorded in THIS call: read with the posterior timings
+    }
+    return ABO_OK;
+}
+
+// mu / var / score for M candidates into device arrays (any may be null)
+// pc outputs per candidate (1 = function value; p_out = all outputs of a gradient-enhanced GP), rows by outputs
+// unless point_major; mu/var/score arrays then have pc·M entries.
+// kstore / ldstore: write K_XZ into a caller-owned candidate-major matrix (pad_up(M,128) rows of ldstore ≥ Np doubles)
+// instead of the per-chunk scratch — the resident K_ZX of a candidate set.
+int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0, double best_y, double* mu_out,
+                  double* var_out, double* score_out, int pc = 1, int point_major = 0, double* kstore = nullptr,
+                  int64_t ldstore = 0) {
+    const int64_t M = Mpts * pc;                         // candidate rows
+    hipStream_t s = g->stream;
+    const int64_t Np = g->Np;
+    const int T = (int)(Np / TB);
+    const bool want_var = var_out || score_out;
+    int nm = 0;
+    bool oz = wants_int8(g, want_var, pc, &nm);
+    int64_t Mc = pick_chunk(g, M, oz);
+    { int32_t rc = oz_acquire(g, nm, M, &Mc, &oz); if (rc) return rc; }
     g->last_chunk = Mc;
     {
         KgenArgs probe{};
@@ -720,14 +744,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     g->tm.var_gemm_launches = 0;
     g->oz_prepare_pending = false;
     g->tm.oz_prepare_ms = 0.0;                                      // planes cached from an earlier call: nothing spent in this one
-    if (oz && (g->oz_gen != g->st->gen || g->oz_N != g->N)) {      // residue planes of this view's W, once per model
-        PHASE_EVENT(g->evs()[8], s);
-        HIPCHK(oz_prepare_w(g->oz_plan, g->st->W.as<double>(), g->st->cap, (int)Np, (int)g->N, g->oz_WR.as<int8_t>(),
-                            g->oz_sexp.as<int>(), g->oz_badr.as<int>(), s, g->p_out, oz_grad_exp(g)));
-        PHASE_EVENT(g->evs()[9], s);
-        g->oz_gen = g->st->gen; g->oz_N = g->N;
-        g->oz_prepare_pending = true;                               // both events recorded in THIS call: read with the posterior timings
-    }
+    if (oz) { int32_t rc = oz_planes_of_w(g); if (rc) return rc; }
     g->tm.contraction_engine = want_var ? (oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64) : 0;
     g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
     for (int64_t c = 0; c < nchunk; ++c) {
@@ -762,8 +779,10 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
             oa.bad_col = g->oz_badc.as<int>(); oa.partial = g->partial.as<double>(); oa.ldp = Mc; oa.Np = (int)Np; oa.Mc = mcp;
             // a gradient-enhanced model's scaled chunk is bounded by σ_f²·√2 (oz_prepare_w), a StandardGP's by σ_f²
-            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->p_out > 1 ? 1.5 * g->prm.sigma_f2 : g->prm.sigma_f2);
+            // (derivative candidates against derivative training rows, both scaled: 2σ_f²)
+            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->p_out > 1 ? (pc > 1 ? 2.0 : 1.5) * g->prm.sigma_f2 : g->prm.sigma_f2);
             oa.kper = g->p_out; oa.ktg = oz_grad_exp(g);
+            if (pc > 1) { oa.rmode = point_major ? 1 : 2; oa.rper = pc; oa.r0 = j0; oa.rpts = Mpts; }
             oa.ev_quant = phase_events() ? e[6] : nullptr; oa.ev_gemm = phase_events() ? e[7] : nullptr; oa.planes_ready = fused ? 1 : 0;
             PHASE_EVENT(e[2], s);
             HIPCHK(launch_var_ozaki(oa, s));
@@ -1345,6 +1364,21 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
     if (pts < 1) pts = 1;
     if (pts > M) pts = M;
     const int64_t rows_pad = pad_up(pts * P, TB);
+    // V = L⁻¹K_XZ on the int8-residue engine when the handle's contraction says so (same rule as the variance calls): the residue
+    // GEMMs and a reconstruction that writes V itself; a chunk whose scratch the device cannot give runs on the fp64 GEMM
+    int nm = 0;
+    bool oz = wants_int8(g, true, P, &nm);
+    if (oz) {
+        int64_t mc = rows_pad;
+        rc = oz_acquire(g, nm, rows_pad, &mc, &oz);
+        if (rc) return rc;
+        if (oz && mc != rows_pad) oz = false;
+    }
+    HIPCHK(g->events(EV_BASE));
+    g->oz_prepare_pending = false;
+    if (oz) { rc = oz_planes_of_w(g); if (rc) return rc; }
+    g->tm.contraction_engine = oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64;
+    g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
     HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
     HIPCHK(g->partial.ensure(sizeof(double) * rows_pad * Np));       // V
     HIPCHK(g->mu_c.ensure(sizeof(double) * rows_pad));
@@ -1362,11 +1396,23 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
         ka.sigma_f2 = g->prm.sigma_f2; ka.pt = P; ka.pc = P; ka.point_major = 1;
         for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
         HIPCHK(launch_kgen(ka, s));
-        GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
-        a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
-        a.C = g->partial.as<double>(); a.ldc = Np; a.M = rows; a.N = (int)Np; a.K = (int)Np;
-        a.kmode = K_FULL; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
-        HIPCHK(launch_gemm_nt(a, s));
+        if (oz) {
+            OzVarArgs oa{};
+            oa.plan = &g->oz_plan; oa.Kxz = g->Kxz.as<double>(); oa.ldk = Np; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
+            oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
+            oa.bad_col = g->oz_badc.as<int>(); oa.partial = nullptr; oa.ldp = 0; oa.Np = (int)Np; oa.Mc = rows;
+            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(2.0 * g->prm.sigma_f2);
+            oa.kper = P; oa.ktg = oz_grad_exp(g);
+            oa.rmode = 1; oa.rper = P; oa.r0 = p0 * P; oa.rpts = M;
+            oa.Vout = g->partial.as<double>(); oa.ldv = Np;
+            HIPCHK(launch_var_ozaki(oa, s));
+        } else {
+            GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
+            a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
+            a.C = g->partial.as<double>(); a.ldc = Np; a.M = rows; a.N = (int)Np; a.K = (int)Np;
+            a.kmode = K_FULL; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
+            HIPCHK(launch_gemm_nt(a, s));
+        }
         GradCovArgs ca{};
         ca.V = g->partial.as<double>(); ca.mu_rows = g->mu_c.as<double>(); ca.ldv = Np; ca.R = (int)g->N; ca.p = P;
         ca.pt0 = p0; ca.prior0 = g->prm.sigma_f2; ca.prior_g = grad_prior_var(g); ca.beta = beta;

@@ -127,6 +127,13 @@ __global__ void __launch_bounds__(256) oz_rowscale_kernel(const double* __restri
     }
 }
 
+// output index of chunk row r of a gradient-enhanced model's all-output posterior (OzVarArgs::rmode): 0 = function value
+__device__ __forceinline__ int oz_row_output(int rmode, int rper, int64_t r0, int64_t rpts, int r) {
+    if (rmode == 1) return (int)((r0 + r) % rper);
+    if (rmode == 2) return (int)((r0 + r) / rpts);
+    return 0;
+}
+
 // ---- fp64 → residue planes -----------------------------------------------------------------------------------------------------------
 // out[l][r][k] (int8, ld bytes per row, plane stride `plane`) = sym_residue(rint(in[r][k]·2^s), p_l) for r < rows_in, k < cols_in;
 // zeros elsewhere up to rows_out × cols_out.  s = srow[r] when given, else sconst.  A thread converts 16 consecutive k of one row.
@@ -139,6 +146,8 @@ struct OzQuantArgs {
     const int* srow;
     int sconst;
     int kper, ktg;             // columns k with k % kper != 0 get 2^ktg on top (kper ≤ 1: none)
+    int rmode, rper, rtg;      // rows whose output index (oz_row_output) is not 0 get 2^rtg on top (rmode 0: none)
+    int64_t r0, rpts;
     int8_t* out;
     int64_t ld, plane;
     int* bad;                  // [rows_out] or nullptr
@@ -154,7 +163,8 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
     const bool live = r < a.rows_in && kc < a.cols_in && !(a.lower && kc > r);
     bool bad = false;
     if (live) {
-        const double sc = __builtin_ldexp(1.0, a.srow ? a.srow[r] : a.sconst);
+        const int rt = oz_row_output(a.rmode, a.rper, a.r0, a.rpts, r) != 0 ? a.rtg : 0;
+        const double sc = __builtin_ldexp(1.0, (a.srow ? a.srow[r] : a.sconst) + rt);
         const double cw = __builtin_ldexp(1.0, a.ktg);
         const double* src = a.in + (int64_t)r * a.ldin + kc;
 #pragma unroll
@@ -819,6 +829,8 @@ struct OzCrtArgs {
     int64_t ldp;
     int Mc;                // columns to write (multiple of 128)
     int nvalid;
+    int rmode, rper, rtg;  // candidate j is a derivative output (oz_row_output != 0): its image was taken at 2^-rtg, sums get 2^(2 rtg)
+    int64_t r0, rpts;
     OzPlan pl;
 };
 
@@ -899,8 +911,92 @@ __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
         for (int b = 0; b < 16; ++b) {
             const double t = ((sum[b] + red[0][lane][b]) + red[1][lane][b]) + red[2][lane][b];
             const bool bb = anybad || (a.bad_col && a.bad_col[j + b]);
-            a.partial[(int64_t)tb * a.ldp + j + b] = bb ? nan : t;
+            const double cf = (a.rmode && oz_row_output(a.rmode, a.rper, a.r0, a.rpts, j + b) != 0) ? __builtin_ldexp(1.0, 2 * a.rtg) : 1.0;
+            a.partial[(int64_t)tb * a.ldp + j + b] = bb ? nan : t * cf;
         }
+    }
+}
+
+// The same reconstruction with V itself as the result (the per-point covariance blocks of a gradient-enhanced model's outputs need
+// products of different columns of V, not only the squares): Vout[j][i] = CRT(U[·][i][j])·2^−(s_i + sK)·(2^rtg for derivative candidates),
+// candidate-major with ldv doubles per candidate.  A workgroup = 4 waves over 128 rows × 256 candidates; a lane reconstructs 4
+// candidates (one dword per residue plane and row) of 8 rows at a time, the wave's 8 × 256 block is transposed through LDS and leaves
+// as 64-byte runs of 8 consecutive rows per candidate.
+struct OzCrtVArgs {
+    const int8_t* U;
+    int64_t ldu, sU;
+    const int* sexp;
+    int sK;
+    const int* bad_row;
+    const int* bad_col;
+    double* V;
+    int64_t ldv;
+    int Mc, nvalid;
+    int rmode, rper, rtg;
+    int64_t r0, rpts;
+    OzPlan pl;
+};
+
+__global__ void __launch_bounds__(256) oz_crt_v_kernel(OzCrtVArgs a) {
+    __shared__ double tile[4][256][9];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 256 + 4 * lane;
+    const bool live = j < a.Mc;                              // Mc is a multiple of 128, blocks cover 256: whole quads are in or out
+    const int n = a.pl.n;
+    double cf[4];
+    bool cbad[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        cf[b] = (a.rmode && oz_row_output(a.rmode, a.rper, a.r0, a.rpts, j + b) != 0) ? __builtin_ldexp(1.0, a.rtg) : 1.0;
+        cbad[b] = live && a.bad_col && a.bad_col[j + b];
+    }
+    const double nan = __builtin_nan("");
+    for (int sub = 0; sub < 4; ++sub) {
+        const int i0 = blockIdx.y * 128 + wave * 32 + sub * 8;
+        if (i0 >= a.nvalid) break;                           // wave-uniform
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            if (live && i < a.nvalid) {
+                const int8_t* u = a.U + (int64_t)i * a.ldu + j;
+                double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int l = 0; l < n; ++l) {
+                    const int w = *reinterpret_cast<const int*>(u + (int64_t)l * a.sU);
+                    const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const double ud = (double)((w << (24 - 8 * b)) >> 24);
+                        c1[b] = __builtin_fma(ud, s1, c1[b]);
+                        c2[b] = __builtin_fma(ud, s2, c2[b]);
+                    }
+                }
+                const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
+                const bool rbad = a.bad_row && a.bad_row[i];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
+                    const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
+                    v[b] = (rbad || cbad[b]) ? nan : cp * sc * cf[b];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) tile[wave][4 * lane + b][ii] = v[b];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // the wave's own LDS writes have landed (in-order queue)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nrow = a.nvalid - i0 < 8 ? a.nvalid - i0 : 8;
+        for (int e = lane; e < 256 * 8; e += 64) {           // 8 consecutive lanes = 64 contiguous bytes of one candidate's row of V
+            const int c = e >> 3, ii = e & 7;
+            const int jc = blockIdx.x * 256 + c;
+            if (jc < a.Mc && ii < nrow) a.V[(int64_t)jc * a.ldv + i0 + ii] = tile[wave][c][ii];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -920,7 +1016,7 @@ hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, 
     hipLaunchKernelGGL(oz_rowscale_kernel, dim3((Np256 + 3) / 4), dim3(256), 0, s, W, ldw, nvalid, Np256, pl.eP, sexp, kper, ktg);
     OzQuantArgs q{};
     q.in = W; q.ldin = ldw; q.rows_in = nvalid; q.cols_in = Np; q.rows_out = Np256; q.cols_out = Np256; q.lower = 1;
-    q.srow = sexp; q.sconst = 0; q.kper = kper; q.ktg = ktg; q.out = WR; q.ld = Np256; q.plane = (int64_t)Np256 * Np256; q.bad = bad_row; q.pl = pl;
+    q.srow = sexp; q.sconst = 0; q.kper = kper; q.ktg = ktg; q.rmode = 0; q.rper = 1; q.rtg = 0; q.r0 = 0; q.rpts = 1; q.out = WR; q.ld = Np256; q.plane = (int64_t)Np256 * Np256; q.bad = bad_row; q.pl = pl;
     const int64_t threads = (int64_t)Np256 * (Np256 / 16);
     hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
     return hipGetLastError();
@@ -941,7 +1037,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     if (!v.planes_ready) {       // the generator did not write the residue planes itself (d > 32, or a caller-made K_XZ)
         OzQuantArgs q{};
         q.in = v.Kxz; q.ldin = v.ldk; q.rows_in = v.Mc; q.cols_in = v.Np; q.rows_out = Mc256; q.cols_out = Np256; q.lower = 0;
-        q.srow = nullptr; q.sconst = v.sK; q.kper = v.kper; q.ktg = -v.ktg; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
+        q.srow = nullptr; q.sconst = v.sK; q.kper = v.kper; q.ktg = -v.ktg; q.rmode = v.rmode; q.rper = v.rper; q.rtg = -v.ktg; q.r0 = v.r0; q.rpts = v.rpts; q.out = v.KR; q.ld = Np256; q.plane = (int64_t)Mc256 * Np256; q.bad = v.bad_col; q.pl = pl;
         const int64_t threads = (int64_t)Mc256 * (Np256 / 16);
         hipLaunchKernelGGL(oz_quant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, q);
     }
@@ -963,9 +1059,18 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     else hipLaunchKernelGGL(oz_gemm16d_kernel, dim3(blocks), dim3(512), 0, s, g);
     if (v.ev_gemm && (e = hipEventRecord(v.ev_gemm, s)) != hipSuccess) return e;
 
+    if (v.Vout) {
+        OzCrtVArgs c{};
+        c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
+        c.V = v.Vout; c.ldv = v.ldv; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
+        c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
+        hipLaunchKernelGGL(oz_crt_v_kernel, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
+        return hipGetLastError();
+    }
     OzCrtArgs c{};
     c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
     c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
+    c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
     static const int crt_generic = getenv("ABO_OZ_CRT_GENERIC") ? 1 : 0;          // A/B: the run-time-n loop for every plan
     if (pl.n == 14 && !crt_generic) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
     else hipLaunchKernelGGL(oz_crt_kernel<0>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);

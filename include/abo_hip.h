@@ -64,9 +64,8 @@ enum { ABO_HOST = 0, ABO_DEVICE = 1 };
  *                      below its L1 norm) on v_mfma_i32_16x16x64_i8,
  *                      through residues modulo `nmod` coprime moduli ≤ 256 and a Chinese-remainder reconstruction in fp64
  *                      (14 moduli: errors of the size of the fp64 kernels' own rounding; each modulus less ≈ 14× more error,
- *                      7 % less time).  Serves function-value posteriors (abo_predict, abo_acq, resident grids) of StandardGP and
- *                      gradient-enhanced handles up to 65536 factor rows; all-output posteriors of a gradient-enhanced model
- *                      (abo_predict_grad*) stay on the fp64 kernels.
+ *                      7 % less time).  Serves the posteriors (abo_predict, abo_acq, resident grids; abo_predict_grad and
+ *                      abo_predict_grad_cov of a gradient-enhanced handle) up to 65536 factor rows.
  *                      Its scratch is 2·nmod bytes per (candidate, factor row) of a chunk plus nmod·rows² bytes of planes; when the
  *                      device cannot give that (or more than ABO_OZ_SCRATCH_LIMIT_MB allows) the chunk is halved down to 4096
  *                      candidates, and below that the call runs on the fp64 kernels — never an error.

@@ -245,9 +245,12 @@ def test_engine_on_arbitrary_operands_against_its_cpu_restatement(Np, Mc, nvalid
 
 @pytest.mark.parametrize("family,d,N,ell", [(O.MATERN52, 3, 150, 0.25), (O.SE, 2, 200, 3.0), (O.MATERN72, 5, 120, 1.0)])
 def test_gradient_enhanced_model_on_the_int8_engine(family, d, N, ell):
-    """function-value posterior of a gradient-enhanced model (the rows of its K_XZ mix function and derivative covariances, apart by
-    √c/ℓ): the engine takes the product as (W·D⁻¹)(D·K_XZ) with an exact power-of-two D — short and long lengthscales alike stay at
-    the fp64 engine's error against oracle/grad_oracle.py"""
+    """posterior of a gradient-enhanced model (the rows of its K_XZ mix function and derivative covariances, apart by √c/ℓ): the
+    engine takes the product as (W·D⁻¹)(D·K_XZ·E) with exact power-of-two D (training rows) and E (candidate outputs) — short and long
+    lengthscales alike stay at the fp64 engine's error against oracle/grad_oracle.py.  Function-value posterior (mean_and_var), all
+    outputs of the candidates (posterior_grad_var: GradientGP.jl:951-953, rows by outputs, the chunk straddles output boundaries) and
+    the per-point covariance blocks + GradientNormUCB scores (posterior_grad_cov: GradientGP.jl:966-971, gradNormUCB.jl:43-51, where
+    the reconstruction writes V itself)."""
     from oracle import grad_oracle as G
     from tests.test_gpu_gradient_gp import make_grad
     p = d + 1
@@ -258,22 +261,47 @@ def test_gradient_enhanced_model_on_the_int8_engine(family, d, N, ell):
     Zc = synth.points(2, 700, d)
     st = G.fit(family, ell, 1.3, 1e-3, np.zeros(p), X, Ys)
     _, vf = G.predict(st, Zc)
+    _, vall = G.predict_grad(st, Zc)
+    Zs = Zc[:37]
+    covs = np.stack([G.predict_grad(st, Zs[j:j + 1], cov=True)[1] for j in range(len(Zs))])
+    ucb = G.grad_norm_ucb(st, Zs, 2.0)
+    pv = G.prior_var(family, ell, 1.3, d)                   # per-output prior variances: the scale of each output's error
     out = {}
     for eng in ("fp64", "int8"):
+        want = abo._lib.CONTRACT_INT8 if eng == "int8" else abo._lib.CONTRACT_FP64
         m = abo.update(make_grad(family, ell, 1.3, 1e-3, p, contraction=eng), X, Ys)
         mu, var = abo.mean_and_var(m, Zc)
-        assert m.timings()["contraction_engine"] == (abo._lib.CONTRACT_INT8 if eng == "int8" else abo._lib.CONTRACT_FP64)
-        out[eng] = (mu, var)
-        # all outputs of the candidates (posterior_grad_var) stay on the fp64 kernels whatever the engine
-        abo.posterior_grad_var(m, Zc[:8])
-        assert m.timings()["contraction_engine"] == abo._lib.CONTRACT_FP64
+        assert m.timings()["contraction_engine"] == want
+        va = abo.posterior_grad_var(m, Zc)
+        assert m.timings()["contraction_engine"] == want
+        mu_pm, cv, sc = abo.posterior_grad_cov(m, Zs, beta=2.0, return_all=True)
+        assert m.timings()["contraction_engine"] == want
+        out[eng] = (mu, var, va, cv, sc, abo.posterior_grad_mean(m, Zc))
     np.testing.assert_array_equal(out["int8"][0], out["fp64"][0])
+    np.testing.assert_array_equal(out["int8"][5], out["fp64"][5])
     e8 = np.max(np.abs(out["int8"][1] - vf)) / 1.3
     e64 = np.max(np.abs(out["fp64"][1] - vf)) / 1.3
     case = f"int8/grad_fam{family}_d{d}_ell{ell:g}"
     check(case, "var", e8, 1e-8)
     check(case, "var_fp64_engine", e64, 1e-8)
     assert e8 <= 4 * e64 + 1e-13, (e8, e64)
+    scale_rows = np.repeat(pv, len(Zc))
+    a8 = np.max(np.abs(out["int8"][2] - vall) / scale_rows)
+    a64 = np.max(np.abs(out["fp64"][2] - vall) / scale_rows)
+    check(case, "var_all_outputs", a8, 1e-8)
+    check(case, "var_all_outputs_fp64_engine", a64, 1e-8)
+    assert a8 <= 4 * a64 + 1e-13, (a8, a64)
+    cs = np.sqrt(np.outer(pv, pv))[None]
+    c8 = np.max(np.abs(out["int8"][3] - covs) / cs)
+    c64 = np.max(np.abs(out["fp64"][3] - covs) / cs)
+    check(case, "cov_blocks", c8, 1e-8)
+    check(case, "cov_blocks_fp64_engine", c64, 1e-8)
+    assert c8 <= 4 * c64 + 1e-13, (c8, c64)
+    us = np.maximum(np.abs(ucb), 1e-6)
+    u8 = np.max(np.abs(out["int8"][4] - ucb) / us)
+    u64 = np.max(np.abs(out["fp64"][4] - ucb) / us)
+    check(case, "grad_norm_ucb_rel", u8, 1e-6)
+    check(case, "grad_norm_ucb_rel_fp64_engine", u64, 1e-6)
 
 
 def test_engine_and_moduli_can_change_on_a_fitted_handle():
