@@ -186,17 +186,60 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
             int failcol = SB;                              // first column whose pivot is not a positive normal number
             double myrp = 0.0;
+            // Right-looking, and scheduled that way: column j's pivot chain (v_rsq_f64 + 14 dependent fp64 operations, the steps of
+            // sqrt_and_reciprocal) is the serial spine, its update of column j+1 is the only update the next pivot waits for, and the
+            // 14 − j updates column j owes to the columns beyond are independent filler.  Left to itself the compiler either sinks
+            // every update of a column to just before that column's pivot (left-looking: j more dependent operations on the spine) or
+            // issues the chain back to back with nothing in its latency; here one owed update of column j−1 is issued behind every
+            // step of column j's chain, and the scheduling fences pin that order.  Every element sees the same operations in the same
+            // order as in the plain loop: same bits.
+            double d = readlane_f64(x[0], 0);
 #pragma unroll
             for (int j = 0; j < SB; ++j) {                 // straight-line: a failed pivot poisons what follows (never
-                const double d = readlane_f64(x[j], j);    // stored) instead of branching out of the dependent chain
+                                                           // stored) instead of branching out of the dependent chain
+                const int jp = j > 0 ? j - 1 : 0;          // the column whose owed updates fill this chain
+                int kq = j + 1;
+#define ABO_FILL() do { if (j > 0 && kq < SB) { x[kq] = fma(-x[jp], readlane_f64(x[jp], kq), x[kq]); ++kq; } \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
                 failcol = (failcol == SB && !(d >= 2.3e-308)) ? j : failcol;       // also catches NaN; wave-uniform
-                double piv, rp;
-                sqrt_and_reciprocal(d, piv, rp);
-                x[j] = (lane == j) ? piv : x[j] * rp;
+                const double y = __builtin_amdgcn_rsq(d);
+                ABO_FILL();
+                double g = d * y, h = 0.5 * y;
+                ABO_FILL();
+                double r = fma(-h, g, 0.5);
+                ABO_FILL();
+                g = fma(g, r, g);
+                h = fma(h, r, h);
+                ABO_FILL();
+                r = fma(-h, g, 0.5);
+                ABO_FILL();
+                g = fma(g, r, g);
+                h = fma(h, r, h);
+                ABO_FILL();
+                const double e = fma(-g, g, d);
+                ABO_FILL();
+                const double piv = fma(e, h, g);
+                const double q = h + h;
+                ABO_FILL();
+                const double u = fma(-piv, q, 1.0);
+                ABO_FILL();
+                const double rp = fma(u, q, q);
+                ABO_FILL();
+                const double xs = x[j] * rp;
+                ABO_FILL();
+                x[j] = (lane == j) ? piv : xs;
                 myrp = (lane == j) ? rp : myrp;
+                ABO_FILL();
 #pragma unroll
-                for (int k = j + 1; k < SB; ++k) x[k] = fma(-x[j], readlane_f64(x[j], k), x[k]);
+                for (int rest = 0; rest < SB; ++rest) ABO_FILL();          // what column j−1 still owes (none once kq reaches SB)
+#undef ABO_FILL
+                if (j + 1 < SB) {
+                    x[j + 1] = fma(-x[j], readlane_f64(x[j], j + 1), x[j + 1]);
+                    d = readlane_f64(x[j + 1], j + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // (column 15 owes nothing)
             if (failcol < SB) {
                 if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
             } else if (valid) {

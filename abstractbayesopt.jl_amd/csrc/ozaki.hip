@@ -223,9 +223,9 @@ struct OzGemmArgs {
 // Row-block offsets inside a group alternate direction from group to group: the CUs that ran a group's lightest tiles are free
 // first and take the next group's first workgroups — which are then its heaviest, so the four row blocks of a patch do not drift
 // apart in k (the candidate panels they share stay in L2 only while they walk k together; L2 hit rate 60 % → 78 %).
-__device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj, int& l) {
+__device__ __forceinline__ bool oz_decode_blk(const OzGemmArgs& a, int blk, int& ti, int& tj, int& l) {
     const int per_group = 4 * a.tjg;
-    const int grp = blockIdx.x / per_group, s = blockIdx.x % per_group;
+    const int grp = blk / per_group, s = blk % per_group;
     const int ngj = (a.Tj + a.tjg - 1) / a.tjg;
     const int ngi = (a.Ti + 3) / 4;
 #ifdef OZ_EXP_ROWGROUP_OUTER
@@ -243,6 +243,7 @@ __device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj,
     l = gl;
     return ti < a.Ti && tj < a.Tj;
 }
+__device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj, int& l) { return oz_decode_blk(a, (int)blockIdx.x, ti, tj, l); }
 
 // ---- epilogue pieces shared by the GEMM kernels -------------------------------------------------------------------------------------------
 // four accumulators (four consecutive candidates of one W row) → their symmetric residues mod p, one byte each.  The quotient is
@@ -686,8 +687,8 @@ __device__ __forceinline__ void oz16_mma_row(const OzFragA& fa, const OzFragB& f
 // unit 0 of wave row wi (rows 128wi … +63) from hs = 2wi + 1 on, unit 1 (rows 128wi+64 … +127) from hs = 2wi + 2 on: 6 of the 16
 // units of a diagonal block are skipped (2.3 % of a C3 launch's MFMAs; measured −1 %).
 template <int SLOT, bool DIAG>
-__device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, int hmax, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
-                                           OzFragB& By, v4i_t (&acc)[4][8], int hs = 0, int wi = 0) {
+__device__ __forceinline__ void oz16d_step_k(char* lds, const OzDmaCtx& c, int k, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
+                                             OzFragB& By, v4i_t (&acc)[4][8], int hs = 0, int wi = 0) {
     const bool sk_prev = DIAG && (hs - 1 >= 2 * wi + 2);      // the held-back unit is unit 1 of half-stage hs − 1
     const bool sk_u0 = DIAG && (hs >= 2 * wi + 1);
     const char* slot = lds + SLOT * OZ_SLOT;
@@ -695,11 +696,6 @@ __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, 
     const char* pb = slot + rb;
     OzFragA& An = A[SLOT & 1];
     const OzFragA& Ao = A[(SLOT & 1) ^ 1];
-#ifdef OZ_EXP_SAMEK
-    const int k = 0;
-#else
-    const int k = (h + 3 < hmax ? h + 3 : hmax) * 16384;      // byte offset of the half-stage's plane block
-#endif
     constexpr int NS = (SLOT + 3) & 3;
     // the previous half-stage's held-back unit (Ao × By, columns 4-7) with this half-stage's A and B0-3 fragments arriving
     An.a[0] = *reinterpret_cast<const v4i_t*>(pa);
@@ -750,6 +746,18 @@ __device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, 
     __builtin_amdgcn_s_barrier();
 #endif
     OZ_FENCE();
+}
+
+// the step of the one-tile-per-workgroup kernel: fetches half-stage h + 3 of its own tile (clamped to the last one)
+template <int SLOT, bool DIAG>
+__device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, int hmax, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
+                                           OzFragB& By, v4i_t (&acc)[4][8], int hs = 0, int wi = 0) {
+#ifdef OZ_EXP_SAMEK
+    const int k = 0;
+#else
+    const int k = (h + 3 < hmax ? h + 3 : hmax) * 16384;      // byte offset of the half-stage's plane block
+#endif
+    oz16d_step_k<SLOT, DIAG>(lds, c, k, ra, rb, A, Bx, By, acc, hs, wi);
 }
 
 __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
@@ -814,6 +822,144 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
     __syncthreads();
 
     oz16_epilogue(a, oz_lds, acc, l, ti, tj, wi, wj, lane);
+}
+
+// ---- the same GEMM as a PERSISTENT kernel -------------------------------------------------------------------------------------------------
+// One workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, … of the launch's tile list (gridDim.x a multiple of the
+// group size: a workgroup keeps its place in the XCD patch, and the alternating row-block order of the groups gives every workgroup
+// the same total k).  What a tile cost beyond its MFMAs in the one-tile-per-workgroup kernel — the dispatch of a 128 KB-LDS
+// workgroup onto the CU that just drained, three half-stages of DMA latency before the first MFMA, the wait for the tail's
+// re-fetches before the epilogue may overlay the ring — was about 7 of 54 µs at N = 8192 and half of the tile at N = 1024, with
+// nothing else resident on the CU to hide it.  Here the last three steps of a tile fetch the first three half-stages of the NEXT
+// tile into ring slots 0-2 (a tile is a multiple of four half-stages: the ring phase carries over), and the epilogue keeps out of
+// their way: the residues leave through slot 3 alone, 64 W rows at a time in two 16 KB buffers (rows of 256 bytes, 16-byte chunks
+// rotated by the row index: conflict-free for the dword writes and the 16-byte reads).  Same products, same residues: same bits.
+__device__ __forceinline__ void oz16p_ctx(const OzGemmArgs& a, int ti, int tj, int l, int wave, OzDmaCtx& c) {
+    c.ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384 + 1024 * wave;
+    c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384 + 1024 * wave;
+}
+
+__device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3, v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
+                                               int lane, int tid) {
+    const double invp = a.invp[l], pd = (double)a.p[l];
+    // the epilogue's lane constants are recomputed per tile from the lane id (v_mbcnt) and the wave's scalar coordinates: kept across
+    // the tile loop they would sit in registers the k-loop has none to spare for (and were spilled to scratch)
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    tid = 64 * (4 * wi + wj) + lane;            // wi, wj are wave-uniform (scalar registers)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)          // the four residues of an accumulator quad, packed, take the place of its first register
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) acc[m][nn][0] = oz_mod_pack4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pd);
+    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
+    const int r15 = lane & 15;
+    // a thread's two 16-byte pieces of a pass: rows tid/16 and tid/16 + 32 (same rotation: the rows are 32 apart), chunk tid%16
+    const int sr = tid >> 4, sc = tid & 15;
+    const unsigned lds_off = (unsigned)(sr * 256 + ((16 * sc + 16 * (sr & 15)) & 255));
+    const unsigned g_off = (unsigned)(sr * (int)a.ldu + 16 * sc);         // < 2^24: 32-bit lane offset on a uniform row base
+    const unsigned g_step = (unsigned)(32 * (int)a.ldu);
+#pragma unroll
+    for (int P = 0; P < 5; ++P) {
+        if (P < 4 && wi == (P >> 1)) {              // pass P: W rows 64P … 64P+63 of the tile = row groups nn = 4(P&1) … +3 of wave row P/2
+            char* buf = slot3 + (P & 1) * 16384;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 16 * q + r15;
+                    const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
+                    *reinterpret_cast<int*>(buf + r * 256 + ((jl + 16 * r15) & 255)) = acc[m][4 * (P & 1) + q][0];
+                }
+        }
+        if (P > 0) {                                // rows of pass P−1 leave as 256-byte segments of U[l][i][·]
+            const char* buf = slot3 + ((P - 1) & 1) * 16384;
+            int8_t* rows = up + (int64_t)(64 * (P - 1)) * a.ldu;          // uniform
+            const v4i_t w0 = *reinterpret_cast<const v4i_t*>(buf + lds_off);
+            const v4i_t w1 = *reinterpret_cast<const v4i_t*>(buf + lds_off + 32 * 256);
+            *reinterpret_cast<v4i_t*>(rows + g_off) = w0;
+            *reinterpret_cast<v4i_t*>(rows + g_off + g_step) = w1;
+        }
+        // workgroup barrier for LDS traffic only: __syncthreads() would also wait for the stores just issued (vmcnt(0), a round trip
+        // to L2 per pass) and for the next tile's half-stages still in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total) {
+    __shared__ __attribute__((aligned(1024))) char oz_lds[4 * OZ_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wj = wave & 3, wi = wave >> 2;
+    int ti, tj, l;
+    int blk = blockIdx.x;
+    while (blk < total && !oz_decode_blk(a, blk, ti, tj, l)) blk += gridDim.x;
+    if (blk >= total) return;                         // uniform over the workgroup
+    OzDmaCtx c, cn;
+    c.wave = wave;
+    {
+        const int chunk = (lane & 3) ^ ((lane >> 3) & 3);
+        c.astep = 8192;
+        c.bstep = 8192;
+        c.ao = (unsigned)((lane >> 2) * 64 + 16 * chunk);
+        c.bo = c.ao;
+    }
+    cn = c;
+    oz16p_ctx(a, ti, tj, l, c.wave, c);
+    const int ro = (lane & 15) * OZ_HS + (((lane >> 4) ^ ((lane >> 1) & 3)) * 16);
+    const int ra = (64 * wj) * OZ_HS + ro;
+    const int rb = OZ_T * OZ_HS + (128 * wi) * OZ_HS + ro;
+
+    oz_dma_issue<0>(oz_lds, c, 0);
+    oz_dma_issue<1>(oz_lds, c, 1);
+    oz_dma_issue<2>(oz_lds, c, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (;;) {
+        // the tile after this one (uniform over the workgroup)
+        int nb = blk + gridDim.x, ti2 = 0, tj2 = 0, l2 = 0;
+        bool have = false;
+        while (nb < total) {
+            if (oz_decode_blk(a, nb, ti2, tj2, l2)) { have = true; break; }
+            nb += gridDim.x;
+        }
+        const int nh = 4 * (ti + 1);
+        int k1, k2, k3;
+        if (have) { oz16p_ctx(a, ti2, tj2, l2, c.wave, cn); k1 = 0; k2 = 16384; k3 = 32768; }
+        else { cn.ab = c.ab; cn.bb = c.bb; k1 = k2 = k3 = (nh - 1) * 16384; }      // no next tile: a harmless re-fetch of the last half-stage
+
+        v4i_t acc[4][8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int nn = 0; nn < 8; ++nn) acc[m][nn] = v4i_t{0, 0, 0, 0};
+        OzFragA A[2];
+        OzFragB Bx, By;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { A[1].a[m] = v4i_t{0, 0, 0, 0}; By.b[m] = v4i_t{0, 0, 0, 0}; }   // the first step's held-back unit adds 0
+
+        int hb = 0;
+        for (; hb < nh - 4; hb += 4) {
+            oz16d_step_k<0, false>(oz_lds, c, (hb + 3) * 16384, ra, rb, A, Bx, By, acc);
+            oz16d_step_k<1, false>(oz_lds, c, (hb + 4) * 16384, ra, rb, A, Bx, By, acc);
+            oz16d_step_k<2, false>(oz_lds, c, (hb + 5) * 16384, ra, rb, A, Bx, By, acc);
+            oz16d_step_k<3, false>(oz_lds, c, (hb + 6) * 16384, ra, rb, A, Bx, By, acc);
+        }
+        oz16d_step_k<0, true>(oz_lds, c, (hb + 3) * 16384, ra, rb, A, Bx, By, acc, 0, wi);      // the diagonal block; hb + 3 = nh − 1
+        oz16d_step_k<1, true>(oz_lds, cn, k1, ra, rb, A, Bx, By, acc, 1, wi);                   // … fetching the next tile's first half-stages
+        oz16d_step_k<2, true>(oz_lds, cn, k2, ra, rb, A, Bx, By, acc, 2, wi);
+        oz16d_step_k<3, true>(oz_lds, cn, k3, ra, rb, A, Bx, By, acc, 3, wi);
+        if (wi != 0) oz16_mma(A[1], By, 1, acc);          // the held-back unit of the last half-stage (slot 3 → A[1]); zeros for wave row 0
+        // the step's closing barrier: every wave has its fragments of slot 3 in registers — the slot is free for the residues
+        oz16p_epilogue(a, oz_lds + 3 * OZ_SLOT, acc, l, ti, tj, wi, wj, lane, tid);
+        // (the epilogue's closing barrier: nobody still reads slot 3.  Nothing is waited for here: the last step's vmcnt(8) saw the
+        // next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two newest half-stages are in flight"
+        // with this tile's stores in the count — they only make the first waits conservative)
+        if (!have) break;
+        blk = nb; ti = ti2; tj = tj2; l = l2;
+        c.ab = cn.ab; c.bb = cn.bb;
+    }
 }
 
 // ---- reconstruction + squares + column sums ------------------------------------------------------------------------------------------
@@ -1054,9 +1200,18 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     const unsigned blocks = (unsigned)(ngi * pl.n * ngj * 4 * g.tjg);
     static const int shape32 = getenv("ABO_OZ_MFMA32") ? 1 : 0;       // A/B: the 32×32×32 kernel
     static const int regstage = getenv("ABO_OZ_REGSTAGE") ? 1 : 0;    // A/B: the register-staged 16×16×64 kernel
+    static const int one_tile = getenv("ABO_OZ_ONE_TILE") ? 1 : 0;    // A/B: one tile per workgroup (the round-2 kernel)
     if (shape32) hipLaunchKernelGGL(oz_gemm_kernel, dim3(blocks), dim3(512), 0, s, g);
     else if (regstage) hipLaunchKernelGGL(oz_gemm16_kernel, dim3(blocks), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL(oz_gemm16d_kernel, dim3(blocks), dim3(512), 0, s, g);
+    else if (one_tile) hipLaunchKernelGGL(oz_gemm16d_kernel, dim3(blocks), dim3(512), 0, s, g);
+    else {
+        // persistent: one workgroup per CU, a whole number of groups (a workgroup keeps its place in the XCD patch)
+        static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+        const int per_group = 4 * g.tjg;
+        int G = per_group * (cus / per_group > 0 ? cus / per_group : 1);
+        if ((unsigned)G > blocks) G = (int)blocks;
+        hipLaunchKernelGGL(oz_gemm16p_kernel, dim3(G), dim3(512), 0, s, g, (int)blocks);
+    }
     if (v.ev_gemm && (e = hipEventRecord(v.ev_gemm, s)) != hipSuccess) return e;
 
     if (v.Vout) {

@@ -2,7 +2,10 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I abstractbayesopt.jl_amd/csrc -I include \
 //              -o tools/chol_diag_probe tools/chol_diag_probe.hip
 #define ABO_CHOL_PROBE 1
-#include "../abstractbayesopt.jl_amd/csrc/chol.hip"
+#ifndef ABO_CHOL_SRC
+#define ABO_CHOL_SRC "../abstractbayesopt.jl_amd/csrc/chol.hip"
+#endif
+#include ABO_CHOL_SRC
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -40,5 +43,14 @@ int main() {
         for (int p = 0; p < 4; ++p) { printf("  %.2f / %.2f", (c[6 + 2 * p] - prev) / 100.0, (c[7 + 2 * p] - c[6 + 2 * p]) / 100.0); prev = c[7 + 2 * p]; }
         printf("\n");
     }
+    // FNV-1a over L, W and WT of the last repetition: two builds of the kernel that print the same value produced the same bits
+    std::vector<double> out(3 * n * n);
+    CK(hipMemcpy(out.data(), dK, n * n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out.data() + n * n, dW, n * n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out.data() + 2 * n * n, dWT, n * n * 8, hipMemcpyDeviceToHost));
+    unsigned long long hsh = 1469598103934665603ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(out.data());
+    for (size_t i = 0; i < out.size() * 8; ++i) { hsh ^= b[i]; hsh *= 1099511628211ull; }
+    printf("hash of L | W | WT: %016llx\n", hsh);
     return 0;
 }
