@@ -63,6 +63,7 @@ int oz_k_scale(double kmax);                 // sK with rint(K·2^sK) < 2^53 for
 // rows ≥ nvalid (identity padding, or the remains of a discarded appended branch) become zero planes
 hipError_t oz_prepare_w(const OzPlan& pl, const double* W, int64_t ldw, int Np, int nvalid, int8_t* WR, int* sexp, int* bad_row, hipStream_t s,
                         int kper = 1, int ktg = 0);
+constexpr int OZ_CTR_INTS = 16;
 struct OzVarArgs {
     const OzPlan* plan;
     const double* Kxz;     // [Mc][ldk] candidate-major chunk (fp64, as launch_var_gemm takes it)
@@ -70,7 +71,7 @@ struct OzVarArgs {
     const int8_t* WR; const int* sexp; const int* bad_row;
     int8_t* KR;            // scratch: oz_k_bytes
     int8_t* U;             // scratch: oz_k_bytes
-    int* bad_col;          // scratch: pad256(Mc) ints
+    int* bad_col;          // scratch: pad256(Mc) + OZ_CTR_INTS ints (the persistent GEMM's tile counters sit behind the flags)
     double* partial;       // [Np/128][ldp]
     int64_t ldp;
     int Np, Mc, nvalid, sK;

@@ -679,7 +679,7 @@ int32_t oz_acquire(abo_gp* g, int nm, int64_t M, int64_t* Mc_io, bool* oz_io) {
             const size_t kb = oz_k_bytes(nm, (int)Np, (int)Mc);
             e = 2 * kb > oz_scratch_limit() ? hipErrorOutOfMemory : g->oz_KR.ensure(kb);
             if (e == hipSuccess) e = g->oz_U.ensure(kb);
-            if (e == hipSuccess) e = g->oz_badc.ensure(sizeof(int) * pad_up(Mc, 256));
+            if (e == hipSuccess) e = g->oz_badc.ensure(sizeof(int) * (pad_up(Mc, 256) + OZ_CTR_INTS));   // + the GEMM's tile counters
             if (e != hipErrorOutOfMemory || Mc <= 4096) break;
             (void)hipGetLastError();
             g->oz_KR.release(); g->oz_U.release();
@@ -2187,7 +2187,7 @@ int32_t abo_test_oz_contract(int32_t device, const double* W, int64_t ldw, int32
     HIPCHK(wr.b.ensure(oz_w_bytes(nmod, Np)));
     HIPCHK(kr.b.ensure(oz_k_bytes(nmod, Np, Mc)));
     HIPCHK(u.b.ensure(oz_k_bytes(nmod, Np, Mc)));
-    HIPCHK(ints.b.ensure(sizeof(int) * (2 * q + mq)));
+    HIPCHK(ints.b.ensure(sizeof(int) * (2 * q + mq + OZ_CTR_INTS)));
     int* sexp = ints.b.as<int>();
     HIPCHK(oz_prepare_w(pl, W, ldw, Np, nvalid, wr.b.as<int8_t>(), sexp, sexp + q, nullptr));
     OzVarArgs oa{};

@@ -839,8 +839,9 @@ __device__ __forceinline__ void oz16p_ctx(const OzGemmArgs& a, int ti, int tj, i
     c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384 + 1024 * wave;
 }
 
+template <class Take>
 __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3, v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
-                                               int lane, int tid) {
+                                               int lane, int tid, int* pick, Take take, int ticket) {
     const double invp = a.invp[l], pd = (double)a.p[l];
     // the epilogue's lane constants are recomputed per tile from the lane id (v_mbcnt) and the wave's scalar coordinates: kept across
     // the tile loop they would sit in registers the k-loop has none to spare for (and were spilled to scratch)
@@ -850,6 +851,15 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
     for (int m = 0; m < 4; ++m)          // the four residues of an accumulator quad, packed, take the place of its first register
 #pragma unroll
         for (int nn = 0; nn < 8; ++nn) acc[m][nn][0] = oz_mod_pack4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pd);
+    // (pinned here: left alone the compiler sinks the residue arithmetic into the passes below, behind the wait for the ticket)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 8; ++nn) asm volatile("" : "+v"(acc[m][nn][0]));
+    if (pick && tid == 0) {                            // thread 0: the tile after next (the ticket's answer has arrived meanwhile)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+        pick[0] = take(ticket);
+    }
     int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
     const int r15 = lane & 15;
     // a thread's two 16-byte pieces of a pass: rows tid/16 and tid/16 + 32 (same rotation: the rows are 32 apart), chunk tid%16
@@ -886,15 +896,54 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
     }
 }
 
-__global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total) {
-    __shared__ __attribute__((aligned(1024))) char oz_lds[4 * OZ_SLOT];
+// The tile list is dealt out dynamically, one list per XCD: list x holds the blocks with blockIdx % 8 == x of the one-tile kernel's
+// order (what the round-robin dispatch gives XCD x there), and a workgroup takes the next entry of the list of the XCD it runs on
+// (HW_REG_XCC_ID) with one atomic increment — the 32 CUs of an XCD so work through consecutive entries, i.e. through a 4 × (tjg/8)
+// patch at a time, whatever the launch's shape (row blocks not a multiple of four, ragged last column group: a static split
+// leaves CUs idle there).  An exhausted list sends its workgroups to the next XCD's list, so every tile is taken whatever the
+// XCD numbering of the partition mode.  The index of the tile after next is fetched one tile ahead, behind the epilogue's
+// residue arithmetic, and handed to the other waves through LDS.
+__device__ __forceinline__ int oz16p_take(const OzGemmArgs& a, int* ctr, int x, int per_group, int per_list, int q) {
+    // q: a ticket already drawn from list x (or per_list: none)
+    const int cpx = per_group >> 3;
+    for (int t = 0; t < 8; ++t) {
+        const int y = (x + t) & 7;
+        for (;;) {
+            if (t > 0 || q < 0) q = __hip_atomic_fetch_add(ctr + y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q >= per_list) break;
+            const int blk = (q / cpx) * per_group + (q % cpx) * 8 + y;
+            int ti, tj, l;
+            if (oz_decode_blk(a, blk, ti, tj, l)) return blk;
+            q = -1;                                   // a padding block of the list: draw again
+        }
+        q = -1;
+    }
+    return -1;
+}
+
+__global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total, int* ctr) {
+    // ONE LDS object (the ring, and two words behind it for the tile indices): with a second __shared__ variable the compiler
+    // starts to order every ds_read behind every LDS-DMA piece in flight (s_waitcnt vmcnt(0) before each fragment read: measured
+    // 2× slower) — with a single object it leaves that ordering to the counted waits of the steps
+    __shared__ __attribute__((aligned(1024))) char oz_lds[4 * OZ_SLOT + 16];
+    int* oz_pick = reinterpret_cast<int*>(oz_lds + 4 * OZ_SLOT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wj = wave & 3, wi = wave >> 2;
+    const int per_group = 4 * a.tjg, per_list = total >> 3;
+    const int x = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;      // hwreg(HW_REG_XCC_ID, 0, 4)
+    if (tid == 0) {
+        const int b0 = oz16p_take(a, ctr, x, per_group, per_list, -1);
+        oz_pick[0] = b0;
+        oz_pick[1] = b0 < 0 ? -1 : oz16p_take(a, ctr, x, per_group, per_list, -1);
+    }
+    __syncthreads();
+    int blk = __builtin_amdgcn_readfirstlane(oz_pick[0]);
+    int nb = __builtin_amdgcn_readfirstlane(oz_pick[1]);
+    __syncthreads();
+    if (blk < 0) return;                              // uniform over the workgroup
     int ti, tj, l;
-    int blk = blockIdx.x;
-    while (blk < total && !oz_decode_blk(a, blk, ti, tj, l)) blk += gridDim.x;
-    if (blk >= total) return;                         // uniform over the workgroup
+    (void)oz_decode_blk(a, blk, ti, tj, l);
     OzDmaCtx c, cn;
     c.wave = wave;
     {
@@ -917,13 +966,9 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
-        // the tile after this one (uniform over the workgroup)
-        int nb = blk + gridDim.x, ti2 = 0, tj2 = 0, l2 = 0;
-        bool have = false;
-        while (nb < total) {
-            if (oz_decode_blk(a, nb, ti2, tj2, l2)) { have = true; break; }
-            nb += gridDim.x;
-        }
+        const bool have = nb >= 0;                    // uniform over the workgroup
+        int ti2 = 0, tj2 = 0, l2 = 0;
+        if (have) (void)oz_decode_blk(a, nb, ti2, tj2, l2);
         const int nh = 4 * (ti + 1);
         int k1, k2, k3;
         if (have) { oz16p_ctx(a, ti2, tj2, l2, c.wave, cn); k1 = 0; k2 = 16384; k3 = 32768; }
@@ -951,14 +996,25 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
         oz16d_step_k<2, true>(oz_lds, cn, k2, ra, rb, A, Bx, By, acc, 2, wi);
         oz16d_step_k<3, true>(oz_lds, cn, k3, ra, rb, A, Bx, By, acc, 3, wi);
         if (wi != 0) oz16_mma(A[1], By, 1, acc);          // the held-back unit of the last half-stage (slot 3 → A[1]); zeros for wave row 0
-        // the step's closing barrier: every wave has its fragments of slot 3 in registers — the slot is free for the residues
-        oz16p_epilogue(a, oz_lds + 3 * OZ_SLOT, acc, l, ti, tj, wi, wj, lane, tid);
-        // (the epilogue's closing barrier: nobody still reads slot 3.  Nothing is waited for here: the last step's vmcnt(8) saw the
-        // next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two newest half-stages are in flight"
-        // with this tile's stores in the count — they only make the first waits conservative)
+        // the step's closing barrier: every wave has its fragments of slot 3 in registers — the slot is free for the residues.
+        // The ticket for the tile after next is drawn now and looked at behind the residue arithmetic.
+        // (issued as written, by hand: the compiler's atomic waits for the answer on the spot — a round trip to L2 with seven waves
+        // at the barrier; the epilogue waits for it behind its arithmetic, with the ticket as the wait's operand)
+        int ticket = per_list;
+        if (have && tid == 0) {
+            const int one = 1;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr + x), "v"(one) : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        oz16p_epilogue(a, oz_lds + 3 * OZ_SLOT, acc, l, ti, tj, wi, wj, lane, tid, have ? oz_pick : nullptr,
+                       [&](int q) { return oz16p_take(a, ctr, x, per_group, per_list, q); }, ticket);
+        // (the epilogue's closing barrier: nobody still reads slot 3, and oz_pick[0] is visible.  Nothing else is waited for here: the
+        // last step's vmcnt(8) saw the next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two
+        // newest half-stages are in flight" with this tile's stores in the count — they only make the first waits conservative)
         if (!have) break;
         blk = nb; ti = ti2; tj = tj2; l = l2;
         c.ab = cn.ab; c.bb = cn.bb;
+        nb = __builtin_amdgcn_readfirstlane(oz_pick[0]);
     }
 }
 
@@ -1205,12 +1261,12 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     else if (regstage) hipLaunchKernelGGL(oz_gemm16_kernel, dim3(blocks), dim3(512), 0, s, g);
     else if (one_tile) hipLaunchKernelGGL(oz_gemm16d_kernel, dim3(blocks), dim3(512), 0, s, g);
     else {
-        // persistent: one workgroup per CU, a whole number of groups (a workgroup keeps its place in the XCD patch)
+        // persistent: one workgroup per CU; the tile counters (one per XCD list) sit behind the chunk's bad_col flags
         static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-        const int per_group = 4 * g.tjg;
-        int G = per_group * (cus / per_group > 0 ? cus / per_group : 1);
-        if ((unsigned)G > blocks) G = (int)blocks;
-        hipLaunchKernelGGL(oz_gemm16p_kernel, dim3(G), dim3(512), 0, s, g, (int)blocks);
+        int* ctr = v.bad_col + Mc256;
+        if ((e = hipMemsetAsync(ctr, 0, sizeof(int) * 8, s)) != hipSuccess) return e;
+        const int G = (unsigned)cus < blocks ? cus : (int)blocks;
+        hipLaunchKernelGGL(oz_gemm16p_kernel, dim3(G), dim3(512), 0, s, g, (int)blocks, ctr);
     }
     if (v.ev_gemm && (e = hipEventRecord(v.ev_gemm, s)) != hipSuccess) return e;
 
