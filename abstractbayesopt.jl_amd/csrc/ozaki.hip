@@ -839,6 +839,16 @@ __device__ __forceinline__ void oz16p_ctx(const OzGemmArgs& a, int ti, int tj, i
     c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384 + 1024 * wave;
 }
 
+// tools/oz_dev.hip defines OZ_PROBE: workgroup 0 sums the 100 MHz clock over its k loops and its epilogues
+#ifdef OZ_PROBE
+__device__ long long oz_probe_acc[8];
+#define OZ_PROBE_T(v) const long long v = wall_clock64()
+#define OZ_PROBE_ADD(i, d) do { if (blockIdx.x == 0 && threadIdx.x == 0) oz_probe_acc[i] += (d); } while (0)
+#else
+#define OZ_PROBE_T(v) do { } while (0)
+#define OZ_PROBE_ADD(i, d) do { } while (0)
+#endif
+
 template <class Take>
 __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3, v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
                                                int lane, int tid, int* pick, Take take, int ticket) {
@@ -856,6 +866,8 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int nn = 0; nn < 8; ++nn) asm volatile("" : "+v"(acc[m][nn][0]));
+    OZ_PROBE_T(pe1);
+    OZ_PROBE_ADD(4, pe1);                              // (probe build: Σ of the clock behind the residue arithmetic)
     if (pick && tid == 0) {                            // thread 0: the tile after next (the ticket's answer has arrived meanwhile)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
         pick[0] = take(ticket);
@@ -974,6 +986,7 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
         if (have) { oz16p_ctx(a, ti2, tj2, l2, c.wave, cn); k1 = 0; k2 = 16384; k3 = 32768; }
         else { cn.ab = c.ab; cn.bb = c.bb; k1 = k2 = k3 = (nh - 1) * 16384; }      // no next tile: a harmless re-fetch of the last half-stage
 
+        OZ_PROBE_T(pt0);
         v4i_t acc[4][8];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -1000,6 +1013,8 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
         // The ticket for the tile after next is drawn now and looked at behind the residue arithmetic.
         // (issued as written, by hand: the compiler's atomic waits for the answer on the spot — a round trip to L2 with seven waves
         // at the barrier; the epilogue waits for it behind its arithmetic, with the ticket as the wait's operand)
+        OZ_PROBE_T(pt1);
+        OZ_PROBE_ADD(5, pt1);
         int ticket = per_list;
         if (have && tid == 0) {
             const int one = 1;
@@ -1011,6 +1026,8 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
         // (the epilogue's closing barrier: nobody still reads slot 3, and oz_pick[0] is visible.  Nothing else is waited for here: the
         // last step's vmcnt(8) saw the next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two
         // newest half-stages are in flight" with this tile's stores in the count — they only make the first waits conservative)
+        OZ_PROBE_T(pt2);
+        OZ_PROBE_ADD(0, pt1 - pt0); OZ_PROBE_ADD(1, pt2 - pt1); OZ_PROBE_ADD(2, 1); OZ_PROBE_ADD(3, nh);
         if (!have) break;
         blk = nb; ti = ti2; tj = tj2; l = l2;
         c.ab = cn.ab; c.bb = cn.bb;
@@ -1251,7 +1268,9 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256; g.sU = (int64_t)Np256 * Mc256;
     g.Ti = Np256 / OZ_T; g.Tj = Mc256 / OZ_T; g.n = pl.n;
     g.tjg = g.Tj >= 64 ? 64 : (int)pad_up(g.Tj, 8);
-    for (int l = 0; l < pl.n; ++l) { g.invp[l] = pl.invp[l]; g.p[l] = pl.p[l]; }
+    for (int l = 0; l < pl.n; ++l) {
+        g.invp[l] = pl.invp[l]; g.p[l] = pl.p[l];
+    }
     const int ngj = (g.Tj + g.tjg - 1) / g.tjg, ngi = (g.Ti + 3) / 4;
     const unsigned blocks = (unsigned)(ngi * pl.n * ngj * 4 * g.tjg);
     static const int shape32 = getenv("ABO_OZ_MFMA32") ? 1 : 0;       // A/B: the 32×32×32 kernel

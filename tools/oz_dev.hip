@@ -2,6 +2,7 @@
 // host at a small size, then kernel timings at the C3 chunk shape (N = 8192, Mc = 16384).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o tools/oz_dev tools/oz_dev.hip
 // Run:   tools/oz_dev [nmod] [Nbig] [Mcbig]
+#define OZ_PROBE 1
 #include "../abstractbayesopt.jl_amd/csrc/ozaki.hip"
 #include <cstdio>
 #include <algorithm>
@@ -45,7 +46,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dW, sizeof(double) * W.size())); CK(hipMalloc(&dK, sizeof(double) * K.size()));
         CK(hipMalloc(&dP, sizeof(double) * (Np / 128) * Mc));
         CK(hipMalloc(&WR, oz_w_bytes(nmod, Np))); CK(hipMalloc(&KR, oz_k_bytes(nmod, Np, Mc))); CK(hipMalloc(&U, oz_k_bytes(nmod, Np, Mc)));
-        CK(hipMalloc(&sexp, 4 * Np256)); CK(hipMalloc(&badr, 4 * Np256)); CK(hipMalloc(&badc, 4 * Mc256));
+        CK(hipMalloc(&sexp, 4 * Np256)); CK(hipMalloc(&badr, 4 * Np256)); CK(hipMalloc(&badc, 4 * (Mc256 + OZ_CTR_INTS)));
         CK(hipMemcpy(dW, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(dK, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         CK(hipMemset(U, 0x55, oz_k_bytes(nmod, Np, Mc)));
@@ -131,7 +132,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dW, sizeof(double) * W.size())); CK(hipMalloc(&dK, sizeof(double) * K.size()));
         CK(hipMalloc(&dP, sizeof(double) * (Np / 128) * Mc));
         CK(hipMalloc(&WR, oz_w_bytes(nmod, Np))); CK(hipMalloc(&KR, oz_k_bytes(nmod, Np, Mc))); CK(hipMalloc(&U, oz_k_bytes(nmod, Np, Mc)));
-        CK(hipMalloc(&sexp, 4 * Np256)); CK(hipMalloc(&badr, 4 * Np256)); CK(hipMalloc(&badc, 4 * Mc256));
+        CK(hipMalloc(&sexp, 4 * Np256)); CK(hipMalloc(&badr, 4 * Np256)); CK(hipMalloc(&badc, 4 * (Mc256 + OZ_CTR_INTS)));
         CK(hipMemcpy(dW, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice));
         CK(hipMemcpy(dK, K.data(), sizeof(double) * K.size(), hipMemcpyHostToDevice));
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -154,6 +155,14 @@ int main(int argc, char** argv) {
             float a, b, c, d;
             CK(hipEventElapsedTime(&a, e0, eq)); CK(hipEventElapsedTime(&b, eq, eg)); CK(hipEventElapsedTime(&c, eg, e1)); CK(hipEventElapsedTime(&d, e0, e1));
             if (rep >= reps / 2) { tq.push_back(a); tg.push_back(b); tc.push_back(c); tt.push_back(d); }
+        }
+        {
+            long long pa[8];
+            CK(hipMemcpyFromSymbol(pa, HIP_SYMBOL(oz_probe_acc), sizeof(pa)));
+            if (pa[2] > 0)
+                printf("persistent GEMM, workgroup 0 over %lld tiles (%lld half-stages): k loop %.2f us per tile (%.3f us per half-stage), epilogue %.2f us per tile\n",
+                       pa[2], pa[3], pa[0] / 100.0 / pa[2], pa[0] / 100.0 / pa[3], pa[1] / 100.0 / pa[2]);
+            if (pa[2] > 0) printf("   of the epilogue: residue arithmetic %.2f us per tile\n", (pa[4] - pa[5]) / 100.0 / pa[2]);
         }
         auto med = [](std::vector<float> x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
         const double macs = (double)nmod * Mc256 * 256.0 * 256.0 * (Np256 / 256) * (Np256 / 256 + 1) / 2.0;
