@@ -265,6 +265,28 @@ __device__ __forceinline__ int oz_mod_pack4(int a0, int a1, int a2, int a3, doub
     return w;
 }
 
+// The same four residues in three VALU operations per accumulator instead of five (the persistent kernel's epilogue: its residue
+// arithmetic is issue-bound, two waves per SIMD taking turns — 4.7 of a tile's 52 µs with the matrix pipe idle): the product x·(1/p)
+// is rounded to the nearest integer by adding 1.5·2^52 inside the fma (one rounding instead of two, the same integer: x/p is at
+// least 1/(2p) away from a half-integer for odd p), the quotient is then the low dword of the sum's mantissa as it stands — no
+// v_rndne, no conversion back —, and r = x − q·p is one v_mad_i32_i24 (|q| ≤ 2^30/199 < 2^23 for every row count the engine takes).
+// p = 256: ties round to even in both forms.  Same residues, bit for bit.
+__device__ __forceinline__ int oz_mod_pack4_mad(int a0, int a1, int a2, int a3, double invp, int p) {
+    const int v[4] = {a0, a1, a2, a3};
+    int r[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const double t = __builtin_fma((double)v[b], invp, 6755399441055744.0);
+        const int q = __double2loint(t);
+        // (as asm: from C the compiler picks the quarter-rate v_mul_lo_u32)
+        asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r[b]) : "v"(q), "s"(-p), "v"(v[b]));
+    }
+    // the four low bytes into one dword: three v_perm_b32 (selector bytes 0-3: second source, 4-7: first source)
+    const unsigned lo = __builtin_amdgcn_perm((unsigned)r[1], (unsigned)r[0], 0x0c0c0400u);
+    const unsigned hi = __builtin_amdgcn_perm((unsigned)r[3], (unsigned)r[2], 0x0c0c0400u);
+    return (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 // the tile's residues, transposed in LDS (Ut [256 rows i][OZ_UROW]), leave as 256-byte row segments of U[l][i][j]
 __device__ __forceinline__ void oz_store_tile(const OzGemmArgs& a, const char* Ut, int l, int ti, int tj) {
     const int tid = threadIdx.x;
@@ -697,6 +719,9 @@ __device__ __forceinline__ void oz16d_step_k(char* lds, const OzDmaCtx& c, int k
     OzFragA& An = A[SLOT & 1];
     const OzFragA& Ao = A[(SLOT & 1) ^ 1];
     constexpr int NS = (SLOT + 3) & 3;
+#ifdef OZ_EXP_SAMEK
+    k = 0;                                             // timing-only build: every fetch hits the same (cached) plane block
+#endif
     // the previous half-stage's held-back unit (Ao × By, columns 4-7) with this half-stage's A and B0-3 fragments arriving
     An.a[0] = *reinterpret_cast<const v4i_t*>(pa);
     An.a[1] = *reinterpret_cast<const v4i_t*>(pa + 16 * OZ_HS);
@@ -841,7 +866,7 @@ __device__ __forceinline__ void oz16p_ctx(const OzGemmArgs& a, int ti, int tj, i
 
 // tools/oz_dev.hip defines OZ_PROBE: workgroup 0 sums the 100 MHz clock over its k loops and its epilogues
 #ifdef OZ_PROBE
-__device__ long long oz_probe_acc[8];
+__device__ long long oz_probe_acc[16];
 #define OZ_PROBE_T(v) const long long v = wall_clock64()
 #define OZ_PROBE_ADD(i, d) do { if (blockIdx.x == 0 && threadIdx.x == 0) oz_probe_acc[i] += (d); } while (0)
 #else
@@ -852,7 +877,8 @@ __device__ long long oz_probe_acc[8];
 template <class Take>
 __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3, v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
                                                int lane, int tid, int* pick, Take take, int ticket) {
-    const double invp = a.invp[l], pd = (double)a.p[l];
+    const double invp = a.invp[l];
+    const int pm = a.p[l];
     // the epilogue's lane constants are recomputed per tile from the lane id (v_mbcnt) and the wave's scalar coordinates: kept across
     // the tile loop they would sit in registers the k-loop has none to spare for (and were spilled to scratch)
     lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -860,7 +886,7 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
 #pragma unroll
     for (int m = 0; m < 4; ++m)          // the four residues of an accumulator quad, packed, take the place of its first register
 #pragma unroll
-        for (int nn = 0; nn < 8; ++nn) acc[m][nn][0] = oz_mod_pack4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pd);
+        for (int nn = 0; nn < 8; ++nn) acc[m][nn][0] = oz_mod_pack4_mad(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pm);
     // (pinned here: left alone the compiler sinks the residue arithmetic into the passes below, behind the wait for the ticket)
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -868,10 +894,6 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
         for (int nn = 0; nn < 8; ++nn) asm volatile("" : "+v"(acc[m][nn][0]));
     OZ_PROBE_T(pe1);
     OZ_PROBE_ADD(4, pe1);                              // (probe build: Σ of the clock behind the residue arithmetic)
-    if (pick && tid == 0) {                            // thread 0: the tile after next (the ticket's answer has arrived meanwhile)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
-        pick[0] = take(ticket);
-    }
     int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
     const int r15 = lane & 15;
     // a thread's two 16-byte pieces of a pass: rows tid/16 and tid/16 + 32 (same rotation: the rows are 32 apart), chunk tid%16
@@ -891,6 +913,9 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
                     const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
                     *reinterpret_cast<int*>(buf + r * 256 + ((jl + 16 * r15) & 255)) = acc[m][4 * (P & 1) + q][0];
                 }
+        } else if (P == 0 && pick && tid == 256) {  // wave 4 is idle in this pass: the tile after next (the ticket's answer is back)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+            pick[0] = take(ticket);
         }
         if (P > 0) {                                // rows of pass P−1 leave as 256-byte segments of U[l][i][·]
             const char* buf = slot3 + ((P - 1) & 1) * 16384;
@@ -905,6 +930,9 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef OZ_PROBE
+        { OZ_PROBE_T(pp); OZ_PROBE_ADD(8 + P, pp); }
+#endif
     }
 }
 
@@ -915,17 +943,39 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
 // leaves CUs idle there).  An exhausted list sends its workgroups to the next XCD's list, so every tile is taken whatever the
 // XCD numbering of the partition mode.  The index of the tile after next is fetched one tile ahead, behind the epilogue's
 // residue arithmetic, and handed to the other waves through LDS.
-__device__ __forceinline__ int oz16p_take(const OzGemmArgs& a, int* ctr, int x, int per_group, int per_list, int q) {
-    // q: a ticket already drawn from list x (or per_list: none)
-    const int cpx = per_group >> 3;
+// x / d and x % d for 0 ≤ x < 2^23, 0 < d < 2^23 without the integer-division expansion (one thread decodes a ticket per tile: the
+// seven divisions of the plain decode were 0.7 µs in front of a workgroup barrier): fp32 estimate, one correction step each way
+__device__ __forceinline__ void oz_divmod(int x, int d, float rd, int& q, int& r) {
+    q = (int)((float)x * rd);
+    r = x - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+}
+
+// ticket q of list y → the tile (ti, tj, l) packed as ti | tj << 9 | l << 20, or −1 for a padding block: the same map as
+// oz_decode_blk for the block (q / cpx)·per_group + (q % cpx)·8 + y
+__device__ __forceinline__ int oz16p_decode_ticket(const OzGemmArgs& a, int q, int y) {
+    const int cpx = a.tjg >> 1, cols_x = a.tjg >> 3;           // per_group / 8, column blocks per XCD patch
+    const int ngi = (a.Ti + 3) / 4;
+    int grp, c, t, gg, gh, gl, ro, cc;
+    oz_divmod(q, cpx, 1.0f / (float)cpx, grp, c);
+    oz_divmod(grp, ngi, 1.0f / (float)ngi, t, gg);
+    oz_divmod(t, a.n, 1.0f / (float)a.n, gh, gl);
+    oz_divmod(c, cols_x, 1.0f / (float)cols_x, ro, cc);
+    const int ti = 4 * (ngi - 1 - gg) + ((grp & 1) ? 3 - ro : ro);
+    const int tj = gh * a.tjg + y * cols_x + cc;
+    return (ti < a.Ti && tj < a.Tj) ? (ti | (tj << 9) | (gl << 20)) : -1;
+}
+
+__device__ __forceinline__ int oz16p_take(const OzGemmArgs& a, int* ctr, int x, int per_list, int q) {
+    // q: a ticket already drawn from list x (or −1: none)
     for (int t = 0; t < 8; ++t) {
         const int y = (x + t) & 7;
         for (;;) {
             if (t > 0 || q < 0) q = __hip_atomic_fetch_add(ctr + y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (q >= per_list) break;
-            const int blk = (q / cpx) * per_group + (q % cpx) * 8 + y;
-            int ti, tj, l;
-            if (oz_decode_blk(a, blk, ti, tj, l)) return blk;
+            const int tile = oz16p_decode_ticket(a, q, y);
+            if (tile >= 0) return tile;
             q = -1;                                   // a padding block of the list: draw again
         }
         q = -1;
@@ -942,20 +992,19 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wj = wave & 3, wi = wave >> 2;
-    const int per_group = 4 * a.tjg, per_list = total >> 3;
+    const int per_list = total >> 3;
     const int x = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;      // hwreg(HW_REG_XCC_ID, 0, 4)
     if (tid == 0) {
-        const int b0 = oz16p_take(a, ctr, x, per_group, per_list, -1);
+        const int b0 = oz16p_take(a, ctr, x, per_list, -1);
         oz_pick[0] = b0;
-        oz_pick[1] = b0 < 0 ? -1 : oz16p_take(a, ctr, x, per_group, per_list, -1);
+        oz_pick[1] = b0 < 0 ? -1 : oz16p_take(a, ctr, x, per_list, -1);
     }
     __syncthreads();
-    int blk = __builtin_amdgcn_readfirstlane(oz_pick[0]);
+    const int cur = __builtin_amdgcn_readfirstlane(oz_pick[0]);
     int nb = __builtin_amdgcn_readfirstlane(oz_pick[1]);
     __syncthreads();
-    if (blk < 0) return;                              // uniform over the workgroup
-    int ti, tj, l;
-    (void)oz_decode_blk(a, blk, ti, tj, l);
+    if (cur < 0) return;                              // uniform over the workgroup
+    int ti = cur & 511, tj = (cur >> 9) & 2047, l = cur >> 20;
     OzDmaCtx c, cn;
     c.wave = wave;
     {
@@ -979,8 +1028,7 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
         const bool have = nb >= 0;                    // uniform over the workgroup
-        int ti2 = 0, tj2 = 0, l2 = 0;
-        if (have) (void)oz_decode_blk(a, nb, ti2, tj2, l2);
+        const int ti2 = nb & 511, tj2 = (nb >> 9) & 2047, l2 = nb >> 20;
         const int nh = 4 * (ti + 1);
         int k1, k2, k3;
         if (have) { oz16p_ctx(a, ti2, tj2, l2, c.wave, cn); k1 = 0; k2 = 16384; k3 = 32768; }
@@ -1016,20 +1064,20 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
         OZ_PROBE_T(pt1);
         OZ_PROBE_ADD(5, pt1);
         int ticket = per_list;
-        if (have && tid == 0) {
+        if (have && tid == 256) {                         // wave 4: it has no residues to write in the epilogue's first pass
             const int one = 1;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr + x), "v"(one) : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         oz16p_epilogue(a, oz_lds + 3 * OZ_SLOT, acc, l, ti, tj, wi, wj, lane, tid, have ? oz_pick : nullptr,
-                       [&](int q) { return oz16p_take(a, ctr, x, per_group, per_list, q); }, ticket);
+                       [&](int q) { return oz16p_take(a, ctr, x, per_list, q); }, ticket);
         // (the epilogue's closing barrier: nobody still reads slot 3, and oz_pick[0] is visible.  Nothing else is waited for here: the
         // last step's vmcnt(8) saw the next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two
         // newest half-stages are in flight" with this tile's stores in the count — they only make the first waits conservative)
         OZ_PROBE_T(pt2);
         OZ_PROBE_ADD(0, pt1 - pt0); OZ_PROBE_ADD(1, pt2 - pt1); OZ_PROBE_ADD(2, 1); OZ_PROBE_ADD(3, nh);
         if (!have) break;
-        blk = nb; ti = ti2; tj = tj2; l = l2;
+        ti = ti2; tj = tj2; l = l2;
         c.ab = cn.ab; c.bb = cn.bb;
         nb = __builtin_amdgcn_readfirstlane(oz_pick[0]);
     }

@@ -157,12 +157,13 @@ int main(int argc, char** argv) {
             if (rep >= reps / 2) { tq.push_back(a); tg.push_back(b); tc.push_back(c); tt.push_back(d); }
         }
         {
-            long long pa[8];
+            long long pa[16];
             CK(hipMemcpyFromSymbol(pa, HIP_SYMBOL(oz_probe_acc), sizeof(pa)));
             if (pa[2] > 0)
                 printf("persistent GEMM, workgroup 0 over %lld tiles (%lld half-stages): k loop %.2f us per tile (%.3f us per half-stage), epilogue %.2f us per tile\n",
                        pa[2], pa[3], pa[0] / 100.0 / pa[2], pa[0] / 100.0 / pa[3], pa[1] / 100.0 / pa[2]);
-            if (pa[2] > 0) printf("   of the epilogue: residue arithmetic %.2f us per tile\n", (pa[4] - pa[5]) / 100.0 / pa[2]);
+            if (pa[2] > 0) printf("   of the epilogue: residue arithmetic %.2f us per tile; to the barrier behind pass 0..4: %.2f %.2f %.2f %.2f %.2f us\n", (pa[4] - pa[5]) / 100.0 / pa[2],
+                                  (pa[8] - pa[4]) / 100.0 / pa[2], (pa[9] - pa[8]) / 100.0 / pa[2], (pa[10] - pa[9]) / 100.0 / pa[2], (pa[11] - pa[10]) / 100.0 / pa[2], (pa[12] - pa[11]) / 100.0 / pa[2]);
         }
         auto med = [](std::vector<float> x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
         const double macs = (double)nmod * Mc256 * 256.0 * 256.0 * (Np256 / 256) * (Np256 / 256 + 1) / 2.0;
