@@ -8,7 +8,7 @@ import hashlib, json, os, re, sys
 path, N, Mc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 INT8 = len(sys.argv) > 4 and sys.argv[4] == "int8"
 NMOD = int(sys.argv[5]) if INT8 else 0
-PREFIX, SRC = ("abo::oz_gemm16d", "ozaki.hip") if INT8 else ("abo::var_gemm", "gemm.hip")
+PREFIX, SRC = ("abo::oz_gemm16p", "ozaki.hip") if INT8 else ("abo::var_gemm", "gemm.hip")
 # every file the kernel is compiled from — the same lists as bench.py's PMC_SOURCES (its staleness guard compares the hash)
 SRCS = ["ozaki.hip", "abo_oz_dev.h", "abo_kernels.h"] if INT8 else ["gemm.hip", "abo_kernels.h"]
 blocks, cur = {}, None

@@ -15,4 +15,4 @@ run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 python3 tools/pmc_summary.py gpurun_out $TAG > gpurun_out/pmc_${TAG}_summary.txt
-grep -A22 "oz_gemm16d" gpurun_out/pmc_${TAG}_summary.txt | head -24
+grep -A22 "oz_gemm16p" gpurun_out/pmc_${TAG}_summary.txt | head -24
