@@ -218,8 +218,8 @@ def dominant_kernel_roofline(abo, med, config, N, M_per):
         tops = med["oz_gemm_ops"] / (med["oz_gemm_ms"] * 1e-3) / 1e12 if med["oz_gemm_ms"] > 0 else 0.0
         np256 = -(-N // 256) * 256
         return {
-            "kernel": f"oz_gemm16d_kernel (V = L^-1 K_XZ as {nmod} exact int8 residue GEMMs, v_mfma_i32_16x16x64_i8, "
-                      "triangular k-range, symmetric-mod epilogue)",
+            "kernel": f"oz_gemm16p_kernel (V = L^-1 K_XZ as {nmod} exact int8 residue GEMMs, v_mfma_i32_16x16x64_i8, persistent: one "
+                      "workgroup per CU draws 256x256 tiles from per-XCD lists, triangular k-range, symmetric-mod epilogue)",
             "bound": "mfma", "achieved": tops, "peak": PEAK_INT8_MFMA_TOPS, "unit": "TOP/s", "frac": tops / PEAK_INT8_MFMA_TOPS,
             "traffic": traffic,
             "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if traffic else None,
