@@ -874,9 +874,8 @@ __device__ long long oz_probe_acc[16];
 #define OZ_PROBE_ADD(i, d) do { } while (0)
 #endif
 
-template <class Take>
 __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3, v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
-                                               int lane, int tid, int* pick, Take take, int ticket) {
+                                               int lane, int tid) {
     const double invp = a.invp[l];
     const int pm = a.p[l];
     // the epilogue's lane constants are recomputed per tile from the lane id (v_mbcnt) and the wave's scalar coordinates: kept across
@@ -887,11 +886,6 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
     for (int m = 0; m < 4; ++m)          // the four residues of an accumulator quad, packed, take the place of its first register
 #pragma unroll
         for (int nn = 0; nn < 8; ++nn) acc[m][nn][0] = oz_mod_pack4_mad(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pm);
-    // (pinned here: left alone the compiler sinks the residue arithmetic into the passes below, behind the wait for the ticket)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 8; ++nn) asm volatile("" : "+v"(acc[m][nn][0]));
     OZ_PROBE_T(pe1);
     OZ_PROBE_ADD(4, pe1);                              // (probe build: Σ of the clock behind the residue arithmetic)
     int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
@@ -913,9 +907,6 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
                     const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
                     *reinterpret_cast<int*>(buf + r * 256 + ((jl + 16 * r15) & 255)) = acc[m][4 * (P & 1) + q][0];
                 }
-        } else if (P == 0 && pick && tid == 256) {  // wave 4 is idle in this pass: the tile after next (the ticket's answer is back)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
-            pick[0] = take(ticket);
         }
         if (P > 0) {                                // rows of pass P−1 leave as 256-byte segments of U[l][i][·]
             const char* buf = slot3 + ((P - 1) & 1) * 16384;
@@ -994,14 +985,9 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
     const int wj = wave & 3, wi = wave >> 2;
     const int per_list = total >> 3;
     const int x = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7;      // hwreg(HW_REG_XCC_ID, 0, 4)
-    if (tid == 0) {
-        const int b0 = oz16p_take(a, ctr, x, per_list, -1);
-        oz_pick[0] = b0;
-        oz_pick[1] = b0 < 0 ? -1 : oz16p_take(a, ctr, x, per_list, -1);
-    }
+    if (tid == 0) oz_pick[0] = oz16p_take(a, ctr, x, per_list, -1);
     __syncthreads();
     const int cur = __builtin_amdgcn_readfirstlane(oz_pick[0]);
-    int nb = __builtin_amdgcn_readfirstlane(oz_pick[1]);
     __syncthreads();
     if (cur < 0) return;                              // uniform over the workgroup
     int ti = cur & 511, tj = (cur >> 9) & 2047, l = cur >> 20;
@@ -1019,6 +1005,7 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
     const int ro = (lane & 15) * OZ_HS + (((lane >> 4) ^ ((lane >> 1) & 3)) * 16);
     const int ra = (64 * wj) * OZ_HS + ro;
     const int rb = OZ_T * OZ_HS + (128 * wi) * OZ_HS + ro;
+    const bool drawer = tid == 256;                   // lane 0 of wave 4 draws and decodes the tickets
 
     oz_dma_issue<0>(oz_lds, c, 0);
     oz_dma_issue<1>(oz_lds, c, 1);
@@ -1027,12 +1014,18 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     for (;;) {
-        const bool have = nb >= 0;                    // uniform over the workgroup
-        const int ti2 = nb & 511, tj2 = (nb >> 9) & 2047, l2 = nb >> 20;
         const int nh = 4 * (ti + 1);
-        int k1, k2, k3;
-        if (have) { oz16p_ctx(a, ti2, tj2, l2, c.wave, cn); k1 = 0; k2 = 16384; k3 = 32768; }
-        else { cn.ab = c.ab; cn.bb = c.bb; k1 = k2 = k3 = (nh - 1) * 16384; }      // no next tile: a harmless re-fetch of the last half-stage
+        // The ticket of the NEXT tile is drawn late — three loop iterations (12 half-stages, ~8 µs) before the diagonal steps that need
+        // it, or at the tile's start when the tile is shorter —, so that tiles start in the order of their tickets, as they do under
+        // the one-tile kernel's dispatch: drawn a whole tile ahead (first version) the tiles of a patch started up to a tile-length
+        // difference apart, the CUs of an XCD drifted in k, and the L2 hit rate fell from 75 % to 67 % (+33 % L2-miss traffic,
+        // tools/pmc_l2_ab.sh).  The atomic is issued by hand (the compiler's waits for its answer on the spot); nobody waits for it:
+        // vector memory operations return in order, so two steps' s_waitcnt vmcnt(8) later it has come back.
+        const int hdraw = nh >= 20 ? nh - 20 : 0;    // drawn here …
+        const int hcons = nh >= 12 ? nh - 8 : -1;     // … decoded and published at the top of the last loop iteration (≥ 4 steps later)
+        int ticket = per_list;
+        const int one = 1;
+        if (drawer && hdraw == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr + x), "v"(one) : "memory");
 
         OZ_PROBE_T(pt0);
         v4i_t acc[4][8];
@@ -1047,39 +1040,53 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
 
         int hb = 0;
         for (; hb < nh - 4; hb += 4) {
+            if (drawer) {
+                if (hb == hdraw && hb != 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr + x), "v"(one) : "memory");
+                if (hb == hcons) {                    // the ticket's answer: decoded, and handed to the other waves through the LDS word
+                    asm volatile("" : "+v"(ticket));
+                    oz_pick[0] = oz16p_take(a, ctr, x, per_list, ticket);
+                }
+            }
             oz16d_step_k<0, false>(oz_lds, c, (hb + 3) * 16384, ra, rb, A, Bx, By, acc);
             oz16d_step_k<1, false>(oz_lds, c, (hb + 4) * 16384, ra, rb, A, Bx, By, acc);
             oz16d_step_k<2, false>(oz_lds, c, (hb + 5) * 16384, ra, rb, A, Bx, By, acc);
             oz16d_step_k<3, false>(oz_lds, c, (hb + 6) * 16384, ra, rb, A, Bx, By, acc);
         }
+        if (hcons < 0) {                              // a one- or two-block tile: nothing (or too little) has been waited for since the draw
+            if (drawer) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+                oz_pick[0] = oz16p_take(a, ctr, x, per_list, ticket);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        // the word has been behind at least one of the steps' barriers: read before the first diagonal step, used behind it
+        int nbv;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(nbv) : "v"((unsigned)(size_t)(oz_lds_ptr)oz_pick) : "memory");
         oz16d_step_k<0, true>(oz_lds, c, (hb + 3) * 16384, ra, rb, A, Bx, By, acc, 0, wi);      // the diagonal block; hb + 3 = nh − 1
+        asm volatile("" : "+v"(nbv));                 // (that step's closing lgkmcnt(0) has seen the read come back)
+        const int nb = __builtin_amdgcn_readfirstlane(nbv);
+        const bool have = nb >= 0;                    // uniform over the workgroup
+        const int ti2 = nb & 511, tj2 = (nb >> 9) & 2047, l2 = nb >> 20;
+        int k1, k2, k3;
+        if (have) { oz16p_ctx(a, ti2, tj2, l2, c.wave, cn); k1 = 0; k2 = 16384; k3 = 32768; }
+        else { cn.ab = c.ab; cn.bb = c.bb; k1 = k2 = k3 = (nh - 1) * 16384; }      // no next tile: a harmless re-fetch of the last half-stage
         oz16d_step_k<1, true>(oz_lds, cn, k1, ra, rb, A, Bx, By, acc, 1, wi);                   // … fetching the next tile's first half-stages
         oz16d_step_k<2, true>(oz_lds, cn, k2, ra, rb, A, Bx, By, acc, 2, wi);
         oz16d_step_k<3, true>(oz_lds, cn, k3, ra, rb, A, Bx, By, acc, 3, wi);
         if (wi != 0) oz16_mma(A[1], By, 1, acc);          // the held-back unit of the last half-stage (slot 3 → A[1]); zeros for wave row 0
-        // the step's closing barrier: every wave has its fragments of slot 3 in registers — the slot is free for the residues.
-        // The ticket for the tile after next is drawn now and looked at behind the residue arithmetic.
-        // (issued as written, by hand: the compiler's atomic waits for the answer on the spot — a round trip to L2 with seven waves
-        // at the barrier; the epilogue waits for it behind its arithmetic, with the ticket as the wait's operand)
+        // the step's closing barrier: every wave has its fragments of slot 3 in registers — the slot is free for the residues
         OZ_PROBE_T(pt1);
         OZ_PROBE_ADD(5, pt1);
-        int ticket = per_list;
-        if (have && tid == 256) {                         // wave 4: it has no residues to write in the epilogue's first pass
-            const int one = 1;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(ctr + x), "v"(one) : "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        oz16p_epilogue(a, oz_lds + 3 * OZ_SLOT, acc, l, ti, tj, wi, wj, lane, tid, have ? oz_pick : nullptr,
-                       [&](int q) { return oz16p_take(a, ctr, x, per_list, q); }, ticket);
-        // (the epilogue's closing barrier: nobody still reads slot 3, and oz_pick[0] is visible.  Nothing else is waited for here: the
-        // last step's vmcnt(8) saw the next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two
-        // newest half-stages are in flight" with this tile's stores in the count — they only make the first waits conservative)
+        oz16p_epilogue(a, oz_lds + 3 * OZ_SLOT, acc, l, ti, tj, wi, wj, lane, tid);
+        // (the epilogue's closing barrier: nobody still reads slot 3.  Nothing else is waited for here: the last step's vmcnt(8) saw
+        // the next tile's half-stage 0 land, and the steps' vmcnt(8) keeps meaning "at most the two newest half-stages are in
+        // flight" with this tile's stores in the count — they only make the first waits conservative)
         OZ_PROBE_T(pt2);
         OZ_PROBE_ADD(0, pt1 - pt0); OZ_PROBE_ADD(1, pt2 - pt1); OZ_PROBE_ADD(2, 1); OZ_PROBE_ADD(3, nh);
         if (!have) break;
         ti = ti2; tj = tj2; l = l2;
         c.ab = cn.ab; c.bb = cn.bb;
-        nb = __builtin_amdgcn_readfirstlane(oz_pick[0]);
     }
 }
 
