@@ -850,9 +850,8 @@ __global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
 }
 
 // ---- the same GEMM as a PERSISTENT kernel -------------------------------------------------------------------------------------------------
-// One workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, … of the launch's tile list (gridDim.x a multiple of the
-// group size: a workgroup keeps its place in the XCD patch, and the alternating row-block order of the groups gives every workgroup
-// the same total k).  What a tile cost beyond its MFMAs in the one-tile-per-workgroup kernel — the dispatch of a 128 KB-LDS
+// One workgroup per CU stays resident and works through tiles of the launch's tile list (dealt out dynamically, below).  What a
+// tile cost beyond its MFMAs in the one-tile-per-workgroup kernel — the dispatch of a 128 KB-LDS
 // workgroup onto the CU that just drained, three half-stages of DMA latency before the first MFMA, the wait for the tail's
 // re-fetches before the epilogue may overlay the ring — was about 7 of 54 µs at N = 8192 and half of the tile at N = 1024, with
 // nothing else resident on the CU to hide it.  Here the last three steps of a tile fetch the first three half-stages of the NEXT
@@ -932,8 +931,9 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
 // (HW_REG_XCC_ID) with one atomic increment — the 32 CUs of an XCD so work through consecutive entries, i.e. through a 4 × (tjg/8)
 // patch at a time, whatever the launch's shape (row blocks not a multiple of four, ragged last column group: a static split
 // leaves CUs idle there).  An exhausted list sends its workgroups to the next XCD's list, so every tile is taken whatever the
-// XCD numbering of the partition mode.  The index of the tile after next is fetched one tile ahead, behind the epilogue's
-// residue arithmetic, and handed to the other waves through LDS.
+// XCD numbering of the partition mode.  The next tile's ticket is drawn inside the k loop, late (see the kernel), decoded by the
+// drawing lane and handed to the other waves through one LDS word.
+
 // x / d and x % d for 0 ≤ x < 2^23, 0 < d < 2^23 without the integer-division expansion (one thread decodes a ticket per tile: the
 // seven divisions of the plain decode were 0.7 µs in front of a workgroup barrier): fp32 estimate, one correction step each way
 __device__ __forceinline__ void oz_divmod(int x, int d, float rd, int& q, int& r) {
@@ -975,7 +975,7 @@ __device__ __forceinline__ int oz16p_take(const OzGemmArgs& a, int* ctr, int x, 
 }
 
 __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total, int* ctr) {
-    // ONE LDS object (the ring, and two words behind it for the tile indices): with a second __shared__ variable the compiler
+    // ONE LDS object (the ring, and a word behind it for the next tile): with a second __shared__ variable the compiler
     // starts to order every ds_read behind every LDS-DMA piece in flight (s_waitcnt vmcnt(0) before each fragment read: measured
     // 2× slower) — with a single object it leaves that ordering to the counted waits of the steps
     __shared__ __attribute__((aligned(1024))) char oz_lds[4 * OZ_SLOT + 16];
