@@ -12,7 +12,7 @@ constexpr int MAX_P = 33; // outputs per point of a gradient-enhanced GP (f + d 
 inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
 // ---- fp64 MFMA GEMM family (gemm.hip) -------------------------------------------------------
-enum KMode { K_FULL = 0, K_A_LOWER = 1, K_A_UPPER = 2 };
+enum KMode { K_FULL = 0, K_A_LOWER = 1, K_A_UPPER = 2, K_B_LOWER = 3 };
 
 struct GemmArgs {
     const double* A;      // [M][lda]   row-major, k contiguous
@@ -22,7 +22,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, ldct;
     int64_t sA, sB, sC, sCt;   // batch strides (elements)
     int M, N, K;          // M, N multiples of 128; K multiple of 16
-    int kmode;            // K_FULL; K_A_LOWER: k < (ti+1)·128; K_A_UPPER: k ≥ ti·128
+    int kmode;            // K_FULL; K_A_LOWER: k < (ti+1)·128; K_A_UPPER: k ≥ ti·128; K_B_LOWER: k < (tj+1)·128 (B lower-triangular)
     int lower_only;       // 1: skip tiles with tj > ti (SYRK on the lower triangle)
     int batch;
     double alpha, beta;

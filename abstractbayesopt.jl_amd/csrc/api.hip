@@ -1410,7 +1410,7 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
             GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
             a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
             a.C = g->partial.as<double>(); a.ldc = Np; a.M = rows; a.N = (int)Np; a.K = (int)Np;
-            a.kmode = K_FULL; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
+            a.kmode = K_B_LOWER; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;       // W[i][k] = 0 for k > i: half the product
             HIPCHK(launch_gemm_nt(a, s));
         }
         GradCovArgs ca{};

@@ -196,12 +196,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     // heaviest tiles first: with K_A_LOWER the k range of a tile grows with its row block, so the row blocks are
     // dealt out from the bottom up (the light tiles then fill the tail of the launch instead of the heavy ones forming it);
     // K_A_UPPER already starts with its longest rows
-    const int tj = blockIdx.x, bz = blockIdx.z;
+    // (K_B_LOWER: B is the lower-triangular operand — the column blocks are dealt out from the right for the same reason)
+    const int tj = p.kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, bz = blockIdx.z;
     const int ti = p.kmode == K_A_LOWER ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
     if (p.lower_only && tj > ti) return;
     int kbeg = 0, kend = p.K;
     if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
     if (p.kmode == K_A_UPPER) kbeg = min(p.K, ti * BM);
+    if (p.kmode == K_B_LOWER) kend = min(p.K, (tj + 1) * BN);
     const double* Ag = p.A + (int64_t)bz * p.sA + (int64_t)ti * BM * p.lda;
     const double* Bg = p.B + (int64_t)bz * p.sB + (int64_t)tj * BN * p.ldb;
     d4_t acc[4][4];
@@ -244,6 +246,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmArgs p) {
     int kbeg = 0, kend = p.K;
     if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
     if (p.kmode == K_A_UPPER) kbeg = min(p.K, ti * BM);
+    if (p.kmode == K_B_LOWER) kend = min(p.K, (tj + 1) * BN);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, g = lane >> 4;
