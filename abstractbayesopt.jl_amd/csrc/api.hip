@@ -166,12 +166,43 @@ struct DevBuf {
 };
 
 // stream + events of a handle, recycled the same way (hipStreamCreate / ~400 hipEventCreate per step otherwise)
+// pin: a small page-locked host block that lives with the context.  A device-to-host copy of a few bytes into PAGEABLE memory blocks
+// the host until it has happened (12 – 14 µs each on this runtime, tools/memcpy_probe.hip; 2.5 – 3.7 µs and asynchronous into
+// pinned memory) — four of them were a quarter of a BO step at the reference's own sizes.  The fit's scalars and the selected
+// (score, index) pairs land here and are copied on by the host after the call's one synchronisation.
+constexpr size_t PIN_BYTES = 32768, PIN_OUT = 64;      // [0,16) fit scalars, [16,24) info, [PIN_OUT, …) selected pairs
 struct ExecCtx {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;
+    char* pin = nullptr;
 };
 std::mutex g_ctx_mu;
 std::vector<ExecCtx*> g_ctx_free[16];
+
+// the small read-backs of ONE call: each goes into the context's pinned block (asynchronously) while it fits, straight to its
+// destination otherwise; flush() — behind the call's stream synchronisation — copies the staged ones on
+struct PinStage {
+    ExecCtx* c;
+    size_t off = PIN_OUT;
+    struct Item { void* dst; size_t off, n; } it[8];
+    int n = 0;
+    explicit PinStage(ExecCtx* ctx) : c(ctx) {}
+    hipError_t d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
+        if (bytes == 0) return hipSuccess;
+        const size_t a = (bytes + 15) & ~(size_t)15;
+        if (c && c->pin && n < 8 && off + a <= PIN_BYTES) {
+            it[n++] = Item{dst, off, bytes};
+            const hipError_t e = hipMemcpyAsync(c->pin + off, src, bytes, hipMemcpyDeviceToHost, s);
+            off += a;
+            return e;
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+    }
+    void flush() {
+        for (int i = 0; i < n; ++i) memcpy(it[i].dst, c->pin + it[i].off, it[i].n);
+        n = 0;
+    }
+};
 
 // padded coordinate count: 1, 2, 4, 8, 16, 32 (register-resident kernels), beyond that a multiple of 32 (slab kernels)
 int dp_for(int d) {
@@ -275,8 +306,10 @@ struct abo_gp {
     // host landing zone of the fit's scalars ({log det, δᵀα} and the LAPACK-style info): read back by one asynchronous copy at
     // the end of the fit's launches and looked at after the NEXT stream synchronisation — the fit's own (abo_fit) or, for
     // abo_fit_acq, the one behind the acquisition launches that were queued right behind the fit
-    double h_sc[2] = {0.0, 0.0};
-    int64_t h_info = 0;
+    double h_sc_[2] = {0.0, 0.0};      // (fallback landing zone when the context has no pinned block)
+    int64_t h_info_ = 0;
+    double* h_sc() { return ctx && ctx->pin ? reinterpret_cast<double*>(ctx->pin) : h_sc_; }
+    int64_t& h_info() { return ctx && ctx->pin ? *reinterpret_cast<int64_t*>(ctx->pin + 16) : h_info_; }
     bool fit_small_path = false;
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
@@ -389,8 +422,8 @@ bool phase_events() {
 
 // the scalars and phase timings of a finished fit (h_sc / h_info have landed: the stream has been synchronised since)
 void fit_collect(abo_gp* g) {
-    g->logdet = g->h_sc[0];
-    g->quad = g->h_sc[1];
+    g->logdet = g->h_sc()[0];
+    g->quad = g->h_sc()[1];
     g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
     if (!phase_events()) {
         g->tm.fit_kernel_matrix_ms = g->tm.fit_cholesky_ms = g->tm.fit_inverse_ms = g->tm.fit_alpha_ms = 0.0;
@@ -567,12 +600,12 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     HIPCHK(launch_nlml_terms(K, ld, st->delta.as<double>(), g->alpha.as<double>(), N, g->scal.as<double>(), s));
     HIPCHK(hipEventRecord(g->evs()[4], s));
     g->fit_small_path = false;
-    HIPCHK(hipMemcpyAsync(g->h_sc, g->scal.as<double>(), sizeof g->h_sc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&g->h_info, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(g->h_sc(), g->scal.as<double>(), 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&g->h_info(), info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (!info_host) return ABO_OK;        // deferred: fit_collect() after the caller's synchronisation
     HIPCHK(hipStreamSynchronize(s));
-    *info_host = g->h_info;
-    if (g->h_info == 0) fit_collect(g);   // else the caller decides (retry with jitter or ENOTPD)
+    *info_host = g->h_info();
+    if (g->h_info() == 0) fit_collect(g);   // else the caller decides (retry with jitter or ENOTPD)
     return ABO_OK;
 }
 
@@ -593,12 +626,12 @@ int32_t fit_small(abo_gp* g, double noise, int64_t* info_host) {
     PHASE_EVENT(g->evs()[2], s);
     HIPCHK(hipEventRecord(g->evs()[4], s));
     g->fit_small_path = true;
-    HIPCHK(hipMemcpyAsync(g->h_sc, g->scal.as<double>(), sizeof g->h_sc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&g->h_info, info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(g->h_sc(), g->scal.as<double>(), 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&g->h_info(), info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (!info_host) return ABO_OK;        // deferred: fit_collect() after the caller's synchronisation
     HIPCHK(hipStreamSynchronize(s));
-    *info_host = g->h_info;
-    if (g->h_info == 0) fit_collect(g);
+    *info_host = g->h_info();
+    if (g->h_info() == 0) fit_collect(g);
     return ABO_OK;
 }
 
@@ -1021,9 +1054,11 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     HIPCHK(launch_append(aa, s));
     double sc[4];
     int64_t inf = 0;
-    HIPCHK(hipMemcpyAsync(sc, n->scal.p, sizeof sc, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&inf, n->info.p, sizeof inf, hipMemcpyDeviceToHost, s));
+    PinStage pin(g->ctx);
+    HIPCHK(pin.d2h(sc, n->scal.p, sizeof sc, s));
+    HIPCHK(pin.d2h(&inf, n->info.p, sizeof inf, s));
     HIPCHK(hipStreamSynchronize(s));
+    pin.flush();
     if (inf != 0) {
         if (info) *info = inf;
         return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
@@ -1106,9 +1141,11 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
     }
     double sc[4 * MAX_P];
     int64_t inf = 0;
-    HIPCHK(hipMemcpyAsync(sc, n->scal.p, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&inf, n->info.p, sizeof inf, hipMemcpyDeviceToHost, s));
+    PinStage pin(g->ctx);
+    HIPCHK(pin.d2h(sc, n->scal.p, sizeof(double) * 4 * P, s));
+    HIPCHK(pin.d2h(&inf, n->info.p, sizeof inf, s));
     HIPCHK(hipStreamSynchronize(s));
+    pin.flush();
     if (inf != 0) {
         if (info) *info = inf;
         return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
@@ -1173,6 +1210,9 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
         if (!g->ctx) { delete g; return fail(ABO_ENOMEM, "abo_create: host allocation failed"); }
         e = hipStreamCreateWithFlags(&g->ctx->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete g->ctx; delete g; return fail(ABO_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        void* pin = nullptr;                               // optional: without it the small read-backs go to pageable memory as before
+        if (hipHostMalloc(&pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess) g->ctx->pin = static_cast<char*>(pin);
+        else (void)hipGetLastError();
     }
     g->stream = g->ctx->stream;
     e = g->events(8);
@@ -1448,6 +1488,7 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
     double* sc_d = nullptr;
+    PinStage pin(g->ctx);
     if (M > 0) {
         const double* Zd = nullptr;
         rc = stage_candidates(g, Z, M, z_space, &Zd);
@@ -1491,8 +1532,8 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
         }
         HIPCHK(launch_topk(sc_d, M, k, idx_base, w, tv, ti, s));
         if (top_space == ABO_HOST) {
-            rc = copy_out(top_val, tv, sizeof(double) * k, ABO_HOST, s); if (rc) return rc;
-            rc = copy_out(top_idx, ti, sizeof(int64_t) * k, ABO_HOST, s); if (rc) return rc;
+            HIPCHK(pin.d2h(top_val, tv, sizeof(double) * k, s));             // through the pinned block, copied on after the sync
+            HIPCHK(pin.d2h(top_idx, ti, sizeof(int64_t) * k, s));
         }
     }
     HIPCHK(hipEventRecord(g->evs()[7], s));
@@ -1501,6 +1542,7 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
+    pin.flush();
     if (M > 0) collect_posterior_timings(g, M, kind != ABO_ACQ_MEAN);
     g->tm.acq_topk_ms = phase_events() ? ev_ms(g->evs()[6], g->evs()[7]) : 0.0;
     g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[7]);
@@ -1510,12 +1552,12 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
 namespace {
 // after the synchronisation that followed a deferred fit: the verdict on the factorisation
 int32_t fit_finish(abo_gp* g, int64_t* info) {
-    if (g->h_info != 0) {
+    if (g->h_info() != 0) {
         if (g->st && g->fitted) g->st->drop_view(g->N);
         g->fitted = false;
-        if (info) *info = g->h_info;
+        if (info) *info = g->h_info();
         return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
-                    (long long)g->h_info);
+                    (long long)g->h_info());
     }
     fit_collect(g);
     return ABO_OK;
@@ -1950,10 +1992,12 @@ int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const doub
     if (rc) return rc;
     HIPCHK(hipEventRecord(g->evs()[6], s));
     std::vector<int> it(2 * (size_t)S);
-    HIPCHK(hipMemcpyAsync(x_out, xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(f_out, fd, sizeof(double) * S, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(it.data(), id, sizeof(int) * 2 * S, hipMemcpyDeviceToHost, s));
+    PinStage pin(g->ctx);
+    HIPCHK(pin.d2h(x_out, xd, sizeof(double) * ns, s));
+    HIPCHK(pin.d2h(f_out, fd, sizeof(double) * S, s));
+    HIPCHK(pin.d2h(it.data(), id, sizeof(int) * 2 * S, s));
     HIPCHK(hipStreamSynchronize(s));
+    pin.flush();
     g->tm.refine_ms = ev_ms(g->evs()[5], g->evs()[6]);
     g->tm.refine_starts = S;
     g->tm.refine_evals = 0;
@@ -2022,12 +2066,14 @@ int32_t abo_optimize_acquisition(abo_gp* g, int32_t kind, double p0, double best
     HIPCHK(hipEventRecord(g->evs()[9], s));
     std::vector<double> hs(ns), hv(k), hx(ns), hf(k);
     std::vector<int> it(2 * (size_t)k);
-    HIPCHK(hipMemcpyAsync(hs.data(), sd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hv.data(), tv, sizeof(double) * k, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hx.data(), xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hf.data(), fd, sizeof(double) * k, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(it.data(), id, sizeof(int) * 2 * k, hipMemcpyDeviceToHost, s));
+    PinStage pin(g->ctx);
+    HIPCHK(pin.d2h(hs.data(), sd, sizeof(double) * ns, s));
+    HIPCHK(pin.d2h(hv.data(), tv, sizeof(double) * k, s));
+    HIPCHK(pin.d2h(hx.data(), xd, sizeof(double) * ns, s));
+    HIPCHK(pin.d2h(hf.data(), fd, sizeof(double) * k, s));
+    HIPCHK(pin.d2h(it.data(), id, sizeof(int) * 2 * k, s));
     HIPCHK(hipStreamSynchronize(s));
+    pin.flush();
     g->tm.acq_total_ms = grid_ms;
     g->tm.refine_ms = ev_ms(g->evs()[8], g->evs()[9]);
     g->tm.refine_starts = k;
@@ -2105,10 +2151,12 @@ int32_t abo_cand_point(abo_gp* g, abo_cand* c, int64_t idx, double* x, double* m
     if (idx < 0 || idx >= c->M) return fail(ABO_EINVAL, "abo_cand_point: index %lld outside 0..%lld", (long long)idx, (long long)c->M - 1);
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
-    if (x) HIPCHK(hipMemcpyAsync(x, c->Z.as<double>() + idx * c->d, sizeof(double) * c->d, hipMemcpyDeviceToHost, s));
-    if (mu) HIPCHK(hipMemcpyAsync(mu, c->mu.as<double>() + idx, sizeof(double), hipMemcpyDeviceToHost, s));
-    if (var) HIPCHK(hipMemcpyAsync(var, c->var.as<double>() + idx, sizeof(double), hipMemcpyDeviceToHost, s));
+    PinStage pin(g->ctx);
+    if (x) HIPCHK(pin.d2h(x, c->Z.as<double>() + idx * c->d, sizeof(double) * c->d, s));
+    if (mu) HIPCHK(pin.d2h(mu, c->mu.as<double>() + idx, sizeof(double), s));
+    if (var) HIPCHK(pin.d2h(var, c->var.as<double>() + idx, sizeof(double), s));
     HIPCHK(hipStreamSynchronize(s));
+    pin.flush();
     return ABO_OK;
 }
 
