@@ -1211,7 +1211,8 @@ int32_t abo_create(const abo_params* params, abo_gp** out) {
         e = hipStreamCreateWithFlags(&g->ctx->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete g->ctx; delete g; return fail(ABO_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         void* pin = nullptr;                               // optional: without it the small read-backs go to pageable memory as before
-        if (hipHostMalloc(&pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess) g->ctx->pin = static_cast<char*>(pin);
+        static const bool no_pin = getenv("ABO_NO_PINNED") != nullptr;         // A/B and the test of the fallback
+        if (!no_pin && hipHostMalloc(&pin, PIN_BYTES, hipHostMallocDefault) == hipSuccess) g->ctx->pin = static_cast<char*>(pin);
         else (void)hipGetLastError();
     }
     g->stream = g->ctx->stream;

@@ -222,3 +222,31 @@ def test_small_batch_topk_single_launch_radix_select():
             np.testing.assert_array_equal(ti[:kk], oi[:kk])
             np.testing.assert_array_equal(tv[:kk], ov[:kk])
             assert np.all(ti[kk:] == -1) and np.all(np.isnan(tv[kk:]))
+
+
+def test_small_read_backs_through_pinned_memory_equal_the_direct_copies():
+    """The fit's scalars, the selected (score, index) pairs, an append's scalars and a refinement's results land in a pinned block of
+    the handle's context and are copied on behind the call's synchronisation; ABO_NO_PINNED=1 (read once per process: a child
+    process) takes the direct copies into the caller's arrays instead.  Same bits either way."""
+    import hashlib, os, subprocess, sys
+    code = (
+        "import hashlib, sys, numpy as np\n"
+        "sys.path.insert(0, '.')\n"
+        "import importlib; abo = importlib.import_module('abstractbayesopt.jl_amd')\n"
+        "from abstractbayesopt.jl_amd import synth\n"
+        "X, y = synth.standardized_problem(60, 2, 0.05)\n"
+        "Z = synth.points(2, 5000, 2)\n"
+        "m = abo.update(abo.HipStandardGP(1.0 * abo.with_lengthscale(abo.Matern52Kernel(), 0.6), 1e-3, n_max=64), X[:59], y[:59])\n"
+        "_, tv, ti = abo.evaluate(abo.ExpectedImprovement(0.01, float(y.min())), m, Z, k=100, return_scores=False)\n"
+        "m2 = abo.append(m, X[59], y[59])\n"
+        "_, tv2, ti2 = abo.evaluate(abo.UpperConfidenceBound(2.0), m2, Z, k=37, return_scores=False)\n"
+        "h = hashlib.sha256()\n"
+        "for a in (tv, ti, tv2, ti2, np.array([abo.nlml_fitted(m), abo.nlml_fitted(m2)])): h.update(np.ascontiguousarray(a).tobytes())\n"
+        "print(h.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for extra in ({}, {"ABO_NO_PINNED": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([ln for ln in r.stdout.split() if len(ln) == 64][-1])
+    assert out[0] == out[1]
