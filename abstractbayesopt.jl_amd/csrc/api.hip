@@ -414,9 +414,12 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 // brackets of the posterior — are profiling instrumentation: each costs a host call and a marker packet between two kernels,
 // ≈ 40 of them per BO step, which at the reference's own sizes (a step of 0.2 ms) is a fifth of the step.  ABO_PHASE_EVENTS=0
 // leaves them out (the phase fields of abo_timings then read 0, the totals stay); default on.
+// ABO_PHASE_EVENTS: 1 = always, 0 = never, unset = automatic — on, except while the calling thread works on a model of one row block
+// (N ≤ 128: the reference's own loops, where the step is 0.2 ms and the instrumentation a fifth of it).
+thread_local int64_t tl_phase_np = (int64_t)1 << 40;     // padded factor rows of the handle the current call works on
 bool phase_events() {
-    static const bool on = [] { const char* e = getenv("ABO_PHASE_EVENTS"); return !(e && e[0] == '0'); }();
-    return on;
+    static const int mode = [] { const char* e = getenv("ABO_PHASE_EVENTS"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    return mode < 0 ? tl_phase_np > TB : mode == 1;
 }
 #define PHASE_EVENT(ev, s) do { if (phase_events()) HIPCHK(hipEventRecord((ev), (s))); } while (0)
 
@@ -871,6 +874,7 @@ void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
 
 int32_t check_fitted(abo_gp* g, int32_t d) {
     if (!g) return fail(ABO_EINVAL, "null handle");
+    tl_phase_np = g->Np;                             // (every posterior / acquisition entry point passes here first)
     if (!g->fitted) return fail(ABO_EINVAL, "surrogate is not conditioned on data yet (call abo_fit first)");
     if (d != g->d) return fail(ABO_EDIM, "DimensionMismatch: candidate dimension %d, model dimension %d", d, g->d);
     return ABO_OK;
@@ -926,6 +930,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     g->st = st;
     g->npts = N; g->N = R; g->d = d; g->dp = st->dp; g->Np = pad_up(R, TB);
     const int64_t Np = g->Np;
+    tl_phase_np = Np;
     HIPCHK(g->alpha.ensure(sizeof(double) * cap));
     HIPCHK(g->tvec.ensure(sizeof(double) * cap));
     HIPCHK(g->T.ensure(sizeof(double) * Np * Np));

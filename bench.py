@@ -303,7 +303,7 @@ def quick_c1_shape(abo, synth, torch, dev, local_rank, k_top=100, steps=200, war
         out[name] = (time.perf_counter() - t0) * 1e3 / steps
     t = model.timings()
     out["device_ms"] = {"fit": t["fit_total_ms"], "acq": t["acq_total_ms"]}
-    out["phase_events"] = os.environ.get("ABO_PHASE_EVENTS", "1") != "0"
+    out["phase_events"] = {"1": "on (ABO_PHASE_EVENTS=1)"}.get(os.environ.get("ABO_PHASE_EVENTS", ""), "automatic: off for a one-block model (N <= 128)")
     # optimize_acquisition in one call at the reference's stock sizes (n_grid = 10 000, n_local = 100)
     N2, d2 = 100, 2
     X2 = synth.points(1, N2, d2)
@@ -645,9 +645,11 @@ def main():
                     help="collective backend; gloo + --share-device rehearses the N>1 path on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use GPU 0 (rehearsal only)")
     args = ap.parse_args()
-    # the roofline figures of this line come from the library's per-kernel HIP events: they stay on here whatever the caller's
-    # environment says (ABO_PHASE_EVENTS=0 is the production setting of a small-N loop, tools/small_n_latency.py measures both)
-    os.environ["ABO_PHASE_EVENTS"] = "1"
+    # the roofline figures of this line come from the library's per-kernel HIP events: ABO_PHASE_EVENTS=0 in the caller's environment
+    # would blank them, so it is dropped here.  Unset, the library records them for every model of more than one row block (C2 / C3 /
+    # C5) and leaves them out for the one-block models of the C1-shaped leg, where they are a fifth of a step (its entry says so).
+    if os.environ.get("ABO_PHASE_EVENTS") == "0":
+        del os.environ["ABO_PHASE_EVENTS"]
 
     if plan_launch(args, os.environ) == "library":
         return run_single_process(args)

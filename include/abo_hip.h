@@ -89,7 +89,10 @@ typedef struct abo_params {
 } abo_params;
 
 /* phase timings of the last fit / acq call, milliseconds, measured with HIP events on the
- * handle's own stream (see abo_get_timings) */
+ * handle's own stream (see abo_get_timings).  The *_total_ms fields are always measured; the phase fields inside a call
+ * (kernel matrix / Cholesky / ..., kxz / var_gemm / finalize / topk, the oz_* fields) are instrumentation: recorded for every
+ * model of more than one 128-row block, left out (they read 0) for a one-block model — N <= 128, the reference's own loops,
+ * where ~40 event records are a fifth of a 0.2 ms step.  ABO_PHASE_EVENTS=1 records them always, =0 never. */
 typedef struct abo_timings {
     double fit_kernel_matrix_ms, fit_cholesky_ms, fit_inverse_ms, fit_alpha_ms, fit_total_ms;
     double acq_kxz_ms, acq_var_gemm_ms, acq_finalize_ms, acq_topk_ms, acq_total_ms;

@@ -292,7 +292,7 @@ static int run_latency(void) {
         }
         printf("latency %s: %.4f ms per step (N=%d, d=1, M=%d, EI, top-%d; host arrays, %d steps; ABO_PHASE_EVENTS=%s)\n",
                fused ? "abo_fit_acq" : "abo_fit + abo_acq", (now_ms() - t0) / STEPS, N, M, K, STEPS,
-               getenv("ABO_PHASE_EVENTS") ? getenv("ABO_PHASE_EVENTS") : "1");
+               getenv("ABO_PHASE_EVENTS") ? getenv("ABO_PHASE_EVENTS") : "automatic");
     }
     return failures ? 1 : 0;
 }
