@@ -16,8 +16,8 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
-           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad"]
-ABI_VERSION = 4
+           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get"]
+ABI_VERSION = 5
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
 
@@ -137,6 +137,7 @@ def lib():
     L.abo_mgpu_cand_refresh.argtypes = [vp, vp]
     L.abo_mgpu_cand_destroy.argtypes = [vp]
     L.abo_mgpu_cand_acq.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp]
+    L.abo_mgpu_cand_get.argtypes = [vp, vp, vp, vp]
     L.abo_mgpu_cand_qei.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp, vp]
     L.abo_refine.argtypes = [vp, i32, f64, f64, vp, vp, i32, vp, i32, C.POINTER(AboRefineOpts), vp, vp, vp]
     L.abo_optimize_acquisition.argtypes = [vp, i32, f64, f64, vp, vp, i32, i64, i32, C.c_uint64, C.POINTER(AboRefineOpts),

@@ -1275,7 +1275,8 @@ int32_t abo_destroy(abo_gp* gp) {
     if (gp->refs.fetch_sub(1) == 1) {
         hipError_t e = hipSetDevice(gp->prm.device);
         if (e == hipSuccess && gp->stream) e = hipStreamSynchronize(gp->stream);
-        if (abo::gone(e)) { g_exiting.store(true); return ABO_OK; }
+        if (abo::gone(e)) { g_exiting.store(true); return ABO_OK; }      // the runtime says it has been torn down: the process is exiting
+        // any other error of these two calls concerns this handle only: its buffers still go back to the pool, nothing is latched
         (void)hipGetLastError();
         gp->free_all();
         delete gp;
@@ -1894,9 +1895,11 @@ struct RefineOpts { int max_iter, ls_max, history; double g_tol, f_abstol, x_abs
 RefineOpts refine_defaults(const abo_refine_opts* o) {
     RefineOpts r{100, 20, 10, 1e-5, 2.2e-9, 1e-4};        // acq_utils.jl:10, :62; Optim's LBFGS keeps m = 10 pairs
     if (o) {
-        if (o->max_iter > 0) r.max_iter = o->max_iter;
-        if (o->linesearch_max > 0) r.ls_max = o->linesearch_max;
-        if (o->history > 0) r.history = o->history;
+        // clamped: "no limit" spelled as INT32_MAX must not overflow the round budget max_iter × linesearch_max (refine.hip) nor
+        // size the curvature-pair storage
+        if (o->max_iter > 0) r.max_iter = o->max_iter < 10000 ? o->max_iter : 10000;
+        if (o->linesearch_max > 0) r.ls_max = o->linesearch_max < 64 ? o->linesearch_max : 64;
+        if (o->history > 0) r.history = o->history < 64 ? o->history : 64;
         if (o->g_tol > 0.0) r.g_tol = o->g_tol;
         if (o->f_abstol > 0.0) r.f_abstol = o->f_abstol;
         if (o->x_abstol > 0.0) r.x_abstol = o->x_abstol;
@@ -2102,9 +2105,9 @@ void abo::arm_exit_guard() {
     if (!g_exit_armed.exchange(true)) std::atexit(exit_hook);
 }
 void abo::at_exit(void (*f)()) { std::lock_guard<std::mutex> lk(g_exit_mu); g_exit_hooks.push_back(f); }
-bool abo::gone(hipError_t e) {
-    return e == hipErrorDeinitialized || e == hipErrorContextIsDestroyed || e == hipErrorNotInitialized || e == hipErrorInvalidContext;
-}
+// only the two codes the runtime reserves for "torn down": hipErrorNotInitialized / hipErrorInvalidContext can be spurious mid-run
+// errors of one call, and latching the process-wide flag on those would turn every later destroy into a leak
+bool abo::gone(hipError_t e) { return e == hipErrorDeinitialized || e == hipErrorContextIsDestroyed; }
 
 // internal accessors for the multi-device driver (mgpu.hip)
 hipStream_t abo::gp_stream(abo_gp* g) { return g->stream; }

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -51,6 +52,7 @@ struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;        // why it is not available
@@ -70,10 +72,11 @@ const Rccl& rccl() {
         if (!x.handle) { x.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?"); return x; }
         x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(x.handle, "ncclCommInitAll"));
         x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+        x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(dlsym(x.handle, "ncclCommAbort"));
         x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
-        if (!x.CommInitAll || !x.CommDestroy || !x.AllGather || !x.GetErrorString) {
-            x.why = "librccl.so.1 lacks ncclCommInitAll / ncclAllGather";
+        if (!x.CommInitAll || !x.CommDestroy || !x.CommAbort || !x.AllGather || !x.GetErrorString) {
+            x.why = "librccl.so.1 lacks ncclCommInitAll / ncclCommAbort / ncclAllGather";
             x.handle = nullptr;
         }
         return x;
@@ -181,13 +184,25 @@ struct CommSet {
     size_t pack_cap[MAXDEV] = {0}, gath_cap[MAXDEV] = {0};
     std::mutex mu;                      // one exchange at a time per device list
     Worker* wk[MAXDEV] = {nullptr};     // the list's worker threads, one per shard (more than one shard only)
-    // another device list of this process names one of these devices too: collectives of the two lists are then serialised
-    // process-wide (two communicators enqueueing on one device from different threads can wait for each other forever);
-    // disjoint lists never take that lock
-    std::atomic<bool> overlaps{false};
+    std::vector<int> lock_order;        // the list's distinct devices, ascending: the order their collective locks are taken in
+    bool rccl_ever = false;             // a communicator set existed (abo_mgpu_info's text after a fall-back)
 };
 
-std::mutex g_overlap_mu;                // the process-wide collective lock of overlapping device lists
+// One collective lock per DEVICE: an exchange holds the locks of every device of its list (taken in ascending device order, so
+// two lists can never wait for each other).  Two communicators enqueueing on one device from different threads can wait for
+// each other forever; lists that share no device share no lock and run their collectives side by side.  (Round 3 kept a
+// per-list `overlaps` flag sampled at entry: an exchange already running on list A without the lock could interleave with the
+// first collective of a newly created overlapping list B.)
+constexpr int MAXDEVID = 64;
+std::mutex g_dev_mu[MAXDEVID];
+
+struct DeviceLocks {
+    const std::vector<int>& order;
+    explicit DeviceLocks(const std::vector<int>& o) : order(o) { for (int dv : order) g_dev_mu[dv & (MAXDEVID - 1)].lock(); }
+    ~DeviceLocks() { for (auto it = order.rbegin(); it != order.rend(); ++it) g_dev_mu[*it & (MAXDEVID - 1)].unlock(); }
+    DeviceLocks(const DeviceLocks&) = delete;
+    DeviceLocks& operator=(const DeviceLocks&) = delete;
+};
 
 CommSet* comm_set(const int* dev, int ndev) {
     static std::mutex mu;
@@ -211,16 +226,14 @@ CommSet* comm_set(const int* dev, int ndev) {
     else if (!rccl().handle) cs->why = rccl().why;
     else {
         const ncclResult_t r = rccl().CommInitAll(cs->comm, ndev, dev);
-        if (r == ncclSuccess) cs->rccl_ok = true;
+        if (r == ncclSuccess) cs->rccl_ok = cs->rccl_ever = true;
         else cs->why = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
         (void)hipGetLastError();
     }
     if (ndev > 1) for (int i = 0; i < ndev; ++i) cs->wk[i] = new_worker();
-    for (auto& kv : sets) {
-        bool shared = false;
-        for (int a : kv.second->dev) for (int b : cs->dev) shared = shared || a == b;
-        if (shared && kv.second->dev != cs->dev) { kv.second->overlaps.store(true); cs->overlaps.store(true); }
-    }
+    cs->lock_order.assign(dev, dev + ndev);
+    std::sort(cs->lock_order.begin(), cs->lock_order.end());
+    cs->lock_order.erase(std::unique(cs->lock_order.begin(), cs->lock_order.end()), cs->lock_order.end());
     sets[key] = cs;
     return cs;
 }
@@ -300,29 +313,59 @@ int32_t check_group(abo_mgpu* mg, const char* fn) {
     return ABO_OK;
 }
 
-// All shards hold k pairs (k values + k indices) in cs->pack[i] on their device.  RCCL: one all-gather per shard, shard 0
-// copies the gathered block to the host.  Host: every shard copies its own block.  out: ndev blocks of `words` 8-byte words.
-int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
-    CommSet* cs = mg->cs;
-    const int n = mg->ndev;
-    // the caller holds cs->mu (one exchange at a time per device list); lists that share a device with another list
-    // additionally serialise process-wide, disjoint lists do not
-    std::unique_lock<std::mutex> xlk(g_overlap_mu, std::defer_lock);
-    if (cs->overlaps.load()) xlk.lock();
-    if (cs->rccl_ok) {
-        int32_t rc = run_all(cs->wk, n, [&](int i) -> int32_t {
-            if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
-            hipStream_t s = abo::gp_stream(mg->gp[i]);
-            const ncclResult_t r = rccl().AllGather(cs->pack[i], cs->gath[i], words, ncclUint64, cs->comm[i], s);
-            if (r != ncclSuccess) return failf(ABO_EHIP, "ncclAllGather: %s", rccl().GetErrorString(r));
-            if (i == 0 && hipMemcpyAsync(out, cs->gath[0], n * words * 8, hipMemcpyDeviceToHost, s) != hipSuccess)
-                return failf(ABO_EHIP, "exchange: device-to-host copy failed");
-            if (hipStreamSynchronize(s) != hipSuccess) return failf(ABO_EHIP, "exchange: stream synchronisation failed");
-            return ABO_OK;
-        });
-        return rc;
+// ---- fault injection (test hook, tests/test_gpu_multigpu.py): ABO_MGPU_FAULT = "<where>:<shard>" -------------------------------
+//   ready:<i>       shard i reports "not ready" in the vote that precedes the collective
+//   collective:<i>  shard i passes the vote and then fails BEFORE enqueueing its all-gather (the other ranks' all-gathers would wait
+//                   for it forever: the case the abort path exists for)
+//   stall:<i>       shard i passes the vote and enqueues, in place of its all-gather, a kernel that waits for a peer that never
+//                   arrives (bounded: it gives up by itself after 20 s) — a collective that does not complete
+// read per exchange, so a test can set and clear it around one call
+struct Fault { int where = 0, shard = -1; };      // where: 1 ready, 2 collective, 3 stall
+Fault fault_from_env() {
+    Fault f;
+    const char* e = getenv("ABO_MGPU_FAULT");
+    if (!e || !*e) return f;
+    const char* c = strchr(e, ':');
+    if (!c) return f;
+    const size_t n = (size_t)(c - e);
+    if (n == 5 && !strncmp(e, "ready", 5)) f.where = 1;
+    else if (n == 10 && !strncmp(e, "collective", 10)) f.where = 2;
+    else if (n == 5 && !strncmp(e, "stall", 5)) f.where = 3;
+    f.shard = atoi(c + 1);
+    return f;
+}
+
+// the stand-in for an all-gather whose peer never enqueues: spins on a device word until it is set, or for at most `limit`
+// ticks of the 100 MHz wall clock — every wave reaches the exit either way
+__global__ void stall_kernel(const int* release, long long limit) {
+    const long long t0 = wall_clock64();
+    while (__atomic_load_n(release, __ATOMIC_RELAXED) == 0 && wall_clock64() - t0 < limit) __builtin_amdgcn_s_sleep(64);
+}
+
+long exchange_timeout_ms() {
+    const char* e = getenv("ABO_MGPU_TIMEOUT_MS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 60000;      // the collective moves 16·k bytes per device behind work that has already been waited for
+}
+
+// wait for everything queued on s, giving up when `abort` is raised by another shard or the deadline passes (then raises it).
+// 0 = completed, 1 = aborted / timed out, −1 = the stream reports an error
+int wait_stream_bounded(hipStream_t s, std::atomic<int>& abort, std::chrono::steady_clock::time_point deadline) {
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return -1; }
+        if (abort.load(std::memory_order_acquire)) return 1;
+        if (std::chrono::steady_clock::now() > deadline) { abort.store(2, std::memory_order_release); return 1; }
+        if (spin < 4000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
-    return run_all(cs->wk, n, [&](int i) -> int32_t {
+}
+
+// host exchange: every shard copies its own block
+int32_t exchange_host(abo_mgpu* mg, size_t words, uint64_t* out) {
+    CommSet* cs = mg->cs;
+    return run_all(cs->wk, mg->ndev, [&](int i) -> int32_t {
         if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "hipSetDevice(%d) failed", mg->dev[i]);
         hipStream_t s = abo::gp_stream(mg->gp[i]);
         if (hipMemcpyAsync(out + (size_t)i * words, cs->pack[i], words * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -330,6 +373,99 @@ int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
             return failf(ABO_EHIP, "exchange: device-to-host copy failed");
         return ABO_OK;
     });
+}
+
+// All shards hold k pairs (k values + k indices) in cs->pack[i] on their device.  out: ndev blocks of `words` 8-byte words.
+// RCCL, in three steps none of which can leave a thread blocked in a collective its peers never entered:
+//   1. vote      every shard answers "ready?" through run_all (device selectable, communicator and buffers present, its stream
+//                healthy).  One "no" and nobody enqueues anything: the status goes back to the caller.
+//   2. gather    every shard enqueues its ncclAllGather (shard 0 also the copy of the gathered block to the host) and then WAITS
+//                WITH A BOUND: it polls its stream, a shared abort word and a deadline (ABO_MGPU_TIMEOUT_MS, default 60 s).  A
+//                shard that fails after the vote raises the abort word; every shard that sees it (or the deadline) calls
+//                ncclCommAbort on its own communicator — which makes a collective kernel waiting for a missing peer exit — and
+//                returns.
+//   3. fall-back after an abort the device list's communicators are gone for the rest of the process (abo_mgpu_info says so and
+//                why) and THIS exchange, like all later ones, is done through the host: the blocks in cs->pack are untouched by
+//                a failed all-gather, so the call still returns the merged selection if the shards themselves are healthy.
+// Host exchange (no RCCL, a device listed twice, ABO_MGPU_EXCHANGE=host, or after a fall-back): every shard copies its own block.
+int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
+    CommSet* cs = mg->cs;
+    const int n = mg->ndev;
+    // the caller holds cs->mu (one exchange at a time per device list); the per-device collective locks order this list's
+    // collectives against those of every other list that names one of its devices
+    DeviceLocks dl(cs->lock_order);
+    if (!cs->rccl_ok) return exchange_host(mg, words, out);
+    const Fault fault = fault_from_env();
+    // 1. vote
+    int32_t rc = run_all(cs->wk, n, [&](int i) -> int32_t {
+        if (fault.where == 1 && fault.shard == i) return failf(ABO_EHIP, "exchange: shard %d is not ready (injected: ABO_MGPU_FAULT)", i);
+        if (hipSetDevice(mg->dev[i]) != hipSuccess) return failf(ABO_EHIP, "exchange: shard %d is not ready: hipSetDevice(%d) failed", i, mg->dev[i]);
+        if (!cs->comm[i] || !cs->pack[i] || !cs->gath[i] || cs->pack_cap[i] < words * 8 || cs->gath_cap[i] < (size_t)n * words * 8)
+            return failf(ABO_EHIP, "exchange: shard %d is not ready: communicator or exchange buffers missing", i);
+        const hipError_t q = hipStreamQuery(abo::gp_stream(mg->gp[i]));
+        if (q != hipSuccess && q != hipErrorNotReady) {
+            (void)hipGetLastError();
+            return failf(ABO_EHIP, "exchange: shard %d is not ready: its stream reports %s", i, hipGetErrorString(q));
+        }
+        return ABO_OK;
+    });
+    if (rc) return rc;                       // nothing was enqueued anywhere
+    // 2. gather, bounded
+    std::atomic<int> abort{0};               // 1 = a shard failed after the vote, 2 = deadline
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(exchange_timeout_ms());
+    int* stall_word = nullptr;
+    std::string first_fault;
+    std::mutex fmu;
+    auto give_up = [&](int i, const char* what) {
+        abort.store(1, std::memory_order_release);
+        std::lock_guard<std::mutex> lk(fmu);
+        if (first_fault.empty()) { char b[256]; snprintf(b, sizeof b, "shard %d: %s", i, what); first_fault = b; }
+    };
+    rc = run_all(cs->wk, n, [&](int i) -> int32_t {
+        hipStream_t s = abo::gp_stream(mg->gp[i]);
+        bool enqueued = false;
+        if (hipSetDevice(mg->dev[i]) != hipSuccess) give_up(i, "hipSetDevice failed after the vote");
+        else if (fault.where == 2 && fault.shard == i) give_up(i, "failed before its all-gather (injected: ABO_MGPU_FAULT)");
+        else if (fault.where == 3 && fault.shard == i) {
+            if (hipMalloc(reinterpret_cast<void**>(&stall_word), sizeof(int)) == hipSuccess && hipMemsetAsync(stall_word, 0, sizeof(int), s) == hipSuccess) {
+                hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, s, stall_word, 20ll * 100000000ll);
+                enqueued = true;
+            } else give_up(i, "stall injection could not allocate");
+        } else {
+            const ncclResult_t r = rccl().AllGather(cs->pack[i], cs->gath[i], words, ncclUint64, cs->comm[i], s);
+            if (r != ncclSuccess) give_up(i, rccl().GetErrorString(r));
+            else if (i == 0 && hipMemcpyAsync(out, cs->gath[0], n * words * 8, hipMemcpyDeviceToHost, s) != hipSuccess)
+                give_up(i, "device-to-host copy of the gathered block failed");
+            else enqueued = true;
+        }
+        int w = enqueued ? wait_stream_bounded(s, abort, deadline) : 1;
+        if (w == 0) return ABO_OK;
+        if (w < 0) give_up(i, "its stream reported an error during the collective");
+        // aborted, timed out or failed: take this shard's communicator down so that whatever it has in flight exits
+        if (cs->comm[i]) { (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
+        if (stall_word && fault.shard == i) {        // release the stand-in kernel (on a stream of its own: s is busy with it)
+            const int one = 1;
+            hipStream_t t = nullptr;
+            if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) == hipSuccess) {
+                (void)hipMemcpyAsync(stall_word, &one, sizeof one, hipMemcpyHostToDevice, t);
+                (void)hipStreamSynchronize(t);
+                (void)hipStreamDestroy(t);
+            }
+        }
+        (void)hipStreamSynchronize(s);       // returns: the collective kernel exits on the abort, the stand-in on its word or its clock
+        (void)hipGetLastError();
+        return failf(ABO_EHIP, "exchange: collective aborted");
+    });
+    if (stall_word) { (void)hipFree(stall_word); stall_word = nullptr; }
+    if (!rc) return ABO_OK;
+    // 3. fall-back: no thread is inside RCCL any more; the set's remaining communicators go too
+    for (int i = 0; i < n; ++i)
+        if (cs->comm[i]) { (void)hipSetDevice(mg->dev[i]); (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
+    (void)hipGetLastError();
+    cs->rccl_ok = false;
+    cs->why = std::string(abort.load() == 2 ? "RCCL exchange timed out" : "RCCL exchange aborted") +
+              (first_fault.empty() ? "" : " (" + first_fault + ")") + ": communicators released, host exchange from now on";
+    return exchange_host(mg, words, out);
 }
 
 int32_t ensure_exchange_buffers(abo_mgpu* mg, int i, size_t words) {
@@ -676,6 +812,16 @@ int32_t abo_mgpu_cand_refresh(abo_mgpu* mg, abo_mcand* mc) {
     if (rc) return rc;
     if (!mc || mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_cand_refresh: candidate set does not belong to this group");
     return run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t { return abo_cand_refresh(mg->gp[i], mc->c[i]); });
+}
+
+int32_t abo_mgpu_cand_get(abo_mgpu* mg, abo_mcand* mc, double* mu, double* var) {
+    int32_t rc = check_group(mg, "abo_mgpu_cand_get");
+    if (rc) return rc;
+    if (!mc || mc->ndev != mg->ndev) return failf(ABO_EINVAL, "abo_mgpu_cand_get: candidate set does not belong to this group");
+    return run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
+        if (mc->lo[i + 1] == mc->lo[i]) return ABO_OK;
+        return abo_cand_get(mg->gp[i], mc->c[i], mu ? mu + mc->lo[i] : nullptr, var ? var + mc->lo[i] : nullptr, ABO_HOST);
+    });
 }
 
 int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, double best_y, int32_t k, double* top_val,

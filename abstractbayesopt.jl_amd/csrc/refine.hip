@@ -591,6 +591,18 @@ __global__ void rl_step_kernel(RefineArgs a, int S, int first, double* __restric
     for (int c = 0; c < d; ++c) cand[c] = fmin(fmax(fma(s.tstep, p[c], x[c]), a.lower[c]), a.upper[c]);
 }
 
+// starts still active when the host stops issuing rounds: their current iterate is the result
+__global__ void rl_flush_kernel(RefineArgs a, int S, int* __restrict__ active, const double* __restrict__ vec, RlState* __restrict__ st) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S || !active[j]) return;
+    const double* x = vec + (size_t)j * rl_vec_doubles(a.d, a.history);
+    for (int c = 0; c < a.d; ++c) a.x_out[(size_t)j * a.d + c] = x[c];
+    a.f_out[j] = st[j].phase == 0 ? __longlong_as_double(0x7ff8000000000000ll) : st[j].f;      // never evaluated: NaN
+    if (a.iters_out) { a.iters_out[2 * j] = st[j].it; a.iters_out[2 * j + 1] = st[j].nev; }
+    active[j] = 0;
+    st[j].phase = 2;
+}
+
 size_t refine_lockstep_bytes(int S, int Np, int d, int history) {
     const size_t Sp = (size_t)pad_up(S, 128);
     return sizeof(double) * (Sp * d + 5 * Sp * (size_t)Np + Sp * (d + 1) + (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S +
@@ -618,9 +630,12 @@ hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStr
     if ((e = hipMemsetAsync(active, 0, sizeof(int) * Sp, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(P, 0, sizeof(double) * (size_t)Sp * d, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 1, P, active, EV, vec, st, counters);
-    const int max_rounds = 1 + a.max_iter * a.ls_max;      // every loop of the one-launch kernel is bounded by the same product
+    // every loop of the one-launch kernel is bounded by the same product (64-bit: the caller's limits are clamped in
+    // api.hip: refine_defaults, but the product of two ints is not an int)
+    const int64_t max_rounds = 1 + (int64_t)a.max_iter * (int64_t)a.ls_max;
     const size_t lds = sizeof(double) * ((size_t)a.dp + RW * 2 * RCH + 2 * RCH);
-    for (int r = 0; r < max_rounds; ++r) {
+    long long left = -1;
+    for (int64_t r = 0; r < max_rounds; ++r) {
         dim3 kg((Np + 255) / 256, Sp);
         switch (a.family) {
             case ABO_KERNEL_SE: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_SE>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
@@ -640,12 +655,14 @@ hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStr
         hipLaunchKernelGGL(rl_reduce_kernel, dim3(S), dim3(RT), lds, s, a, P, active, KX, GV, V, U, EV);
         hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 0, P, active, EV, vec, st, counters);
         if ((r & 7) == 7 || r + 1 == max_rounds) {
-            long long left = 0;
             if ((e = hipMemcpyAsync(&left, counters, sizeof left, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
             if (left == 0) break;
         }
     }
+    // a start still active here has used up the round budget (cannot happen while every start stops after max_iter accepted steps of
+    // ≤ ls_max trials each, but the outputs must never be left unwritten): publish its current iterate
+    if (left != 0) hipLaunchKernelGGL(rl_flush_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, active, vec, st);
     return hipGetLastError();
 }
 

@@ -231,6 +231,12 @@ class ShardedCandidates:
                                                 tv.ctypes.data, ti.ctypes.data))
         return tv, ti
 
+    def mean_and_var(self, model: HipShardedGP):
+        """the stored posterior of all M candidates, in their global order"""
+        mu, var = np.empty(self.M), np.empty(self.M)
+        _lib.check(_lib.lib().abo_mgpu_cand_get(model._require_group(), self._h.ptr, mu.ctypes.data, var.ctypes.data))
+        return mu, var
+
     def greedy_qei(self, model: HipShardedGP, q: int, xi: float, best_y: float, distinct: bool = False):
         """Greedy (Kriging-believer) q-EI inside the library: (points (q, d), global indices, EI values); the model and
         the stored posterior are unchanged on return."""

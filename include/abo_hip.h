@@ -27,10 +27,13 @@
 extern "C" {
 #endif
 
-#define ABO_ABI_VERSION 4   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
+#define ABO_ABI_VERSION 5   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
                                3: abo_set_contraction, abo_timings grew (contraction engine and its phases)
                                4: abo_refine, abo_optimize_acquisition, abo_mgpu_optimize_acquisition, abo_fit_acq, abo_mgpu_create_grad,
-                                  abo_mgpu_append_grad; abo_timings grew (refinement stage) */
+                                  abo_mgpu_append_grad; abo_timings grew (refinement stage)
+                               5: abo_mgpu_cand_get; abo_acq_lhs (the grid stage on a single handle); weighted-sum objectives and
+                                  gradient-enhanced handles in the refinement stage (abo_acq_term, abo_refine_terms,
+                                  abo_optimize_acquisition_terms, abo_mgpu_optimize_acquisition_terms, ABO_ACQ_GRADNORM_UCB) */
 
 /* status codes */
 enum {
@@ -375,6 +378,9 @@ int32_t abo_mgpu_cand_refresh(abo_mgpu* mg, abo_mcand* mc);
 int32_t abo_mgpu_cand_destroy(abo_mcand* mc);
 int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, double best_y, int32_t k, double* top_val,
                           int64_t* top_idx);
+/* the stored posterior of the whole sharded set in the candidates' global order (abo_cand_get shard by shard; mu / var: M host
+ * doubles each, either may be NULL) */
+int32_t abo_mgpu_cand_get(abo_mgpu* mg, abo_mcand* mc, double* mu, double* var);
 int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, double best_y, int32_t distinct, double* x_out,
                           int64_t* idx_out, double* ei_out);
 

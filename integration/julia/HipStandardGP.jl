@@ -23,7 +23,7 @@
 # abstractbayesopt.jl_amd/, which is this binding written with ctypes.
 
 const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
-const ABO_ABI = Int32(4)                 # ABO_ABI_VERSION of the header this file was written against
+const ABO_ABI = Int32(5)                 # ABO_ABI_VERSION of the header this file was written against
 const _abi_checked = Ref(false)
 # a stale libabo_hip.so on the load path would otherwise fail at the first missing symbol, somewhere inside a BO step
 function _ensure_abi()

@@ -184,6 +184,129 @@ def test_eight_shards_config4_shape_at_reduced_size():
     np.testing.assert_array_equal(tv3, ov)
 
 
+def test_full_size_c4_eight_shards_on_one_device():
+    """BASELINE config 4 at ITS OWN size through the 8-shard path (d = 8 Matérn-5/2, N = 8192, M = 8 388 608 = 8 × 2²⁰, EI,
+    top-100; acq_utils.jl:50-52 reproduced globally): eight shards of the in-library multi-device handle, all on the one GPU
+    of the test box (host exchange; > 1 RCCL rank needs more devices), against ONE handle scoring all 2²³ candidates — merged
+    top-100 and every score bit for bit — and a 3 × 768 slice (first / a middle / the last shard) against an independent
+    oracle refit (host LAPACK; shared with test_full_size_parity_c3 through tests.test_gpu_parity.c3_oracle)."""
+    from tests.parity_record import check
+    from tests.test_gpu_parity import c3_oracle
+    N, d, M, k = 8192, 8, 1 << 23, 100
+    ell, sf2, noise = 1.0, 1.0, 1e-3
+    X, y, st = c3_oracle()
+    Z = synth.points(2, M, d)                                    # the first 2²⁰ rows are config 3's candidates
+    best = float(y.min())
+    acq = abo.ExpectedImprovement(0.01, best)
+    one = abo.update(make_model(O.MATERN52, ell, sf2, noise), X, y)
+    s1, tv1, ti1 = abo.evaluate(acq, one, Z, k=k)
+    t = one.timings()
+    assert t["contraction_engine"] == abo._lib.CONTRACT_INT8 and t["oz_nmod"] == 14, t
+    del one
+    grp = abo.update(sharded(O.MATERN52, ell, sf2, noise, (0,) * 8), X, y)
+    assert grp.exchange() == "host" and "listed twice" in grp.exchange_note()
+    s8, tv8, ti8 = abo.evaluate(acq, grp, Z, k=k)
+    for i in range(8):                                           # every shard ran the engine the metric is quoted on
+        tt = abo._lib.AboTimings()
+        abo._lib.check(abo._lib.lib().abo_get_timings(grp.shard(i), tt))
+        assert tt.contraction_engine == abo._lib.CONTRACT_INT8 and tt.oz_nmod == 14
+    np.testing.assert_array_equal(ti8, ti1)
+    np.testing.assert_array_equal(tv8, tv1)
+    np.testing.assert_array_equal(s8, s1)
+    ov, oi = O.top_k(s8, k)                                      # the stable reverse sort of the scores themselves
+    np.testing.assert_array_equal(ti8, oi)
+    np.testing.assert_array_equal(tv8, ov)
+    assert len(set(int(i) >> 20 for i in ti8)) > 1               # the winners come from more than one shard
+    # selection only, no scores back (the benchmarked shape)
+    _, tv9, ti9 = abo.evaluate(acq, grp, Z, k=k, return_scores=False)
+    np.testing.assert_array_equal(ti9, ti1)
+    np.testing.assert_array_equal(tv9, tv1)
+    sl = np.concatenate([np.arange(0, 768), np.arange(M // 2 - 384, M // 2 + 384), np.arange(M - 768, M)])
+    mu_o, var_o = O.predict(st, Z[sl])
+    ei_o = O.expected_improvement(mu_o, var_o, best, 0.01)
+    case = "c4/N8192_d8_M8388608_8shards"
+    check(case, "ei_abs", np.max(np.abs(s8[sl] - ei_o)), 1e-9)
+    mu8, var8 = abo.mean_and_var(grp, Z[sl])
+    check(case, "mu", np.max(np.abs(mu8 - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
+    check(case, "var", np.max(np.abs(var8 - var_o)) / sf2, 1e-8)
+
+
+def test_full_size_c5_sharded_greedy_qei(monkeypatch):
+    """BASELINE config 5 across shards at its own size: d = 16, N = 16384, noisy, a resident grid of 131 072 candidates PER
+    SHARD, greedy q-EI with q = 8 (per pick: EI + arg-max per shard, one exchange of the shards' pick records, the same
+    fantasy append + O(N·M) down-date on every shard), then the real observation appended with the grid's down-date.  Four
+    shards share the one GPU of the test box (eight would need 8 × (17 GB K_ZX + 6 GB factor + 15 GB int8 scratch) > 288 GB);
+    the reference is ONE handle over all 524 288 candidates: same picks, same EI values, same grid posterior, bit for bit."""
+    monkeypatch.setenv("ABO_CAND_KZX_GIB", "80")                 # the single handle's K_ZX (69 GB) stays resident like the shards'
+    d, N, G, q = 16, 16384, 4, 8
+    M = G * 131072
+    ell, sf2, noise = 2.0, 1.0, 1e-2
+    X = synth.points(1, N, d)
+    y = synth.objective(X, 0.1)
+    y = (y - y.mean()) / y.std(ddof=1)
+    Z = synth.points(2, M, d)
+    best = float(y.min())
+    one = abo.update(make_model(O.MATERN52, ell, sf2, noise, n_max=N + 64), X, y)
+    c1 = abo.ResidentCandidates(one, Z)
+    c1.save()
+    pts1, idx1, val1, mq = abo.greedy_qei(one, c1, q, 0.01, best)
+    del mq
+    c1.restore()
+    y_real = 0.25
+    one2 = abo.append(one, pts1[0], y_real)
+    c1.downdate(one2)
+    mu1, var1 = c1.mean_and_var()
+    acq = abo.ExpectedImprovement(0.01, best)
+    _, tv1, ti1 = c1.evaluate(acq, k=100)
+    del c1, one, one2
+    abo._lib.lib().abo_pool_trim(0)
+    grp = abo.update(sharded(O.MATERN52, ell, sf2, noise, (0,) * G, n_max=N + 64), X, y)
+    cg = abo.ShardedCandidates(grp, Z)
+    pts2, idx2, val2 = cg.greedy_qei(grp, q, 0.01, best)
+    np.testing.assert_array_equal(idx2, idx1)
+    np.testing.assert_array_equal(val2, val1)
+    np.testing.assert_array_equal(pts2, pts1)
+    grp2 = multigpu.append(grp, pts2[0], y_real, cg)
+    tv2, ti2 = cg.evaluate(grp2, acq, 100)
+    np.testing.assert_array_equal(ti2, ti1)
+    np.testing.assert_array_equal(tv2, tv1)
+    assert len(set(int(i) // 131072 for i in ti2)) > 1           # the merged top-100 draws on more than one shard
+    # the down-dated posterior of every shard's grid equals the single handle's
+    mu2, var2 = cg.mean_and_var(grp2)
+    np.testing.assert_array_equal(mu2, mu1)
+    np.testing.assert_array_equal(var2, var1)
+
+
+@pytest.mark.parametrize("mode", ["collective", "stall"])
+def test_collective_faults_end_in_a_status_or_the_host_exchange_never_in_a_hang(mode):
+    """csrc/mgpu.hip: exchange() = vote → bounded all-gather → fall-back.  A shard that is not ready makes the call return a
+    status before anything is enqueued; a shard that fails AFTER the vote (or whose collective never completes: `stall`, a
+    stand-in kernel that waits for a peer that never arrives) raises the abort word, every shard leaves its bounded wait,
+    the communicators are aborted and the SAME call completes through the host exchange with the right selection.  Run as a
+    child process with a time limit: the regression this guards against is a hang (and an aborted communicator set stays
+    aborted for the rest of its process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("ABO_MGPU_FAULT", "ABO_MGPU_TIMEOUT_MS")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "mgpu_fault_child.py"), mode], env=env, capture_output=True,
+                       text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["transport_before"] == "rccl", out
+    assert out["clean_call_equal"]
+    assert "not ready" in out["ready_fault"] and out["ready_fault_s"] < 10.0
+    assert out["transport_after_ready_fault"] == "rccl" and out["call_after_ready_fault_equal"]
+    assert out.get("faulted_call_equal") is True, out           # the faulted call itself returned the right selection …
+    assert out["faulted_call_s"] < 30.0                          # … in bounded time (stall: ABO_MGPU_TIMEOUT_MS = 1500)
+    assert out["transport_after_fault"] == "host"
+    assert ("timed out" if mode == "stall" else "aborted") in out["note_after_fault"], out["note_after_fault"]
+    assert out["call_after_fault_equal"] and len(out["qei_after_fault"]) == 3
+    assert out["new_group_transport"] == "host"
+
+
 def test_group_errors_are_statuses_and_leave_the_group_usable():
     d = 2
     X = np.array([[-1.0, -1.0], [5.0, -5.0]])

@@ -380,6 +380,18 @@ def test_sharded_optimize_acquisition_walks_the_single_device_trajectory():
 
 
 # ------------------------------------------------------------------------------------------------
+_C3_ORACLE = []
+
+
+def c3_oracle():
+    """(X, y, oracle state) of BASELINE config 3 / 4's training set: the independent host-LAPACK refit (≈ 7 s), computed once per
+    test process (test_full_size_parity_c3 here and the 8-shard config-4 test in tests/test_gpu_multigpu.py share it)."""
+    if not _C3_ORACLE:
+        X, y = synth.standardized_problem(8192, 8, 0.03)
+        _C3_ORACLE.append((X, y, O.fit(O.MATERN52, 1.0, 1.0, 1e-3, 0.0, X, y)))
+    return _C3_ORACLE[0]
+
+
 def test_full_size_parity_c3():
     """BASELINE config 3 at the size the metric is quoted on (N = 8192, d = 8, Matérn-5/2, M = 2²⁰, EI): an INDEPENDENT
     oracle refit (O.fit: LAPACK dpotrf on the host, ≈7 s) and the oracle posterior on 2304 candidates taken from the first,
@@ -387,10 +399,9 @@ def test_full_size_parity_c3():
     side comes from the device.  Plus the size-independent properties: prior recovery far from the data, determinism."""
     N, d, M = 8192, 8, 1 << 20
     ell, sf2, noise = 1.0, 1.0, 1e-3
-    X, y = synth.standardized_problem(N, d, 0.03)
+    X, y, st = c3_oracle()
     Z = synth.points(2, M, d)
     m = abo.update(make_model(O.MATERN52, ell, sf2, noise), X, y)
-    st = O.fit(O.MATERN52, ell, sf2, noise, 0.0, X, y)
     L, alpha, Linv = abo.get_factor(m)
     case = "c3/N8192_d8_M1048576"
     check(case, "L", np.max(np.abs(L - st.L)) / np.sqrt(sf2 + noise), 1e-9)
