@@ -16,7 +16,8 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
-           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get"]
+           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
+           "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms", "abo_test_acq_grad_terms"]
 ABI_VERSION = 5
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
@@ -43,6 +44,11 @@ class AboTimings(C.Structure):
 class AboRefineOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("linesearch_max", C.c_int32), ("history", C.c_int32), ("reserved", C.c_int32),
                 ("g_tol", C.c_double), ("f_abstol", C.c_double), ("x_abstol", C.c_double)]
+
+
+class AboAcqTerm(C.Structure):
+    """one term of a weighted-sum objective (include/abo_hip.h: abo_acq_term)"""
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("p0", C.c_double), ("best_y", C.c_double), ("weight", C.c_double)]
 
 
 class PosDefException(Exception):
@@ -144,6 +150,14 @@ def lib():
                                            vp, C.POINTER(f64), vp, vp, vp, vp]
     L.abo_mgpu_optimize_acquisition.argtypes = L.abo_optimize_acquisition.argtypes
     L.abo_test_acq_grad.argtypes = [vp, i32, f64, f64, vp, i64, i32, vp, vp]
+    tp = C.POINTER(AboAcqTerm)
+    L.abo_test_acq_grad_terms.argtypes = [vp, tp, i32, vp, i64, i32, vp, vp]
+    L.abo_acq_terms.argtypes = [vp, vp, i64, i32, i32, tp, i32, i64, vp, i32, vp, vp, i32]
+    L.abo_acq_lhs.argtypes = [vp, i64, i32, vp, vp, C.c_uint64, i32, f64, f64, i32, vp, vp, vp]
+    L.abo_refine_terms.argtypes = [vp, tp, i32, vp, vp, i32, vp, i32, C.POINTER(AboRefineOpts), vp, vp, vp]
+    L.abo_optimize_acquisition_terms.argtypes = [vp, tp, i32, vp, vp, i32, i64, i32, C.c_uint64, C.POINTER(AboRefineOpts),
+                                                 vp, C.POINTER(f64), vp, vp, vp, vp]
+    L.abo_mgpu_optimize_acquisition_terms.argtypes = L.abo_optimize_acquisition_terms.argtypes
     L.abo_fit_acq.argtypes = [vp, vp, i64, i32, vp, i32, C.POINTER(i64), vp, i64, i32, i32, f64, f64, i64, vp, i32, vp, vp, i32]
     for name in EXPORTS:
         getattr(L, name).restype = i32

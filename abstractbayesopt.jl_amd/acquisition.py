@@ -16,7 +16,8 @@ from . import _lib
 from ._lib import DEVICE, HOST
 from .surrogate import AbstractSurrogate, HipStandardGP, _get_minimum, as_points
 
-ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN = 0, 1, 2, 3
+ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN, ACQ_GRADNORM_UCB = 0, 1, 2, 3, 4
+MAX_TERMS = 8
 
 
 class AbstractAcquisition:
@@ -95,6 +96,9 @@ class EnsembleAcquisition(AbstractAcquisition):
         from .surrogate import mean_and_var
         if np.isscalar(x):
             x = [float(x)]
+        terms = flatten_terms(self, surrogate)
+        if terms is not None and not hasattr(surrogate, "devices"):
+            return evaluate_terms(terms, surrogate, x)[0]       # ONE C-ABI call: one posterior pass, every member's epilogue on it
         zp, m, d, zspace, keep = as_points(x)
         dev = torch.device("cuda", surrogate.device)
         zt = keep if zspace == DEVICE else torch.from_numpy(keep).to(dev)
@@ -140,6 +144,11 @@ def evaluate(acq: AbstractAcquisition, surrogate: HipStandardGP, x, k: int = 0, 
     Host inputs give NumPy outputs; a CUDA tensor gives CUDA tensors (nothing crosses PCIe)."""
     if not isinstance(surrogate, HipStandardGP):
         raise TypeError("the fused acquisition path needs a HipStandardGP surrogate")
+    if isinstance(acq, EnsembleAcquisition) or getattr(acq, "kind", None) == ACQ_GRADNORM_UCB:
+        terms = flatten_terms(acq, surrogate)
+        if terms is None or hasattr(surrogate, "devices"):
+            raise TypeError("this objective is not served by the fused acquisition call on this surrogate")
+        return evaluate_terms(terms, surrogate, x, k=k, idx_base=idx_base, return_scores=return_scores)
     L = _lib.lib()
     zp, m, d, zspace, keep = as_points(x)
     if hasattr(surrogate, "devices") and zspace == HOST and idx_base == 0:   # HipShardedGP: sharded inside the library
@@ -252,10 +261,62 @@ def device_latin_hypercube(n: int, lower, upper, seed: int, device: int = 0, fir
     return Z
 
 
+def flatten_terms(acqf, surrogate=None):
+    """[(kind, p0, best_y, weight), …] of an acquisition function as a weighted-sum objective (include/abo_hip.h: abo_acq_term) —
+    a plain function is one term of weight 1, an EnsembleAcquisition (nested ones included) the list of its members with the
+    weights multiplied through (EnsembleAcq.jl:53-55).  None when the library cannot take it: more than 8 terms, an unknown
+    member, or a GradientNormUCB member on a model without gradient outputs."""
+    out = []
+
+    def walk(a, w):
+        if isinstance(a, EnsembleAcquisition):
+            return all(walk(m, w * float(wi)) for wi, m in zip(a.weights, a.acquisitions))
+        k = getattr(a, "kind", None)
+        if k not in (ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN, ACQ_GRADNORM_UCB):
+            return False
+        if k == ACQ_GRADNORM_UCB and surrogate is not None and not hasattr(surrogate, "p"):
+            return False
+        out.append((int(k), float(a._p0()), float(a._best()), float(w)))
+        return True
+
+    if not walk(acqf, 1.0) or not 1 <= len(out) <= MAX_TERMS:
+        return None
+    return out
+
+
+def _term_array(terms):
+    arr = (_lib.AboAcqTerm * len(terms))()
+    for i, (k, p0, b, w) in enumerate(terms):
+        arr[i].kind, arr[i].reserved, arr[i].p0, arr[i].best_y, arr[i].weight = k, 0, p0, b, w
+    return arr
+
+
+def evaluate_terms(terms, surrogate, x, k: int = 0, idx_base: int = 0, return_scores: bool = True):
+    """`evaluate` for a weighted-sum objective (abo_acq_terms): scores and the stable reverse sort's first k in one call"""
+    L = _lib.lib()
+    zp, m, d, zspace, keep = as_points(x)
+    if zspace == DEVICE:
+        import torch
+        dev = keep.device
+        scores = torch.empty(m, dtype=torch.float64, device=dev) if return_scores else None
+        tv = torch.empty(k, dtype=torch.float64, device=dev) if k > 0 else None
+        ti = torch.empty(k, dtype=torch.int64, device=dev) if k > 0 else None
+        ptr = lambda t: t.data_ptr() if t is not None else None
+    else:
+        scores = np.empty(m) if return_scores else None
+        tv = np.empty(k) if k > 0 else None
+        ti = np.empty(k, dtype=np.int64) if k > 0 else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+    arr = _term_array(terms)
+    _lib.check(L.abo_acq_terms(surrogate._require(), zp, m, d, zspace, arr, len(terms), idx_base, ptr(scores), k, ptr(tv), ptr(ti),
+                               zspace))
+    return scores, tv, ti
+
+
 def _library_refinable(acqf, surrogate) -> bool:
-    """the on-device refinement serves EI / UCB / PI on a StandardGP handle (single device or sharded group)"""
-    return (not isinstance(acqf, EnsembleAcquisition) and getattr(acqf, "kind", None) in (ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN)
-            and not hasattr(surrogate, "p"))
+    """the on-device refinement serves every objective that flattens into ≤ 8 weighted EI / UCB / PI / GradientNormUCB terms, on
+    StandardGP and gradient-enhanced handles (single device or sharded group)"""
+    return flatten_terms(acqf, surrogate) is not None
 
 
 def _refine_opts(max_iter, g_tol, f_abstol, x_abstol, history):
@@ -269,9 +330,11 @@ def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, l
     reference (Fminbox(LBFGS(HagerZhang(linesearchmax=20))), g_tol=1e-5, f_abstol=2.2e-9, x_abstol=1e-4, central finite
     differences of M = 1 posterior calls).  Here a thin caller of `abo_refine` (include/abo_hip.h): ONE launch, one workgroup per
     start running that start's whole projected L-BFGS on the device with the analytic gradient of the acquisition function.
-    Returns (points (S, d), values (S,)).  Ensemble acquisitions and gradient-enhanced models take the host loop below
+    Returns (points (S, d), values (S,)).  Ensemble acquisitions (weighted sums of ≤ 8 members) and gradient-enhanced models are
+    served by the same call (`abo_refine_terms`); only an objective the library cannot express takes the host loop below
     (`_refine_starts_fd`: the same algorithm on batched finite-difference stencils)."""
-    if not _library_refinable(acqf, surrogate):
+    terms = flatten_terms(acqf, surrogate)
+    if terms is None:                      # more than 8 members / a member the library does not know: the host loop
         return _refine_starts_fd(acqf, surrogate, starts, lower, upper, max_iter, g_tol, f_abstol, x_abstol, history)
     lower = np.ascontiguousarray(np.asarray(lower, dtype=np.float64))
     upper = np.ascontiguousarray(np.asarray(upper, dtype=np.float64))
@@ -280,8 +343,9 @@ def refine_starts(acqf: AbstractAcquisition, surrogate: HipStandardGP, starts, l
     x, f, it = np.empty((S, d)), np.empty(S), np.zeros((S, 2), dtype=np.int32)
     opts = _refine_opts(max_iter, g_tol, f_abstol, x_abstol, history)
     h = surrogate.shard(0) if hasattr(surrogate, "devices") else surrogate._require()
-    _lib.check(_lib.lib().abo_refine(h, acqf.kind, acqf._p0(), acqf._best(), lower.ctypes.data, upper.ctypes.data, d,
-                                     st.ctypes.data, S, C.byref(opts), x.ctypes.data, f.ctypes.data, it.ctypes.data))
+    arr = _term_array(terms)
+    _lib.check(_lib.lib().abo_refine_terms(h, arr, len(terms), lower.ctypes.data, upper.ctypes.data, d,
+                                           st.ctypes.data, S, C.byref(opts), x.ctypes.data, f.ctypes.data, it.ctypes.data))
     return (x, f, it) if return_iters else (x, f)
 
 
@@ -292,16 +356,21 @@ def acquisition_value_and_grad(acqf: AbstractAcquisition, surrogate: HipStandard
     if z.ndim == 1:
         z = z[:, None]
     f, g = np.empty(z.shape[0]), np.empty(z.shape)
-    _lib.check(_lib.lib().abo_test_acq_grad(surrogate._require(), acqf.kind, acqf._p0(), acqf._best(), z.ctypes.data, z.shape[0],
-                                            z.shape[1], f.ctypes.data, g.ctypes.data))
+    terms = flatten_terms(acqf, surrogate)
+    if terms is None:
+        raise ValueError("the objective does not flatten into at most 8 library terms")
+    arr = _term_array(terms)
+    _lib.check(_lib.lib().abo_test_acq_grad_terms(surrogate._require(), arr, len(terms), z.ctypes.data, z.shape[0], z.shape[1],
+                                                  f.ctypes.data, g.ctypes.data))
     return f, g
 
 
 def optimize_acquisition_device(acqf: AbstractAcquisition, surrogate: HipStandardGP, domain, n_grid: int = 10_000,
                                 n_local: int = 100, seed: int = 0, return_all: bool = False, **opts):
     """optimize_acquisition (acq_utils.jl:33-73) in ONE C-ABI call: Latin-hypercube grid generated on the device(s), scored,
-    reduced to the n_local best, every start refined by its own workgroup, the best point returned.  Works on a HipStandardGP
-    (abo_optimize_acquisition) and on a HipShardedGP (abo_mgpu_optimize_acquisition: grid and starts sharded over the group)."""
+    reduced to the n_local best, every start refined on the device, the best point returned.  Serves EI / UCB / PI, GradientNormUCB
+    and EnsembleAcquisitions of them (abo_acq_term) on a HipStandardGP, a HipGradientGP (abo_optimize_acquisition_terms) and their
+    sharded groups (abo_mgpu_optimize_acquisition_terms: grid and starts sharded over the group)."""
     lower = np.ascontiguousarray(np.asarray(domain.lower, dtype=np.float64))
     upper = np.ascontiguousarray(np.asarray(domain.upper, dtype=np.float64))
     d, k = lower.shape[0], min(int(n_local), int(n_grid))
@@ -309,11 +378,15 @@ def optimize_acquisition_device(acqf: AbstractAcquisition, surrogate: HipStandar
     sx, sv, rx, rv = np.empty((k, d)), np.empty(k), np.empty((k, d)), np.empty(k)
     o = _refine_opts(opts.get("max_iter", 0), opts.get("g_tol", 0), opts.get("f_abstol", 0), opts.get("x_abstol", 0), opts.get("history", 0))
     L = _lib.lib()
+    terms = flatten_terms(acqf, surrogate)
+    if terms is None:
+        raise ValueError("the objective does not flatten into at most 8 library terms (use optimize_acquisition)")
+    arr = _term_array(terms)
     if hasattr(surrogate, "devices"):
-        fn, h = L.abo_mgpu_optimize_acquisition, surrogate._require_group()
+        fn, h = L.abo_mgpu_optimize_acquisition_terms, surrogate._require_group()
     else:
-        fn, h = L.abo_optimize_acquisition, surrogate._require()
-    _lib.check(fn(h, acqf.kind, acqf._p0(), acqf._best(), lower.ctypes.data, upper.ctypes.data, d, int(n_grid), int(n_local),
+        fn, h = L.abo_optimize_acquisition_terms, surrogate._require()
+    _lib.check(fn(h, arr, len(terms), lower.ctypes.data, upper.ctypes.data, d, int(n_grid), int(n_local),
                   int(seed) & (2 ** 64 - 1), C.byref(o), best.ctypes.data, C.byref(val), sx.ctypes.data, sv.ctypes.data,
                   rx.ctypes.data, rv.ctypes.data))
     if return_all:
@@ -430,7 +503,12 @@ def optimize_acquisition(acqf: AbstractAcquisition, surrogate: HipStandardGP, do
         best, _, sx, sv, _, _ = optimize_acquisition_device(acqf, surrogate, domain, n_grid, n_local,
                                                             seed=int(rng.integers(0, 2 ** 63)), return_all=True)
         return (best, sx, sv) if return_starts else best
-    if device_grid and not isinstance(acqf, EnsembleAcquisition):
+    if device_grid and flatten_terms(acqf, surrogate) is not None and not hasattr(surrogate, "devices"):
+        grid = device_latin_hypercube(n_grid, domain.lower, domain.upper, int(rng.integers(0, 2 ** 63)), surrogate.device)
+        _, vals, idx = evaluate_terms(flatten_terms(acqf, surrogate), surrogate, grid, k=k, return_scores=False)
+        vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+        starts = grid[torch_index(idx, grid)].cpu().numpy()
+    elif device_grid and not isinstance(acqf, EnsembleAcquisition):
         # the grid is generated, scored and reduced on the GPU; only the k starts come back
         grid = device_latin_hypercube(n_grid, domain.lower, domain.upper, int(rng.integers(0, 2 ** 63)), surrogate.device)
         _, vals, idx = evaluate(acqf, surrogate, grid, k=k, return_scores=False)

@@ -14,6 +14,17 @@ int32_t acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space
 int32_t cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double best_y, int64_t idx_base, double* scores,
                     int32_t scores_space, int32_t k, double* top_val, int64_t* top_idx, int32_t top_space);
 
+int32_t acq_terms_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, const abo_acq_term* terms, int32_t nterms,
+                     int64_t idx_base, double* scores, int32_t scores_space, int32_t k, double* top_val, int64_t* top_idx,
+                     int32_t top_space);
+// a shard's part of the grid stage (acq_utils.jl:44-52): rows j0 … j0+count−1 of the n-point Latin hypercube generated into grid_d
+// (device, count·d doubles), scored under the objective, the k best (score, global index) pairs left in tv_d / ti_d (device)
+int32_t acq_lhs_shard(abo_gp* g, const abo_acq_term* terms, int32_t nterms, int64_t n, int32_t d, const double* lower,
+                      const double* upper, uint64_t seed, int64_t j0, int64_t count, int32_t k, double* grid_d, double* tv_d,
+                      int64_t* ti_d);
+int32_t refine_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const double* lower, const double* upper, int32_t d,
+                     const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out);
+
 // optimize_acquisition's last step on the host (acq_utils.jl:66-72): the refined point with the largest finite value (first on
 // ties), or the best grid point when no refined value reaches its score
 void pick_best_point(const double* starts_x, const double* starts_val, const double* rx, const double* rf, int k, int d,

@@ -251,6 +251,27 @@ hipError_t launch_pick_record(const double* tv, const int64_t* ti, int64_t idx_b
 hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                       int64_t count, hipStream_t s);
 
+// ---- objectives of the acquisition stage: a weighted sum of epilogues on ONE posterior evaluation ------------------
+// f(x) = Σ_t w_t · acq_t(x)  (EnsembleAcquisition, EnsembleAcq.jl:53-55; a plain acquisition function is one term of weight 1).
+// acq_t ∈ {EI, UCB, PI, MEAN} on the function-value posterior (μ, σ²), or GRADNORM_UCB on the posterior of the gradient outputs
+// of a gradient-enhanced model (gradNormUCB.jl:43-51).
+constexpr int MAX_TERMS = 8;
+constexpr int ACQ_GRADNORM_UCB = 4;            // == ABO_ACQ_GRADNORM_UCB (include/abo_hip.h)
+struct AcqTerms {
+    int n;
+    int kind[MAX_TERMS];
+    double p0[MAX_TERMS], best_y[MAX_TERMS], w[MAX_TERMS];
+};
+inline bool terms_have_gradnorm(const AcqTerms& t) {
+    for (int i = 0; i < t.n; ++i) if (t.kind[i] == ACQ_GRADNORM_UCB) return true;
+    return false;
+}
+inline bool terms_plain(const AcqTerms& t) { return t.n == 1 && t.w[0] == 1.0 && t.kind[0] != ACQ_GRADNORM_UCB; }
+// score[j] = Σ_t w_t·acq_t(mu[j], var[j]) (function-value terms only)
+hipError_t launch_score_terms(const double* mu, const double* var, double* score, int64_t M, const AcqTerms& t, hipStream_t s);
+// gradient-enhanced model: score[j] from the per-point mean mu[j][p] and covariance block cov[j][p][p]
+hipError_t launch_score_terms_grad(const double* mu, const double* cov, double* score, int64_t M, int p, const AcqTerms& t, hipStream_t s);
+
 // ---- local refinement of optimize_acquisition on the device (refine.hip) ---------------------------------------
 struct RefineArgs {
     const double* Xs;      // [Np][dp] scaled training points
@@ -260,8 +281,7 @@ struct RefineArgs {
     int64_t ld;
     int N, Np, d, dp, family;
     double s, sigma_f2, mean_c;            // 1/ℓ, σ_f², prior mean
-    int kind;                              // ABO_ACQ_*
-    double p0, best_y;
+    AcqTerms terms;                        // the objective
     const double* lower;   // device [d]
     const double* upper;   // device [d]
     const double* starts;  // device [S][d]
@@ -280,6 +300,20 @@ hipError_t launch_refine(const RefineArgs& a, int S, int grad_only, hipStream_t 
 // once per round instead of once per start); work = refine_lockstep_bytes(S, Np, d, history) of device memory
 size_t refine_lockstep_bytes(int S, int Np, int d, int history);
 hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStream_t s);
+// Gradient-enhanced models (and any objective with a GRADNORM_UCB term): the same lockstep state machine, a round's evaluations
+// delivered by the caller.  eval(points [npts][d] (device), npts, mu [npts][p], cov [npts][p][p]) queues the all-output posterior of
+// the round's points on the stream (api.hip: the kernels behind abo_predict_grad_cov); the driver derives value and gradient of the
+// objective from it — function-value terms analytically (∇μ = E[∇f] − m_∇, ∇σ² = 2·Cov(f, ∇f)), GRADNORM_UCB terms by central
+// differences over a 2d-point stencil evaluated in the same batch (the reference differentiates every objective that way,
+// acq_utils.jl:55-71).  p = d + 1 outputs; mean_g[d]: prior means of the gradient outputs.
+size_t refine_lockstep_grad_bytes(int S, int d, int history, bool stencil);
+struct GradEval {
+    void* ctx;
+    hipError_t (*eval)(void* ctx, const double* pts, int npts, double* mu, double* cov, hipStream_t s);
+};
+hipError_t launch_refine_lockstep_grad(const RefineArgs& a, int S, const double* mean_g, void* work, const GradEval& ev, hipStream_t s);
+// value and gradient of the objective at S points through the same evaluation (the test hook behind abo_test_acq_grad)
+hipError_t launch_acq_grad_via_eval(const RefineArgs& a, int S, const double* mean_g, void* work, const GradEval& ev, hipStream_t s);
 // out[j][0..d) = Z[idx[j] − idx_base][0..d) for j < k (zeros for idx[j] < 0): the coordinates of selected candidates
 hipError_t launch_gather_points(const double* Z, const int64_t* idx, int64_t idx_base, int k, int d, double* out, hipStream_t s);
 

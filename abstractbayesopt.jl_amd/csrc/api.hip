@@ -847,6 +847,73 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
     return ABO_OK;
 }
 
+// Gradient-enhanced model: per-point posterior mean of all P outputs (mu_d [M][P]), P×P covariance block (cov_d [M][P][P]) and
+// GradientNormUCB score (sc_d [M]) of M points in DEVICE memory (any output may be null) — queued on the handle's stream, no
+// synchronisation.  The arithmetic behind abo_predict_grad_cov (GradientGP.jl:936-971, gradNormUCB.jl:43-51) and behind the
+// refinement rounds of a gradient-enhanced handle (refine.hip: launch_refine_lockstep_grad).
+int32_t grad_eval_device(abo_gp* g, const double* Zd, int64_t M, double beta, double* mu_d, double* cov_d, double* sc_d) {
+    hipStream_t s = g->stream;
+    const int P = g->p_out;
+    const int64_t Np = g->Np;
+    // points per chunk: V chunk (rows·Np doubles) ≤ 256 MiB, rows padded to 128
+    int64_t pts = (((int64_t)1 << 28) / (Np * (int64_t)sizeof(double))) / P;
+    if (pts < 1) pts = 1;
+    if (pts > M) pts = M;
+    const int64_t rows_pad = pad_up(pts * P, TB);
+    // V = L⁻¹K_XZ on the int8-residue engine when the handle's contraction says so (same rule as the variance calls): the residue
+    // GEMMs and a reconstruction that writes V itself; a chunk whose scratch the device cannot give runs on the fp64 GEMM
+    int nm = 0;
+    bool oz = wants_int8(g, true, P, &nm);
+    if (oz) {
+        int64_t mc = rows_pad;
+        int32_t rc = oz_acquire(g, nm, rows_pad, &mc, &oz);
+        if (rc) return rc;
+        if (oz && mc != rows_pad) oz = false;
+    }
+    HIPCHK(g->events(EV_BASE));
+    g->oz_prepare_pending = false;
+    if (oz) { int32_t rc = oz_planes_of_w(g); if (rc) return rc; }
+    g->tm.contraction_engine = oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64;
+    g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
+    HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
+    HIPCHK(g->partial.ensure(sizeof(double) * rows_pad * Np));       // V
+    HIPCHK(g->mu_c.ensure(sizeof(double) * rows_pad));
+    for (int64_t p0 = 0; p0 < M; p0 += pts) {
+        const int64_t np = (M - p0) < pts ? (M - p0) : pts;
+        const int rows = (int)pad_up(np * P, TB);
+        KgenArgs ka{};
+        ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
+        ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = p0 * P; ka.Mc = rows; ka.N = (int)g->npts;
+        ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
+        ka.sigma_f2 = g->prm.sigma_f2; ka.pt = P; ka.pc = P; ka.point_major = 1;
+        for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
+        HIPCHK(launch_kgen(ka, s));
+        if (oz) {
+            OzVarArgs oa{};
+            oa.plan = &g->oz_plan; oa.Kxz = g->Kxz.as<double>(); oa.ldk = Np; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
+            oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
+            oa.bad_col = g->oz_badc.as<int>(); oa.partial = nullptr; oa.ldp = 0; oa.Np = (int)Np; oa.Mc = rows;
+            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(2.0 * g->prm.sigma_f2);
+            oa.kper = P; oa.ktg = oz_grad_exp(g);
+            oa.rmode = 1; oa.rper = P; oa.r0 = p0 * P; oa.rpts = M;
+            oa.Vout = g->partial.as<double>(); oa.ldv = Np;
+            HIPCHK(launch_var_ozaki(oa, s));
+        } else {
+            GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
+            a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
+            a.C = g->partial.as<double>(); a.ldc = Np; a.M = rows; a.N = (int)Np; a.K = (int)Np;
+            a.kmode = K_B_LOWER; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;       // W[i][k] = 0 for k > i: half the product
+            HIPCHK(launch_gemm_nt(a, s));
+        }
+        GradCovArgs ca{};
+        ca.V = g->partial.as<double>(); ca.mu_rows = g->mu_c.as<double>(); ca.ldv = Np; ca.R = (int)g->N; ca.p = P;
+        ca.pt0 = p0; ca.prior0 = g->prm.sigma_f2; ca.prior_g = grad_prior_var(g); ca.beta = beta;
+        ca.cov_out = cov_d; ca.mu_out = mu_d; ca.score_out = sc_d;
+        HIPCHK(launch_grad_cov(ca, (int)np, s));
+    }
+    return ABO_OK;
+}
+
 void collect_posterior_timings(abo_gp* g, int64_t M, bool with_var) {
     const int64_t Mc = g->last_chunk;
     const int64_t nchunk = (M + Mc - 1) / Mc;
@@ -1402,70 +1469,15 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
     const int P = g->p_out;
-    const int64_t Np = g->Np;
     const double* Zd = nullptr;
     rc = stage_candidates(g, Z, M, z_space, &Zd);
     if (rc) return rc;
-    // points per chunk: V chunk (rows·Np doubles) ≤ 256 MiB, rows padded to 128
-    int64_t pts = (((int64_t)1 << 28) / (Np * (int64_t)sizeof(double))) / P;
-    if (pts < 1) pts = 1;
-    if (pts > M) pts = M;
-    const int64_t rows_pad = pad_up(pts * P, TB);
-    // V = L⁻¹K_XZ on the int8-residue engine when the handle's contraction says so (same rule as the variance calls): the residue
-    // GEMMs and a reconstruction that writes V itself; a chunk whose scratch the device cannot give runs on the fp64 GEMM
-    int nm = 0;
-    bool oz = wants_int8(g, true, P, &nm);
-    if (oz) {
-        int64_t mc = rows_pad;
-        rc = oz_acquire(g, nm, rows_pad, &mc, &oz);
-        if (rc) return rc;
-        if (oz && mc != rows_pad) oz = false;
-    }
-    HIPCHK(g->events(EV_BASE));
-    g->oz_prepare_pending = false;
-    if (oz) { rc = oz_planes_of_w(g); if (rc) return rc; }
-    g->tm.contraction_engine = oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64;
-    g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
-    HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
-    HIPCHK(g->partial.ensure(sizeof(double) * rows_pad * Np));       // V
-    HIPCHK(g->mu_c.ensure(sizeof(double) * rows_pad));
     double* mu_d = nullptr; double* cov_d = nullptr; double* sc_d = nullptr;
     if (mu) { if (out_space == ABO_DEVICE) mu_d = mu; else { HIPCHK(g->mu_all.ensure(sizeof(double) * M * P)); mu_d = g->mu_all.as<double>(); } }
     if (cov) { if (out_space == ABO_DEVICE) cov_d = cov; else { HIPCHK(g->var_all.ensure(sizeof(double) * M * P * P)); cov_d = g->var_all.as<double>(); } }
     if (score) { if (out_space == ABO_DEVICE) sc_d = score; else { HIPCHK(g->score_all.ensure(sizeof(double) * M)); sc_d = g->score_all.as<double>(); } }
-    for (int64_t p0 = 0; p0 < M; p0 += pts) {
-        const int64_t np = (M - p0) < pts ? (M - p0) : pts;
-        const int rows = (int)pad_up(np * P, TB);
-        KgenArgs ka{};
-        ka.Xs = g->st->Xs.as<double>(); ka.Z = Zd; ka.alpha = g->alpha.as<double>(); ka.Kout = g->Kxz.as<double>();
-        ka.mu = g->mu_c.as<double>(); ka.ldk = Np; ka.M = M; ka.j0 = p0 * P; ka.Mc = rows; ka.N = (int)g->npts;
-        ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
-        ka.sigma_f2 = g->prm.sigma_f2; ka.pt = P; ka.pc = P; ka.point_major = 1;
-        for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
-        HIPCHK(launch_kgen(ka, s));
-        if (oz) {
-            OzVarArgs oa{};
-            oa.plan = &g->oz_plan; oa.Kxz = g->Kxz.as<double>(); oa.ldk = Np; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
-            oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
-            oa.bad_col = g->oz_badc.as<int>(); oa.partial = nullptr; oa.ldp = 0; oa.Np = (int)Np; oa.Mc = rows;
-            oa.nvalid = (int)g->N; oa.sK = oz_k_scale(2.0 * g->prm.sigma_f2);
-            oa.kper = P; oa.ktg = oz_grad_exp(g);
-            oa.rmode = 1; oa.rper = P; oa.r0 = p0 * P; oa.rpts = M;
-            oa.Vout = g->partial.as<double>(); oa.ldv = Np;
-            HIPCHK(launch_var_ozaki(oa, s));
-        } else {
-            GemmArgs a{};           // V[row][i] = Σ_k Kxz[row][k]·W[i][k]
-            a.A = g->Kxz.as<double>(); a.lda = Np; a.B = g->st->W.as<double>(); a.ldb = g->st->cap;
-            a.C = g->partial.as<double>(); a.ldc = Np; a.M = rows; a.N = (int)Np; a.K = (int)Np;
-            a.kmode = K_B_LOWER; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;       // W[i][k] = 0 for k > i: half the product
-            HIPCHK(launch_gemm_nt(a, s));
-        }
-        GradCovArgs ca{};
-        ca.V = g->partial.as<double>(); ca.mu_rows = g->mu_c.as<double>(); ca.ldv = Np; ca.R = (int)g->N; ca.p = P;
-        ca.pt0 = p0; ca.prior0 = g->prm.sigma_f2; ca.prior_g = grad_prior_var(g); ca.beta = beta;
-        ca.cov_out = cov_d; ca.mu_out = mu_d; ca.score_out = sc_d;
-        HIPCHK(launch_grad_cov(ca, (int)np, s));
-    }
+    rc = grad_eval_device(g, Zd, M, beta, mu_d, cov_d, sc_d);
+    if (rc) return rc;
     if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
     if (cov && out_space == ABO_HOST) { rc = copy_out(cov, cov_d, sizeof(double) * M * P * P, ABO_HOST, s); if (rc) return rc; }
     if (score && out_space == ABO_HOST) { rc = copy_out(score, sc_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
@@ -1481,14 +1493,74 @@ int32_t abo_acq(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_spac
 
 }  // extern "C"
 
-// abo_acq with separate memory spaces for the M scores and for the k selected pairs (the multi-device driver keeps the
-// pairs on the device for the RCCL exchange while the scores, when asked for, go to the caller's host array)
-int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind, double p0,
-                    double best_y, int64_t idx_base, double* scores, int32_t out_space, int32_t k, double* top_val,
-                    int64_t* top_idx, int32_t top_space) {
-    int32_t rc = check_fitted(g, d);
-    if (rc) return rc;
-    if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_acq: unknown acquisition kind %d", kind);
+namespace {
+
+// C-ABI terms → the kernels' form; validates kinds against the handle (GRADNORM_UCB needs gradient outputs)
+int32_t make_terms(const abo_gp* g, const abo_acq_term* terms, int32_t n, AcqTerms* out, const char* fn) {
+    if (!terms || n < 1) return fail(ABO_EINVAL, "%s: an objective needs at least one term", fn);
+    if (n > MAX_TERMS) return fail(ABO_EINVAL, "%s: %d terms, the library takes at most %d", fn, n, MAX_TERMS);
+    out->n = n;
+    for (int i = 0; i < n; ++i) {
+        const int k = terms[i].kind;
+        if (k < ABO_ACQ_EI || k > ABO_ACQ_GRADNORM_UCB) return fail(ABO_EINVAL, "%s: unknown acquisition kind %d (term %d)", fn, k, i);
+        if (k == ABO_ACQ_GRADNORM_UCB && (!g || g->p_out < 2))
+            return fail(ABO_EINVAL, "%s: GradientNormUCB (term %d) needs a gradient-enhanced model", fn, i);
+        if (!(terms[i].weight == terms[i].weight)) return fail(ABO_EINVAL, "%s: weight of term %d is not a number", fn, i);
+        out->kind[i] = k; out->p0[i] = terms[i].p0; out->best_y[i] = terms[i].best_y; out->w[i] = terms[i].weight;
+    }
+    return ABO_OK;
+}
+
+AcqTerms one_term(int32_t kind, double p0, double best_y) {
+    AcqTerms t{};
+    t.n = 1; t.kind[0] = kind; t.p0[0] = p0; t.best_y[0] = best_y; t.w[0] = 1.0;
+    return t;
+}
+
+// scores of M device-resident candidates under the objective `t` into sc_d (device), queued on the handle's stream:
+//   one plain term            the fused posterior + epilogue pass (what abo_acq has always run: same bits)
+//   function-value terms      ONE posterior pass, then every member's epilogue on that μ, σ² (EnsembleAcq.jl:53-55)
+//   a GRADNORM_UCB term       the all-output posterior per point (mean[p], covariance block) in slabs, epilogue on those
+int32_t score_terms_device(abo_gp* g, const double* Zd, int64_t M, const AcqTerms& t, double* sc_d) {
+    hipStream_t s = g->stream;
+    if (terms_plain(t)) {
+        if (t.kind[0] != ABO_ACQ_MEAN) return posterior(g, Zd, M, t.kind[0], t.p0[0], t.best_y[0], nullptr, nullptr, sc_d);
+        // −mu only: skip the contraction (scores come from the mean pass)
+        HIPCHK(g->mu_all.ensure(sizeof(double) * M));
+        int32_t rc = posterior(g, Zd, M, -1, 0.0, 0.0, g->mu_all.as<double>(), nullptr, nullptr);
+        if (rc) return rc;
+        FinalizeArgs fa{};
+        fa.partial = nullptr; fa.mu_in = g->mu_all.as<double>(); fa.score_out = sc_d; fa.ldp = 0; fa.j0 = 0; fa.M = M;
+        fa.T = 0; fa.Mc = (int)M; fa.kind = ABO_ACQ_MEAN; fa.sigma_f2 = g->prm.sigma_f2;
+        HIPCHK(launch_finalize(fa, s));
+        return ABO_OK;
+    }
+    if (!terms_have_gradnorm(t)) {
+        HIPCHK(g->mu_all.ensure(sizeof(double) * M));
+        HIPCHK(g->var_all.ensure(sizeof(double) * M));
+        int32_t rc = posterior(g, Zd, M, -1, 0.0, 0.0, g->mu_all.as<double>(), g->var_all.as<double>(), nullptr);
+        if (rc) return rc;
+        HIPCHK(launch_score_terms(g->mu_all.as<double>(), g->var_all.as<double>(), sc_d, M, t, s));
+        return ABO_OK;
+    }
+    const int P = g->p_out;
+    int64_t slab = ((int64_t)64 << 20) / ((int64_t)sizeof(double) * P * P);       // ≤ 64 MiB of covariance blocks at a time
+    if (slab < 1) slab = 1;
+    if (slab > M) slab = M;
+    HIPCHK(g->mu_all.ensure(sizeof(double) * slab * P));
+    HIPCHK(g->var_all.ensure(sizeof(double) * slab * P * P));
+    for (int64_t j0 = 0; j0 < M; j0 += slab) {
+        const int64_t np = (M - j0) < slab ? (M - j0) : slab;
+        int32_t rc = grad_eval_device(g, Zd + j0 * g->d, np, 0.0, g->mu_all.as<double>(), g->var_all.as<double>(), nullptr);
+        if (rc) return rc;
+        HIPCHK(launch_score_terms_grad(g->mu_all.as<double>(), g->var_all.as<double>(), sc_d + j0, np, P, t, s));
+    }
+    return ABO_OK;
+}
+
+// scores + selection for host or device candidates; separate memory spaces for the M scores and for the k selected pairs
+int32_t acq_terms_impl(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, const AcqTerms& t, int64_t idx_base,
+                       double* scores, int32_t out_space, int32_t k, double* top_val, int64_t* top_idx, int32_t top_space) {
     if (M < 0 || (M > 0 && !Z)) return fail(ABO_EINVAL, "abo_acq: bad candidate buffer");
     if (k < 0) return fail(ABO_EINVAL, "abo_acq: k = %d is negative", k);
     if (k > 0 && (!top_val || !top_idx)) return fail(ABO_EINVAL, "abo_acq: k > 0 needs top_val and top_idx");
@@ -1496,26 +1568,16 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
     hipStream_t s = g->stream;
     double* sc_d = nullptr;
     PinStage pin(g->ctx);
+    const bool with_var = !(terms_plain(t) && t.kind[0] == ABO_ACQ_MEAN);
+    const bool fused_timings = !terms_have_gradnorm(t);           // the slab path does not keep per-chunk events
     if (M > 0) {
         const double* Zd = nullptr;
-        rc = stage_candidates(g, Z, M, z_space, &Zd);
+        int32_t rc = stage_candidates(g, Z, M, z_space, &Zd);
         if (rc) return rc;
         if (scores && out_space == ABO_DEVICE) sc_d = scores;
         else { HIPCHK(g->score_all.ensure(sizeof(double) * M)); sc_d = g->score_all.as<double>(); }
         HIPCHK(hipEventRecord(g->evs()[5], s));
-        const bool need_var = kind != ABO_ACQ_MEAN;
-        if (need_var) {
-            rc = posterior(g, Zd, M, kind, p0, best_y, nullptr, nullptr, sc_d);
-        } else {
-            // −mu only: skip the contraction (scores come from the mean pass)
-            HIPCHK(g->mu_all.ensure(sizeof(double) * M));
-            rc = posterior(g, Zd, M, -1, 0.0, 0.0, g->mu_all.as<double>(), nullptr, nullptr);
-            if (rc) return rc;
-            FinalizeArgs fa{};
-            fa.partial = nullptr; fa.mu_in = g->mu_all.as<double>(); fa.score_out = sc_d; fa.ldp = 0; fa.j0 = 0; fa.M = M;
-            fa.T = 0; fa.Mc = (int)M; fa.kind = ABO_ACQ_MEAN; fa.sigma_f2 = g->prm.sigma_f2;
-            HIPCHK(launch_finalize(fa, s));
-        }
+        rc = score_terms_device(g, Zd, M, t, sc_d);
         if (rc) return rc;
         PHASE_EVENT(g->evs()[6], s);
     } else {
@@ -1545,15 +1607,45 @@ int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
     }
     HIPCHK(hipEventRecord(g->evs()[7], s));
     if (scores && out_space == ABO_HOST && M > 0) {
-        rc = copy_out(scores, sc_d, sizeof(double) * M, ABO_HOST, s);
+        int32_t rc = copy_out(scores, sc_d, sizeof(double) * M, ABO_HOST, s);
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(s));
     pin.flush();
-    if (M > 0) collect_posterior_timings(g, M, kind != ABO_ACQ_MEAN);
+    if (M > 0 && fused_timings) collect_posterior_timings(g, M, with_var);
     g->tm.acq_topk_ms = phase_events() ? ev_ms(g->evs()[6], g->evs()[7]) : 0.0;
     g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[7]);
     return ABO_OK;
+}
+
+}  // namespace
+
+// abo_acq with separate memory spaces for the M scores and for the k selected pairs (the multi-device driver keeps the
+// pairs on the device for the RCCL exchange while the scores, when asked for, go to the caller's host array)
+int32_t abo::acq_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, int32_t kind, double p0,
+                    double best_y, int64_t idx_base, double* scores, int32_t out_space, int32_t k, double* top_val,
+                    int64_t* top_idx, int32_t top_space) {
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_acq: unknown acquisition kind %d", kind);
+    return acq_terms_impl(g, Z, M, d, z_space, one_term(kind, p0, best_y), idx_base, scores, out_space, k, top_val, top_idx, top_space);
+}
+
+int32_t abo::acq_terms_ex(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, const abo_acq_term* terms, int32_t nterms,
+                          int64_t idx_base, double* scores, int32_t out_space, int32_t k, double* top_val, int64_t* top_idx,
+                          int32_t top_space) {
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    AcqTerms t{};
+    rc = make_terms(g, terms, nterms, &t, "abo_acq_terms");
+    if (rc) return rc;
+    return acq_terms_impl(g, Z, M, d, z_space, t, idx_base, scores, out_space, k, top_val, top_idx, top_space);
+}
+
+extern "C" int32_t abo_acq_terms(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_space, const abo_acq_term* terms,
+                                 int32_t nterms, int64_t idx_base, double* scores, int32_t k, double* top_val, int64_t* top_idx,
+                                 int32_t out_space) {
+    return abo::acq_terms_ex(g, Z, M, d, z_space, terms, nterms, idx_base, scores, out_space, k, top_val, top_idx, out_space);
 }
 
 namespace {
@@ -1907,24 +1999,29 @@ RefineOpts refine_defaults(const abo_refine_opts* o) {
     return r;
 }
 
-int32_t check_refinable(abo_gp* g, int32_t d, int32_t kind, const char* fn) {
+int32_t check_refinable(abo_gp* g, int32_t d, const char* fn) {
     int32_t rc = check_fitted(g, d);
     if (rc) return rc;
-    if (g->p_out > 1) return fail(ABO_EINVAL, "%s: gradient-enhanced handles are not served (function-value acquisitions of a StandardGP only)", fn);
-    if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "%s: unknown acquisition kind %d", fn, kind);
+    if (g->p_out > 1 && d + 1 != g->p_out) return fail(ABO_EINVAL, "%s: gradient-enhanced handle with p = %d outputs and d = %d", fn, g->p_out, d);
     return ABO_OK;
+}
+
+hipError_t grad_eval_cb(void* ctx, const double* pts, int npts, double* mu, double* cov, hipStream_t) {
+    abo_gp* g = static_cast<abo_gp*>(ctx);
+    // (a failure inside is reported through the calling thread's error slot; the launcher only needs "not hipSuccess")
+    return grad_eval_device(g, pts, npts, 0.0, mu, cov, nullptr) == ABO_OK ? hipSuccess : hipErrorUnknown;
 }
 
 // bounds (2·d doubles: lower, upper), starts (S·d) and the outputs all in DEVICE memory; asynchronous on the handle's stream
 // between events 5 and 6
-int32_t refine_device(abo_gp* g, int32_t kind, double p0, double best_y, const double* bounds_d, const double* starts_d, int S,
+int32_t refine_device(abo_gp* g, const AcqTerms& terms, const double* bounds_d, const double* starts_d, int S,
                       RefineOpts o, double* x_out_d, double* f_out_d, int* iters_d, int grad_only) {
     hipStream_t s = g->stream;
     RefineArgs ra{};
     ra.Xs = g->st->Xs.as<double>(); ra.W = g->st->W.as<double>(); ra.WT = g->st->WT.as<double>(); ra.alpha = g->alpha.as<double>();
     ra.ld = g->st->cap; ra.N = (int)g->N; ra.Np = (int)g->Np; ra.d = g->d; ra.dp = g->dp; ra.family = g->prm.family;
     ra.s = 1.0 / g->prm.ell; ra.sigma_f2 = g->prm.sigma_f2; ra.mean_c = g->prm.mean_c;
-    ra.kind = kind; ra.p0 = p0; ra.best_y = best_y;
+    ra.terms = terms;
     ra.lower = bounds_d; ra.upper = bounds_d ? bounds_d + g->d : nullptr; ra.starts = starts_d;
     ra.x_out = x_out_d; ra.f_out = f_out_d; ra.iters_out = iters_d;
     // the L-BFGS state of a start lives in its workgroup's LDS (64 KiB without opting into more): fewer pairs for very wide inputs
@@ -1933,6 +2030,21 @@ int32_t refine_device(abo_gp* g, int32_t kind, double p0, double best_y, const d
     if (refine_lds_bytes(g->d, g->dp, m) > 65536)
         return fail(ABO_EINVAL, "abo_refine: input dimension %d too large for the on-device refinement (library limit: %d)", g->d, 700);
     ra.max_iter = o.max_iter; ra.ls_max = o.ls_max; ra.history = m; ra.g_tol = o.g_tol; ra.f_abstol = o.f_abstol; ra.x_abstol = o.x_abstol;
+    if (g->p_out > 1) {
+        // gradient-enhanced model: lockstep rounds over the all-output posterior (refine.hip: launch_refine_lockstep_grad) — value
+        // and gradient of the function-value terms come out of ONE mean / covariance-block evaluation per point
+        const bool stencil = terms_have_gradnorm(terms);
+        const size_t wb = refine_lockstep_grad_bytes(S, g->d, m, stencil);
+        HIPCHK(g->T.ensure(wb + sizeof(double) * MAX_P));
+        double* mean_g = reinterpret_cast<double*>(static_cast<char*>(g->T.p) + wb);
+        HIPCHK(hipMemcpyAsync(mean_g, g->mean_vec + 1, sizeof(double) * g->d, hipMemcpyHostToDevice, s));
+        GradEval ev{g, grad_eval_cb};
+        const hipError_t e = grad_only ? launch_acq_grad_via_eval(ra, S, mean_g, g->T.p, ev, s)
+                                       : launch_refine_lockstep_grad(ra, S, mean_g, g->T.p, ev, s);
+        if (e == hipErrorUnknown) return ABO_EHIP;            // grad_eval_device has set the error text
+        HIPCHK(e);
+        return ABO_OK;
+    }
     // from 1024 factor rows on the starts advance in lockstep rounds whose evaluations are batched on the MFMA tile core (L⁻¹ read once
     // per round instead of once per start and evaluation; measured crossover, profiles/r03_optimize_acquisition_latency.txt: N = 500
     // 2.56 ms one launch / 2.96 lockstep, N = 1024 6.98 / 4.16); ABO_REFINE_LOCKSTEP_NP moves the switch (0 = never)
@@ -1975,11 +2087,9 @@ void abo::pick_best_point(const double* starts_x, const double* starts_val, cons
 
 extern "C" {
 
-int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const double* lower, const double* upper, int32_t d,
-                   const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out, int32_t* iters_out) {
-    if (!g) return fail(ABO_EINVAL, "abo_refine: null handle");
-    int32_t rc = check_refinable(g, d, kind, "abo_refine");
-    if (rc) return rc;
+static int32_t refine_terms_impl(abo_gp* g, const AcqTerms& terms, const double* lower, const double* upper, int32_t d,
+                                 const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out,
+                                 int32_t* iters_out) {
     if (S < 0 || (S > 0 && (!starts || !x_out || !f_out)) || !lower || !upper) return fail(ABO_EINVAL, "abo_refine: bad argument");
     for (int c = 0; c < d; ++c)
         if (!(lower[c] <= upper[c])) return fail(ABO_EINVAL, "abo_refine: lower[%d] > upper[%d]", c, c);
@@ -1997,7 +2107,7 @@ int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const doub
     HIPCHK(hipMemcpyAsync(sd, starts, sizeof(double) * ns, hipMemcpyHostToDevice, s));
     HIPCHK(g->events(8));
     HIPCHK(hipEventRecord(g->evs()[5], s));
-    rc = refine_device(g, kind, p0, best_y, bd, sd, S, refine_defaults(opts), xd, fd, id, 0);
+    int32_t rc = refine_device(g, terms, bd, sd, S, refine_defaults(opts), xd, fd, id, 0);
     if (rc) return rc;
     HIPCHK(hipEventRecord(g->evs()[6], s));
     std::vector<int> it(2 * (size_t)S);
@@ -2015,10 +2125,36 @@ int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const doub
     return ABO_OK;
 }
 
-int32_t abo_test_acq_grad(abo_gp* g, int32_t kind, double p0, double best_y, const double* Z, int64_t M, int32_t d, double* f,
-                          double* grad) {
+int32_t abo_refine_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const double* lower, const double* upper, int32_t d,
+                         const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out, int32_t* iters_out) {
+    if (!g) return fail(ABO_EINVAL, "abo_refine_terms: null handle");
+    int32_t rc = check_refinable(g, d, "abo_refine_terms");
+    if (rc) return rc;
+    AcqTerms t{};
+    rc = make_terms(g, terms, nterms, &t, "abo_refine_terms");
+    if (rc) return rc;
+    return refine_terms_impl(g, t, lower, upper, d, starts, S, opts, x_out, f_out, iters_out);
+}
+
+int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const double* lower, const double* upper, int32_t d,
+                   const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out, int32_t* iters_out) {
+    if (!g) return fail(ABO_EINVAL, "abo_refine: null handle");
+    int32_t rc = check_refinable(g, d, "abo_refine");
+    if (rc) return rc;
+    const abo_acq_term one{kind, 0, p0, best_y, 1.0};
+    AcqTerms t{};
+    rc = make_terms(g, &one, 1, &t, "abo_refine");
+    if (rc) return rc;
+    return refine_terms_impl(g, t, lower, upper, d, starts, S, opts, x_out, f_out, iters_out);
+}
+
+int32_t abo_test_acq_grad_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const double* Z, int64_t M, int32_t d, double* f,
+                                double* grad) {
     if (!g) return fail(ABO_EINVAL, "abo_test_acq_grad: null handle");
-    int32_t rc = check_refinable(g, d, kind, "abo_test_acq_grad");
+    int32_t rc = check_refinable(g, d, "abo_test_acq_grad");
+    if (rc) return rc;
+    AcqTerms t{};
+    rc = make_terms(g, terms, nterms, &t, "abo_test_acq_grad");
     if (rc) return rc;
     if (M < 0 || M > 65535 || (M > 0 && (!Z || !f || !grad))) return fail(ABO_EINVAL, "abo_test_acq_grad: bad argument (M ≤ 65535)");
     if (M == 0) return ABO_OK;
@@ -2028,7 +2164,7 @@ int32_t abo_test_acq_grad(abo_gp* g, int32_t kind, double p0, double best_y, con
     HIPCHK(g->Zdev.ensure(sizeof(double) * (2 * ns + M)));
     double *sd = g->Zdev.as<double>(), *xd = sd + ns, *fd = xd + ns;
     HIPCHK(hipMemcpyAsync(sd, Z, sizeof(double) * ns, hipMemcpyHostToDevice, s));
-    rc = refine_device(g, kind, p0, best_y, nullptr, sd, (int)M, refine_defaults(nullptr), xd, fd, nullptr, 1);
+    rc = refine_device(g, t, nullptr, sd, (int)M, refine_defaults(nullptr), xd, fd, nullptr, 1);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(grad, xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(f, fd, sizeof(double) * M, hipMemcpyDeviceToHost, s));
@@ -2036,13 +2172,30 @@ int32_t abo_test_acq_grad(abo_gp* g, int32_t kind, double p0, double best_y, con
     return ABO_OK;
 }
 
-int32_t abo_optimize_acquisition(abo_gp* g, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
-                                 int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
-                                 double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
-                                 double* refined_val) {
-    if (!g) return fail(ABO_EINVAL, "abo_optimize_acquisition: null handle");
-    int32_t rc = check_refinable(g, d, kind, "abo_optimize_acquisition");
+int32_t abo_test_acq_grad(abo_gp* g, int32_t kind, double p0, double best_y, const double* Z, int64_t M, int32_t d, double* f,
+                          double* grad) {
+    const abo_acq_term one{kind, 0, p0, best_y, 1.0};
+    return abo_test_acq_grad_terms(g, &one, 1, Z, M, d, f, grad);
+}
+
+}  // extern "C"
+
+// The grid stage on one handle (acq_utils.jl:44-52): n-point Latin hypercube generated on the device (rows j0 … j0+count−1 of it),
+// scored under `t`, the k best (score, global index) pairs left in DEVICE memory (tv, ti) and — when sd is given — their
+// coordinates gathered to sd [k][d].  bounds_d: device {lower[d], upper[d]}.  grid: scratch of count·d doubles.  Synchronises.
+static int32_t grid_stage_device(abo_gp* g, const AcqTerms& t, const double* bounds_d, int d, int64_t n, int64_t j0, int64_t count,
+                                 uint64_t seed, int k, double* grid, double* tv, int64_t* ti, double* sd) {
+    hipStream_t s = g->stream;
+    HIPCHK(launch_lhs(grid, n, d, bounds_d, bounds_d + d, seed, j0, count, s));
+    int32_t rc = acq_terms_impl(g, grid, count, d, ABO_DEVICE, t, j0, nullptr, ABO_DEVICE, k, tv, ti, ABO_DEVICE);
     if (rc) return rc;
+    if (sd) HIPCHK(launch_gather_points(grid, ti, j0, k, d, sd, s));
+    return ABO_OK;
+}
+
+static int32_t optimize_terms_impl(abo_gp* g, const AcqTerms& t, const double* lower, const double* upper, int32_t d, int64_t n_grid,
+                                   int32_t n_local, uint64_t seed, const abo_refine_opts* opts, double* best_x, double* best_val,
+                                   double* starts_x, double* starts_val, double* refined_x, double* refined_val) {
     if (!lower || !upper || !best_x) return fail(ABO_EINVAL, "abo_optimize_acquisition: null argument");
     if (n_grid < 1 || n_local < 1) return fail(ABO_EINVAL, "abo_optimize_acquisition: n_grid and n_local must be positive");
     for (int c = 0; c < d; ++c)
@@ -2062,15 +2215,13 @@ int32_t abo_optimize_acquisition(abo_gp* g, int32_t kind, double p0, double best
     HIPCHK(hipMemcpyAsync(bd, lower, sizeof(double) * d, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(bd + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, s));
     // grid stage (acq_utils.jl:44-52): Latin hypercube on the device, fused scores, stable reverse sort's first k
-    HIPCHK(launch_lhs(grid.b.as<double>(), n_grid, d, bd, bd + d, seed, 0, n_grid, s));
-    rc = abo::acq_ex(g, grid.b.as<double>(), n_grid, d, ABO_DEVICE, kind, p0, best_y, 0, nullptr, ABO_DEVICE, k, tv, ti, ABO_DEVICE);
+    int32_t rc = grid_stage_device(g, t, bd, d, n_grid, 0, n_grid, seed, k, grid.b.as<double>(), tv, ti, sd);
     if (rc) return rc;
     const double grid_ms = g->tm.acq_total_ms;
-    HIPCHK(launch_gather_points(grid.b.as<double>(), ti, 0, k, d, sd, s));
     // refinement stage (:55-71): one launch
     HIPCHK(g->events(10));
     HIPCHK(hipEventRecord(g->evs()[8], s));
-    rc = refine_device(g, kind, p0, best_y, bd, sd, k, refine_defaults(opts), xd, fd, id, 0);
+    rc = refine_device(g, t, bd, sd, k, refine_defaults(opts), xd, fd, id, 0);
     if (rc) return rc;
     HIPCHK(hipEventRecord(g->evs()[9], s));
     std::vector<double> hs(ns), hv(k), hx(ns), hf(k);
@@ -2093,6 +2244,93 @@ int32_t abo_optimize_acquisition(abo_gp* g, int32_t kind, double p0, double best
     if (starts_val) memcpy(starts_val, hv.data(), sizeof(double) * k);
     if (refined_x) memcpy(refined_x, hx.data(), sizeof(double) * ns);
     if (refined_val) memcpy(refined_val, hf.data(), sizeof(double) * k);
+    return ABO_OK;
+}
+
+// internal (mgpu.hip): a shard's part of the grid stage with the selection left on the device
+int32_t abo::acq_lhs_shard(abo_gp* g, const abo_acq_term* terms, int32_t nterms, int64_t n, int32_t d, const double* lower,
+                           const double* upper, uint64_t seed, int64_t j0, int64_t count, int32_t k, double* grid_d, double* tv_d,
+                           int64_t* ti_d) {
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    AcqTerms t{};
+    rc = make_terms(g, terms, nterms, &t, "abo_mgpu_acq_lhs");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    ScratchBuf bnd(g->prm.device, s);
+    HIPCHK(bnd.b.ensure(sizeof(double) * 2 * (size_t)d));
+    double* bd = bnd.b.as<double>();
+    HIPCHK(hipMemcpyAsync(bd, lower, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(bd + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    if (count > 0) HIPCHK(launch_lhs(grid_d, n, d, bd, bd + d, seed, j0, count, s));
+    return acq_terms_impl(g, grid_d, count, d, ABO_DEVICE, t, j0, nullptr, ABO_DEVICE, k, tv_d, ti_d, ABO_DEVICE);
+}
+
+int32_t abo::refine_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const double* lower, const double* upper, int32_t d,
+                          const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out) {
+    return abo_refine_terms(g, terms, nterms, lower, upper, d, starts, S, opts, x_out, f_out, nullptr);
+}
+
+extern "C" {
+
+int32_t abo_optimize_acquisition_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const double* lower, const double* upper,
+                                       int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                       double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                       double* refined_val) {
+    if (!g) return fail(ABO_EINVAL, "abo_optimize_acquisition_terms: null handle");
+    int32_t rc = check_refinable(g, d, "abo_optimize_acquisition_terms");
+    if (rc) return rc;
+    AcqTerms t{};
+    rc = make_terms(g, terms, nterms, &t, "abo_optimize_acquisition_terms");
+    if (rc) return rc;
+    return optimize_terms_impl(g, t, lower, upper, d, n_grid, n_local, seed, opts, best_x, best_val, starts_x, starts_val, refined_x,
+                               refined_val);
+}
+
+int32_t abo_optimize_acquisition(abo_gp* g, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
+                                 int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                 double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                 double* refined_val) {
+    const abo_acq_term one{kind, 0, p0, best_y, 1.0};
+    return abo_optimize_acquisition_terms(g, &one, 1, lower, upper, d, n_grid, n_local, seed, opts, best_x, best_val, starts_x,
+                                          starts_val, refined_x, refined_val);
+}
+
+// the grid stage alone on ONE handle: what abo_mgpu_acq_lhs is for a group (the Julia shim's grid_stage on a single-device model)
+int32_t abo_acq_lhs(abo_gp* g, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed, int32_t kind, double p0,
+                    double best_y, int32_t k, double* top_val, int64_t* top_idx, double* top_x) {
+    if (!g) return fail(ABO_EINVAL, "abo_acq_lhs: null handle");
+    int32_t rc = check_fitted(g, d);
+    if (rc) return rc;
+    if (n < 1 || !lower || !upper) return fail(ABO_EINVAL, "abo_acq_lhs: bad grid");
+    if (k < 1 || !top_val || !top_idx) return fail(ABO_EINVAL, "abo_acq_lhs: needs k >= 1, top_val and top_idx");
+    const abo_acq_term one{kind, 0, p0, best_y, 1.0};
+    AcqTerms t{};
+    rc = make_terms(g, &one, 1, &t, "abo_acq_lhs");
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    ScratchBuf blk(g->prm.device, s), grid(g->prm.device, s);
+    const size_t nb = 2 * (size_t)d, ns = (size_t)k * d;
+    HIPCHK(blk.b.ensure(sizeof(double) * (nb + ns + (size_t)k) + sizeof(int64_t) * k));
+    HIPCHK(grid.b.ensure(sizeof(double) * (size_t)n * d));
+    double* bd = blk.b.as<double>();
+    double *sd = bd + nb, *tv = sd + ns;
+    int64_t* ti = reinterpret_cast<int64_t*>(tv + k);
+    HIPCHK(hipMemcpyAsync(bd, lower, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(bd + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    rc = grid_stage_device(g, t, bd, d, n, 0, n, seed, k, grid.b.as<double>(), tv, ti, top_x ? sd : nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(top_val, tv, sizeof(double) * k, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(top_idx, ti, sizeof(int64_t) * k, hipMemcpyDeviceToHost, s));
+    if (top_x) HIPCHK(hipMemcpyAsync(top_x, sd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (top_x) {
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        for (int e = 0; e < k; ++e)
+            if (top_idx[e] < 0) for (int c = 0; c < d; ++c) top_x[(size_t)e * d + c] = nan;
+    }
     return ABO_OK;
 }
 

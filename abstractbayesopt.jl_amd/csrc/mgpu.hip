@@ -623,8 +623,8 @@ int32_t abo_mgpu_acq(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, int32_
     return ABO_OK;
 }
 
-int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
-                         int32_t kind, double p0, double best_y, int32_t k, double* top_val, int64_t* top_idx, double* top_x) {
+static int32_t mgpu_acq_lhs_terms(abo_mgpu* mg, const abo_acq_term* terms, int32_t nterms, int64_t n, int32_t d, const double* lower,
+                                  const double* upper, uint64_t seed, int32_t k, double* top_val, int64_t* top_idx, double* top_x) {
     int32_t rc = check_group(mg, "abo_mgpu_acq_lhs");
     if (rc) return rc;
     if (n < 1 || !lower || !upper) return failf(ABO_EINVAL, "abo_mgpu_acq_lhs: bad grid");
@@ -642,18 +642,14 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
         shard_range(n, i, mg->ndev, &lo, &hi);
         int32_t r = ensure_exchange_buffers(mg, i, words);
         if (r) return r;
-        if (hi > lo) {
-            if (hipMalloc(reinterpret_cast<void**>(&zdev[i]), sizeof(double) * (hi - lo) * d) != hipSuccess)
-                return failf(ABO_ENOMEM, "abo_mgpu_acq_lhs: device allocation of the grid shard failed");
-            r = abo_lhs(mg->dev[i], n, d, lower, upper, seed, lo, hi - lo, zdev[i]);
-            if (r) return r;
-        }
-        return abo::acq_ex(mg->gp[i], zdev[i], hi - lo, d, ABO_DEVICE, kind, p0, best_y, lo, nullptr, ABO_DEVICE, k,
-                           static_cast<double*>(cs->pack[i]), static_cast<int64_t*>(cs->pack[i]) + k, ABO_DEVICE);
+        if (hi > lo && hipMalloc(reinterpret_cast<void**>(&zdev[i]), sizeof(double) * (hi - lo) * d) != hipSuccess)
+            return failf(ABO_ENOMEM, "abo_mgpu_acq_lhs: device allocation of the grid shard failed");
+        return abo::acq_lhs_shard(mg->gp[i], terms, nterms, n, d, lower, upper, seed, lo, hi - lo, k, zdev[i],
+                                  static_cast<double*>(cs->pack[i]), static_cast<int64_t*>(cs->pack[i]) + k);
     });
     std::vector<uint64_t> blocks((size_t)mg->ndev * words);
     if (!rc) rc = exchange(mg, words, blocks.data());
-    if (rc) { free_grids(); return rc; }
+    if (rc) { const std::string keep = abo::last_error_text(); free_grids(); return abo::set_error(rc, keep.c_str()); }
     merge_blocks(blocks.data(), mg->ndev, k, top_val, top_idx);
     if (top_x) {
         // coordinates of the winners, fetched from the shard that generated them
@@ -679,28 +675,34 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
     return rc;
 }
 
+int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
+                         int32_t kind, double p0, double best_y, int32_t k, double* top_val, int64_t* top_idx, double* top_x) {
+    const abo_acq_term one{kind, 0, p0, best_y, 1.0};
+    return mgpu_acq_lhs_terms(mg, &one, 1, n, d, lower, upper, seed, k, top_val, top_idx, top_x);
+}
+
 // optimize_acquisition (acq_utils.jl:33-73) across the group: grid stage sharded (abo_mgpu_acq_lhs), the selected starts dealt
-// out contiguously, every device refines its share in one launch (abo_refine), the host keeps the best
-int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
-                                      int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
-                                      double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
-                                      double* refined_val) {
+// out contiguously, every device refines its share (abo_refine_terms), the host keeps the best
+int32_t abo_mgpu_optimize_acquisition_terms(abo_mgpu* mg, const abo_acq_term* terms, int32_t nterms, const double* lower,
+                                            const double* upper, int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed,
+                                            const abo_refine_opts* opts, double* best_x, double* best_val, double* starts_x,
+                                            double* starts_val, double* refined_x, double* refined_val) {
     int32_t rc = check_group(mg, "abo_mgpu_optimize_acquisition");
     if (rc) return rc;
-    if (!lower || !upper || !best_x) return failf(ABO_EINVAL, "abo_mgpu_optimize_acquisition: null argument");
+    if (!lower || !upper || !best_x || !terms) return failf(ABO_EINVAL, "abo_mgpu_optimize_acquisition: null argument");
     if (n_grid < 1 || n_local < 1) return failf(ABO_EINVAL, "abo_mgpu_optimize_acquisition: n_grid and n_local must be positive");
     const int k = (int)(n_local < n_grid ? n_local : n_grid);
     std::vector<double> tv(k), tx((size_t)k * d), rx((size_t)k * d), rf(k);
     std::vector<int64_t> ti(k);
-    rc = abo_mgpu_acq_lhs(mg, n_grid, d, lower, upper, seed, kind, p0, best_y, k, tv.data(), ti.data(), tx.data());
+    rc = mgpu_acq_lhs_terms(mg, terms, nterms, n_grid, d, lower, upper, seed, k, tv.data(), ti.data(), tx.data());
     if (rc) return rc;
     // a selection shorter than k cannot happen (k ≤ n_grid), but a NaN score can: such a start is returned unchanged by abo_refine
     rc = run_all(mg->cs->wk, mg->ndev, [&](int i) -> int32_t {
         int64_t lo, hi;
         shard_range(k, i, mg->ndev, &lo, &hi);
         if (hi == lo) return ABO_OK;
-        return abo_refine(mg->gp[i], kind, p0, best_y, lower, upper, d, tx.data() + lo * d, (int32_t)(hi - lo), opts,
-                          rx.data() + lo * d, rf.data() + lo, nullptr);
+        return abo::refine_terms(mg->gp[i], terms, nterms, lower, upper, d, tx.data() + lo * d, (int32_t)(hi - lo), opts,
+                                 rx.data() + lo * d, rf.data() + lo);
     });
     if (rc) return rc;
     abo::pick_best_point(tx.data(), tv.data(), rx.data(), rf.data(), k, d, best_x, best_val);
@@ -709,6 +711,15 @@ int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, dou
     if (refined_x) memcpy(refined_x, rx.data(), sizeof(double) * k * d);
     if (refined_val) memcpy(refined_val, rf.data(), sizeof(double) * k);
     return ABO_OK;
+}
+
+int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, double best_y, const double* lower, const double* upper,
+                                      int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
+                                      double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
+                                      double* refined_val) {
+    const abo_acq_term one{kind, 0, p0, best_y, 1.0};
+    return abo_mgpu_optimize_acquisition_terms(mg, &one, 1, lower, upper, d, n_grid, n_local, seed, opts, best_x, best_val, starts_x,
+                                               starts_val, refined_x, refined_val);
 }
 
 // ---- config 5 across devices -----------------------------------------------------------------------------------

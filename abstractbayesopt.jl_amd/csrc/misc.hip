@@ -11,22 +11,9 @@
 #include "abo_kernels.h"
 #include <cstdlib>
 #include "../../include/abo_hip.h"
+#include "abo_acq_dev.h"
 
 namespace abo {
-
-__device__ __forceinline__ double norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440084436210485); }
-__device__ __forceinline__ double norm_pdf(double z) { return exp(-0.5 * z * z) * 0.39894228040143267793994605993438; }
-
-__device__ __forceinline__ double acq_score(int kind, double mu, double var, double p0, double best_y) {
-    if (kind == ABO_ACQ_UCB) return -mu + p0 * sqrt(fmax(var, 0.0));
-    if (kind == ABO_ACQ_MEAN) return -mu;
-    const double delta = (best_y - p0) - mu;
-    if (var <= 1e-12) return fmax(delta, 0.0);
-    const double sg = sqrt(var);
-    const double z = delta / sg;
-    if (kind == ABO_ACQ_EI) return delta * norm_cdf(z) + sg * norm_pdf(z);
-    return norm_cdf(z);
-}
 
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs p) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,6 +119,34 @@ hipError_t launch_score(const double* mu, const double* var, double* score, int6
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) score_terms_kernel(const double* mu, const double* var, double* score, int64_t M, AcqTerms t) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < M) score[j] = terms_score(t, mu[j], var[j]);
+}
+
+hipError_t launch_score_terms(const double* mu, const double* var, double* score, int64_t M, const AcqTerms& t, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(score_terms_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, mu, var, score, M, t);
+    return hipGetLastError();
+}
+
+// gradient-enhanced model: one thread per point over its mean mu[j][p] and covariance block cov[j][p][p] — function-value terms on
+// (mu[0], cov[0][0]), GRADNORM_UCB terms on the gradient block
+__global__ void __launch_bounds__(128) score_terms_grad_kernel(const double* mu, const double* cov, double* score, int64_t M, int p,
+                                                                AcqTerms t) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const double* m = mu + j * p;
+    const double* C = cov + j * p * p;
+    score[j] = terms_score(t, m[0], C[0]) + terms_gradnorm(t, m, C, p);
+}
+
+hipError_t launch_score_terms_grad(const double* mu, const double* cov, double* score, int64_t M, int p, const AcqTerms& t, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(score_terms_grad_kernel, dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, mu, cov, score, M, p, t);
+    return hipGetLastError();
+}
+
 // Greedy q-EI, multi-device: one record per device and pick — {score, global index, μ(z), z[0..d)} of the device's best
 // candidate — assembled on the device so that it can go straight into the RCCL all-gather (or one D2H copy).
 __global__ void pick_record_kernel(const double* tv, const int64_t* ti, int64_t idx_base, const double* Z, const double* mu,
@@ -186,18 +201,9 @@ __global__ void __launch_bounds__(256) grad_cov_kernel(GradCovArgs a) {
     if (a.mu_out && t < p) a.mu_out[gp * p + t] = m[t];
     if (a.score_out && t == 0) {
         // −(mᵀm + trΣ) + β·sqrt(max(4mᵀΣm + 2‖Σ‖_F², 1e-12)) on the gradient block (outputs 1..p−1)
-        double mm = 0.0, tr = 0.0, msm = 0.0, fro = 0.0;
-        for (int q = 1; q < p; ++q) {
-            mm = fma(m[q], m[q], mm);
-            tr += C[q * p + q];
-            double row = 0.0;
-            for (int q2 = 1; q2 < p; ++q2) {
-                row = fma(C[q * p + q2], m[q2], row);
-                fro = fma(C[q * p + q2], C[q * p + q2], fro);
-            }
-            msm = fma(m[q], row, msm);
-        }
-        a.score_out[gp] = -(mm + tr) + a.beta * sqrt(fmax(4.0 * msm + 2.0 * fro, 1e-12));
+        double ms, vs;
+        gradnorm_moments(m, C, p, ms, vs);
+        a.score_out[gp] = gradnorm_ucb(ms, vs, a.beta);
     }
 }
 

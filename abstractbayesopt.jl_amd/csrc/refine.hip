@@ -26,6 +26,7 @@
 #include "abo_kappa.h"
 #include "abo_kernels.h"
 #include "../../include/abo_hip.h"
+#include "abo_acq_dev.h"
 
 namespace abo {
 
@@ -52,26 +53,6 @@ __device__ __forceinline__ void kappa_and_deriv(double u, double& k, double& dk)
         const double r = sqrt_pos(u), e = exp_nonpos(-a * r);
         k = fma(a, r, 1.0) * e; dk = -1.5 * e;
     }
-}
-
-__device__ __forceinline__ double r_norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440084436210485); }
-__device__ __forceinline__ double r_norm_pdf(double z) { return exp(-0.5 * z * z) * 0.39894228040143267793994605993438; }
-
-// acquisition value (the arithmetic of misc.hip: acq_score) and its partial derivatives with respect to μ and σ²
-__device__ __forceinline__ double acq_value_and_partials(int kind, double mu, double var, double p0, double best_y, double& dmu,
-                                                         double& dvar) {
-    if (kind == ABO_ACQ_UCB) {
-        const double sg = sqrt(fmax(var, 0.0));
-        dmu = -1.0; dvar = var > 0.0 ? 0.5 * p0 / sg : 0.0;
-        return -mu + p0 * sg;
-    }
-    if (kind == ABO_ACQ_MEAN) { dmu = -1.0; dvar = 0.0; return -mu; }
-    const double delta = (best_y - p0) - mu;
-    if (var <= 1e-12) { dmu = delta > 0.0 ? -1.0 : 0.0; dvar = 0.0; return fmax(delta, 0.0); }
-    const double sg = sqrt(var), z = delta / sg, cdf = r_norm_cdf(z), pdf = r_norm_pdf(z);
-    if (kind == ABO_ACQ_EI) { dmu = -cdf; dvar = 0.5 * pdf / sg; return delta * cdf + sg * pdf; }
-    dmu = -pdf / sg; dvar = -0.5 * pdf * z / var;                 // PI = Φ(z)
-    return cdf;
 }
 
 constexpr int RCH = 8;          // gradient components reduced per pass
@@ -222,7 +203,7 @@ __device__ void eval_point(const RefineArgs& a, const double* x, double* xs, dou
     }
     __syncthreads();
     double dmu, dvar;
-    const double f = acq_value_and_partials(a.kind, mu, var, a.p0, a.best_y, dmu, dvar);
+    const double f = terms_value_and_partials(a.terms, mu, var, dmu, dvar);
     // gradient, RCH components per pass: ∂k_i/∂x_c = g_i · 2 (xs_c − Xs_ic) · s
     for (int c0 = 0; c0 < d; c0 += RCH) {
         const int nc = (d - c0) < RCH ? (d - c0) : RCH;
@@ -491,7 +472,7 @@ __global__ void __launch_bounds__(RT) rl_reduce_kernel(RefineArgs a, const doubl
     const double var = a.sigma_f2 - out[1] + 1e-18;
     __syncthreads();
     double dmu, dvar;
-    const double f = acq_value_and_partials(a.kind, mu, var, a.p0, a.best_y, dmu, dvar);
+    const double f = terms_value_and_partials(a.terms, mu, var, dmu, dvar);
     double* ev = EV + (int64_t)j * (d + 1);
     for (int c0 = 0; c0 < d; c0 += RCH) {
         const int nc = (d - c0) < RCH ? (d - c0) : RCH;
@@ -663,6 +644,139 @@ hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStr
     // a start still active here has used up the round budget (cannot happen while every start stops after max_iter accepted steps of
     // ≤ ls_max trials each, but the outputs must never be left unwritten): publish its current iterate
     if (left != 0) hipLaunchKernelGGL(rl_flush_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, active, vec, st);
+    return hipGetLastError();
+}
+
+// ---- gradient-enhanced models and objectives with a GRADNORM_UCB term: the lockstep state machine over a caller-supplied evaluation ----
+// (abo_kernels.h: launch_refine_lockstep_grad).  A round: rl_stencil_kernel (the pending points, plus their 2d central-difference
+// neighbours when the objective has a GRADNORM_UCB term) → ev.eval (all-output posterior mean[p] and covariance[p][p] of every
+// point: the kernels behind abo_predict_grad_cov) → rl_grad_ev_kernel (f, ∇f per start) → rl_step_kernel (the same state machine
+// as the StandardGP variants).
+//   function-value terms:  μ = m₀, σ² = Σ₀₀, ∇μ = E[∇f] − m_∇ (the posterior mean of the gradient outputs IS the gradient of the
+//                          posterior mean), ∇σ² = 2·Cov(f, ∇f) (row 0 of the block: k(x,x) is constant and the prior covariance
+//                          of f(x) with ∇f(x) at the same point vanishes for a stationary kernel)
+//   GRADNORM_UCB terms:    central differences of the term's value over x ± h·e_c, h = ∛ε·max(1, |x_c|) — the reference
+//                          differentiates every objective by finite differences of M = 1 calls (acq_utils.jl:55-71); an analytic
+//                          form would need third derivatives of the kernel
+__global__ void rl_stencil_kernel(const double* __restrict__ P, int S, int d, int npp, double* __restrict__ PTS, double* __restrict__ H) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S * d) return;
+    const int j = e / d, c = e % d;
+    const double* x = P + (size_t)j * d;
+    const double h = 6.0554544523933429e-06 * fmax(1.0, fabs(x[c]));          // cbrt(2^-52)
+    const double xp = x[c] + h, xm = x[c] - h;
+    H[e] = xp - xm;
+    double* base = PTS + (size_t)j * npp * d;
+    base[c] = x[c];
+    for (int q = 0; q < d; ++q) {                       // thread (j, c) writes column c of every stencil point of start j
+        base[(size_t)(1 + 2 * q) * d + c] = q == c ? xp : x[c];
+        base[(size_t)(2 + 2 * q) * d + c] = q == c ? xm : x[c];
+    }
+}
+
+// one thread per start: EV[j] = {f, ∇f[0..d)}; f_out / g_out (optional): the same for the test hook
+__global__ void rl_grad_ev_kernel(RefineArgs a, const double* __restrict__ mean_g, const double* __restrict__ MU,
+                                  const double* __restrict__ COV, const double* __restrict__ H, int S, int npp,
+                                  const int* __restrict__ active, double* __restrict__ EV, double* __restrict__ f_out,
+                                  double* __restrict__ g_out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= S || (active && !active[j])) return;
+    const int d = a.d, p = d + 1;
+    const double* m = MU + (size_t)j * npp * p;
+    const double* C = COV + (size_t)j * npp * p * p;
+    double dmu, dvar;
+    double f = terms_value_and_partials(a.terms, m[0], C[0], dmu, dvar);
+    const bool st = npp > 1;
+    if (st) f += terms_gradnorm(a.terms, m, C, p);
+    double* ev = EV ? EV + (size_t)j * (d + 1) : nullptr;
+    for (int c = 0; c < d; ++c) {
+        double g = dmu * (m[1 + c] - mean_g[c]) + dvar * (2.0 * C[1 + c]);
+        if (st) {
+            const double* mp = m + (size_t)(1 + 2 * c) * p;
+            const double* Cp = C + (size_t)(1 + 2 * c) * p * p;
+            const double fp = terms_gradnorm(a.terms, mp, Cp, p), fm = terms_gradnorm(a.terms, mp + p, Cp + p * p, p);
+            g += (fp - fm) / H[(size_t)j * d + c];
+        }
+        if (ev) ev[1 + c] = g;
+        if (g_out) g_out[(size_t)j * d + c] = g;
+    }
+    if (ev) ev[0] = f;
+    if (f_out) f_out[j] = f;
+}
+
+size_t refine_lockstep_grad_bytes(int S, int d, int history, bool stencil) {
+    const size_t npp = stencil ? 2 * (size_t)d + 1 : 1, p = (size_t)d + 1;
+    return sizeof(double) * ((size_t)S * d * 2 + (size_t)S * npp * (d + p + p * p) + (size_t)S * (d + 1) +
+                             (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S + sizeof(int) * S + 64 + 64;
+}
+
+namespace {
+struct GradWork {
+    long long* counters;
+    double *P, *PTS, *H, *MU, *COV, *EV, *vec;
+    RlState* st;
+    int* active;
+    int npp;
+};
+GradWork carve_grad_work(void* work, int S, int d, int m, bool stencil) {
+    GradWork w{};
+    const size_t npp = stencil ? 2 * (size_t)d + 1 : 1, p = (size_t)d + 1;
+    char* c = static_cast<char*>(work);
+    w.counters = reinterpret_cast<long long*>(c); c += 64;
+    w.P = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * d;
+    w.H = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * d;
+    w.PTS = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * npp * d;
+    w.MU = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * npp * p;
+    w.COV = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * npp * p * p;
+    w.EV = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * (d + 1);
+    w.vec = reinterpret_cast<double*>(c); c += sizeof(double) * (size_t)S * rl_vec_doubles(d, m);
+    w.st = reinterpret_cast<RlState*>(c); c += sizeof(RlState) * S;
+    w.active = reinterpret_cast<int*>(c);
+    w.npp = (int)npp;
+    if (!stencil) w.PTS = w.P;                           // one point per start: evaluated in place
+    return w;
+}
+}  // namespace
+
+hipError_t launch_refine_lockstep_grad(const RefineArgs& a, int S, const double* mean_g, void* work, const GradEval& ev, hipStream_t s) {
+    if (S <= 0) return hipSuccess;
+    const int d = a.d, m = a.history;
+    const bool stencil = terms_have_gradnorm(a.terms);
+    GradWork w = carve_grad_work(work, S, d, m, stencil);
+    hipError_t e;
+    if ((e = hipMemsetAsync(w.counters, 0, 64, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.active, 0, sizeof(int) * S, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(w.P, 0, sizeof(double) * (size_t)S * d, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 1, w.P, w.active, w.EV, w.vec, w.st, w.counters);
+    const int64_t max_rounds = 1 + (int64_t)a.max_iter * (int64_t)a.ls_max;
+    long long left = -1;
+    for (int64_t r = 0; r < max_rounds; ++r) {
+        if (stencil) hipLaunchKernelGGL(rl_stencil_kernel, dim3((S * d + 127) / 128), dim3(128), 0, s, w.P, S, d, w.npp, w.PTS, w.H);
+        if ((e = ev.eval(ev.ctx, w.PTS, S * w.npp, w.MU, w.COV, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(rl_grad_ev_kernel, dim3((S + 63) / 64), dim3(64), 0, s, a, mean_g, w.MU, w.COV, w.H, S, w.npp, w.active, w.EV,
+                           (double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 0, w.P, w.active, w.EV, w.vec, w.st, w.counters);
+        if ((r & 7) == 7 || r + 1 == max_rounds) {
+            if ((e = hipMemcpyAsync(&left, w.counters, sizeof left, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+            if (left == 0) break;
+        }
+    }
+    if (left != 0) hipLaunchKernelGGL(rl_flush_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, w.active, w.vec, w.st);
+    return hipGetLastError();
+}
+
+hipError_t launch_acq_grad_via_eval(const RefineArgs& a, int S, const double* mean_g, void* work, const GradEval& ev, hipStream_t s) {
+    if (S <= 0) return hipSuccess;
+    const int d = a.d;
+    const bool stencil = terms_have_gradnorm(a.terms);
+    GradWork w = carve_grad_work(work, S, d, a.history, stencil);
+    hipError_t e;
+    if ((e = hipMemcpyAsync(w.P, a.starts, sizeof(double) * (size_t)S * d, hipMemcpyDeviceToDevice, s)) != hipSuccess) return e;
+    if (stencil) hipLaunchKernelGGL(rl_stencil_kernel, dim3((S * d + 127) / 128), dim3(128), 0, s, w.P, S, d, w.npp, w.PTS, w.H);
+    if ((e = ev.eval(ev.ctx, w.PTS, S * w.npp, w.MU, w.COV, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(rl_grad_ev_kernel, dim3((S + 63) / 64), dim3(64), 0, s, a, mean_g, w.MU, w.COV, w.H, S, w.npp, (const int*)nullptr,
+                       (double*)nullptr, a.f_out, a.x_out);
     return hipGetLastError();
 }
 

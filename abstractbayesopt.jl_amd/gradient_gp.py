@@ -242,8 +242,13 @@ class GradientNormUCB(AbstractAcquisition):
     """GradientNormUCB(β) (gradNormUCB.jl:12-51): UCB on the squared gradient norm, one point at a time in the
     reference; here all points in one call (per-point p×p covariance blocks on the device)."""
 
+    kind = 4                                  # ABO_ACQ_GRADNORM_UCB: a term of the *_terms entry points (refinement, ensembles)
+
     def __init__(self, beta: float):
         self.beta = float(beta)
+
+    def _p0(self):
+        return self.beta
 
     def __call__(self, surrogate: HipGradientGP, x):
         if not isinstance(surrogate, HipGradientGP):

@@ -56,8 +56,21 @@ enum {
     ABO_ACQ_EI = 0,   /* src/acquisition_functions/ExpectedImprovement.jl:40-66   p0 = xi   */
     ABO_ACQ_UCB = 1,  /* src/acquisition_functions/UpperConfidenceBound.jl:38-45  p0 = beta */
     ABO_ACQ_PI = 2,   /* src/acquisition_functions/ProbabilityImprovement.jl:38-63 p0 = xi  */
-    ABO_ACQ_MEAN = 3  /* score = −mu (exploitation only; no reference counterpart) */
+    ABO_ACQ_MEAN = 3, /* score = −mu (exploitation only; no reference counterpart) */
+    ABO_ACQ_GRADNORM_UCB = 4  /* src/acquisition_functions/gradNormUCB.jl:43-51  p0 = beta; gradient-enhanced handles, and only in
+                                 the abo_*_terms entry points (abo_predict_grad_cov scores a batch with it directly) */
 };
+
+/* An objective of the acquisition stage: f(x) = Σ_t weight_t · acq_t(x) on ONE posterior evaluation — EnsembleAcquisition
+ * (src/acquisition_functions/EnsembleAcq.jl:12-27, :53-55; the host normalises the weights as the reference's constructor does);
+ * a plain acquisition function is one term of weight 1.  At most 8 terms. */
+typedef struct abo_acq_term {
+    int32_t kind;       /* ABO_ACQ_* */
+    int32_t reserved;
+    double p0;          /* xi (EI, PI) or beta (UCB, GradientNormUCB) */
+    double best_y;      /* EI, PI */
+    double weight;
+} abo_acq_term;
 
 enum { ABO_HOST = 0, ABO_DEVICE = 1 };
 
@@ -209,6 +222,18 @@ int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_spa
                 double p0, double best_y, int64_t idx_base, double* scores, int32_t k,
                 double* top_val, int64_t* top_idx, int32_t out_space);
 
+/* abo_acq for a weighted-sum objective (EnsembleAcq.jl:53-55): the posterior is evaluated once, every member's epilogue runs on
+ * it; with a GRADNORM_UCB term (gradient-enhanced handles) the per-point mean and covariance block of all outputs are evaluated
+ * instead.  One term of weight 1 is abo_acq, bit for bit. */
+int32_t abo_acq_terms(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_space, const abo_acq_term* terms,
+                      int32_t nterms, int64_t idx_base, double* scores, int32_t k, double* top_val, int64_t* top_idx,
+                      int32_t out_space);
+/* the grid stage of optimize_acquisition (acq_utils.jl:44-52) on ONE handle, the grid never crossing PCIe: an n-point Latin
+ * hypercube generated on the device (abo_lhs), scored, the k best returned — top_val / top_idx (k), top_x (k × d, optional: their
+ * coordinates).  What abo_mgpu_acq_lhs is for a group.  Host outputs. */
+int32_t abo_acq_lhs(abo_gp* gp, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed, int32_t kind,
+                    double p0, double best_y, int32_t k, double* top_val, int64_t* top_idx, double* top_x);
+
 /* --- optimize_acquisition (src/acquisition_functions/acq_utils.jl:33-73) on the device -------------------------------
  * The reference: Latin-hypercube grid of n_grid points → scores → the n_local best as starts (:44-52) → for EVERY start one
  * box-constrained L-BFGS run, Fminbox(LBFGS(HagerZhang(linesearchmax = 20))) with Optim.Options(g_tol = 1e-5, f_abstol = 2.2e-9,
@@ -219,7 +244,19 @@ int32_t abo_acq(abo_gp* gp, const double* Z, int64_t M, int32_t d, int32_t z_spa
  * likewise), Armijo backtracking with at most linesearch_max trials, the reference's three stopping rules.  Maximises the
  * acquisition function inside the box [lower, upper].  x_out S × d, f_out S (the acquisition value at x_out: what abo_acq returns
  * for that point up to the rounding of a differently ordered sum), iters_out (optional) S × 2 = {iterations, evaluations}.  A start whose value is not finite
- * is returned unchanged.  All buffers HOST memory.  StandardGP handles only (a gradient-enhanced handle: ABO_EINVAL).
+ * is returned unchanged.  All buffers HOST memory.
+ * PARITY UNPINNED: the result is a local maximiser of the acquisition function in the box at the reference's tolerances — NOT Optim's
+ * iterate.  The reference runs Fminbox (a log-barrier outer loop that keeps iterates strictly interior) around L-BFGS with HagerZhang
+ * line searches and Optim's convergence bookkeeping; this is a projected L-BFGS with Armijo backtracking that may return a maximiser
+ * ON the bound, and the reference holds no fixture of optimize_acquisition outputs.  What is tested: never below the start, inside
+ * the box, at least SciPy L-BFGS-B's optimum on the CPU oracle's acquisition from the same start (tests/test_gpu_refine.py).
+ * The option fields are clamped (max_iter ≤ 10000, linesearch_max ≤ 64, history ≤ 64).
+ * Gradient-enhanced handles (ABI 5; the reference's tutorials drive optimize_acquisition with GradientGP, gradNormUCB.jl:39-51):
+ * the starts advance in lockstep rounds; a round evaluates the all-output posterior of every pending point (the kernels of
+ * abo_predict_grad_cov) and takes ∇μ = E[∇f(x)] − m_∇ and ∇σ² = 2·Cov(f(x), ∇f(x)) from it — the analytic gradient of EI / UCB /
+ * PI at no extra cost; a GRADNORM_UCB term is differentiated by central differences over a 2d-point stencil evaluated in the same
+ * batch (the reference differentiates every objective that way).
+ * The *_terms forms take a weighted-sum objective (abo_acq_term: EnsembleAcquisition; ∇ = Σ w_t ∇acq_t on one posterior).
  * abo_optimize_acquisition is the whole function in ONE call: grid generated on the device (abo_lhs, `seed`), scored and
  * reduced to the min(n_local, n_grid) best (abo_acq), those refined, the best point returned: best_x (d), best_val; optional
  * starts_x (k × d) / starts_val (k): the selected grid points and their scores in selection order; refined_x / refined_val: what
@@ -238,6 +275,13 @@ int32_t abo_optimize_acquisition(abo_gp* gp, int32_t kind, double p0, double bes
                                  int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
                                  double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
                                  double* refined_val);
+int32_t abo_refine_terms(abo_gp* gp, const abo_acq_term* terms, int32_t nterms, const double* lower, const double* upper, int32_t d,
+                         const double* starts, int32_t S, const abo_refine_opts* opts, double* x_out, double* f_out,
+                         int32_t* iters_out);
+int32_t abo_optimize_acquisition_terms(abo_gp* gp, const abo_acq_term* terms, int32_t nterms, const double* lower,
+                                       const double* upper, int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed,
+                                       const abo_refine_opts* opts, double* best_x, double* best_val, double* starts_x,
+                                       double* starts_val, double* refined_x, double* refined_val);
 
 /* --- resident candidate sets (BASELINE config 5: greedy q-EI over a fixed grid) --------------------
  * abo_cand_create copies M candidates to the device and evaluates their posterior with `gp`
@@ -330,7 +374,7 @@ int32_t abo_mgpu_create(const abo_params* params, int32_t ndev, const int32_t* d
  * 617-639).  abo_mgpu_fit then takes y of length p·N ordered by outputs, abo_mgpu_predict / _acq / _acq_lhs / _cand_* address the
  * function output, abo_mgpu_append_grad appends one observation {f, ∂f/∂x_1 …} on every device (abo_append_grad), and
  * abo_mgpu_cand_qei conditions each pick on the posterior mean of all p outputs at the picked point (the Kriging-believer fantasy of a
- * model that observes gradients).  abo_mgpu_optimize_acquisition is not offered for it (abo_refine serves StandardGP handles). */
+ * model that observes gradients). */
 int32_t abo_mgpu_create_grad(const abo_params* params, int32_t p, const double* mean_c, int32_t ndev, const int32_t* dev, abo_mgpu** out);
 /* Base.copy (StandardGP.jl:26): a new group sharing every per-device state (abo_retain) */
 int32_t abo_mgpu_clone(abo_mgpu* mg, abo_mgpu** out);
@@ -371,6 +415,10 @@ int32_t abo_mgpu_optimize_acquisition(abo_mgpu* mg, int32_t kind, double p0, dou
                                       int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed, const abo_refine_opts* opts,
                                       double* best_x, double* best_val, double* starts_x, double* starts_val, double* refined_x,
                                       double* refined_val);
+int32_t abo_mgpu_optimize_acquisition_terms(abo_mgpu* mg, const abo_acq_term* terms, int32_t nterms, const double* lower,
+                                            const double* upper, int32_t d, int64_t n_grid, int32_t n_local, uint64_t seed,
+                                            const abo_refine_opts* opts, double* best_x, double* best_val, double* starts_x,
+                                            double* starts_val, double* refined_x, double* refined_val);
 int32_t abo_mgpu_cand_create(abo_mgpu* mg, const double* Z, int64_t M, int32_t d, abo_mcand** out);
 int32_t abo_mgpu_cand_create_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed,
                                  abo_mcand** out);
@@ -411,6 +459,8 @@ int32_t abo_test_oz_contract(int32_t device, const double* W, int64_t ldw, int32
  * the refinement stage is built on, one workgroup per point */
 int32_t abo_test_acq_grad(abo_gp* gp, int32_t kind, double p0, double best_y, const double* Z, int64_t M, int32_t d, double* f,
                           double* grad);
+int32_t abo_test_acq_grad_terms(abo_gp* gp, const abo_acq_term* terms, int32_t nterms, const double* Z, int64_t M, int32_t d,
+                                double* f, double* grad);
 /* out[i] = kappa(family, d2[i]) evaluated with the device math of the kernel-matrix generator */
 int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n);
 int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M,

@@ -1,4 +1,4 @@
-# HipGradientGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 4; checked by HipStandardGP.jl's _ensure_abi) for the gradient-enhanced surrogate of
+# HipGradientGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 5; checked by HipStandardGP.jl's _ensure_abi) for the gradient-enhanced surrogate of
 # AbstractBayesOpt.jl (`GradientGP`, src/surrogates/GradientGP.jl).  `include` it after HipStandardGP.jl (it uses that file's
 # AboParams, AboHandle, _check, _pack, _family, LIBABO) and export HipGradientGP.
 #
@@ -10,6 +10,7 @@
 #   posterior_grad_mean / _var :936, :953 (all p outputs)          same names                  abo_predict_grad
 #   posterior_grad_cov :969 (one point: p×p)                       same name                   abo_predict_grad_cov
 #   GradientNormUCB functor, gradNormUCB.jl:43-51                  functor method              abo_predict_grad_cov (score)
+#   optimize_acquisition(acqf, model, domain), acq_utils.jl:33-73  optimize_acquisition        abo_optimize_acquisition_terms
 #   nlml / nlml_ls :684, :719                                      same names                  abo_nlml (+ abo_nlml_grad)
 #   get_mean_std / std_y / rescale_model :753, :785, :802          same names                  host only
 #   _update_model_parameters :834, get_lengthscale / get_scale / get_kernel_constructor :849-875,
@@ -91,12 +92,12 @@ function update(m::HipGradientGP, xs::AbstractVector, ys::AbstractVector)       
         GC.@preserve mv devs _check(@ccall LIBABO.abo_mgpu_create_grad(prm::Ptr{AboParams}, m.p::Int32, mv::Ptr{Float64},
                                                                         length(devs)::Int32, devs::Ptr{Int32}, h::Ptr{Ptr{Cvoid}})::Int32)
         g = AboHandle(h[], true)
-        GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_mgpu_fit(g.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64, d::Int32,
+        GC.@preserve X y _check(@abocall(LIBABO.abo_mgpu_fit(g.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64, d::Int32,
             y::Ptr{Float64}, info::Ptr{Int64})::Int32), info[])
         return _with(m, g)
     end
     hd = _create(m)
-    GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64, d::Int32,
+    GC.@preserve X y _check(@abocall(LIBABO.abo_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64, d::Int32,
         y::Ptr{Float64}, 0::Int32, info::Ptr{Int64})::Int32), info[])
     _with(m, hd)
 end
@@ -121,10 +122,10 @@ function _predict_f(m::HipGradientGP, x, want_mu, want_var)                     
     pm = want_mu ? pointer(mu) : Ptr{Float64}(C_NULL); pv = want_var ? pointer(var) : Ptr{Float64}(C_NULL)
     GC.@preserve Z mu var begin
         if m.gpx.multi                                       # function output, candidates sharded over the group's devices
-            _check(@ccall gc_safe=true LIBABO.abo_mgpu_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+            _check(@abocall LIBABO.abo_mgpu_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
                                                                  pm::Ptr{Float64}, pv::Ptr{Float64})::Int32)
         else
-            _check(@ccall gc_safe=true LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+            _check(@abocall LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
                                                             0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
         end
     end
@@ -146,7 +147,7 @@ function _predict_all(m::HipGradientGP, x, want_mu, want_var)                   
     Z = _pack(x); d, M = size(Z)
     mu = want_mu ? Vector{Float64}(undef, M * m.p) : Float64[]; var = want_var ? Vector{Float64}(undef, M * m.p) : Float64[]
     pm = want_mu ? pointer(mu) : Ptr{Float64}(C_NULL); pv = want_var ? pointer(var) : Ptr{Float64}(C_NULL)
-    GC.@preserve Z mu var _check(@ccall gc_safe=true LIBABO.abo_predict_grad(_shard0(m)::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64,
+    GC.@preserve Z mu var _check(@abocall LIBABO.abo_predict_grad(_shard0(m)::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64,
         d::Int32, 0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
     mu, var
 end
@@ -157,12 +158,41 @@ posterior_grad_var(m::HipGradientGP, x)  = _predict_all(m, x isa Real ? [x] : x,
 function _grad_cov(m::HipGradientGP, x, β)
     Z = _pack(x); d, M = size(Z); p = m.p
     mu = Matrix{Float64}(undef, p, M); cov = Array{Float64}(undef, p, p, M); sc = Vector{Float64}(undef, M)
-    GC.@preserve Z mu cov sc _check(@ccall gc_safe=true LIBABO.abo_predict_grad_cov(_shard0(m)::Ptr{Cvoid}, Z::Ptr{Float64},
+    GC.@preserve Z mu cov sc _check(@abocall LIBABO.abo_predict_grad_cov(_shard0(m)::Ptr{Cvoid}, Z::Ptr{Float64},
         M::Int64, d::Int32, 0::Int32, Float64(β)::Float64, mu::Ptr{Float64}, cov::Ptr{Float64}, sc::Ptr{Float64}, 0::Int32)::Int32)
     mu, cov, sc
 end
 posterior_grad_cov(m::HipGradientGP, x) = (c = _grad_cov(m, x isa Real ? [x] : x, 0.0)[2]; size(c, 3) == 1 ? c[:, :, 1] : c)   # :969
 (a::GradientNormUCB)(m::HipGradientGP, x::AbstractVector) = _grad_cov(m, x, a.β)[3]       # gradNormUCB.jl:43-51, all points at once
+
+# optimize_acquisition (acq_utils.jl:33-73) on a gradient-enhanced model in ONE ccall — what the reference's tutorials run
+# (GradientGP + GradientNormUCB / EI; the stock path: up to n_local serial Optim runs of M = 1 ccalls, each refactoring nothing
+# but paying O(((d+1)N)²) per objective value and 2d more per finite-difference gradient).  Function-value acquisitions get their
+# analytic gradient from the all-output posterior (∇μ = E[∇f] − m_∇, ∇σ² = 2·Cov(f, ∇f)); GradientNormUCB is differentiated by
+# central differences on the device, as the reference differentiates everything.
+_terms(a::GradientNormUCB, w=1.0) = [AboAcqTerm(Int32(4), Int32(0), Float64(a.β), 0.0, Float64(w))]
+function optimize_acquisition(acqf::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityImprovement,GradientNormUCB,EnsembleAcquisition},
+                              m::HipGradientGP, domain::ContinuousDomain; n_grid::Int=10_000, n_local::Int=100, seed::UInt64=rand(UInt64))
+    m.gpx === nothing && throw(ArgumentError("surrogate is not conditioned on data yet (gpx === nothing)"))
+    _optimize_terms(_terms(acqf), m.gpx, domain, n_grid, n_local, seed)
+end
+# fused function-value acquisitions on the gradient-enhanced model (more specific than the ::AbstractSurrogate methods)
+function _acq_f(m::HipGradientGP, x, kind, p0, best)
+    Z = _pack(x); d, M = size(Z); s = Vector{Float64}(undef, M)
+    GC.@preserve Z s begin
+        if m.gpx.multi
+            _check(@abocall LIBABO.abo_mgpu_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, kind::Int32, p0::Float64,
+                best::Float64, s::Ptr{Float64}, 0::Int32, C_NULL::Ptr{Float64}, C_NULL::Ptr{Int64})::Int32)
+        else
+            _check(@abocall LIBABO.abo_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, 0::Int32, kind::Int32,
+                p0::Float64, best::Float64, 0::Int64, s::Ptr{Float64}, 0::Int32, C_NULL::Ptr{Float64}, C_NULL::Ptr{Int64}, 0::Int32)::Int32)
+        end
+    end
+    s
+end
+(a::ExpectedImprovement)(m::HipGradientGP, x::AbstractVector)    = _acq_f(m, x, _acq_args(a)...)
+(a::UpperConfidenceBound)(m::HipGradientGP, x::AbstractVector)   = _acq_f(m, x, _acq_args(a)...)
+(a::ProbabilityImprovement)(m::HipGradientGP, x::AbstractVector) = _acq_f(m, x, _acq_args(a)...)
 
 function unstandardized_mean_and_var(m::HipGradientGP, X, params::Tuple)           # :1019
     μ, σ = params[1], params[2][1]

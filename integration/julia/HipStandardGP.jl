@@ -1,4 +1,4 @@
-# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 4) for AbstractBayesOpt.jl.
+# HipStandardGP.jl — binding of libabo_hip.so (include/abo_hip.h, ABI version 5) for AbstractBayesOpt.jl.
 #
 # Drop next to src/surrogates/StandardGP.jl, `include("surrogates/HipStandardGP.jl")` from src/AbstractBayesOpt.jl
 # (after StandardGP.jl and the acquisition functions) and export HipStandardGP.  Every method the BO driver calls on
@@ -23,6 +23,14 @@
 # abstractbayesopt.jl_amd/, which is this binding written with ctypes.
 
 const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
+# Long calls (a config-3 step is half a second) should not hold up Julia's GC: `@ccall gc_safe=true` exists from Julia 1.12 on;
+# the reference supports 1.11 too (Project.toml:37), where the plain `@ccall` is used.  Every call that can take more than a few
+# microseconds goes through @abocall.
+@static if VERSION >= v"1.12.0-"
+    macro abocall(ex) esc(:(@ccall gc_safe=true $ex)) end
+else
+    macro abocall(ex) esc(:(@ccall $ex)) end
+end
 const ABO_ABI = Int32(5)                 # ABO_ABI_VERSION of the header this file was written against
 const _abi_checked = Ref(false)
 # a stale libabo_hip.so on the load path would otherwise fail at the first missing symbol, somewhere inside a BO step
@@ -151,13 +159,13 @@ function update(m::HipStandardGP, xs::AbstractVector, ys::AbstractVector)       
         GC.@preserve devs _check(@ccall LIBABO.abo_mgpu_create(p::Ptr{AboParams}, length(devs)::Int32, devs::Ptr{Int32},
                                                                 h::Ptr{Ptr{Cvoid}})::Int32)
         hd = AboHandle(h[], true)
-        GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_mgpu_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64,
+        GC.@preserve X y _check(@abocall(LIBABO.abo_mgpu_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64,
             d::Int32, y::Ptr{Float64}, info::Ptr{Int64})::Int32), info[])
         return _with(m, hd)
     end
     _check(@ccall LIBABO.abo_create(p::Ptr{AboParams}, h::Ptr{Ptr{Cvoid}})::Int32)
     hd = AboHandle(h[])
-    GC.@preserve X y _check(@ccall(gc_safe=true, LIBABO.abo_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64,
+    GC.@preserve X y _check(@abocall(LIBABO.abo_fit(hd.ptr::Ptr{Cvoid}, X::Ptr{Float64}, N::Int64,
         d::Int32, y::Ptr{Float64}, 0::Int32, info::Ptr{Int64})::Int32), info[])
     _with(m, hd)
 end
@@ -170,10 +178,10 @@ function _predict(m::HipStandardGP, x, want_mu, want_var)
     pm = want_mu ? pointer(mu) : Ptr{Float64}(C_NULL); pv = want_var ? pointer(var) : Ptr{Float64}(C_NULL)
     GC.@preserve Z mu var begin
         if m.gpx.multi
-            _check(@ccall gc_safe=true LIBABO.abo_mgpu_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+            _check(@abocall LIBABO.abo_mgpu_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
                                                                  pm::Ptr{Float64}, pv::Ptr{Float64})::Int32)
         else
-            _check(@ccall gc_safe=true LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+            _check(@abocall LIBABO.abo_predict(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
                                                             0::Int32, pm::Ptr{Float64}, pv::Ptr{Float64}, 0::Int32)::Int32)
         end
     end
@@ -191,10 +199,10 @@ function _acq(m::HipStandardGP, x, kind, p0, best; k=0, scores=true)
     tv = Vector{Float64}(undef, k); ti = Vector{Int64}(undef, k)
     GC.@preserve Z s tv ti begin
         if m.gpx.multi
-            _check(@ccall gc_safe=true LIBABO.abo_mgpu_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+            _check(@abocall LIBABO.abo_mgpu_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
                 kind::Int32, p0::Float64, best::Float64, ps::Ptr{Float64}, k::Int32, tv::Ptr{Float64}, ti::Ptr{Int64})::Int32)
         else
-            _check(@ccall gc_safe=true LIBABO.abo_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, 0::Int32,
+            _check(@abocall LIBABO.abo_acq(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, 0::Int32,
                 kind::Int32, p0::Float64, best::Float64, 0::Int64, ps::Ptr{Float64}, k::Int32, tv::Ptr{Float64},
                 ti::Ptr{Int64}, 0::Int32)::Int32)
         end
@@ -212,12 +220,20 @@ _acq_args(a::ProbabilityImprovement) = (Int32(2), Float64(a.ξ), Float64(a.best_
 # devices (shard by shard), scored, and only the n_local best starts come back.  Returns (points::Vector{Vector}, scores).
 function grid_stage(acqf::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityImprovement}, m::HipStandardGP,
                     lower::Vector{Float64}, upper::Vector{Float64}; n_grid=10_000, n_local=100, seed=rand(UInt64))
+    m.gpx === nothing && throw(ArgumentError("surrogate is not conditioned on data yet (gpx === nothing)"))
     kind, p0, best = _acq_args(acqf); d = length(lower); k = min(n_local, n_grid)
     tv = Vector{Float64}(undef, k); ti = Vector{Int64}(undef, k); tx = Matrix{Float64}(undef, d, k)
-    g = m.gpx.multi ? m.gpx : _group_of(m)
-    GC.@preserve lower upper tv ti tx _check(@ccall gc_safe=true LIBABO.abo_mgpu_acq_lhs(g.ptr::Ptr{Cvoid}, n_grid::Int64,
-        d::Int32, lower::Ptr{Float64}, upper::Ptr{Float64}, seed::UInt64, kind::Int32, p0::Float64, best::Float64, k::Int32,
-        tv::Ptr{Float64}, ti::Ptr{Int64}, tx::Ptr{Float64})::Int32)
+    GC.@preserve lower upper tv ti tx begin
+        if m.gpx.multi
+            _check(@abocall LIBABO.abo_mgpu_acq_lhs(m.gpx.ptr::Ptr{Cvoid}, n_grid::Int64, d::Int32, lower::Ptr{Float64},
+                upper::Ptr{Float64}, seed::UInt64, kind::Int32, p0::Float64, best::Float64, k::Int32, tv::Ptr{Float64},
+                ti::Ptr{Int64}, tx::Ptr{Float64})::Int32)
+        else                                     # the same stage on the model's own handle (abo_acq_lhs): no refit, no group
+            _check(@abocall LIBABO.abo_acq_lhs(m.gpx.ptr::Ptr{Cvoid}, n_grid::Int64, d::Int32, lower::Ptr{Float64},
+                upper::Ptr{Float64}, seed::UInt64, kind::Int32, p0::Float64, best::Float64, k::Int32, tv::Ptr{Float64},
+                ti::Ptr{Int64}, tx::Ptr{Float64})::Int32)
+        end
+    end
     [tx[:, j] for j in 1:k], tv
 end
 # optimize_acquisition (acq_utils.jl:33-73) in ONE ccall — more specific than the generic method (concrete acquisition and surrogate
@@ -238,12 +254,12 @@ function optimize_acquisition(acqf::Union{ExpectedImprovement,UpperConfidenceBou
     bx = Vector{Float64}(undef, d); bv = Ref{Float64}(); opts = Ref(AboRefineOpts(0, 0, 0, 0, 0.0, 0.0, 0.0))
     GC.@preserve lower upper bx begin
         if m.gpx.multi
-            _check(@ccall gc_safe=true LIBABO.abo_mgpu_optimize_acquisition(m.gpx.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
+            _check(@abocall LIBABO.abo_mgpu_optimize_acquisition(m.gpx.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
                 best::Float64, lower::Ptr{Float64}, upper::Ptr{Float64}, d::Int32, n_grid::Int64, n_local::Int32, seed::UInt64,
                 opts::Ptr{AboRefineOpts}, bx::Ptr{Float64}, bv::Ptr{Float64}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64},
                 C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
         else
-            _check(@ccall gc_safe=true LIBABO.abo_optimize_acquisition(m.gpx.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
+            _check(@abocall LIBABO.abo_optimize_acquisition(m.gpx.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
                 best::Float64, lower::Ptr{Float64}, upper::Ptr{Float64}, d::Int32, n_grid::Int64, n_local::Int32, seed::UInt64,
                 opts::Ptr{AboRefineOpts}, bx::Ptr{Float64}, bv::Ptr{Float64}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64},
                 C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
@@ -251,18 +267,47 @@ function optimize_acquisition(acqf::Union{ExpectedImprovement,UpperConfidenceBou
     end
     bx
 end
-# a single-device model joins the multi-device entry points as a one-shard group on its data
-function _group_of(m::HipStandardGP)
-    X = Matrix{Float64}(undef, 0, 0)      # training data back from the device (abo_get_data), then a one-shard group
-    n = Ref{Int64}(); d = Ref{Int32}(); _check(@ccall LIBABO.abo_get_n(m.gpx.ptr::Ptr{Cvoid}, n::Ptr{Int64}, d::Ptr{Int32})::Int32)
-    X = Matrix{Float64}(undef, d[], n[]); y = Vector{Float64}(undef, n[])
-    GC.@preserve X y _check(@ccall LIBABO.abo_get_data(m.gpx.ptr::Ptr{Cvoid}, X::Ptr{Float64}, y::Ptr{Float64})::Int32)
-    p = Ref(_params(m)); h = Ref{Ptr{Cvoid}}(); info = Ref{Int64}(0); devs = m.devices
-    GC.@preserve devs _check(@ccall LIBABO.abo_mgpu_create(p::Ptr{AboParams}, 1::Int32, devs::Ptr{Int32}, h::Ptr{Ptr{Cvoid}})::Int32)
-    g = AboHandle(h[], true)
-    GC.@preserve X y _check(@ccall(LIBABO.abo_mgpu_fit(g.ptr::Ptr{Cvoid}, X::Ptr{Float64}, n[]::Int64, d[]::Int32,
-                                                         y::Ptr{Float64}, info::Ptr{Int64})::Int32), info[])
-    g
+# Weighted-sum objectives: an EnsembleAcquisition (EnsembleAcq.jl:12-27, :53-55; nested ones included) flattens into at most 8
+# (kind, p0, best_y, weight) terms — value Σ wᵢ·acqᵢ on ONE posterior evaluation, gradient Σ wᵢ ∇acqᵢ — and the whole
+# optimize_acquisition is again one ccall (abo_optimize_acquisition_terms).  HipGradientGP.jl adds the GradientNormUCB term.
+struct AboAcqTerm           # must match `struct abo_acq_term`
+    kind::Int32; reserved::Int32
+    p0::Float64; best_y::Float64; weight::Float64
+end
+_terms(a::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityImprovement}, w=1.0) =
+    (t = _acq_args(a); [AboAcqTerm(t[1], Int32(0), t[2], t[3], Float64(w))])
+_terms(a::EnsembleAcquisition, w=1.0) = reduce(vcat, [_terms(a.acquisitions[i], w * a.weights[i]) for i in eachindex(a.weights)])
+function _optimize_terms(terms::Vector{AboAcqTerm}, gpx::AboHandle, domain::ContinuousDomain, n_grid::Int, n_local::Int, seed::UInt64)
+    length(terms) <= 8 || throw(ArgumentError("the library takes at most 8 acquisition terms, got $(length(terms))"))
+    lower = collect(Float64, domain.lower); upper = collect(Float64, domain.upper); d = length(lower)
+    bx = Vector{Float64}(undef, d); bv = Ref{Float64}(); opts = Ref(AboRefineOpts(0, 0, 0, 0, 0.0, 0.0, 0.0)); nt = length(terms)
+    GC.@preserve terms lower upper bx begin
+        if gpx.multi
+            _check(@abocall LIBABO.abo_mgpu_optimize_acquisition_terms(gpx.ptr::Ptr{Cvoid}, terms::Ptr{AboAcqTerm}, nt::Int32,
+                lower::Ptr{Float64}, upper::Ptr{Float64}, d::Int32, n_grid::Int64, n_local::Int32, seed::UInt64,
+                opts::Ptr{AboRefineOpts}, bx::Ptr{Float64}, bv::Ptr{Float64}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64},
+                C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
+        else
+            _check(@abocall LIBABO.abo_optimize_acquisition_terms(gpx.ptr::Ptr{Cvoid}, terms::Ptr{AboAcqTerm}, nt::Int32,
+                lower::Ptr{Float64}, upper::Ptr{Float64}, d::Int32, n_grid::Int64, n_local::Int32, seed::UInt64,
+                opts::Ptr{AboRefineOpts}, bx::Ptr{Float64}, bv::Ptr{Float64}, C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64},
+                C_NULL::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
+        end
+    end
+    bx
+end
+function optimize_acquisition(acqf::EnsembleAcquisition, m::HipStandardGP, domain::ContinuousDomain; n_grid::Int=10_000,
+                              n_local::Int=100, seed::UInt64=rand(UInt64))
+    m.gpx === nothing && throw(ArgumentError("surrogate is not conditioned on data yet (gpx === nothing)"))
+    _optimize_terms(_terms(acqf), m.gpx, domain, n_grid, n_local, seed)
+end
+# (EA::EnsembleAcquisition)(m, x): one posterior pass, every member's epilogue on it (abo_acq_terms)
+function (a::EnsembleAcquisition)(m::HipStandardGP, x::AbstractVector)
+    m.gpx.multi && return sum([a.weights[i] .* a.acquisitions[i](m, x) for i in eachindex(a.weights)])    # (the reference's form)
+    terms = _terms(a); Z = _pack(x); d, M = size(Z); s = Vector{Float64}(undef, M); nt = length(terms)
+    GC.@preserve terms Z s _check(@abocall LIBABO.abo_acq_terms(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, 0::Int32,
+        terms::Ptr{AboAcqTerm}, nt::Int32, 0::Int64, s::Ptr{Float64}, 0::Int32, C_NULL::Ptr{Float64}, C_NULL::Ptr{Int64}, 0::Int32)::Int32)
+    s
 end
 
 # ---- NLML (value; StandardGP.jl:99-114, :133-149) and its analytic gradient ------------------------------------------

@@ -364,6 +364,37 @@ int main(int argc, char** argv) {
         CHECK(bval2 == bval && memcmp(bx, bx2, sizeof(double) * d) == 0 && memcmp(rv, rv2, sizeof rv) == 0,
               "mgpu optimize_acquisition differs from the single-device call");
         ok_or_die(abo_mgpu_destroy(mg), "abo_mgpu_destroy");
+        /* ABI 5: the same call as a one-term objective is the same bits; a two-member ensemble (EnsembleAcq.jl:53-55) scores as the
+         * weighted sum of its members' scores; the grid stage on one handle (abo_acq_lhs) returns the starts of the one call */
+        {
+            abo_acq_term one = {(int32_t)a[0], 0, a[1], a[2], 1.0};
+            double bx3[8], bval3 = 0.0, rv3[KL];
+            ok_or_die(abo_optimize_acquisition_terms(g, &one, 1, lower, upper, d, 4000, KL, 3u, NULL, bx3, &bval3, NULL, NULL, NULL, rv3),
+                      "abo_optimize_acquisition_terms");
+            CHECK(bval3 == bval && memcmp(bx, bx3, sizeof(double) * d) == 0 && memcmp(rv, rv3, sizeof rv) == 0,
+                  "one-term abo_optimize_acquisition_terms differs from abo_optimize_acquisition");
+            double lv[KL], lx[KL * 8];
+            int64_t li[KL];
+            ok_or_die(abo_acq_lhs(g, 4000, d, lower, upper, 3u, (int32_t)a[0], a[1], a[2], KL, lv, li, lx), "abo_acq_lhs");
+            CHECK(memcmp(lv, sv, sizeof sv) == 0 && memcmp(lx, sx, sizeof(double) * KL * d) == 0, "abo_acq_lhs: starts differ from the one call's");
+            abo_acq_term two[2] = {{ABO_ACQ_EI, 0, a[1], a[2], 0.25}, {ABO_ACQ_UCB, 0, 2.0, 0.0, 0.75}};
+            double s_ei[64], s_ucb[64], s_ens[64];
+            ok_or_die(abo_acq(g, Z->v, 64, d, ABO_HOST, ABO_ACQ_EI, a[1], a[2], 0, s_ei, 0, NULL, NULL, ABO_HOST), "abo_acq (EI)");
+            ok_or_die(abo_acq(g, Z->v, 64, d, ABO_HOST, ABO_ACQ_UCB, 2.0, 0.0, 0, s_ucb, 0, NULL, NULL, ABO_HOST), "abo_acq (UCB)");
+            ok_or_die(abo_acq_terms(g, Z->v, 64, d, ABO_HOST, two, 2, 0, s_ens, 0, NULL, NULL, ABO_HOST), "abo_acq_terms");
+            double worst = 0.0;
+            for (int e = 0; e < 64; ++e) worst = fmax(worst, fabs(s_ens[e] - (0.25 * s_ei[e] + 0.75 * s_ucb[e])));
+            CHECK(worst <= 1e-14, "abo_acq_terms: ensemble off the weighted sum of its members by %.3e", worst);
+            double bx4[8], bval4 = 0.0, sb4 = 0.0;
+            ok_or_die(abo_optimize_acquisition_terms(g, two, 2, lower, upper, d, 4000, KL, 3u, NULL, bx4, &bval4, NULL, NULL, NULL, NULL),
+                      "abo_optimize_acquisition_terms (ensemble)");
+            ok_or_die(abo_acq_terms(g, bx4, 1, d, ABO_HOST, two, 2, 0, &sb4, 0, NULL, NULL, ABO_HOST), "abo_acq_terms (best point)");
+            CHECK(fabs(sb4 - bval4) <= 1e-9 * fmax(1.0, fabs(bval4)), "ensemble optimize_acquisition: value %.17g, score there %.17g", bval4, sb4);
+            abo_acq_term bad = {ABO_ACQ_GRADNORM_UCB, 0, 2.0, 0.0, 1.0};
+            CHECK(abo_acq_terms(g, Z->v, 4, d, ABO_HOST, &bad, 1, 0, s_ens, 0, NULL, NULL, ABO_HOST) == ABO_EINVAL,
+                  "GradientNormUCB accepted on a model without gradient outputs");
+            printf("ok objectives as terms (one term = the plain call; ensemble = weighted sum to %.1e; abo_acq_lhs = the one call's starts)\n", worst);
+        }
         CHECK(abo_refine(g, 9, 0.0, 0.0, lower, upper, d, sx, 1, NULL, rx, rv, NULL) == ABO_EINVAL, "abo_refine accepts an unknown acquisition");
         CHECK(abo_refine(g, 0, 0.0, 0.0, lower, upper, d + 1, sx, 1, NULL, rx, rv, NULL) == ABO_EDIM, "abo_refine accepts a wrong dimension");
         printf("ok optimize_acquisition (n_grid=4000 n_local=%d: best %.6g vs best grid score %.6g, %lld evaluations, refinement %.3f ms)\n",

@@ -240,3 +240,215 @@ def test_lockstep_variant_equals_the_one_launch_kernel_to_rounding(family, d, N,
     monkeypatch.setenv("ABO_REFINE_LOCKSTEP_NP", "0")
     xd, fd = refine_starts(acq, m, starts, lower, upper)
     np.testing.assert_allclose(fc, fd, rtol=1e-6, atol=1e-8)
+
+
+# ---- round 4: weighted-sum objectives (EnsembleAcquisition) and gradient-enhanced models on the device -----------------------------
+def _fd4(fun, Z, h):
+    """fourth-order central differences of fun over the points Z (all coordinates in one batch)"""
+    n, d = Z.shape
+    pts = np.repeat(Z[:, None, :], 4 * d, axis=1)
+    for c in range(d):
+        for q, mult in enumerate((2.0, 1.0, -1.0, -2.0)):
+            pts[:, 4 * c + q, c] += mult * h
+    vals = fun(pts.reshape(-1, d)).reshape(n, 4 * d)
+    return (-vals[:, 0::4] + 8.0 * vals[:, 1::4] - 8.0 * vals[:, 2::4] + vals[:, 3::4]) / (12.0 * h)
+
+
+def _no_host_loop(monkeypatch):
+    """the finite-difference host loop must not be reached any more from the device paths"""
+    import abstractbayesopt.jl_amd.acquisition as A
+
+    def boom(*a, **k):
+        raise AssertionError("_refine_starts_fd reached: the objective should have been served by abo_refine_terms")
+    monkeypatch.setattr(A, "_refine_starts_fd", boom)
+
+
+@pytest.mark.parametrize("family,d,N", [(O.MATERN52, 3, 200), (O.SE, 2, 1100)])
+def test_ensemble_objective_gradient_and_refinement_on_the_device(family, d, N, monkeypatch):
+    """EnsembleAcquisition (EnsembleAcq.jl:53-55) as ONE objective of the refinement stage: value = Σ wᵢ·acqᵢ on one posterior
+    evaluation, ∇ = Σ wᵢ ∇acqᵢ — against the oracle's weighted sum and its central differences; refinement vs SciPy on the
+    oracle; the one-launch kernel (N = 200) and the lockstep variant (N = 1100 ≥ 1024 rows)."""
+    from scipy.optimize import minimize
+    _no_host_loop(monkeypatch)
+    X, y = synth.standardized_problem(N, d, 0.03)
+    ell, sf2, noise = 0.7 * np.sqrt(d), 1.3, 0.1
+    m = abo.update(make_model(family, ell, sf2, noise), X, y)
+    st = O.fit(family, ell, sf2, noise, 0.0, X, y)
+    best = float(np.median(y))
+    members = [abo.ExpectedImprovement(0.01, best), abo.UpperConfidenceBound(2.0), abo.ProbabilityImprovement(0.05, best)]
+    ens = abo.EnsembleAcquisition([0.5, 0.2, 0.3], members)
+    nested = abo.EnsembleAcquisition([1.0, 1.0], [ens, abo.UpperConfidenceBound(0.5)])
+    for acq in (ens, nested):
+        def oracle(z, acq=acq):
+            def val(a, w):
+                if isinstance(a, abo.EnsembleAcquisition):
+                    return sum(val(mm, w * wi) for wi, mm in zip(a.weights, a.acquisitions))
+                return w * _oracle_acq(a, st)(z)
+            return val(acq, 1.0)
+        Z = synth.points(5, 20, d) * 2.0 - 0.5
+        f, g = acquisition_value_and_grad(acq, m, Z)
+        np.testing.assert_allclose(f, oracle(Z), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(acq(m, Z), f, rtol=1e-9, atol=1e-10)             # abo_acq_terms: the scored value
+        fd = _fd4(oracle, Z, 2e-5)
+        scale = np.maximum(np.max(np.abs(fd), axis=1, keepdims=True), 1e-3)
+        err = float(np.max(np.abs(g - fd) / scale))
+        check(f"refine/ensemble_fam{family}_d{d}_N{N}", f"{'nested' if acq is nested else 'flat'}_grad_rel_vs_oracle_cd", err, 2e-5)
+    lower, upper = np.full(d, -0.5), np.full(d, 1.5)
+    starts = synth.points(7, 12, d) * 2.0 - 0.5
+    f0 = ens(m, starts)
+    xr, fr, it = refine_starts(ens, m, starts, lower, upper, return_iters=True)
+    assert np.all(fr >= f0 - 1e-12) and np.all(xr >= lower) and np.all(xr <= upper)
+    np.testing.assert_allclose(ens(m, xr), fr, rtol=1e-9, atol=1e-10)
+    assert np.median(fr - f0) > 1e-4
+    # as in the single-acquisition test: the same basin is not guaranteed for every start, and the reference's stopping rules
+    # (x_abstol = 1e-4, f_abstol = 2.2e-9) end a run earlier than SciPy's ftol = 1e-14 — count the starts that end below SciPy's
+    # optimum AND below the finite-difference host loop's (the same algorithm under the same rules, round 2's path)
+    xf, ff = _refine_starts_fd(ens, m, starts, lower, upper)
+    worse, gap = 0, []
+    for i in range(len(starts)):
+        res = minimize(lambda z: -float(oracle(z[None, :], ens)[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
+                       options={"ftol": 1e-14, "gtol": 1e-8})
+        tol = 1e-5 * max(1.0, abs(res.fun))
+        worse += fr[i] < -res.fun - tol and fr[i] < ff[i] - tol
+        gap.append(fr[i] + res.fun)
+    assert worse <= 1 and np.median(gap) >= -1e-6, (worse, np.median(gap))
+    assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
+    # the whole optimize_acquisition in one call, and the sharded group returns the same bits
+    dom = abo.ContinuousDomain(lower, upper)
+    b1, v1, sx, sv, rx, rv = abo.optimize_acquisition_device(ens, m, dom, n_grid=4000, n_local=20, seed=5, return_all=True)
+    assert v1 >= sv[0] and np.all(b1 >= lower) and np.all(b1 <= upper)
+    grid = abo.device_latin_hypercube(4000, lower, upper, 5)
+    s_all = ens(m, grid).cpu().numpy()
+    ov, oi = O.top_k(s_all, 20)
+    np.testing.assert_array_equal(sv, ov)
+    if N < 1024:
+        from tests.test_gpu_multigpu import sharded
+        g2 = abo.update(sharded(family, ell, sf2, noise, (0, 0)), X, y)
+        b2, v2, *_ = abo.optimize_acquisition_device(ens, g2, dom, n_grid=4000, n_local=20, seed=5, return_all=True)
+        np.testing.assert_array_equal(b2, b1)
+        assert v2 == v1
+
+
+def _grad_problem(N, d, seed=1):
+    X = synth.points(seed, N, d)
+    f = np.sin(2 * np.pi * X).sum(axis=1) / np.sqrt(d)
+    g = 2 * np.pi * np.cos(2 * np.pi * X) / np.sqrt(d)
+    return X, np.column_stack([f, g])
+
+
+@pytest.mark.parametrize("family,d,N", [(O.MATERN52, 2, 40), (O.SE, 3, 60), (O.MATERN72, 5, 70)])
+def test_gradient_enhanced_objective_gradients_against_the_oracle(family, d, N):
+    """Value and gradient of EI / UCB / PI, GradientNormUCB (gradNormUCB.jl:43-51) and an ensemble of them on a gradient-enhanced
+    handle — ∇μ = E[∇f] − m_∇ and ∇σ² = 2·Cov(f, ∇f) from ONE all-output posterior evaluation, GradientNormUCB by central
+    differences on the device — against fourth-order central differences of oracle/grad_oracle.py's acquisition (≤ 2e-5)."""
+    from oracle import grad_oracle as G
+    from tests.test_gpu_gradient_gp import make_grad
+    p = d + 1
+    X, Y = _grad_problem(N, d)
+    ell, sf2, noise = 0.6, 1.2, 0.05
+    mean_c = np.concatenate([[0.1], np.linspace(-0.2, 0.3, d)])           # non-zero prior means of the gradient outputs on purpose
+    m = abo.update(make_grad(family, ell, sf2, noise, p, mean_c), X, Y)
+    st = G.fit(family, ell, sf2, noise, mean_c, X, Y)
+    best = float(np.median(Y[:, 0]))
+    Z = synth.points(5, 16, d) * 1.4 - 0.2
+
+    def o_fv(acq):
+        def f(z):
+            mu, var = G.predict(st, z)
+            if isinstance(acq, abo.UpperConfidenceBound):
+                return O.upper_confidence_bound(mu, var, acq.beta)
+            return O.acquisition(O.ACQ_EI if isinstance(acq, abo.ExpectedImprovement) else O.ACQ_PI, mu, var, acq.xi, acq.best_y)
+        return f
+
+    cases = [(a, o_fv(a)) for a in (abo.ExpectedImprovement(0.01, best), abo.UpperConfidenceBound(2.0),
+                                    abo.ProbabilityImprovement(0.01, best))]
+    gn = abo.GradientNormUCB(1.5)
+    cases.append((gn, lambda z: G.grad_norm_ucb(st, z, 1.5)))
+    ens = abo.EnsembleAcquisition([0.6, 0.4], [abo.UpperConfidenceBound(2.0), gn])
+    cases.append((ens, lambda z: 0.6 * o_fv(abo.UpperConfidenceBound(2.0))(z) + 0.4 * G.grad_norm_ucb(st, z, 1.5)))
+    for acq, oracle in cases:
+        f, g = acquisition_value_and_grad(acq, m, Z)
+        np.testing.assert_allclose(f, oracle(Z), rtol=1e-8, atol=1e-10)
+        fd = _fd4(oracle, Z, 2e-5)
+        scale = np.maximum(np.max(np.abs(fd), axis=1, keepdims=True), 1e-3)
+        assert np.percentile(np.max(np.abs(fd), axis=1), 75) > 1e-3      # (EI / PI underflow where μ is far above best_y)
+        err = float(np.max(np.abs(g - fd) / scale))
+        check(f"refine/gradgp_fam{family}_d{d}_N{N}", f"{type(acq).__name__}_rel_vs_oracle_central_differences", err, 2e-5)
+
+
+@pytest.mark.parametrize("family,d,N", [(O.MATERN52, 2, 40), (O.SE, 3, 50)])
+def test_gradient_enhanced_refinement_and_optimize_acquisition_on_the_device(family, d, N, monkeypatch):
+    """optimize_acquisition(acqf, ::GradientGP, domain) — what the reference's tutorials run (gradNormUCB.jl:39-51 on a
+    GradientGP) — as one C-ABI call: refinement never below the start, inside the box, ≥ SciPy L-BFGS-B on the oracle's
+    acquisition; the finite-difference host loop is not reached; the sharded group returns the single handle's bits."""
+    from scipy.optimize import minimize
+    from oracle import grad_oracle as G
+    from tests.test_gpu_gradient_gp import make_grad
+    _no_host_loop(monkeypatch)
+    p = d + 1
+    X, Y = _grad_problem(N, d)
+    ell, sf2, noise = 0.5, 1.0, 0.02
+    m = abo.update(make_grad(family, ell, sf2, noise, p), X, Y)
+    st = G.fit(family, ell, sf2, noise, np.zeros(p), X, Y)
+    best = float(np.median(Y[:, 0]))
+    lower, upper = np.full(d, -0.2), np.full(d, 1.2)
+    dom = abo.ContinuousDomain(lower, upper)
+
+    def o_ei(z):
+        mu, var = G.predict(st, z)
+        return O.expected_improvement(mu, var, best, 0.01)
+
+    for acq, oracle in ((abo.ExpectedImprovement(0.01, best), o_ei), (abo.GradientNormUCB(2.0), lambda z: G.grad_norm_ucb(st, z, 2.0))):
+        starts = synth.points(7, 14, d) * 1.4 - 0.2
+        f0 = oracle(starts)
+        xr, fr, it = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+        assert np.all(fr >= f0 - 1e-9) and np.all(xr >= lower) and np.all(xr <= upper)
+        np.testing.assert_allclose(oracle(xr), fr, rtol=1e-8, atol=1e-9)          # the reported value is the oracle's value there
+        assert it[:, 1].sum() > 2 * len(starts) and np.all(it[:, 0] <= 100)
+        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)    # (the host loop itself, called directly: the reference point)
+        worse = 0
+        for i in range(len(starts)):
+            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
+                           options={"ftol": 1e-14, "gtol": 1e-8})
+            tol = 1e-5 * max(1.0, abs(res.fun))
+            worse += fr[i] < -res.fun - tol and fr[i] < ff[i] - tol
+        assert worse <= 1, (type(acq).__name__, worse)
+        assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
+        # deterministic
+        xr2, fr2 = refine_starts(acq, m, starts, lower, upper)
+        np.testing.assert_array_equal(xr, xr2)
+        np.testing.assert_array_equal(fr, fr2)
+        b1, v1, sx, sv, rx, rv = abo.optimize_acquisition_device(acq, m, dom, n_grid=3000, n_local=16, seed=9, return_all=True)
+        assert v1 >= sv[0] - 1e-12 and np.all(b1 >= lower) and np.all(b1 <= upper)
+        np.testing.assert_allclose(oracle(b1[None, :])[0], v1, rtol=1e-8, atol=1e-9)
+        grid = abo.device_latin_hypercube(3000, lower, upper, 9).cpu().numpy()
+        ov, oi = O.top_k(oracle(grid), 16)
+        np.testing.assert_allclose(sv, ov, rtol=1e-8, atol=1e-10)                  # the grid stage picked the oracle's starts
+        # the host API reaches the same one call
+        rng = np.random.default_rng(3)
+        seed = int(np.random.default_rng(3).integers(0, 2 ** 63))
+        b3 = abo.optimize_acquisition(acq, m, dom, n_grid=3000, n_local=16, rng=rng, device_grid=True)
+        np.testing.assert_array_equal(b3, abo.optimize_acquisition_device(acq, m, dom, 3000, 16, seed=seed))
+        grp = abo.update(abo.HipShardedGradientGP(sf2 * abo.with_lengthscale(FAMS_[family](), ell), p, noise, devices=(0, 0)), X, Y)
+        b2, v2, *_ = abo.optimize_acquisition_device(acq, grp, dom, n_grid=3000, n_local=16, seed=9, return_all=True)
+        np.testing.assert_array_equal(b2, b1)
+        assert v2 == v1
+
+
+def test_refinement_limits_are_clamped_not_overflowed():
+    """abo_refine_opts with max_iter = INT32_MAX ("no limit") on a model that takes the lockstep rounds (≥ 1024 factor rows): the
+    round budget max_iter × linesearch_max is computed in 64 bits and the fields are clamped — every start comes back refined"""
+    d, N = 2, 1100
+    X, y = synth.standardized_problem(N, d, 0.03)
+    m = abo.update(make_model(O.SE, 0.5, 1.0, 0.05), X, y)
+    acq = abo.UpperConfidenceBound(2.0)
+    starts = synth.points(7, 9, d)
+    ref_x, ref_f = refine_starts(acq, m, starts, np.zeros(d), np.ones(d))
+    x, f, it = refine_starts(acq, m, starts, np.zeros(d), np.ones(d), max_iter=2 ** 31 - 1, return_iters=True)
+    assert np.all(np.isfinite(f)) and np.all(f >= acq(m, starts) - 1e-12)
+    np.testing.assert_allclose(acq(m, x), f, rtol=1e-9, atol=1e-10)
+    assert np.all(f >= ref_f - 1e-9)                     # more iterations allowed: never worse than the default budget
+    assert np.all(it[:, 0] <= 10000)
+
+
+from tests.test_gpu_parity import FAMS as FAMS_  # noqa: E402
