@@ -12,7 +12,7 @@ constexpr int MAX_P = 33; // outputs per point of a gradient-enhanced GP (f + d 
 inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 
 // ---- fp64 MFMA GEMM family (gemm.hip) -------------------------------------------------------
-enum KMode { K_FULL = 0, K_A_LOWER = 1, K_A_UPPER = 2, K_B_LOWER = 3 };
+enum KMode { K_FULL = 0, K_A_LOWER = 1, K_A_UPPER = 2, K_B_LOWER = 3, K_B_UPPER = 4 };
 
 struct GemmArgs {
     const double* A;      // [M][lda]   row-major, k contiguous
@@ -22,13 +22,27 @@ struct GemmArgs {
     int64_t lda, ldb, ldc, ldct;
     int64_t sA, sB, sC, sCt;   // batch strides (elements)
     int M, N, K;          // M, N multiples of 128; K multiple of 16
-    int kmode;            // K_FULL; K_A_LOWER: k < (ti+1)·128; K_A_UPPER: k ≥ ti·128; K_B_LOWER: k < (tj+1)·128 (B lower-triangular)
+    int kmode;            // K_FULL; K_A_LOWER: k < (ti+1)·128; K_A_UPPER: k ≥ ti·128; K_B_LOWER: k < (tj+1)·128 (B lower-triangular);
+                          // K_B_UPPER: k ≥ tj·128 (B upper-triangular)
     int lower_only;       // 1: skip tiles with tj > ti (SYRK on the lower triangle)
     int batch;
     double alpha, beta;
     const int64_t* info;  // optional: if *info != 0 the kernel exits at once (failed factorisation)
+    // split-k (batch == 1, beta == 0): the k range is cut into chunks of `ksplit` (multiple of 128), chunk z of a tile is computed by
+    // its own workgroup into the partial product C + z·sC (a chunk outside the tile's triangular k range writes nothing);
+    // launch_splitk_reduce sums the partials of every tile in chunk order (fixed order: deterministic).  For products with few output
+    // tiles and a long k — the 128-row batches of the lockstep refinement against L⁻¹.
+    int ksplit = 0;
+    // split-k only: when 16 ≤ mrows ≤ 64 only the first mrows rows of A (a multiple of 16) matter and M == 128: the product is taken by
+    // a kernel without LDS whose waves stream their 32 rows of B once and hold mrows/16 row groups of A — HBM-bound on B instead of
+    // MFMA-bound on 128 rows (the lockstep refinement once most starts have finished)
+    int mrows = 0;
 };
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s);
+// out[r][c] = Σ_z P[z][r][c] over the chunks z that intersect the k range of column tile c/128 under `kmode` (K_FULL, K_B_LOWER,
+// K_B_UPPER); P: nz partial products of rows × cols (leading dimension ldp, stride sP), K the full k length
+hipError_t launch_splitk_reduce(const double* P, int64_t ldp, int64_t sP, int nz, int rows, int cols, int K, int ksplit, int kmode,
+                                double* out, int64_t ldo, hipStream_t s);
 
 // V = W·K_XZ restricted to k ≤ i (W lower-triangular), reduced on the fly to per-row-block column
 // sums of squares: partial[ti][j] = Σ_{i in block ti} (Σ_k W[i][k]·Kxz[j][k])²

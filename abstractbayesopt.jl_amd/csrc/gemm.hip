@@ -204,8 +204,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
     if (p.kmode == K_A_UPPER) kbeg = min(p.K, ti * BM);
     if (p.kmode == K_B_LOWER) kend = min(p.K, (tj + 1) * BN);
-    const double* Ag = p.A + (int64_t)bz * p.sA + (int64_t)ti * BM * p.lda;
-    const double* Bg = p.B + (int64_t)bz * p.sB + (int64_t)tj * BN * p.ldb;
+    if (p.kmode == K_B_UPPER) kbeg = min(p.K, tj * BN);
+    const double* Ag = p.A + (p.ksplit ? 0 : (int64_t)bz * p.sA) + (int64_t)ti * BM * p.lda;
+    const double* Bg = p.B + (p.ksplit ? 0 : (int64_t)bz * p.sB) + (int64_t)tj * BN * p.ldb;
+    if (p.ksplit) {                                  // chunk bz of this tile's k range; an empty chunk writes nothing
+        kbeg = max(kbeg, bz * p.ksplit);
+        kend = min(kend, (bz + 1) * p.ksplit);
+        if (kbeg >= kend) return;
+    }
     d4_t acc[4][4];
     acc_zero(acc);
     tile_loop(Ag, p.lda, Bg, p.ldb, kbeg, kend, smem, acc);
@@ -247,6 +253,7 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmArgs p) {
     if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
     if (p.kmode == K_A_UPPER) kbeg = min(p.K, ti * BM);
     if (p.kmode == K_B_LOWER) kend = min(p.K, (tj + 1) * BN);
+    if (p.kmode == K_B_UPPER) kbeg = min(p.K, tj * BN);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r16 = lane & 15, g = lane >> 4;
@@ -318,6 +325,60 @@ __global__ void __launch_bounds__(256) gemm_nt_rowpanel_kernel(GemmArgs p) {
         }
 }
 
+// Split-k chunk of a product with FEW rows of A (16·RG ≤ 64) against a 128-row block of B: no LDS, no barriers.  Wave w owns B rows
+// 32w … 32w+31 of the block (two 16-row MFMA groups) and streams them exactly once; the RG row groups of A are re-read by every wave
+// (they are small and sit in L2).  Lane ↔ k map and k order of gemm_nt_small_kernel.  P[z][r][i] = Σ_{k in chunk z} A[r][k]·B[i][k].
+template <int RG>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs p) {
+    if (p.info != nullptr && *p.info != 0) return;
+    const int tj = p.kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, bz = blockIdx.z;
+    int kbeg = 0, kend = p.K;
+    if (p.kmode == K_B_LOWER) kend = min(p.K, (tj + 1) * BN);
+    if (p.kmode == K_B_UPPER) kbeg = min(p.K, tj * BN);
+    kbeg = max(kbeg, bz * p.ksplit);
+    kend = min(kend, (bz + 1) * p.ksplit);
+    if (kbeg >= kend) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const double* Bp = p.B + (int64_t)(tj * BN + wave * 32 + r16) * p.ldb + 2 * g;
+    const double* Ap = p.A + (int64_t)r16 * p.lda + 2 * g;
+    d4_t acc[RG][2];
+#pragma unroll
+    for (int q = 0; q < RG; ++q) { acc[q][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[q][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+    for (int k = kbeg; k < kend; k += 64) {                // kbeg, kend are multiples of 128
+        d2_t b0[8], b1[8], a[RG][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            b0[q] = *reinterpret_cast<const d2_t*>(Bp + k + 8 * q);          // (a lane group covers 64 bytes of its row per load: the two halves of a
+            b1[q] = *reinterpret_cast<const d2_t*>(Bp + 16 * p.ldb + k + 8 * q);    //  128-byte line arrive with consecutive q — through L2, not past it)
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[r][q] = *reinterpret_cast<const d2_t*>(Ap + (int64_t)(16 * r) * p.lda + k + 8 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][q][0], b0[q][0], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][q][0], b1[q][0], acc[r][1], 0, 0, 0);
+                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][q][1], b0[q][1], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][q][1], b1[q][1], acc[r][1], 0, 0, 0);
+            }
+    }
+    double* Cg = p.C + (int64_t)bz * p.sC;
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = 16 * r + g + 4 * e;                                   // C/D map: lane l, reg e → row (l>>4) + 4e, col l&15
+                const int64_t col = (int64_t)tj * BN + wave * 32 + 16 * h + r16;
+                Cg[row * p.ldc + col] = p.alpha * acc[r][h][e];
+            }
+}
+
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
     const int64_t Tm = a.M / BM, Tn = a.N / BN;
@@ -329,8 +390,23 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     tiles *= a.batch;
     const char* fe = getenv("ABO_GEMM_SMALL");                      // A/B runs and tests: 0 never, 1 always
     const int force = fe ? atoi(fe) : -1;
-    const bool small = force >= 0 ? force == 1 : tiles <= 64;      // measured crossover: small ≈ tiles·K·1.7 ns, tiled ≈ 6 µs + K·0.11 µs
+    const bool small = a.ksplit ? false : (force >= 0 ? force == 1 : tiles <= 64);      // measured crossover: small ≈ tiles·K·1.7 ns, tiled ≈ 6 µs + K·0.11 µs
     const bool in_place = a.C == a.A || a.C == a.B;
+    if (a.ksplit) {
+        if (a.batch != 1 || a.beta != 0.0 || a.ksplit % 128 != 0 || a.Ct) return hipErrorInvalidValue;
+        dim3 grid(a.N / BN, a.M / BM, (a.K + a.ksplit - 1) / a.ksplit);
+        if (a.mrows >= 16 && a.mrows <= 64 && a.mrows % 16 == 0 && a.M == BM && !getenv("ABO_GEMM_NO_SKINNY")) {
+            switch (a.mrows / 16) {
+                case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, dim3(256), 0, s, a); break;
+                case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, dim3(256), 0, s, a); break;
+                case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), grid, dim3(256), 0, s, a); break;
+                default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, dim3(256), 0, s, a); break;
+            }
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (small && in_place && a.C == a.A && a.N == BN && a.K == 128 && a.kmode == K_FULL && !a.lower_only && !a.Ct) {
         hipLaunchKernelGGL(gemm_nt_rowpanel_kernel, dim3(a.M / 16, a.batch), dim3(256), 0, s, a);
     } else if (small && !in_place && a.K % 128 == 0) {
@@ -340,6 +416,33 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
         dim3 grid(a.N / BN, a.M / BM, a.batch);
         hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
     }
+    return hipGetLastError();
+}
+
+// sum of the split-k partial products, chunk order (the same chunks gemm_nt_kernel computed: the others hold nothing)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __restrict__ P, int64_t ldp, int64_t sP, int nz, int rows, int cols,
+                                                             int K, int ksplit, int kmode, double* __restrict__ out, int64_t ldo) {
+    const int c2 = (blockIdx.x * 256 + threadIdx.x) * 2, r = blockIdx.y;
+    if (c2 >= cols) return;
+    const int tj = c2 / BN;
+    int kbeg = 0, kend = K;
+    if (kmode == K_B_LOWER) kend = min(K, (tj + 1) * BN);
+    if (kmode == K_B_UPPER) kbeg = min(K, tj * BN);
+    d2_t acc = {0.0, 0.0};
+    const double* p = P + (int64_t)r * ldp + c2;
+    for (int z = 0; z < nz; ++z) {
+        if (max(kbeg, z * ksplit) >= min(kend, (z + 1) * ksplit)) continue;
+        const d2_t v = *reinterpret_cast<const d2_t*>(p + (int64_t)z * sP);
+        acc[0] += v[0]; acc[1] += v[1];
+    }
+    *reinterpret_cast<d2_t*>(out + (int64_t)r * ldo + c2) = acc;
+}
+
+hipError_t launch_splitk_reduce(const double* P, int64_t ldp, int64_t sP, int nz, int rows, int cols, int K, int ksplit, int kmode,
+                                double* out, int64_t ldo, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((cols / 2 + 255) / 256, rows), dim3(256), 0, s, P, ldp, sP, nz, rows, cols, K, ksplit,
+                       kmode, out, ldo);
     return hipGetLastError();
 }
 

@@ -418,12 +418,16 @@ struct RlState {                 // per-start scalars
 __host__ __device__ inline size_t rl_vec_doubles(int d, int m) { return (size_t)6 * d + (size_t)2 * m * d + 2 * m; }
 
 template <int FAM>
-__global__ void __launch_bounds__(256) rl_kgen_kernel(RefineArgs a, const double* __restrict__ P, const int* __restrict__ active,
-                                                      double* __restrict__ KX, double* __restrict__ GV) {
+// Rows of a round's batch are COMPACT: row c belongs to the c-th still-active start, start_of[c] (ascending start index; built by
+// rl_compact_kernel after every step), rows ≥ *nact are zero.  2175 evaluations over 100 starts in 75 rounds means 29 active
+// starts per round on average: the products below are sized by the active count, not by the number of starts.
+__global__ void __launch_bounds__(256) rl_kgen_kernel(RefineArgs a, const double* __restrict__ P, const int* __restrict__ start_of,
+                                                      const int* __restrict__ nact, double* __restrict__ KX, double* __restrict__ GV) {
     __shared__ double xs[1024];
-    const int j = blockIdx.y, t = threadIdx.x;
+    const int c0 = blockIdx.y, t = threadIdx.x;
     const int i = blockIdx.x * 256 + t;
-    const bool on = active[j] != 0;
+    const bool on = c0 < *nact;
+    const int j = on ? start_of[c0] : 0;
     for (int c = t; c < a.dp; c += 256) xs[c] = (on && c < a.d) ? P[(int64_t)j * a.d + c] * a.s : 0.0;
     __syncthreads();
     if (i >= a.Np) return;
@@ -435,8 +439,32 @@ __global__ void __launch_bounds__(256) rl_kgen_kernel(RefineArgs a, const double
         kappa_and_deriv<FAM>(u, k, dk);
         k *= a.sigma_f2; dk *= a.sigma_f2;
     }
-    KX[(int64_t)j * a.Np + i] = k;
-    GV[(int64_t)j * a.Np + i] = dk;
+    KX[(int64_t)c0 * a.Np + i] = k;
+    GV[(int64_t)c0 * a.Np + i] = dk;
+}
+
+// start_of[0 .. nact) = the active starts in ascending order, *nact = their number (one workgroup; S is a few hundred at most)
+__global__ void __launch_bounds__(256) rl_compact_kernel(const int* __restrict__ active, int S, int* __restrict__ start_of,
+                                                         int* __restrict__ nact) {
+    __shared__ int wsum[4], base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < S; j0 += 256) {
+        const int j = j0 + t;
+        const int on = j < S && active[j] != 0 ? 1 : 0;
+        const unsigned long long m = __ballot(on);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (on) start_of[off + before] = j;
+        __syncthreads();
+        if (t == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (t == 0) *nact = base;
 }
 
 __global__ void rl_zero_tail_kernel(double* V, int Np, int N, int Sp) {
@@ -446,20 +474,22 @@ __global__ void rl_zero_tail_kernel(double* V, int Np, int N, int Sp) {
 }
 
 // EV[j] = {f, ∇f[0..d)} of pending point j
-__global__ void __launch_bounds__(RT) rl_reduce_kernel(RefineArgs a, const double* __restrict__ P, const int* __restrict__ active,
-                                                       const double* __restrict__ KX, const double* __restrict__ GV,
-                                                       const double* __restrict__ V, const double* __restrict__ U, double* __restrict__ EV) {
+__global__ void __launch_bounds__(RT) rl_reduce_kernel(RefineArgs a, const double* __restrict__ P, const int* __restrict__ start_of,
+                                                       const int* __restrict__ nact, const double* __restrict__ KX,
+                                                       const double* __restrict__ GV, const double* __restrict__ V,
+                                                       const double* __restrict__ U, double* __restrict__ EV) {
     extern __shared__ double sm[];
     double* xs = sm;                         // [dp]
     double* red = xs + a.dp;                 // [RW·2·RCH]
     double* out = red + RW * 2 * RCH;        // [2·RCH]
-    const int j = blockIdx.x, t = threadIdx.x, N = a.N, d = a.d, dp = a.dp;
-    if (!active[j]) return;                  // uniform
-    const double* kv = KX + (int64_t)j * a.Np;
-    const double* gv = GV + (int64_t)j * a.Np;
-    const double* vv = V + (int64_t)j * a.Np;
-    const double* uv = U + (int64_t)j * a.Np;
-    for (int c = t; c < dp; c += RT) xs[c] = c < d ? P[(int64_t)j * d + c] * a.s : 0.0;
+    const int c = blockIdx.x, t = threadIdx.x, N = a.N, d = a.d, dp = a.dp;
+    if (c >= *nact) return;                  // uniform
+    const int j = start_of[c];               // compact row c → its start: P and EV are indexed by start
+    const double* kv = KX + (int64_t)c * a.Np;
+    const double* gv = GV + (int64_t)c * a.Np;
+    const double* vv = V + (int64_t)c * a.Np;
+    const double* uv = U + (int64_t)c * a.Np;
+    for (int q = t; q < dp; q += RT) xs[q] = q < d ? P[(int64_t)j * d + q] * a.s : 0.0;
     __syncthreads();
     double acc[2 * RCH];
     acc[0] = 0.0; acc[1] = 0.0;
@@ -497,14 +527,40 @@ __global__ void __launch_bounds__(RT) rl_reduce_kernel(RefineArgs a, const doubl
     if (t == 0) ev[0] = f;
 }
 
-// one thread per start: phase −1 (first call) sets the pending point to the clipped start; afterwards consume EV, advance, publish the
-// next pending point.  counters[0] = number of active starts after this round (int64: the GEMMs' early-exit word is counters[1] = 1 when 0).
-__global__ void rl_step_kernel(RefineArgs a, int S, int first, double* __restrict__ P, int* __restrict__ active, const double* __restrict__ EV,
-                               double* __restrict__ vec, RlState* __restrict__ st, long long* __restrict__ counters) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// one 64-thread workgroup per start: phase −1 (first call) sets the pending point to the clipped start; afterwards consume EV, advance,
+// publish the next pending point.  The start's vector state (x, g, pg, p, xprev, pgprev, the curvature pairs) is staged through LDS:
+// the L-BFGS algebra is a chain of short dependent loops, and run by one thread straight on global memory every step of it paid a
+// memory round trip (46 µs per round at d = 8, m = 10 — 8 % of a round at N = 8192); the lanes move the state in and out, lane 0
+// runs the same arithmetic in the same order on the LDS copy.  counters[0] = number of active starts after this round (int64: the
+// GEMMs' early-exit word is counters[1] = 1 when 0).
+__global__ void __launch_bounds__(64) rl_step_kernel(RefineArgs a, int S, int first, double* __restrict__ P, int* __restrict__ active,
+                                                     const double* __restrict__ EV, double* __restrict__ vec, RlState* __restrict__ st,
+                                                     long long* __restrict__ counters) {
+    extern __shared__ double sv[];
+    const int j = blockIdx.x, t = threadIdx.x;
     if (j >= S) return;
     const int d = a.d, m = a.history;
-    double* x = vec + (size_t)j * rl_vec_doubles(d, m);
+    const int nv = (int)rl_vec_doubles(d, m);
+    double* gvec = vec + (size_t)j * nv;
+    double* cand = P + (size_t)j * d;              // the pending point doubles as the line search's trial point
+    if (first) {
+        for (int c = t; c < d; c += 64) {
+            const double v = a.starts[(size_t)j * d + c];
+            const double x = v == v ? fmin(fmax(v, a.lower[c]), a.upper[c]) : v;
+            gvec[c] = x;
+            cand[c] = x;
+        }
+        if (t == 0) {
+            RlState& s = st[j];
+            s.f = 0.0; s.tstep = 1.0; s.phase = 0; s.it = 0; s.ls = 0; s.nh = 0; s.nev = 0; s.have_prev = 0;
+            active[j] = 1;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), 1ull);
+        }
+        return;
+    }
+    if (!active[j]) return;                        // uniform over the workgroup
+    // stage: state, bounds, the evaluation, the trial point
+    double* x = sv;
     double* g = x + d;
     double* pg = g + d;
     double* p = pg + d;
@@ -514,63 +570,73 @@ __global__ void rl_step_kernel(RefineArgs a, int S, int first, double* __restric
     double* Yh = Sh + (size_t)m * d;
     double* rho = Yh + (size_t)m * d;
     double* al = rho + m;
-    double* cand = P + (size_t)j * d;              // the pending point doubles as the line search's trial point
-    RlState& s = st[j];
-    if (first) {
-        for (int c = 0; c < d; ++c) {
-            const double v = a.starts[(size_t)j * d + c];
-            x[c] = v == v ? fmin(fmax(v, a.lower[c]), a.upper[c]) : v;
-            cand[c] = x[c];
-        }
-        s.f = 0.0; s.tstep = 1.0; s.phase = 0; s.it = 0; s.ls = 0; s.nh = 0; s.nev = 0; s.have_prev = 0;
-        active[j] = 1;
-        atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), 1ull);
-        return;
-    }
-    if (!active[j]) return;
-    const double* ev = EV + (size_t)j * (d + 1);
-    const double fc = ev[0];
-    ++s.nev;
-    bool begin_iteration = false, finished = false;
-    if (s.phase == 0) {                              // the start's own value and gradient
-        s.f = fc;
-        for (int c = 0; c < d; ++c) g[c] = ev[1 + c];
-        if (!(fc == fc && fabs(fc) < 1.0e300)) finished = true;      // a non-finite start value: nothing to refine
-        else begin_iteration = true;
-    } else {                                         // a line-search trial came back
-        double lin = 0.0;
-        for (int c = 0; c < d; ++c) lin = fma(pg[c], cand[c] - x[c], lin);
-        const bool ok = fc == fc && fabs(fc) < 1.0e300 && fc >= s.f + 1e-4 * lin;
-        if (ok) {
-            double dx = 0.0;
-            for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(cand[c] - x[c]));
-            const bool done = dx <= a.x_abstol || fabs(fc - s.f) <= a.f_abstol;
-            for (int c = 0; c < d; ++c) { xprev[c] = x[c]; pgprev[c] = pg[c]; x[c] = cand[c]; g[c] = ev[1 + c]; }
-            s.f = fc; s.have_prev = 1; ++s.it;
-            if (done || s.it >= a.max_iter) finished = true;
+    double* lo = sv + nv;
+    double* up = lo + d;
+    double* ev = up + d;                           // [d + 1]
+    double* cd = ev + d + 1;                       // [d]
+    for (int e = t; e < nv; e += 64) sv[e] = gvec[e];
+    for (int c = t; c < d; c += 64) { lo[c] = a.lower[c]; up[c] = a.upper[c]; cd[c] = cand[c]; }
+    for (int c = t; c <= d; c += 64) ev[c] = EV[(size_t)j * (d + 1) + c];
+    __syncthreads();
+    __shared__ int fin;
+    if (t == 0) {
+        RlState s = st[j];
+        const double fc = ev[0];
+        ++s.nev;
+        bool begin_iteration = false, finished = false;
+        if (s.phase == 0) {                              // the start's own value and gradient
+            s.f = fc;
+            for (int c = 0; c < d; ++c) g[c] = ev[1 + c];
+            if (!(fc == fc && fabs(fc) < 1.0e300)) finished = true;      // a non-finite start value: nothing to refine
             else begin_iteration = true;
-        } else {
-            s.tstep *= 0.5;
-            if (++s.ls >= a.ls_max) finished = true;                 // no acceptable step: keep x
+        } else {                                         // a line-search trial came back
+            double lin = 0.0;
+            for (int c = 0; c < d; ++c) lin = fma(pg[c], cd[c] - x[c], lin);
+            const bool ok = fc == fc && fabs(fc) < 1.0e300 && fc >= s.f + 1e-4 * lin;
+            if (ok) {
+                double dx = 0.0;
+                for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(cd[c] - x[c]));
+                const bool done = dx <= a.x_abstol || fabs(fc - s.f) <= a.f_abstol;
+                for (int c = 0; c < d; ++c) { xprev[c] = x[c]; pgprev[c] = pg[c]; x[c] = cd[c]; g[c] = ev[1 + c]; }
+                s.f = fc; s.have_prev = 1; ++s.it;
+                if (done || s.it >= a.max_iter) finished = true;
+                else begin_iteration = true;
+            } else {
+                s.tstep *= 0.5;
+                if (++s.ls >= a.ls_max) finished = true;                 // no acceptable step: keep x
+            }
         }
+        if (begin_iteration) {
+            double t0 = 1.0;
+            if (lbfgs_direction(d, m, x, g, pg, p, xprev, pgprev, lo, up, Sh, Yh, rho, al, s.have_prev != 0, s.nh, a.g_tol, t0)) finished = true;
+            else { s.tstep = t0; s.ls = 0; s.phase = 1; }
+        }
+        if (finished) {
+            s.phase = 2;
+            a.f_out[j] = s.f;
+            if (a.iters_out) { a.iters_out[2 * j] = s.it; a.iters_out[2 * j + 1] = s.nev; }
+        } else {
+            for (int c = 0; c < d; ++c) cd[c] = fmin(fmax(fma(s.tstep, p[c], x[c]), lo[c]), up[c]);
+        }
+        st[j] = s;
+        fin = finished ? 1 : 0;
     }
-    if (begin_iteration) {
-        double t0 = 1.0;
-        if (lbfgs_direction(d, m, x, g, pg, p, xprev, pgprev, a.lower, a.upper, Sh, Yh, rho, al, s.have_prev != 0, s.nh, a.g_tol, t0)) finished = true;
-        else { s.tstep = t0; s.ls = 0; s.phase = 1; }
+    __syncthreads();
+    for (int e = t; e < nv; e += 64) gvec[e] = sv[e];
+    if (fin) {
+        for (int c = t; c < d; c += 64) a.x_out[(size_t)j * d + c] = x[c];
+        if (t == 0) {
+            active[j] = 0;
+            const unsigned long long left = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), ~0ull) - 1ull;
+            if (left == 0) counters[1] = 1;              // the GEMMs of later rounds exit on this word
+        }
+    } else {
+        for (int c = t; c < d; c += 64) cand[c] = cd[c];
     }
-    if (finished) {
-        active[j] = 0;
-        s.phase = 2;
-        for (int c = 0; c < d; ++c) a.x_out[(size_t)j * d + c] = x[c];
-        a.f_out[j] = s.f;
-        if (a.iters_out) { a.iters_out[2 * j] = s.it; a.iters_out[2 * j + 1] = s.nev; }
-        const unsigned long long left = atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), ~0ull) - 1ull;
-        if (left == 0) counters[1] = 1;              // the GEMMs of later rounds exit on this word
-        return;
-    }
-    for (int c = 0; c < d; ++c) cand[c] = fmin(fmax(fma(s.tstep, p[c], x[c]), a.lower[c]), a.upper[c]);
 }
+
+// LDS of rl_step_kernel: the start's state + bounds + evaluation + trial point
+__host__ inline size_t rl_step_lds(int d, int m) { return sizeof(double) * (rl_vec_doubles(d, m) + 4 * (size_t)d + 1); }
 
 // starts still active when the host stops issuing rounds: their current iterate is the result
 __global__ void rl_flush_kernel(RefineArgs a, int S, int* __restrict__ active, const double* __restrict__ vec, RlState* __restrict__ st) {
@@ -584,10 +650,29 @@ __global__ void rl_flush_kernel(RefineArgs a, int S, int* __restrict__ active, c
     st[j].phase = 2;
 }
 
+// k-chunk of the split-k form of a round's two GEMMs (0: the plain launch).  A round's products have ONE row of 128×128 output tiles
+// per 128 starts and a k range of up to Np: 64 tiles at Np = 8192 — a quarter of the CUs, each running a 1 ms k loop through the
+// small-launch path.  Cut into 16 k-chunks per tile the same product is ≈ 8·Np/128 workgroups of Np/16 k each on the LDS-tiled core.
+static int lockstep_ksplit(int Np) {
+    const char* e = getenv("ABO_REFINE_KSPLIT");                     // A/B runs: 0 = the plain launch
+    if (e) { const int v = atoi(e); return v > 0 ? (v + 127) / 128 * 128 : 0; }
+    if (Np < 2048) return 0;
+    // the longest chunk for which the (tile, chunk) workgroups still fill the device's 512 slots (2 per CU): a launch that needs a
+    // second round of workgroups pays a whole chunk for its last few
+    const int Tn = Np / 128;
+    for (int ks = 128;; ks += 128) {
+        int wg = 0;
+        for (int tj = 0; tj < Tn; ++tj) wg += ((tj + 1) * 128 + ks - 1) / ks;
+        if (wg <= 512 || ks >= Np) return ks;
+    }
+}
+
 size_t refine_lockstep_bytes(int S, int Np, int d, int history) {
     const size_t Sp = (size_t)pad_up(S, 128);
-    return sizeof(double) * (Sp * d + 5 * Sp * (size_t)Np + Sp * (d + 1) + (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S +
-           sizeof(int) * Sp + 64;
+    const int ks = lockstep_ksplit(Np);
+    const size_t nz = ks ? (size_t)(Np + ks - 1) / ks : 1;           // partial products of the split-k form (else the unused plain output)
+    return sizeof(double) * (Sp * d + (4 + nz) * Sp * (size_t)Np + Sp * (d + 1) + (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S +
+           sizeof(int) * 2 * Sp + 64;
 }
 
 // work: refine_lockstep_bytes(…) of device memory.  Synchronous with respect to the stream only at the round-counter reads.
@@ -596,49 +681,77 @@ hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStr
     const int Sp = (int)pad_up(S, 128), Np = a.Np, d = a.d, m = a.history;
     char* w = static_cast<char*>(work);
     long long* counters = reinterpret_cast<long long*>(w); w += 64;
+    int* nact = reinterpret_cast<int*>(&counters[2]);
     double* P = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * d;
     double* KX = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
     double* GV = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
     double* V = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
     double* U = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;
-    double* Ct = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * Np;      // the GEMMs' untransposed outputs (unused)
+    const int ks = lockstep_ksplit(Np);
+    const int nz = ks ? (Np + ks - 1) / ks : 1;
+    double* Ct = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)nz * Sp * Np;  // split-k partials / the plain GEMMs' untransposed outputs
     double* EV = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)Sp * (d + 1);
     double* vec = reinterpret_cast<double*>(w); w += sizeof(double) * (size_t)S * rl_vec_doubles(d, m);
     RlState* st = reinterpret_cast<RlState*>(w); w += sizeof(RlState) * S;
-    int* active = reinterpret_cast<int*>(w);
+    int* active = reinterpret_cast<int*>(w); w += sizeof(int) * Sp;
+    int* start_of = reinterpret_cast<int*>(w);
     hipError_t e;
     if ((e = hipMemsetAsync(counters, 0, 64, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(active, 0, sizeof(int) * Sp, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(P, 0, sizeof(double) * (size_t)Sp * d, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 1, P, active, EV, vec, st, counters);
+    hipLaunchKernelGGL(rl_step_kernel, dim3(S), dim3(64), rl_step_lds(d, m), s, a, S, 1, P, active, EV, vec, st, counters);
+    hipLaunchKernelGGL(rl_compact_kernel, dim3(1), dim3(256), 0, s, active, S, start_of, nact);
     // every loop of the one-launch kernel is bounded by the same product (64-bit: the caller's limits are clamped in
     // api.hip: refine_defaults, but the product of two ints is not an int)
     const int64_t max_rounds = 1 + (int64_t)a.max_iter * (int64_t)a.ls_max;
     const size_t lds = sizeof(double) * ((size_t)a.dp + RW * 2 * RCH + 2 * RCH);
     long long left = -1;
+    // what the host knows of the active count: S at first, then what the last counter read said (it only falls) — an upper bound that
+    // sizes the round's launches (rows of the batch, 16-row groups of the split-k products); the kernels themselves go by *nact
+    int bound = S;
     for (int64_t r = 0; r < max_rounds; ++r) {
-        dim3 kg((Np + 255) / 256, Sp);
+        const int rows = bound < Sp ? bound : Sp;                 // compact rows that can be active this round
+        const int R128 = (int)pad_up(rows, 128), R16 = (int)pad_up(rows, 16);
+        dim3 kg((Np + 255) / 256, R16);
         switch (a.family) {
-            case ABO_KERNEL_SE: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_SE>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
-            case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN52>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
-            case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN72>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
-            default: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN32>), kg, dim3(256), 0, s, a, P, active, KX, GV); break;
+            case ABO_KERNEL_SE: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_SE>), kg, dim3(256), 0, s, a, P, start_of, nact, KX, GV); break;
+            case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN52>), kg, dim3(256), 0, s, a, P, start_of, nact, KX, GV); break;
+            case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN72>), kg, dim3(256), 0, s, a, P, start_of, nact, KX, GV); break;
+            default: hipLaunchKernelGGL((rl_kgen_kernel<ABO_KERNEL_MATERN32>), kg, dim3(256), 0, s, a, P, start_of, nact, KX, GV); break;
         }
-        GemmArgs g1{};       // Ct1[i][j] = Σ_{k ≤ i} W[i][k]·KX[j][k]; transposed copy V[j][i]
-        g1.A = a.W; g1.lda = a.ld; g1.B = KX; g1.ldb = Np; g1.C = Ct; g1.ldc = Sp; g1.Ct = V; g1.ldct = Np;
-        g1.M = Np; g1.N = Sp; g1.K = Np; g1.kmode = K_A_LOWER; g1.lower_only = 0; g1.batch = 1; g1.alpha = 1.0; g1.beta = 0.0;
-        g1.info = reinterpret_cast<const int64_t*>(&counters[1]);
-        if ((e = launch_gemm_nt(g1, s)) != hipSuccess) return e;
-        if (Np > a.N) hipLaunchKernelGGL(rl_zero_tail_kernel, dim3(((Np - a.N) * Sp + 255) / 256), dim3(256), 0, s, V, Np, a.N, Sp);
-        GemmArgs g2 = g1;    // U[j][i] = Σ_{k ≥ i} WT[i][k]·V[j][k]
-        g2.A = a.WT; g2.B = V; g2.Ct = U; g2.kmode = K_A_UPPER;
-        if ((e = launch_gemm_nt(g2, s)) != hipSuccess) return e;
-        hipLaunchKernelGGL(rl_reduce_kernel, dim3(S), dim3(RT), lds, s, a, P, active, KX, GV, V, U, EV);
-        hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 0, P, active, EV, vec, st, counters);
+        if (ks) {
+            // split-k: V[c][i] = Σ_{k ≤ i} KX[c][k]·W[i][k] as k-chunks per tile + a fixed-order sum of the partials; with at most 64
+            // active rows the skinny kernel (gemm.hip: GemmArgs::mrows) streams L⁻¹ once instead of multiplying 128 rows
+            GemmArgs g1{};
+            g1.A = KX; g1.lda = Np; g1.B = a.W; g1.ldb = a.ld; g1.C = Ct; g1.ldc = Np; g1.sC = (int64_t)Sp * Np;
+            g1.M = R128; g1.N = Np; g1.K = Np; g1.kmode = K_B_LOWER; g1.lower_only = 0; g1.batch = 1; g1.alpha = 1.0; g1.beta = 0.0;
+            g1.ksplit = ks; g1.mrows = R16 <= 64 ? R16 : 0; g1.info = reinterpret_cast<const int64_t*>(&counters[1]);
+            if ((e = launch_gemm_nt(g1, s)) != hipSuccess) return e;
+            if ((e = launch_splitk_reduce(Ct, Np, g1.sC, nz, R16, Np, Np, ks, K_B_LOWER, V, Np, s)) != hipSuccess) return e;
+            if (Np > a.N) hipLaunchKernelGGL(rl_zero_tail_kernel, dim3(((Np - a.N) * R16 + 255) / 256), dim3(256), 0, s, V, Np, a.N, R16);
+            GemmArgs g2 = g1;    // U[c][i] = Σ_{k ≥ i} V[c][k]·WT[i][k]
+            g2.A = V; g2.B = a.WT; g2.kmode = K_B_UPPER;
+            if ((e = launch_gemm_nt(g2, s)) != hipSuccess) return e;
+            if ((e = launch_splitk_reduce(Ct, Np, g2.sC, nz, R16, Np, Np, ks, K_B_UPPER, U, Np, s)) != hipSuccess) return e;
+        } else {
+            GemmArgs g1{};       // Ct1[i][c] = Σ_{k ≤ i} W[i][k]·KX[c][k]; transposed copy V[c][i]
+            g1.A = a.W; g1.lda = a.ld; g1.B = KX; g1.ldb = Np; g1.C = Ct; g1.ldc = Sp; g1.Ct = V; g1.ldct = Np;
+            g1.M = Np; g1.N = R128; g1.K = Np; g1.kmode = K_A_LOWER; g1.lower_only = 0; g1.batch = 1; g1.alpha = 1.0; g1.beta = 0.0;
+            g1.info = reinterpret_cast<const int64_t*>(&counters[1]);
+            if ((e = launch_gemm_nt(g1, s)) != hipSuccess) return e;
+            if (Np > a.N) hipLaunchKernelGGL(rl_zero_tail_kernel, dim3(((Np - a.N) * R128 + 255) / 256), dim3(256), 0, s, V, Np, a.N, R128);
+            GemmArgs g2 = g1;    // U[c][i] = Σ_{k ≥ i} WT[i][k]·V[c][k]
+            g2.A = a.WT; g2.B = V; g2.Ct = U; g2.kmode = K_A_UPPER;
+            if ((e = launch_gemm_nt(g2, s)) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(rl_reduce_kernel, dim3(rows), dim3(RT), lds, s, a, P, start_of, nact, KX, GV, V, U, EV);
+        hipLaunchKernelGGL(rl_step_kernel, dim3(S), dim3(64), rl_step_lds(d, m), s, a, S, 0, P, active, EV, vec, st, counters);
+        hipLaunchKernelGGL(rl_compact_kernel, dim3(1), dim3(256), 0, s, active, S, start_of, nact);
         if ((r & 7) == 7 || r + 1 == max_rounds) {
             if ((e = hipMemcpyAsync(&left, counters, sizeof left, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
             if (left == 0) break;
+            if (left < bound) bound = (int)left;
         }
     }
     // a start still active here has used up the round budget (cannot happen while every start stops after max_iter accepted steps of
@@ -747,7 +860,7 @@ hipError_t launch_refine_lockstep_grad(const RefineArgs& a, int S, const double*
     if ((e = hipMemsetAsync(w.counters, 0, 64, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.active, 0, sizeof(int) * S, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.P, 0, sizeof(double) * (size_t)S * d, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 1, w.P, w.active, w.EV, w.vec, w.st, w.counters);
+    hipLaunchKernelGGL(rl_step_kernel, dim3(S), dim3(64), rl_step_lds(d, m), s, a, S, 1, w.P, w.active, w.EV, w.vec, w.st, w.counters);
     const int64_t max_rounds = 1 + (int64_t)a.max_iter * (int64_t)a.ls_max;
     long long left = -1;
     for (int64_t r = 0; r < max_rounds; ++r) {
@@ -755,7 +868,7 @@ hipError_t launch_refine_lockstep_grad(const RefineArgs& a, int S, const double*
         if ((e = ev.eval(ev.ctx, w.PTS, S * w.npp, w.MU, w.COV, s)) != hipSuccess) return e;
         hipLaunchKernelGGL(rl_grad_ev_kernel, dim3((S + 63) / 64), dim3(64), 0, s, a, mean_g, w.MU, w.COV, w.H, S, w.npp, w.active, w.EV,
                            (double*)nullptr, (double*)nullptr);
-        hipLaunchKernelGGL(rl_step_kernel, dim3((S + 127) / 128), dim3(128), 0, s, a, S, 0, w.P, w.active, w.EV, w.vec, w.st, w.counters);
+        hipLaunchKernelGGL(rl_step_kernel, dim3(S), dim3(64), rl_step_lds(d, m), s, a, S, 0, w.P, w.active, w.EV, w.vec, w.st, w.counters);
         if ((r & 7) == 7 || r + 1 == max_rounds) {
             if ((e = hipMemcpyAsync(&left, w.counters, sizeof left, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
             if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;

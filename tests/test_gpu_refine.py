@@ -452,3 +452,35 @@ def test_refinement_limits_are_clamped_not_overflowed():
 
 
 from tests.test_gpu_parity import FAMS as FAMS_  # noqa: E402
+
+
+@pytest.mark.parametrize("family,d,N,S", [(O.MATERN52, 3, 700, 40), (O.SE, 2, 2100, 130)])
+def test_split_k_form_of_the_lockstep_round_equals_the_plain_launch_to_rounding(family, d, N, S, monkeypatch):
+    """From 2048 factor rows on a round's two products (128 starts × Np against L⁻¹: one row of output tiles, k up to Np) are cut
+    into k-chunks — one workgroup per (tile, chunk) on the LDS-tiled MFMA core, partial products summed in chunk order
+    (gemm.hip: GemmArgs::ksplit, splitk_reduce_kernel).  Same algorithm, another summation order: forced on (ABO_REFINE_KSPLIT)
+    and off (= 0), the two forms must agree on every start's optimum to rounding; a chunk that is not a divisor of Np and a
+    view with fewer valid rows than Np are part of the cases (N = 700 → Np = 768 with chunks of 256 and 128)."""
+    X, y = synth.standardized_problem(N, d, 0.02)
+    m = abo.update(make_model(family, 0.5, 1.0, 0.05), X, y)
+    lower, upper = np.full(d, -0.5), np.full(d, 1.5)
+    acq = abo.ExpectedImprovement(0.01, float(np.median(y)))
+    starts = synth.points(11, S, d) * 2.0 - 0.5
+    monkeypatch.setenv("ABO_REFINE_LOCKSTEP_NP", "128")
+    monkeypatch.setenv("ABO_REFINE_KSPLIT", "0")
+    xa, fa, ita = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+    for ks in ("256", "128"):
+        monkeypatch.setenv("ABO_REFINE_KSPLIT", ks)
+        xb, fb, itb = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+        xb2, fb2 = refine_starts(acq, m, starts, lower, upper)
+        np.testing.assert_array_equal(fb, fb2)                   # deterministic: fixed-order sum of the partials
+        np.testing.assert_array_equal(xb, xb2)
+        assert np.all(fb >= acq(m, starts) - 1e-10) and np.all(xb >= lower) and np.all(xb <= upper)
+        np.testing.assert_allclose(acq(m, xb), fb, rtol=1e-9, atol=1e-10)
+        close = np.abs(fa - fb) <= 1e-6 * np.maximum(1.0, np.abs(fa))
+        assert close.mean() >= 0.9, (ks, close.mean())
+    monkeypatch.delenv("ABO_REFINE_KSPLIT")
+    if N >= 2048:                                                # the default at this size IS the split-k form
+        xc, fc = refine_starts(acq, m, starts, lower, upper)
+        close = np.abs(fa - fc) <= 1e-6 * np.maximum(1.0, np.abs(fa))
+        assert close.mean() >= 0.9
