@@ -128,9 +128,10 @@ struct KgenArgs {
     int64_t res_ld = 0, res_plane = 0;
     int* res_bad = nullptr;
     int res_n = 0, res_sK = 0;
+    int res_ktg = 0;      // gradient-enhanced GP: derivative training rows and derivative candidate outputs each carry 2^-res_ktg on top
 };
 // true when launch_kgen honours KgenArgs::res for this shape and n moduli (the fused output is instantiated for the default plan)
-inline bool kgen_writes_residues(const KgenArgs& a, int n) { return a.pt == 1 && a.dp <= 32 && n == 14; }
+inline bool kgen_writes_residues(const KgenArgs& a, int n) { return a.dp <= 32 && n == 14 && !a.dlogell; }
 hipError_t launch_kgen(const KgenArgs& a, hipStream_t s);
 // NLML gradient reduction: Σ_ij (Kinv − ααᵀ)_ij ∂K_ij/∂log ℓ over the lower tiles, plus tr(Kinv), αᵀα, αᵀδ
 struct NlmlGradArgs {

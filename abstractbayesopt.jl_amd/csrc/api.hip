@@ -803,7 +803,11 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         if (fused) {
             const int64_t q = pad_up(Np, 256);
             ka.res = g->oz_KR.as<int8_t>(); ka.res_ld = q; ka.res_plane = pad_up(mcp, 256) * q;
-            ka.res_bad = g->oz_badc.as<int>(); ka.res_n = g->oz_plan.n; ka.res_sK = oz_k_scale(g->prm.sigma_f2);
+            // (a gradient-enhanced model's scaled chunk is bounded by σ_f²·√2, its all-output chunk by 2σ_f²: the exponent the
+            // contraction below is told, oa.sK)
+            ka.res_bad = g->oz_badc.as<int>(); ka.res_n = g->oz_plan.n;
+            ka.res_sK = oz_k_scale(g->p_out > 1 ? (pc > 1 ? 2.0 : 1.5) * g->prm.sigma_f2 : g->prm.sigma_f2);
+            ka.res_ktg = oz_grad_exp(g);
             if (!kstore) ka.Kout = nullptr;
         }
         PHASE_EVENT(e[0], s);
@@ -875,7 +879,14 @@ int32_t grad_eval_device(abo_gp* g, const double* Zd, int64_t M, double beta, do
     if (oz) { int32_t rc = oz_planes_of_w(g); if (rc) return rc; }
     g->tm.contraction_engine = oz ? ABO_CONTRACT_INT8 : ABO_CONTRACT_FP64;
     g->tm.oz_nmod = oz ? g->oz_plan.n : 0;
-    HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
+    // int8 engine: the generator writes the residue planes of the chunk itself; the fp64 chunk is then not materialised
+    bool fused = false;
+    if (oz) {
+        KgenArgs probe{};
+        probe.pt = P; probe.dp = g->dp;
+        fused = kgen_writes_residues(probe, g->oz_plan.n) && !getenv("ABO_OZ_UNFUSED");
+    }
+    if (!fused) HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
     HIPCHK(g->partial.ensure(sizeof(double) * rows_pad * Np));       // V
     HIPCHK(g->mu_c.ensure(sizeof(double) * rows_pad));
     for (int64_t p0 = 0; p0 < M; p0 += pts) {
@@ -887,6 +898,13 @@ int32_t grad_eval_device(abo_gp* g, const double* Zd, int64_t M, double beta, do
         ka.Np = (int)Np; ka.d = g->d; ka.dp = g->dp; ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell;
         ka.sigma_f2 = g->prm.sigma_f2; ka.pt = P; ka.pc = P; ka.point_major = 1;
         for (int q = 0; q < MAX_P; ++q) ka.mean_vec[q] = g->mean_vec[q];
+        if (fused) {
+            const int64_t q256 = pad_up(Np, 256);
+            ka.Kout = nullptr;
+            ka.res = g->oz_KR.as<int8_t>(); ka.res_ld = q256; ka.res_plane = pad_up(rows, 256) * q256;
+            ka.res_bad = g->oz_badc.as<int>(); ka.res_n = g->oz_plan.n; ka.res_sK = oz_k_scale(2.0 * g->prm.sigma_f2);
+            ka.res_ktg = oz_grad_exp(g);
+        }
         HIPCHK(launch_kgen(ka, s));
         if (oz) {
             OzVarArgs oa{};
@@ -894,7 +912,7 @@ int32_t grad_eval_device(abo_gp* g, const double* Zd, int64_t M, double beta, do
             oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
             oa.bad_col = g->oz_badc.as<int>(); oa.partial = nullptr; oa.ldp = 0; oa.Np = (int)Np; oa.Mc = rows;
             oa.nvalid = (int)g->N; oa.sK = oz_k_scale(2.0 * g->prm.sigma_f2);
-            oa.kper = P; oa.ktg = oz_grad_exp(g);
+            oa.kper = P; oa.ktg = oz_grad_exp(g); oa.planes_ready = fused ? 1 : 0;
             oa.rmode = 1; oa.rper = P; oa.r0 = p0 * P; oa.rpts = M;
             oa.Vout = g->partial.as<double>(); oa.ldv = Np;
             HIPCHK(launch_var_ozaki(oa, s));
