@@ -130,7 +130,8 @@ def _cpu_baseline(cfg, sample_m):
     s = O.acquisition(O.ACQ_EI if acq == "ei" else O.ACQ_UCB, mu, var, p0, float(y.min()))
     O.top_k(s, 100)
     t2 = time.perf_counter()
-    threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    pools = threadpool_info()
+    threads = max([p.get("num_threads", 1) for p in pools] + [1])
     fit_ms, acq_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
     # the LAPACK/BLAS-3 part alone (dpotrf + dtrsm): a floor for ANY host implementation of the path, however the
     # kernel matrices are assembled
@@ -139,7 +140,19 @@ def _cpu_baseline(cfg, sample_m):
     sla.cholesky(K, lower=True, check_finite=False, overwrite_a=True)
     potrf_ms = (time.perf_counter() - tb) * 1e3
     del K
+    # what the host BLAS actually delivered: a threaded LAPACK is expected at ≥ 10 GFLOP/s per core on dpotrf / dtrsm of this
+    # size; a baseline far below that is a handicapped one (a cgroup CPU share spread over many logical CPUs, a reference BLAS) and
+    # the ratio against it says little — the line then flags it and does not print a speed-up
+    potrf_gflops = (N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e9
+    trsm_gflops = (float(N) * N * sample_m) / max(trsm_s, 1e-9) / 1e9
+    under = min(potrf_gflops, trsm_gflops) < 10.0 * threads
     return {
+        "host_blas": {"libraries": [{k: p.get(k) for k in ("user_api", "internal_api", "version", "num_threads", "threading_layer")}
+                                    for p in pools],
+                      "dpotrf_gflops": potrf_gflops, "dtrsm_gflops": trsm_gflops, "threads": threads,
+                      "under_threaded": bool(under),
+                      "note": "achieved rate of scipy.linalg.cholesky (N x N) and solve_triangular (N x N against the sample) inside "
+                              "this baseline; under_threaded = below 10 GFLOP/s per thread on either"},
         "value": fit_ms + acq_ms * (M / sample_m), "unit": "ms per BO step (extrapolated)", "cores": threads,
         "kind": "port",
         "sample": f"CPU restatement (NumPy/SciPy LAPACK), not the Julia reference: full N={N} refit measured "
@@ -801,8 +814,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_m, args.cpu_reps)
-                out["speedup_vs_cpu_port"] = out["cpu_baseline"]["value"] / ms_per_step
-                out["speedup_vs_cpu_blas3_floor"] = out["cpu_baseline"]["blas3_floor"]["value"] / ms_per_step
+                if out["cpu_baseline"].get("host_blas", {}).get("under_threaded"):
+                    out["cpu_baseline"]["flag"] = ("baseline under-threaded: the host BLAS ran far below a threaded LAPACK's rate on "
+                                                   "this box (host_blas) - no speed-up ratio is printed against it")
+                else:
+                    out["speedup_vs_cpu_port"] = out["cpu_baseline"]["value"] / ms_per_step
+                    out["speedup_vs_cpu_blas3_floor"] = out["cpu_baseline"]["blas3_floor"]["value"] / ms_per_step
             except Exception as e:                      # noqa: BLE001 - reported, not swallowed
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
                 print(f"bench: cpu_baseline leg failed: {e!r}", file=sys.stderr)

@@ -3,7 +3,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 bash tools/run_pmc_int8.sh ${TAG}i > gpurun_out/final_pmc_int8_run.log 2>&1 || { tail -5 gpurun_out/final_pmc_int8_run.log; exit 1; }
 cp gpurun_out/pmc_${TAG}i_summary.txt gpurun_out/final_pmc_int8_summary.txt
 MC=$(grep '^{' gpurun_out/pmc_${TAG}i_fetch.log | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(int(d['config']['M_per_gpu'] // d['roofline']['launches_per_step']))")

@@ -4,7 +4,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 timeout -k 10 300 python __graft_entry__.py smoke > gpurun_out/final_smoke.txt 2>&1 || { tail -5 gpurun_out/final_smoke.txt; exit 1; }
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/final_pytest_gpu.txt 2>&1 || { tail -30 gpurun_out/final_pytest_gpu.txt; exit 1; }
 tail -1 gpurun_out/final_pytest_gpu.txt
@@ -28,11 +28,16 @@ timeout -k 10 300 python bench.py --config c2 --steps 30 --warmup 5 --cpu-sample
 timeout -k 10 300 python bench.py --config c5 --steps 5 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 600 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 > gpurun_out/final_bench_c3_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 --config c5 > gpurun_out/final_bench_c5_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+# BASELINE config 4 at its own size through the 8-shard path, all shards on this one GPU (a rehearsal of the fan-out, NOT a scaling figure)
+timeout -k 10 600 python bench.py --gpus 8 --share-device --config c4 --steps 2 --warmup 1 > gpurun_out/final_bench_c4_8shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 600 python bench.py --gpus 4 --share-device --config c5 --steps 3 --warmup 1 > gpurun_out/final_bench_c5_4shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 echo "bench done"
 (echo "tools/small_n_latency.py: refit + EI over M + top-100 at the sizes the reference's own loops live at"; echo "--- default (phase events automatic: off for N <= 128)"; timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N="; echo "--- ABO_PHASE_EVENTS=1"; ABO_PHASE_EVENTS=1 timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N="; echo "--- ABO_PHASE_EVENTS=0"; ABO_PHASE_EVENTS=0 timeout -k 10 200 python tools/small_n_latency.py 2>&1 | grep "^N=") > gpurun_out/final_small_n_latency.txt
-(timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep -v amdgpu.ids; echo; echo "--- the one-launch kernel at every size (ABO_REFINE_LOCKSTEP_NP=0)"; ABO_REFINE_LOCKSTEP_NP=0 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N="; echo "--- lockstep rounds at every size (ABO_REFINE_LOCKSTEP_NP=128)"; ABO_REFINE_LOCKSTEP_NP=128 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N=") > gpurun_out/final_optimize_acquisition_latency.txt
+(timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep -v amdgpu.ids; echo; echo "--- the one-launch kernel at every size (ABO_REFINE_LOCKSTEP_NP=0)"; ABO_REFINE_LOCKSTEP_NP=0 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N="; echo "--- lockstep rounds at every size (ABO_REFINE_LOCKSTEP_NP=128)"; ABO_REFINE_LOCKSTEP_NP=128 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N="; echo "--- lockstep rounds without the split-k / skinny products (ABO_REFINE_KSPLIT=0: round 3)"; ABO_REFINE_KSPLIT=0 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2048 8192 2>/dev/null | grep "^N=") > gpurun_out/final_optimize_acquisition_latency.txt
 (echo "tools/c_host_latency.sh: per-step latency from the plain-C host (tests/c_abi_harness.c latency; system HIP runtime, no interpreter, host arrays in, top-100 out)"; bash tools/c_host_latency.sh 2>&1 | grep "^latency") > gpurun_out/final_c_host_latency.txt
 timeout -k 10 300 bash tools/fit_times.sh > gpurun_out/final_fit_times.txt 2>&1 || true
+(timeout -k 10 300 python tools/grad_engine_latency.py 2>&1 | grep -v amdgpu; timeout -k 10 300 python tools/grad_engine_latency.py 400 16 2048 2>&1 | grep -v amdgpu; echo "--- ABO_OZ_UNFUSED=1 (fp64 chunk + separate quantiser pass: round 3)"; ABO_OZ_UNFUSED=1 timeout -k 10 300 python tools/grad_engine_latency.py 2>&1 | grep "^int8") > gpurun_out/final_grad_engine_latency.txt
+timeout -k 10 600 python tools/oz_soak.py 40 2>&1 | grep "^N=" > gpurun_out/final_oz_soak.txt || true
 timeout -k 10 600 python tools/soak.py > gpurun_out/final_soak.txt 2>&1 || { tail -5 gpurun_out/final_soak.txt; exit 1; }
 echo "latency tools done"
 rm -rf gpurun_out/prof_${TAG}_c3fp64
