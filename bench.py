@@ -685,10 +685,14 @@ def main():
     # that is how the RCCL calls are exercised on a one-GPU box (tests/test_gpu_distributed.py)
     use_dist = world > 1 or bool(os.environ.get("ABO_FORCE_DIST"))
     if use_dist:
+        # a rank that dies or never arrives must end the run with an error, not hold the others in a collective for ever: the
+        # process group's watchdog aborts a collective that has not completed after 5 minutes (a step is ≤ a few seconds)
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("ABO_BENCH_COLLECTIVE_TIMEOUT_S", "300")))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
 
     cfg = CONFIGS[args.config]
     if args.config == "c5":
