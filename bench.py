@@ -187,7 +187,7 @@ def pmc_traffic(config, mc_per_launch):
     traffic of that pass scaled to this run's candidates per launch.  The pass records the hash of the kernel's
     source file; when the file has changed since, the figure is STALE and `traffic` is reported as null."""
     key = config.replace("c4", "c3")                         # C4 = C3 per launch
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -211,7 +211,7 @@ def contraction_label(abo, med):
     return (f"int8-residue, {int(med['oz_nmod'])} moduli: exact integer products and sums of fixed-point images of the fp64 operands "
             "(K_XZ kept to 2^-52 of sigma_f2; each row of L^-1 kept to >= 50 bits below that row's L1 norm, i.e. an entry far below its "
             "row's L1 norm keeps fewer of its own bits - at most log2(N) fewer than 53 for a dense equal-magnitude row); results fp64, "
-            "parity vs the oracle recorded in profiles/parity_r03.json")
+            "parity vs the oracle recorded in profiles/parity_r04.json")
 
 
 def dominant_kernel_roofline(abo, med, config, N, M_per):

@@ -484,3 +484,24 @@ def test_split_k_form_of_the_lockstep_round_equals_the_plain_launch_to_rounding(
         xc, fc = refine_starts(acq, m, starts, lower, upper)
         close = np.abs(fa - fc) <= 1e-6 * np.maximum(1.0, np.abs(fa))
         assert close.mean() >= 0.9
+
+
+def test_boundary_maximisers_are_returned_on_the_bound_and_match_the_finite_difference_loop():
+    """The reference's Fminbox keeps its iterates strictly inside the box (log barrier); this stage projects and may stop ON a
+    bound — stated in include/abo_hip.h ("parity unpinned").  What must hold: a start whose ascent leaves the box ends on the
+    face, its value is the score of that point, and the best refined value is at least the finite-difference host loop's best
+    (the same projected L-BFGS under the same rules) within f_abstol — on a box small enough that most maxima sit on its faces."""
+    d, N = 2, 150
+    X, y = synth.standardized_problem(N, d, 0.02)
+    m = abo.update(make_model(O.MATERN52, 0.5, 1.0, 0.05), X, y)
+    lower, upper = np.full(d, 0.42), np.full(d, 0.58)        # a small box inside the data: UCB keeps rising towards some face
+    starts = lower + (upper - lower) * synth.points(13, 24, d)
+    for acq in (abo.UpperConfidenceBound(2.0), abo.ExpectedImprovement(0.01, float(np.median(y)))):
+        xr, fr = refine_starts(acq, m, starts, lower, upper)
+        assert np.all(xr >= lower) and np.all(xr <= upper)
+        on_face = np.any((xr == lower) | (xr == upper), axis=1)
+        assert on_face.sum() >= 3, on_face.sum()                # maximisers ON the bound are returned as such
+        np.testing.assert_allclose(acq(m, xr), fr, rtol=1e-9, atol=1e-10)
+        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)
+        assert fr.max() >= ff.max() - 2.2e-9
+        assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
