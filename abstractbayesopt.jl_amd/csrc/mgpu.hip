@@ -54,6 +54,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;        // why it is not available
 };
@@ -75,7 +77,9 @@ const Rccl& rccl() {
         x.CommAbort = reinterpret_cast<decltype(x.CommAbort)>(dlsym(x.handle, "ncclCommAbort"));
         x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
-        if (!x.CommInitAll || !x.CommDestroy || !x.CommAbort || !x.AllGather || !x.GetErrorString) {
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.handle, "ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.handle, "ncclGroupEnd"));
+        if (!x.CommInitAll || !x.CommDestroy || !x.CommAbort || !x.AllGather || !x.GetErrorString || !x.GroupStart || !x.GroupEnd) {
             x.why = "librccl.so.1 lacks ncclCommInitAll / ncclCommAbort / ncclAllGather";
             x.handle = nullptr;
         }
@@ -204,6 +208,17 @@ struct DeviceLocks {
     DeviceLocks& operator=(const DeviceLocks&) = delete;
 };
 
+hipError_t ensure_dev(void** p, size_t* cap, size_t bytes) {
+    if (bytes <= *cap) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    size_t want = 4096;
+    while (want < bytes) want <<= 1;
+    hipError_t e = hipMalloc(p, want);
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+
 CommSet* comm_set(const int* dev, int ndev) {
     static std::mutex mu;
     static std::map<std::vector<int>, CommSet*> sets;
@@ -229,6 +244,31 @@ CommSet* comm_set(const int* dev, int ndev) {
         if (r == ncclSuccess) cs->rccl_ok = cs->rccl_ever = true;
         else cs->why = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
         (void)hipGetLastError();
+        // One tiny all-gather over every rank NOW, issued as one group from this thread: recent NCCL / RCCL set their transport
+        // connections up lazily inside the first collective — a host-side exchange between the ranks — and the bounded wait of
+        // exchange() only bounds what has been ENQUEUED.  After this warm-up a collective call is an asynchronous kernel launch, so a
+        // rank that never arrives later costs the others a time-out, not a host call that never returns.
+        if (cs->rccl_ok) {
+            bool ok = true;
+            for (int i = 0; ok && i < ndev; ++i)
+                ok = hipSetDevice(dev[i]) == hipSuccess && ensure_dev(&cs->pack[i], &cs->pack_cap[i], 8) == hipSuccess &&
+                     ensure_dev(&cs->gath[i], &cs->gath_cap[i], 8 * (size_t)ndev) == hipSuccess;
+            ncclResult_t w = ok ? rccl().GroupStart() : ncclSystemError;
+            for (int i = 0; w == ncclSuccess && i < ndev; ++i) {
+                (void)hipSetDevice(dev[i]);
+                w = rccl().AllGather(cs->pack[i], cs->gath[i], 1, ncclUint64, cs->comm[i], nullptr);
+            }
+            if (ok) { const ncclResult_t e = rccl().GroupEnd(); if (w == ncclSuccess) w = e; }
+            for (int i = 0; w == ncclSuccess && i < ndev; ++i)
+                if (hipSetDevice(dev[i]) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) w = ncclUnhandledCudaError;
+            if (w != ncclSuccess) {
+                for (int i = 0; i < ndev; ++i)
+                    if (cs->comm[i]) { (void)hipSetDevice(dev[i]); (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
+                cs->rccl_ok = false;
+                cs->why = std::string("RCCL warm-up all-gather failed: ") + (ok ? rccl().GetErrorString(w) : "device buffers");
+            }
+            (void)hipGetLastError();
+        }
     }
     if (ndev > 1) for (int i = 0; i < ndev; ++i) cs->wk[i] = new_worker();
     cs->lock_order.assign(dev, dev + ndev);
@@ -236,17 +276,6 @@ CommSet* comm_set(const int* dev, int ndev) {
     cs->lock_order.erase(std::unique(cs->lock_order.begin(), cs->lock_order.end()), cs->lock_order.end());
     sets[key] = cs;
     return cs;
-}
-
-hipError_t ensure_dev(void** p, size_t* cap, size_t bytes) {
-    if (bytes <= *cap) return hipSuccess;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr; *cap = 0;
-    size_t want = 4096;
-    while (want < bytes) want <<= 1;
-    hipError_t e = hipMalloc(p, want);
-    if (e == hipSuccess) *cap = want;
-    return e;
 }
 
 void shard_range(int64_t M, int i, int n, int64_t* lo, int64_t* hi) {
