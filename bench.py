@@ -84,6 +84,12 @@ def cpu_baseline(cfg, sample_m=21846, reps=3):
     candidates timed and scaled linearly in M): by default 3 × 21 846 = 65 538 candidates in all, ≈ 80 s of host time
     at C3 — each repetition is a full N-point refit + the posterior / acquisition over its candidates."""
     from threadpoolctl import threadpool_limits
+    # every BLAS this baseline will call must be LOADED before the limit is set: threadpool_limits only reaches the libraries that
+    # are in the process at that moment — round 3's baseline imported scipy.linalg inside the limited region, SciPy's own OpenBLAS
+    # came in afterwards with its default of one thread per LOGICAL cpu of the host (64 on a 16-core share) and dpotrf ran
+    # oversubscribed at 28 GFLOP/s
+    import scipy.linalg  # noqa: F401
+    from oracle import gp_oracle  # noqa: F401
     cores = usable_cores()
     with threadpool_limits(limits=cores):
         runs = [_cpu_baseline(cfg, sample_m) for _ in range(max(1, reps))]
