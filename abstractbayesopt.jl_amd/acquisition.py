@@ -261,25 +261,28 @@ def device_latin_hypercube(n: int, lower, upper, seed: int, device: int = 0, fir
     return Z
 
 
+def _walk_terms(a, w, grad_ok, out) -> bool:
+    """(module level on purpose: a nested recursive function is a reference cycle — function ↔ its own closure cell — that would keep
+    the surrogate it closes over, and with it a GPU model, alive until the cyclic garbage collector happens to run)"""
+    if isinstance(a, EnsembleAcquisition):
+        return all(_walk_terms(m, w * float(wi), grad_ok, out) for wi, m in zip(a.weights, a.acquisitions))
+    k = getattr(a, "kind", None)
+    if k not in (ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN, ACQ_GRADNORM_UCB):
+        return False
+    if k == ACQ_GRADNORM_UCB and not grad_ok:
+        return False
+    out.append((int(k), float(a._p0()), float(a._best()), float(w)))
+    return True
+
+
 def flatten_terms(acqf, surrogate=None):
     """[(kind, p0, best_y, weight), …] of an acquisition function as a weighted-sum objective (include/abo_hip.h: abo_acq_term) —
     a plain function is one term of weight 1, an EnsembleAcquisition (nested ones included) the list of its members with the
     weights multiplied through (EnsembleAcq.jl:53-55).  None when the library cannot take it: more than 8 terms, an unknown
     member, or a GradientNormUCB member on a model without gradient outputs."""
     out = []
-
-    def walk(a, w):
-        if isinstance(a, EnsembleAcquisition):
-            return all(walk(m, w * float(wi)) for wi, m in zip(a.weights, a.acquisitions))
-        k = getattr(a, "kind", None)
-        if k not in (ACQ_EI, ACQ_UCB, ACQ_PI, ACQ_MEAN, ACQ_GRADNORM_UCB):
-            return False
-        if k == ACQ_GRADNORM_UCB and surrogate is not None and not hasattr(surrogate, "p"):
-            return False
-        out.append((int(k), float(a._p0()), float(a._best()), float(w)))
-        return True
-
-    if not walk(acqf, 1.0) or not 1 <= len(out) <= MAX_TERMS:
+    grad_ok = surrogate is None or hasattr(surrogate, "p")
+    if not _walk_terms(acqf, 1.0, grad_ok, out) or not 1 <= len(out) <= MAX_TERMS:
         return None
     return out
 

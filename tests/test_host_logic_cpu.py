@@ -246,3 +246,34 @@ def test_pmc_traffic_is_dropped_when_the_kernel_source_changed(tmp_path, monkeyp
     monkeypatch.setattr(b, "source_sha", lambda names: "0" * 16)
     traffic, src = b.pmc_traffic("c3", 16384)
     assert traffic is None and src["stale"] is True
+
+
+def test_flattening_an_objective_leaves_no_reference_cycle_on_the_surrogate():
+    """`flatten_terms` runs on every acquisition call and refinement: if it closed over the surrogate in a recursive nested function
+    (a function ↔ closure-cell cycle), a dropped model — hundreds of MB of device memory — would live on until the cyclic garbage
+    collector happened to run (tools/soak.py caught exactly that as device memory growing to 12 GB)."""
+    import gc
+    import weakref
+
+    import abstractbayesopt.jl_amd as abo
+    from abstractbayesopt.jl_amd.acquisition import flatten_terms
+
+    class Model:
+        p = 3
+
+    ens = abo.EnsembleAcquisition([1.0, 3.0], [abo.UpperConfidenceBound(2.0),
+                                               abo.EnsembleAcquisition([1.0, 1.0], [abo.ExpectedImprovement(0.01, 0.5), abo.GradientNormUCB(1.5)])])
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        m = Model()
+        r = weakref.ref(m)
+        terms = flatten_terms(ens, m)
+        del m
+        assert r() is None, "flatten_terms keeps the surrogate alive through a reference cycle"
+    finally:
+        if was:
+            gc.enable()
+    assert terms == [(1, 2.0, 0.0, 0.25), (0, 0.01, 0.5, 0.375), (4, 1.5, 0.0, 0.375)]
+    assert flatten_terms(abo.GradientNormUCB(1.0), object()) is None              # needs a model with gradient outputs
+    assert flatten_terms(abo.EnsembleAcquisition([1.0] * 9, [abo.UpperConfidenceBound(float(b)) for b in range(9)])) is None   # > 8 terms
