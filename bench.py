@@ -501,6 +501,10 @@ def run_single_process(args):
     have = torch.cuda.device_count()
     if not args.share_device and have < G:
         raise SystemExit(f"bench.py --gpus {G}: this machine shows {have} GPU(s); --share-device rehearses {G} shards on GPU 0")
+    if args.share_device:
+        # all shards on one device share ITS buffer pool (32 GiB by default: sized for one shard per device); eight shards recycle
+        # 8 × 19 GB of factor + int8 scratch per step — beyond the limit every step would pay hipFree / hipMalloc for the excess
+        os.environ.setdefault("ABO_POOL_LIMIT_MB", str(230 * 1024))
     if args.config == "c5":
         return run_single_process_c5(args)
     # a resident grid would otherwise also keep its fp64 K_ZX (64 GiB per device at C3: the down-date path of config 5);
