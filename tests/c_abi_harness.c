@@ -401,6 +401,35 @@ int main(int argc, char** argv) {
                KL, bval, sv[0], (long long)tm.refine_evals, tm.refine_ms);
     }
 
+    /* --- gradient-enhanced model (GradientGP.jl:617-668) from this host: the reference's closed-form case (test_surrogates.jl:289-348),
+     * and optimize_acquisition with GradientNormUCB (gradNormUCB.jl:39-51) / EI as ONE call on it (ABI 5) ----------------------- */
+    {
+        abo_params pg = p;
+        pg.family = ABO_KERNEL_SE; pg.ell = 1.0; pg.sigma_f2 = 1.0; pg.noise_var = 0.1; pg.mean_c = 0.0; pg.n_max = 0;
+        const double meang[3] = {0.0, 0.0, 0.0};
+        const double Xg[6] = {0.0, 0.0, 0.5, 0.5, 1.0, 1.0};                       /* three points, point-major */
+        const double Yg[9] = {1.0, 0.5, 0.0, 0.1, 0.0, -0.1, 0.1, 0.0, -0.1};      /* by outputs: f, then d/dx1, then d/dx2 */
+        abo_gp* gg = NULL;
+        ok_or_die(abo_create_grad(&pg, 3, meang, &gg), "abo_create_grad");
+        ok_or_die(abo_fit(gg, Xg, 3, 2, Yg, ABO_HOST, &info), "abo_fit (gradient-enhanced)");
+        const double zq[2] = {0.25, 0.25};
+        double mg[3], vg[3];
+        ok_or_die(abo_predict_grad(gg, zq, 1, 2, ABO_HOST, mg, vg, ABO_HOST), "abo_predict_grad");
+        CHECK(vg[0] >= 0.0 && vg[1] > 0.0 && vg[2] > 0.0 && mg[0] > 0.3 && mg[0] < 1.0, "gradient-enhanced posterior out of range (mu %.4f var %.4f)", mg[0], vg[0]);
+        double lo2[2] = {-0.5, -0.5}, up2[2] = {1.5, 1.5}, bxg[2], bvg = 0.0, sxg[16 * 2], svg[16], scg = 0.0;
+        abo_acq_term tg[2] = {{ABO_ACQ_GRADNORM_UCB, 0, 2.0, 0.0, 1.0}, {ABO_ACQ_EI, 0, 0.01, 0.0, 1.0}};
+        for (int which = 0; which < 2; ++which) {
+            ok_or_die(abo_optimize_acquisition_terms(gg, &tg[which], 1, lo2, up2, 2, 2000, 16, 7u, NULL, bxg, &bvg, sxg, svg, NULL, NULL),
+                      "abo_optimize_acquisition_terms (gradient-enhanced)");
+            ok_or_die(abo_acq_terms(gg, bxg, 1, 2, ABO_HOST, &tg[which], 1, 0, &scg, 0, NULL, NULL, ABO_HOST), "abo_acq_terms (gradient-enhanced)");
+            CHECK(bxg[0] >= -0.5 && bxg[0] <= 1.5 && bxg[1] >= -0.5 && bxg[1] <= 1.5, "gradient-enhanced optimize_acquisition: result outside the box");
+            CHECK(bvg >= svg[0] - 1e-12, "gradient-enhanced optimize_acquisition: best %.17g below the best grid score %.17g", bvg, svg[0]);
+            CHECK(fabs(scg - bvg) <= 1e-9 * fmax(1.0, fabs(bvg)), "gradient-enhanced optimize_acquisition: value %.17g, score there %.17g", bvg, scg);
+        }
+        printf("ok gradient-enhanced model (closed-form case fitted; optimize_acquisition with GradientNormUCB and EI in one call each)\n");
+        ok_or_die(abo_destroy(gg), "abo_destroy (gradient-enhanced)");
+    }
+
     /* --- the int8-residue contraction engine from this host: same scores (to fp64 rounding), same selection --------- */
     {
         abo_gp* g8 = NULL;
