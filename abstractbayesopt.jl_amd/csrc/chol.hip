@@ -492,16 +492,17 @@ hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int
 }
 
 // out[r] = Σ_k Wm[r][k]·v[k] over the triangular part of rows r < Np (lower: k ≤ r; upper: r ≤ k < Np).
-// One wave per 4 consecutive rows: the four rows share every 16-byte load of v, lanes stride k by 128, partial sums
-// per lane and then the fixed xor tree (deterministic).  The k range is that of the longest of the four rows — the
-// entries it adds for the shorter ones are structural zeros of the triangular factor — and v is masked at the range
-// end, so stale values beyond Np (the remains of a discarded append) never enter.  HBM-bound: 4·Np² bytes.
-__global__ void __launch_bounds__(256) trmv_kernel(const double* __restrict__ Wm, int64_t ld, const double* __restrict__ v,
-                                                   double* __restrict__ out, int Np, int lower) {
+// A wave takes TWO groups of 4 consecutive rows — group q and group nq−1−q, a short and a long one, so that every wave of the
+// launch streams the same number of bytes (with one group per wave, handed out top to bottom, the launch ended in a tail of
+// the longest rows alone, latency-bound: 5.3 TB/s at N = 16384; balanced and with four steps of loads in flight per lane it is
+// HBM-bound).  Within a group the four rows share every 16-byte load of v, lanes stride k by 128, partial sums per lane in
+// increasing k and then the fixed xor tree — the order of round 1, same bits.  The k range is that of the longest of the four
+// rows — the entries it adds for the shorter ones are structural zeros of the triangular factor — and v is masked at the
+// range end, so stale values beyond Np (the remains of a discarded append) never enter.  HBM-bound: 4·Np² bytes.
+constexpr int TRMV_U = 4;     // k steps of 128 whose loads are issued together
+__device__ __forceinline__ void trmv_rows4(const double* __restrict__ Wm, int64_t ld, const double* __restrict__ v,
+                                           double* __restrict__ out, int Np, int lower, int row0, int lane) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (row0 >= Np) return;
     const int kb = lower ? 0 : (row0 & ~1);
     const int ke = lower ? min(row0 + 4, Np) : Np;
     const double* r0 = Wm + (int64_t)row0 * ld;
@@ -509,10 +510,31 @@ __global__ void __launch_bounds__(256) trmv_kernel(const double* __restrict__ Wm
     const double* r2 = r0 + (row0 + 2 < Np ? 2 * ld : 0);
     const double* r3 = r0 + (row0 + 3 < Np ? 3 * ld : 0);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int k = kb + 2 * lane; k < ke; k += 128) {          // ld is even and > k + 1: the pair load stays inside the row
+    int k = kb + 2 * lane;                                   // ld is even and > k + 1: the pair load stays inside the row
+    for (; k + 128 * (TRMV_U - 1) < ke; k += 128 * TRMV_U) {
+        d2_t vv[TRMV_U], x0[TRMV_U], x1[TRMV_U], x2[TRMV_U], x3[TRMV_U];
+#pragma unroll
+        for (int u = 0; u < TRMV_U; ++u) {
+            const int ku = k + 128 * u;
+            vv[u] = *reinterpret_cast<const d2_t*>(v + ku);
+            if (ku + 1 >= ke) vv[u][1] = 0.0;
+            x0[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r0 + ku));   // read once: stream
+            x1[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r1 + ku));
+            x2[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r2 + ku));
+            x3[u] = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r3 + ku));
+        }
+#pragma unroll
+        for (int u = 0; u < TRMV_U; ++u) {
+            a0 = fma(x0[u][1], vv[u][1], fma(x0[u][0], vv[u][0], a0));
+            a1 = fma(x1[u][1], vv[u][1], fma(x1[u][0], vv[u][0], a1));
+            a2 = fma(x2[u][1], vv[u][1], fma(x2[u][0], vv[u][0], a2));
+            a3 = fma(x3[u][1], vv[u][1], fma(x3[u][0], vv[u][0], a3));
+        }
+    }
+    for (; k < ke; k += 128) {
         d2_t vv = *reinterpret_cast<const d2_t*>(v + k);
         if (k + 1 >= ke) vv[1] = 0.0;
-        const d2_t x0 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r0 + k));   // read once: stream
+        const d2_t x0 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r0 + k));
         const d2_t x1 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r1 + k));
         const d2_t x2 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r2 + k));
         const d2_t x3 = __builtin_nontemporal_load(reinterpret_cast<const d2_t*>(r3 + k));
@@ -536,9 +558,21 @@ __global__ void __launch_bounds__(256) trmv_kernel(const double* __restrict__ Wm
     }
 }
 
+__global__ void __launch_bounds__(256) trmv_kernel(const double* __restrict__ Wm, int64_t ld, const double* __restrict__ v,
+                                                   double* __restrict__ out, int Np, int lower) {
+    const int lane = threadIdx.x & 63;
+    const int nq = (Np + 3) / 4;                             // groups of 4 rows
+    const int q1 = blockIdx.x * 4 + (threadIdx.x >> 6);      // wave-uniform
+    const int q2 = nq - 1 - q1;
+    if (q1 > q2) return;
+    trmv_rows4(Wm, ld, v, out, Np, lower, 4 * q1, lane);
+    if (q2 != q1) trmv_rows4(Wm, ld, v, out, Np, lower, 4 * q2, lane);
+}
+
 hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* out, int Np, int lower, hipStream_t s) {
     if (Np <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trmv_kernel, dim3((Np + 15) / 16), dim3(256), 0, s, Wm, ld, v, out, Np, lower);
+    const int nq = (Np + 3) / 4, nw = (nq + 1) / 2;          // waves: one per pair of row groups
+    hipLaunchKernelGGL(trmv_kernel, dim3((nw + 3) / 4), dim3(256), 0, s, Wm, ld, v, out, Np, lower);
     return hipGetLastError();
 }
 

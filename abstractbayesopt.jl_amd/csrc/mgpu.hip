@@ -944,6 +944,9 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
         ei_out[j] = w[0];
         idx_out[j] = gidx;
         memcpy(x_out + (size_t)j * d, x, sizeof(double) * d);
+        // the last pick conditions nothing: set and models are rolled back below, so its fantasy append and the O(N·M)
+        // down-date pass behind it (one ninth of a config-5 step) would only be thrown away
+        if (j == q - 1) break;
         abo_gp* nw[MAXDEV] = {nullptr};
         status = run_all(mg->cs->wk, n, [&](int i) -> int32_t {
             int64_t inf = 0;

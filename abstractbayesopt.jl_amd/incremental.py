@@ -122,7 +122,7 @@ class ResidentCandidates:
 
 
 def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: float, best_y: float, idx_base: int = 0,
-               group=None, distinct: bool = False):
+               group=None, distinct: bool = False, condition_last: bool = True):
     """Greedy q-EI (Kriging believer): for j = 1..q  pick argmax EI over the resident grid, condition on the
     fantasy (z_j, μ(z_j)) with a bordered append, down-date the grid's posterior, repeat.
     With torch.distributed initialised (`group`), every rank holds a shard of the grid: the arg-max is the
@@ -130,7 +130,10 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
     same append.  Returns (batch points (q, d), their global indices, their EI values, the final model).
     `cands` must be in sync with `model`; on return it is in sync with the returned model.
     distinct=True takes every picked candidate out of the running (abo_cand_exclude): with observation noise the
-    fantasy does not collapse the variance at a picked point, and the plain rule may return it again."""
+    fantasy does not collapse the variance at a picked point, and the plain rule may return it again.
+    condition_last=False leaves the q-th pick unconditioned (the batch does not depend on it): model and `cands` then hold
+    q − 1 fantasies on return — for callers that roll the fantasies back anyway (`cands.save()` … `cands.restore()`), it
+    saves one bordered append and one O(N·M) down-date pass per batch."""
     acq = ExpectedImprovement(xi, best_y)
     picks, idxs, vals = [], [], []
     dist = None
@@ -146,6 +149,9 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
         if dist is not None and dist.get_world_size(group) > 1:
             rec = _allgather_best(rec, dist, group)
         score, gidx, mu, x = rec[0], int(rec[1]), rec[2], rec[3:]
+        picks.append(x.copy()); idxs.append(gidx); vals.append(score)
+        if not condition_last and len(picks) == q:
+            break
         if hasattr(model, "p"):
             # gradient-enhanced model: the fantasy observation is the posterior mean of all p outputs at x (every rank
             # evaluates it on its own identical model; its first entry is the μ of the record)
@@ -155,7 +161,6 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
         cands.downdate(model)
         if distinct and idx_base <= gidx < idx_base + cands.M:
             cands.exclude(gidx - idx_base)     # the rank that owns the candidate masks it
-        picks.append(x.copy()); idxs.append(gidx); vals.append(score)
     return np.array(picks), np.array(idxs, dtype=np.int64), np.array(vals), model
 
 

@@ -401,7 +401,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
             t_start = time.perf_counter()
         ta = time.perf_counter()
         cands.save()
-        pts, idxs, vals, m_q = abo.greedy_qei(model, cands, Q, xi, best_y, idx_base=lo)
+        pts, idxs, vals, m_q = abo.greedy_qei(model, cands, Q, xi, best_y, idx_base=lo, condition_last=False)   # rolled back below
         del m_q
         tb = time.perf_counter()
         cands.restore()
@@ -433,7 +433,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
         n_now = N + n_warm + n_steps
         append_bytes = 8.0 * n_now * n_now                 # W (lower) + WT (upper), read once each
         ach = append_bytes / (med["append_ms"] * 1e-3) / 1e9
-        # dominant kernel of the step: the O(N*M) down-date pass, 9 launches per step (8 fantasies + the real point)
+        # dominant kernel of the step: the O(N*M) down-date pass, 8 launches per step (7 fantasies — the last pick of a batch that
+        # is rolled back conditions nothing — + the real point)
         if med["downdate_pass_bytes"] > 0:
             gbs = med["downdate_pass_bytes"] / (med["downdate_pass_ms"] * 1e-3) / 1e9
             tr, tr_src = pmc_traffic("c5", M_per)                        # committed rocprofv3 FETCH_SIZE pass (null when stale)
@@ -441,13 +442,13 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
                     "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr,
                     "traffic_source": {k: tr_src.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if tr_src and k in tr_src},
                     "algorithmic_bytes_per_launch": med["downdate_pass_bytes"], "avg_launch_ms": med["downdate_pass_ms"],
-                    "launches_per_step": Q + 1,
+                    "launches_per_step": Q,
                     "note": "algorithmic bytes = 8*N*M (K_ZX read once); duration = HIP events on the library stream"}
         else:
             pairs = n_now * M_per / (med["downdate_pass_ms"] * 1e-3)
             roof = {"kernel": "kgen_kernel, dot-only mode (K_ZX re-evaluated: ABO_CAND_KZX_GIB budget too small)", "bound": "valu",
                     "achieved": pairs / 1e9, "peak": None, "unit": "Gpair/s", "frac": None, "traffic": None,
-                    "avg_launch_ms": med["downdate_pass_ms"], "launches_per_step": Q + 1}
+                    "avg_launch_ms": med["downdate_pass_ms"], "launches_per_step": Q}
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
             "value": ms, "unit": "ms", "n_gpus": world, "steps": n_steps, "warmup": n_warm, "ms_per_step": ms,

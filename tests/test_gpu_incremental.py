@@ -138,6 +138,14 @@ def test_greedy_qei_matches_from_scratch_loop():
         yo = np.append(yo, mu[i[0]])              # Kriging believer
     L, al, _ = abo.get_factor(m_q)
     assert L.shape == (N0 + q, N0 + q)
+    # the batch does not depend on the q-th conditioning: without it the same picks, bit for bit, and q − 1 fantasies in the model
+    del m_q                                       # (while the fantasy models live, an append to `m` is a copy-on-write refit)
+    cands.refresh(m)
+    pts2, idxs2, vals2, m_q2 = abo.greedy_qei(m, cands, q, 0.01, best, condition_last=False)
+    np.testing.assert_array_equal(idxs2, idxs)
+    np.testing.assert_array_equal(vals2, vals)
+    np.testing.assert_array_equal(pts2, pts)
+    assert abo.get_factor(m_q2)[0].shape == (N0 + q - 1, N0 + q - 1)
 
 
 def test_qei_exploration_then_real_append_on_the_parent():
