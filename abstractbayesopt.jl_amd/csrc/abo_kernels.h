@@ -37,6 +37,10 @@ struct GemmArgs {
     // a kernel without LDS whose waves stream their 32 rows of B once and hold mrows/16 row groups of A — HBM-bound on B instead of
     // MFMA-bound on 128 rows (the lockstep refinement once most starts have finished)
     int mrows = 0;
+    // square SYRK on the lower triangle (kmode K_FULL, batch 1), set by launch_gemm_nt: number of lower tiles T(T+1)/2 of a 1-D launch
+    // whose workgroup → tile map is XCD-aware (gemm_nt_kernel); 0 = the plain 2-D launch
+    int swz = 0;
+    int swz_g = 4;        // tile rows per super-row of that map
 };
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 // out[r][c] = Σ_z P[z][r][c] over the chunks z that intersect the k range of column tile c/128 under `kmode` (K_FULL, K_B_LOWER,

@@ -197,8 +197,36 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     // dealt out from the bottom up (the light tiles then fill the tail of the launch instead of the heavy ones forming it);
     // K_A_UPPER already starts with its longest rows
     // (K_B_LOWER: B is the lower-triangular operand — the column blocks are dealt out from the right for the same reason)
-    const int tj = p.kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, bz = blockIdx.z;
-    const int ti = p.kmode == K_A_LOWER ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    int tj = p.kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    int ti = p.kmode == K_A_LOWER ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int bz = blockIdx.z;
+    if (p.swz) {
+        // Square SYRK, 1-D launch over its lower tiles only.  Workgroups go round-robin to the 8 XCDs, each with its own L2: XCD x
+        // takes the x-th eighth of the tile sequence, and the sequence runs through super-rows of G tile rows column by column — the
+        // 64 workgroups an XCD holds at a time are a patch of G rows × 64/G columns (G = 4: 20 operand panels for 64 tiles),
+        // where the row-major 2-D launch had every XCD touch every panel of 8 tile rows (its L2 held none of them until reuse).
+        const int L = blockIdx.x;
+        const int per = (p.swz + 7) >> 3;
+        const int Q = (L & 7) * per + (L >> 3);
+        if (Q >= p.swz) return;
+        const int T = p.M / BM, G = p.swz_g;
+        int g = (int)((sqrt(8.0 * (double)Q + 1.0) - 1.0) / (2.0 * G));        // super-row: G·g·(G·g+1)/2 tiles lie before it
+        while ((G * (g + 1)) * (G * (g + 1) + 1) / 2 <= Q) ++g;
+        while ((G * g) * (G * g + 1) / 2 > Q) --g;
+        int w = Q - (G * g) * (G * g + 1) / 2;
+        const int r0 = G * g;
+        const int R = min(G, T - r0);
+        if (w < R * (r0 + 1)) {                                              // full columns 0 … r0: R tiles each
+            tj = w / R;
+            ti = r0 + w - tj * R;
+        } else {                                                             // the triangle at the right end
+            w -= R * (r0 + 1);
+            int c = 1;
+            while (w >= R - c) { w -= R - c; ++c; }
+            tj = r0 + c;
+            ti = tj + w;
+        }
+    }
     if (p.lower_only && tj > ti) return;
     int kbeg = 0, kend = p.K;
     if (p.kmode == K_A_LOWER) kend = min(p.K, (ti + 1) * BM);
@@ -412,6 +440,13 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     } else if (small && !in_place && a.K % 128 == 0) {
         dim3 grid(a.N / 32, a.M / 32, a.batch);
         hipLaunchKernelGGL(gemm_nt_small_kernel, grid, dim3(256), 0, s, a);
+    } else if (a.lower_only && a.kmode == K_FULL && a.M == a.N && a.batch == 1 && Tm >= 16 && !getenv("ABO_GEMM_NO_SWIZZLE")) {
+        GemmArgs b = a;
+        b.swz = (int)tiles;
+        const char* ge = getenv("ABO_GEMM_SWZ_G");
+        b.swz_g = ge ? atoi(ge) : 4;
+        if (b.swz_g < 1 || b.swz_g > 64) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(((tiles + 7) / 8) * 8)), dim3(256), 0, s, b);
     } else {
         dim3 grid(a.N / BN, a.M / BM, a.batch);
         hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
