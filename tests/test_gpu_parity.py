@@ -78,6 +78,28 @@ def test_small_tile_gemm_is_bit_identical_to_the_lds_tiled_one(monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------
+def test_lower_tiles_only_syrk_launch_is_bit_identical_to_the_2d_one(monkeypatch):
+    """The square trailing updates of the factorisation run as a 1-D launch over the lower tiles (XCD-chunked tile order);
+    a tile's arithmetic does not depend on the workgroup that runs it: the factor equals the 2-D launch's bit for bit
+    (18 and 20 tile rows: a last super-row of 2 and a whole number of them)."""
+    for N in (2700, 3000):
+        X = synth.points(1, N, 5)
+        y = synth.objective(X, 0.05)
+        monkeypatch.delenv("ABO_GEMM_NO_SWIZZLE", raising=False)
+        L1, a1, W1 = abo.get_factor(abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y))
+        monkeypatch.setenv("ABO_GEMM_NO_SWIZZLE", "1")
+        L0, a0, W0 = abo.get_factor(abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y))
+        monkeypatch.delenv("ABO_GEMM_NO_SWIZZLE")
+        np.testing.assert_array_equal(L1, L0)
+        np.testing.assert_array_equal(a1, a0)
+        np.testing.assert_array_equal(W1, W0)
+        for g in ("1", "3", "8"):                      # other super-row heights: the same tiles in another order
+            monkeypatch.setenv("ABO_GEMM_SWZ_G", g)
+            Lg, _, _ = abo.get_factor(abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y))
+            monkeypatch.delenv("ABO_GEMM_SWZ_G")
+            np.testing.assert_array_equal(Lg, L0)
+
+
 @pytest.mark.parametrize("name", ["kat1", "kat3", "kat4", "kat5"])
 def test_kat_closed_forms(name):
     """test/test_surrogates.jl:59-105,:145-170; test/test_acquisition.jl; test/test_bayesian_opt.jl:
@@ -173,6 +195,8 @@ CASES = [
     (O.MATERN52, 16, 1152, 2048, 2.0, 1.0, 1e-2, 0.0),   # C5 dimension, 9 blocks
     (O.MATERN52, 5, 1664, 700, 0.9, 1.0, 1e-3, 0.3),     # 13 blocks: three 512-wide Cholesky strips + a 128 remainder
     (O.SE, 7, 2304, 600, 1.2, 1.5, 1e-3, 0.0),           # 18 blocks: both GEMM variants (small-launch and LDS-tiled) in one fit
+    (O.MATERN52, 6, 2700, 400, 1.0, 1.0, 1e-3, 0.0),     # 22 blocks: the first trailing update (18 tile rows, not a multiple of
+                                                         # the super-row height) goes through the 1-D lower-tiles-only launch
     (O.MATERN72, 32, 200, 300, 3.0, 1.0, 1e-3, 0.0),     # largest supported dimension
     (O.MATERN32, 13, 520, 129, 1.5, 0.7, 1e-2, 0.0),     # odd dimension (padded to 16), ragged everything
 ]
