@@ -483,13 +483,13 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // per tile than a panel-by-panel SYRK.
     const char* swe = getenv("ABO_CHOL_STRIP");
     const int SW = swe ? atoi(swe) : 512;
-    // Optional third level (ABO_CHOL_SUPER = super-strip width; default off): strips grouped into super-strips, behind a strip only
-    // the rest of its super-strip is updated (K = SW), the matrix behind the super-strip once per super-strip with K = SS — a
-    // quarter of the passes over the trailing matrix.  Measured in round 3 and NOT adopted: Cholesky at N = 16384 38.2 → 36.6 ms
-    // at best (SS = 1024), N = 8192 8.67 → 8.76 … 9.03 (profiles/r03_chol_super_sweep.txt) — the trailing products are bound by
-    // the 128×128 tile's operand traffic from L2 (16 flop per byte), not by the passes over C.
+    // Third level (ABO_CHOL_SUPER = super-strip width; 0 = off): strips grouped into super-strips, behind a strip only the rest of
+    // its super-strip is updated (K = SW), the matrix behind the super-strip once per super-strip with K = SS — half the passes
+    // over the trailing matrix and tiles twice as long at SS = 1024.  On by default from 12288 factor rows: Cholesky at N = 16384
+    // 35.0 → 32.8 ms (SS = 1024; 32.7 at 2048), at N = 8192 8.20 → 8.23 (no gain: off there).  Round 3 had measured 38.2 → 36.6 /
+    // 8.67 → 8.76 (profiles/r03_chol_super_sweep.txt) and left it off everywhere.
     const char* sse = getenv("ABO_CHOL_SUPER");
-    int SS = sse ? atoi(sse) : 0;
+    int SS = sse ? atoi(sse) : (Np >= 12288 ? 1024 : 0);
     if (SS <= SW) SS = SW;
     SS = SS / SW * SW;
     // Panel chain: potf2 of the diagonal block → triangular solve of the rows below it on L itself → in-strip update.  The
