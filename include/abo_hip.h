@@ -402,8 +402,9 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
  * same call (abo_cand_downdate).  abo_mgpu_cand_create / _lhs: shard a candidate grid over the devices and evaluate its
  * posterior; _refresh after a refit.  abo_mgpu_cand_acq: epilogue + merged top-k on the stored posterior.
  * abo_mgpu_cand_qei: greedy (Kriging-believer) q-EI — q × [EI + arg-max per device, ONE all-gather of the devices' pick
- * records {score, index, μ, x}, the same fantasy append (y = μ(x)) and O(N·M) down-date on every device] — then the stored
- * posterior is rolled back and the fantasy models are dropped: on return model and set are as before.  x_out q × d,
+ * records {score, index, μ, x}] with the same fantasy append (y = μ(x)) and O(N·M) down-date on every device between picks
+ * (q − 1 of them: the last pick conditions nothing) — then the stored posterior is rolled back and the fantasy models are
+ * dropped: on return model and set are as before.  x_out q × d,
  * idx_out / ei_out q.  distinct != 0 excludes every picked candidate for the rest of the call. */
 int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* cands);
 int32_t abo_mgpu_append_grad(abo_mgpu* mg, const double* x, int32_t d, const double* y, int64_t* info, abo_mcand* cands);
