@@ -361,4 +361,99 @@ function append(m::HipStandardGP, x::AbstractVector{Float64}, y::Float64)       
 end
 # update(BO, x, y, i) (bayesian_opt.jl:113-150) can call `append(BO.model, x, y)` instead of
 # `update(BO.model, BO.xs, BO.ys)`; `prev_gp = copy(BO.model)` stays valid because rows ≤ N are never touched.
-# Resident grids for q-EI: abo_cand_* on one device, abo_mgpu_cand_{create,create_lhs,refresh,acq,qei} across devices.
+
+# ---- resident candidate grid + greedy q-EI (BASELINE config 5; no reference counterpart) ------------------------------
+# The grid's points, posterior (μ, σ²) and K_ZX stay on the device(s); an `append` is followed by an O(N·M) down-date instead
+# of a re-evaluation.  One device: abo_cand_*; a sharded model: abo_mgpu_cand_* (the grid is split over the model's devices).
+mutable struct HipCandidates
+    ptr::Ptr{Cvoid}
+    multi::Bool
+    model::HipStandardGP          # the model the stored posterior is in sync with
+    M::Int
+    d::Int
+    function HipCandidates(m::HipStandardGP, zs::AbstractVector)
+        m.gpx === nothing && error("HipCandidates: the model has not been fitted (call update first)")
+        Z = _pack(zs); d, M = size(Z); h = Ref{Ptr{Cvoid}}()
+        if m.gpx.multi
+            GC.@preserve Z _check(@abocall LIBABO.abo_mgpu_cand_create(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32,
+                                                                        h::Ptr{Ptr{Cvoid}})::Int32)
+        else
+            GC.@preserve Z _check(@abocall LIBABO.abo_cand_create(m.gpx.ptr::Ptr{Cvoid}, Z::Ptr{Float64}, M::Int64, d::Int32, 0::Int32,
+                                                                   h::Ptr{Ptr{Cvoid}})::Int32)
+        end
+        c = new(h[], m.gpx.multi, m, M, d)
+        finalizer(c) do x
+            x.multi ? (@ccall LIBABO.abo_mgpu_cand_destroy(x.ptr::Ptr{Cvoid})::Int32) : (@ccall LIBABO.abo_cand_destroy(x.ptr::Ptr{Cvoid})::Int32)
+        end
+        c
+    end
+end
+
+# after update(model, xs, ys) or a hyper-parameter change: full re-evaluation of the grid
+function refresh!(c::HipCandidates, m::HipStandardGP)
+    if c.multi
+        _check(@abocall LIBABO.abo_mgpu_cand_refresh(m.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
+    else
+        _check(@abocall LIBABO.abo_cand_refresh(m.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
+    end
+    c.model = m; c
+end
+
+# append(model, x, y) with the grid's posterior down-dated in the same step; returns the N+1-point model
+function append_observation!(c::HipCandidates, x::AbstractVector{Float64}, y::Float64)   # (not `append!`: that name is Base's)
+    m = c.model; info = Ref{Int64}(0)
+    if c.multi
+        n = copy(m)
+        GC.@preserve x _check(@abocall(LIBABO.abo_mgpu_append(n.gpx.ptr::Ptr{Cvoid}, x::Ptr{Float64}, length(x)::Int32, y::Float64,
+                                                               info::Ptr{Int64}, c.ptr::Ptr{Cvoid})::Int32), info[])
+        c.model = n; return n
+    end
+    n = append(m, x, y)
+    _check(@abocall LIBABO.abo_cand_downdate(n.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
+    c.model = n; n
+end
+
+# acquisition epilogue + top-k on the stored posterior (no kernel evaluations): (values, 1-based grid indices)
+function top_k(acqf::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityImprovement}, c::HipCandidates, k::Int)
+    kind, p0, best = _acq_args(acqf); tv = Vector{Float64}(undef, k); ti = Vector{Int64}(undef, k)
+    if c.multi
+        GC.@preserve tv ti _check(@abocall LIBABO.abo_mgpu_cand_acq(c.model.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
+                                                                     best::Float64, k::Int32, tv::Ptr{Float64}, ti::Ptr{Int64})::Int32)
+    else
+        GC.@preserve tv ti _check(@abocall LIBABO.abo_cand_acq(c.model.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, kind::Int32, p0::Float64,
+                                                                best::Float64, 0::Int64, C_NULL::Ptr{Float64}, k::Int32, tv::Ptr{Float64},
+                                                                ti::Ptr{Int64}, 0::Int32)::Int32)
+    end
+    tv, ti .+ 1
+end
+
+# Greedy (Kriging-believer) q-EI over the grid: q × (EI + arg-max) with a fantasy append y = μ(x) and a down-date between
+# picks; model and grid are as before on return.  (points d × q, 1-based grid indices, EI values)
+function greedy_qei(c::HipCandidates, q::Int; ξ::Float64=0.01, best_y::Float64, distinct::Bool=false)
+    X = Matrix{Float64}(undef, c.d, q); idx = Vector{Int64}(undef, q); ei = Vector{Float64}(undef, q)
+    if c.multi
+        GC.@preserve X idx ei _check(@abocall LIBABO.abo_mgpu_cand_qei(c.model.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, q::Int32, ξ::Float64,
+                                                                        best_y::Float64, Int32(distinct)::Int32, X::Ptr{Float64},
+                                                                        idx::Ptr{Int64}, ei::Ptr{Float64})::Int32)
+        return X, idx .+ 1, ei
+    end
+    base = c.model
+    _check(@abocall LIBABO.abo_cand_save(base.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
+    cur = base; tv = Ref{Float64}(); ti = Ref{Int64}(); mu = Ref{Float64}(); x = Vector{Float64}(undef, c.d)
+    try
+        for j in 1:q
+            _check(@abocall LIBABO.abo_cand_acq(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, 0::Int32, ξ::Float64, best_y::Float64, 0::Int64,
+                                                 C_NULL::Ptr{Float64}, 1::Int32, tv::Ptr{Float64}, ti::Ptr{Int64}, 0::Int32)::Int32)
+            GC.@preserve x _check(@abocall LIBABO.abo_cand_point(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, ti[]::Int64, x::Ptr{Float64},
+                                                                  mu::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
+            X[:, j] .= x; idx[j] = ti[] + 1; ei[j] = tv[]
+            j == q && break                                     # the last pick conditions nothing
+            cur = append(cur, copy(x), mu[])                    # fantasy observation y = μ(x)
+            _check(@abocall LIBABO.abo_cand_downdate(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
+            distinct && _check(@abocall LIBABO.abo_cand_exclude(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, ti[]::Int64)::Int32)
+        end
+    finally
+        _check(@abocall LIBABO.abo_cand_restore(base.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
+    end
+    X, idx, ei
+end

@@ -204,3 +204,16 @@ def test_the_parser_notices_a_dropped_argument(tmp_path):
     retyped = src.replace("LIBABO.abo_abi_version()::Int32", "LIBABO.abo_abi_version()::Int64", 1)
     p.write_text(retyped)
     assert any(r != "Int32" for _, _, r, _ in julia_calls(str(p)))
+
+
+def test_private_helpers_called_by_the_shims_are_defined_in_them():
+    """A call of a helper that does not exist (`_kind(acqf)` for `_acq_args(acqf)`) only shows at run time in Julia — and the
+    shims never run here.  Every `_name(` the two files call must be defined in one of them (`function _name(` or `_name(…) =`)."""
+    code = "\n".join(re.sub(r"#[^\n]*", "", open(p).read()) for p in SHIMS)
+    called = set(re.findall(r"(?<![\w.!])(_[a-z][a-z0-9_]*!?)\(", code))
+    defined = set(re.findall(r"^\s*function\s+(_[a-z][a-z0-9_]*!?)\s*[({]", code, flags=re.M))
+    defined |= set(re.findall(r"^\s*(_[a-z][a-z0-9_]*!?)\([^\n]*\)\s*(?:where[^\n=]*)?=", code, flags=re.M))
+    # helpers the shims take from the package they are included into (src/surrogates/*.jl)
+    from_reference = {"_get_minimum", "_update_model_parameters"}
+    missing = sorted(called - defined - from_reference)
+    assert not missing, f"helpers called but not defined in integration/julia/*.jl: {missing}"
