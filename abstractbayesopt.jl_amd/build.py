@@ -13,12 +13,36 @@ SOURCES = ["kgen.hip", "kgen_res.hip", "kgen_grad_res.hip", "gemm.hip", "ozaki.h
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-mfma-vgpr-form", "-ldl", "-pthread"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
+MANIFEST = os.path.join(PKG, "lib", "libabo_hip.manifest")
+
+
+def _deps():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(PKG, "..", "include", "abo_hip.h")]
+
+
+def _manifest():
+    """sha256 over every file the library is compiled from and the flags: what the library in lib/ claims to be built from"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in _deps():
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _newer_than_lib():
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "abo_hip.h")]
-    return any(os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def _stale():
+    # by CONTENT, not by time stamps alone: a library file copied over lib/libabo_hip.so (an A/B build put back, a checkout of
+    # older sources) is newer than every source and would pass a time-stamp test while being built from something else
+    if not os.path.exists(LIB) or not os.path.exists(MANIFEST):
+        return True
+    with open(MANIFEST) as f:
+        return f.read().strip() != _manifest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -26,6 +50,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     then one link."""
     if not force and not _stale():
         return LIB
+    if not force and os.path.exists(LIB) and not _newer_than_lib():
+        force = True          # the manifest disagrees although no source is newer: the objects cannot be trusted either
     from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -53,6 +79,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(MANIFEST, "w") as f:
+        f.write(_manifest() + "\n")
     return LIB
 
 

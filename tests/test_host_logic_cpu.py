@@ -277,3 +277,28 @@ def test_flattening_an_objective_leaves_no_reference_cycle_on_the_surrogate():
     assert terms == [(1, 2.0, 0.0, 0.25), (0, 0.01, 0.5, 0.375), (4, 1.5, 0.0, 0.375)]
     assert flatten_terms(abo.GradientNormUCB(1.0), object()) is None              # needs a model with gradient outputs
     assert flatten_terms(abo.EnsembleAcquisition([1.0] * 9, [abo.UpperConfidenceBound(float(b)) for b in range(9)])) is None   # > 8 terms
+
+
+def test_build_staleness_is_decided_by_content_not_by_time_stamps(monkeypatch, tmp_path):
+    """A library file copied over lib/libabo_hip.so (an A/B build put back, older sources checked out) is newer than every source:
+    a time-stamp test would keep it.  build() compares a manifest (sha256 over csrc/, the public header and the flags)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_abo_build_t", os.path.join(root, "abstractbayesopt.jl_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    m0 = b._manifest()
+    assert len(m0) == 64 and m0 == b._manifest()
+    monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DX"])
+    assert b._manifest() != m0                                   # flags are part of what a library is built from
+    monkeypatch.undo()
+    lib = tmp_path / "libabo_hip.so"
+    lib.write_bytes(b"not a library")
+    monkeypatch.setattr(b, "LIB", str(lib))
+    monkeypatch.setattr(b, "MANIFEST", str(tmp_path / "libabo_hip.manifest"))
+    assert b._stale()                                            # a library without a manifest is not trusted
+    (tmp_path / "libabo_hip.manifest").write_text("0" * 64 + "\n")
+    assert b._stale()                                            # … nor one whose manifest names other sources
+    (tmp_path / "libabo_hip.manifest").write_text(m0 + "\n")
+    assert not b._stale()
