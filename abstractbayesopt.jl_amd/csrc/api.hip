@@ -483,22 +483,27 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // per tile than a panel-by-panel SYRK.
     const char* swe = getenv("ABO_CHOL_STRIP");
     const int SW = swe ? atoi(swe) : 512;
-    // Third level (ABO_CHOL_SUPER = super-strip width; 0 = off): strips grouped into super-strips, behind a strip only the rest of
-    // its super-strip is updated (K = SW), the matrix behind the super-strip once per super-strip with K = SS — half the passes
-    // over the trailing matrix and tiles twice as long at SS = 1024.  On by default from 12288 factor rows: Cholesky at N = 16384
-    // 35.0 → 32.8 ms (SS = 1024; 32.7 at 2048), at N = 8192 8.20 → 8.23 (no gain: off there).  Round 3 had measured 38.2 → 36.6 /
-    // 8.67 → 8.76 (profiles/r03_chol_super_sweep.txt) and left it off everywhere.
+    // Third level (ABO_CHOL_SUPER = super-strip width, default 1024; 0 = off): strips grouped into super-strips, behind a strip only
+    // the rest of its super-strip is updated (K = SW), the matrix behind the super-strip once per super-strip with K = SS — half
+    // the passes over the trailing matrix and tiles twice as long.  Everywhere: Cholesky at N = 16384 35.0 → 32.8 ms (32.7 at
+    // 2048), at N = 8192 8.20 → 8.23 (round 3 had measured 38.2 → 36.6 / 8.67 → 8.76, profiles/r03_chol_super_sweep.txt).
+    // A super-strip pays while the square update behind it is large: its in-super-strip update is a launch of 4 × T tiles that
+    // lasts ≈ 150 µs whatever T is, against K = 1024 tiles at 70 TFLOP/s instead of 52 (profiles/r04_fit_trace_summary.txt) — so
+    // super-strips are used while at least ABO_CHOL_SUPER_ROWS (default 6144) rows remain, plain strips from there on.
     const char* sse = getenv("ABO_CHOL_SUPER");
-    int SS = sse ? atoi(sse) : (Np >= 12288 ? 1024 : 0);
-    if (SS <= SW) SS = SW;
-    SS = SS / SW * SW;
+    int SSmax = sse ? atoi(sse) : 1024;
+    if (SSmax <= SW) SSmax = SW;
+    SSmax = SSmax / SW * SW;
+    const char* sre = getenv("ABO_CHOL_SUPER_ROWS");
+    const int super_rows = sre ? atoi(sre) : 6144;
     // Panel chain: potf2 of the diagonal block → triangular solve of the rows below it on L itself → in-strip update.  The
     // 128×128 inverses of the diagonal blocks (the seeds of the blocked L⁻¹ below) are not on that chain: all of them are
     // formed by ONE batched launch behind the factorisation.  ABO_CHOL_SPLIT=0 restores the round-1 chain (factor + inverse
     // in one kernel, panel solve as a product with the inverse) for A/B runs.
     const char* spe = getenv("ABO_CHOL_SPLIT");
     const bool split = (!spe || atoi(spe) != 0) && Np > TB;     // a single block has no chain: factor + inverse in one launch
-    for (int S0 = 0; S0 < Np; S0 += SS) {
+    for (int S0 = 0, SS = SW; S0 < Np; S0 += SS) {
+        SS = (Np - S0) >= super_rows ? SSmax : SW;
         const int ss = (Np - S0) < SS ? (Np - S0) : SS;
         for (int s0 = S0; s0 < S0 + ss; s0 += SW) {
             const int sw = (S0 + ss - s0) < SW ? (S0 + ss - s0) : SW;
