@@ -274,6 +274,27 @@ def test_topk_ties_nan_and_short_batches():
     assert s.shape == (0,) and ti.tolist() == [-1, -1]
 
 
+def test_argmax_path_of_a_large_batch_is_the_first_entry_of_the_sorted_selection():
+    """k = 1 over more than 16384 scores runs two plain reductions instead of the block sorts (a greedy q-EI pick): same total
+    order — larger score first, ties → lowest index, NaN first — i.e. exactly entry 0 of a k = 2 selection."""
+    X, y = synth.standardized_problem(60, 3)
+    m = abo.update(make_model(O.MATERN52, 0.7, 1.0, 1e-3), X, y)
+    acq = abo.ExpectedImprovement(0.01, float(y.min()))
+    for M in (16385, 50000, 131072 + 5):
+        Z = synth.points(7, M, 3)
+        s, tv1, ti1 = abo.evaluate(acq, m, Z, k=1, idx_base=7)
+        _, tv2, ti2 = abo.evaluate(acq, m, Z, k=2, idx_base=7)
+        assert ti1[0] == ti2[0] == 7 + int(np.argmax(s)) and tv1[0] == tv2[0] == s.max()
+    # all scores tie → index 0; a NaN candidate comes first wherever it sits
+    far = abo.update(make_model(O.SE, 0.01, 1.0, 1e-2), [[0.0, 0.0]], [0.0])
+    Z = np.full((40000, 2), 50.0) + np.arange(40000)[:, None]
+    _, tv, ti = abo.evaluate(abo.UpperConfidenceBound(2.0), far, Z, k=1)
+    assert ti[0] == 0
+    Z[33333, 1] = np.nan
+    _, tv, ti = abo.evaluate(abo.UpperConfidenceBound(2.0), far, Z, k=1, idx_base=5)
+    assert ti[0] == 5 + 33333 and np.isnan(tv[0])
+
+
 def test_device_resident_candidates_match_host_path():
     import torch
     X, y = synth.standardized_problem(500, 4)
