@@ -197,6 +197,8 @@ CASES = [
     (O.SE, 7, 2304, 600, 1.2, 1.5, 1e-3, 0.0),           # 18 blocks: both GEMM variants (small-launch and LDS-tiled) in one fit
     (O.MATERN52, 6, 2700, 400, 1.0, 1.0, 1e-3, 0.0),     # 22 blocks: the first trailing update (18 tile rows, not a multiple of
                                                          # the super-row height) goes through the 1-D lower-tiles-only launch
+    (O.MATERN52, 5, 6300, 300, 1.2, 1.0, 1e-3, 0.0),     # 50 blocks: one super-strip of 1024 (≥ 6144 rows remain), plain strips of
+                                                         # 512 behind it, a ragged last strip — the factorisation's third blocking level
     (O.MATERN72, 32, 200, 300, 3.0, 1.0, 1e-3, 0.0),     # largest supported dimension
     (O.MATERN32, 13, 520, 129, 1.5, 0.7, 1e-2, 0.0),     # odd dimension (padded to 16), ragged everything
 ]
