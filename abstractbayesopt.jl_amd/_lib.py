@@ -17,8 +17,10 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
            "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
-           "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms", "abo_test_acq_grad_terms"]
-ABI_VERSION = 5
+           "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms", "abo_test_acq_grad_terms",
+           "abo_set_qei_block", "abo_cand_qei", "abo_cand_qei_begin", "abo_cand_qei_top", "abo_cand_qei_block", "abo_cand_qei_pick",
+           "abo_cand_qei_end", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats"]
+ABI_VERSION = 6
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
 
@@ -35,7 +37,17 @@ class AboTimings(C.Structure):
                [("var_gemm_launches", C.c_int64), ("var_gemm_flop", C.c_double), ("downdate_ms", C.c_double),
                 ("downdate_bytes", C.c_double), ("contraction_engine", C.c_int64), ("oz_nmod", C.c_int64)] + \
                [(n, C.c_double) for n in ("oz_prepare_ms", "oz_quant_ms", "oz_gemm_ms", "oz_crt_ms", "oz_gemm_ops", "refine_ms")] + \
-               [("refine_starts", C.c_int64), ("refine_evals", C.c_int64)]
+               [("refine_starts", C.c_int64), ("refine_evals", C.c_int64), ("downdate_from_chain", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class AboQeiStats(C.Structure):
+    """statistics of a block-form greedy q-EI batch (include/abo_hip.h: abo_qei_stats)"""
+    _fields_ = [("picks", C.c_int32), ("block", C.c_int32), ("block_builds", C.c_int32), ("block_hits", C.c_int32),
+                ("total_ms", C.c_double), ("block_ms", C.c_double), ("pass_ms", C.c_double), ("pass_bytes", C.c_double),
+                ("pass_flop", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -145,6 +157,15 @@ def lib():
     L.abo_mgpu_cand_acq.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp]
     L.abo_mgpu_cand_get.argtypes = [vp, vp, vp, vp]
     L.abo_mgpu_cand_qei.argtypes = [vp, vp, i32, f64, f64, i32, vp, vp, vp]
+    L.abo_mgpu_cand_qei_stats.argtypes = [vp, vp, C.POINTER(AboQeiStats)]
+    L.abo_set_qei_block.argtypes = [i32]
+    L.abo_cand_qei.argtypes = [vp, vp, i32, f64, f64, i32, i64, i32, vp, vp, vp, C.POINTER(AboQeiStats)]
+    L.abo_cand_qei_begin.argtypes = [vp, vp, i32, i32]
+    L.abo_cand_qei_top.argtypes = [vp, vp, f64, f64, i64, i32, vp]
+    L.abo_cand_qei_block.argtypes = [vp, vp, vp, vp, i32]
+    L.abo_cand_qei_pick.argtypes = [vp, vp, i64, f64, vp, i32, i64, C.POINTER(i64)]
+    L.abo_cand_qei_end.argtypes = [vp, vp]
+    L.abo_cand_qei_stats.argtypes = [vp, vp, C.POINTER(AboQeiStats)]
     L.abo_refine.argtypes = [vp, i32, f64, f64, vp, vp, i32, vp, i32, C.POINTER(AboRefineOpts), vp, vp, vp]
     L.abo_optimize_acquisition.argtypes = [vp, i32, f64, f64, vp, vp, i32, i64, i32, C.c_uint64, C.POINTER(AboRefineOpts),
                                            vp, C.POINTER(f64), vp, vp, vp, vp]

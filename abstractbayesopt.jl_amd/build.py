@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libabo_hip.so")
-SOURCES = ["kgen.hip", "kgen_res.hip", "kgen_grad_res.hip", "gemm.hip", "ozaki.hip", "chol.hip", "misc.hip", "refine.hip", "api.hip", "mgpu.hip"]
+SOURCES = ["kgen.hip", "kgen_res.hip", "kgen_grad_res.hip", "gemm.hip", "ozaki.hip", "chol.hip", "misc.hip", "qei.hip", "refine.hip", "api.hip", "mgpu.hip"]
 # -amdgpu-mfma-vgpr-form: keep fp64 MFMA accumulators in VGPRs; the AGPR form makes hipcc shuttle
 # every accumulator through v_accvgpr_read/write each k-step (2.2x slower, profiles/r01_mfma_f64_probe.txt)
 # -ldl / -pthread: the multi-device driver resolves RCCL with dlopen and runs one host thread per shard

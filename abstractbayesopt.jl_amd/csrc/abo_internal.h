@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
+
 #include "../../include/abo_hip.h"
 
 namespace abo {
@@ -29,6 +31,31 @@ int32_t refine_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const
 // ties), or the best grid point when no refined value reaches its score
 void pick_best_point(const double* starts_x, const double* starts_val, const double* rx, const double* rf, int k, int d,
                      double* best_x, double* best_val);
+
+// ---- greedy q-EI, block form (api.hip; include/abo_hip.h: abo_cand_qei_*): the per-shard steps with records in DEVICE memory, and
+// the batch driver over the n shards of one set (n = 1: abo_cand_qei; n > 1: abo_mgpu_cand_qei, whose shards run on their worker
+// threads and exchange records through the group's all-gather)
+int32_t qei_eligible(abo_gp* g, abo_cand* c, int q);       // ABO_OK when the block form can run on this shard (else the reason)
+int32_t qei_begin(abo_gp* g, abo_cand* c, int q, int T);
+int32_t qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int k, double* rec_d);
+int32_t qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t* gidx, int T);
+int32_t qei_has(const abo_cand* c, int64_t gidx);
+int32_t qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, const double* cx, int n, int64_t excl, int64_t* info);
+int32_t qei_end(abo_gp* g, abo_cand* c);
+void qei_get_stats(const abo_cand* c, int picks, double total_ms, abo_qei_stats* out);
+struct QeiShards {
+    int n;
+    abo_gp* const* gp;
+    abo_cand* const* cd;
+    const int64_t* lo;                                               // global index of each shard's first candidate
+    std::function<int32_t(const std::function<int32_t(int)>&)> run;  // f(i) on every shard
+    std::function<double*(int)> rec;                                 // shard i's record block (device)
+    std::function<int32_t(size_t, double*)> gather;                  // (words, out): every shard's block → host, n × words doubles
+};
+int qei_block_default();                                            // the process default block size (0: the plain loop)
+size_t qei_max_words(int d, int q, int T);                           // doubles a record block must hold
+int32_t qei_drive(const QeiShards& S, int q, double xi, double best_y, int distinct, int T, double* x_out, int64_t* idx_out,
+                  double* ei_out, int64_t* info);
 
 hipStream_t gp_stream(abo_gp* g);
 int gp_device(const abo_gp* g);

@@ -266,6 +266,34 @@ hipError_t launch_score(const double* mu, const double* var, double* score, int6
 hipError_t launch_pick_record(const double* tv, const int64_t* ti, int64_t idx_base, const double* Z, const double* mu, int d,
                               double* rec, hipStream_t s);
 
+// ---- block form of greedy q-EI (qei.hip): covariance columns of T points from ONE pass over the resident K_ZX ----------
+constexpr int QEI_MAXQ = 64;       // picks of one batch (chain vectors kept; their coefficients travel as kernel arguments)
+constexpr int QEI_MAXT = 64;       // points of one block (the skinny product holds at most four 16-row groups)
+// KXT[t][i] = sigma_f2·kappa(‖Xs_i − s·P_t‖²) for i < N, t < T; zeros for N ≤ i < Np and for T ≤ t < rows.  P: raw points [T][d]
+hipError_t launch_qei_kxt(const double* Xs, int dp, int N, int Np, const double* P, int d, int T, int rows, int family, double s,
+                          double sigma_f2, double* KXT, hipStream_t st);
+// V[r][N … Np) = 0 for r < rows (V: [rows][ld])
+hipError_t launch_qei_zero_tail(double* V, int64_t ld, int N, int Np, int rows, hipStream_t st);
+// C[t][j] += sigma_f2·kappa(‖Ps_t − s·z_j‖²) for t < T, j < M   (Ps: the block points pre-scaled, [T][dp]; C: [T][Mp])
+hipError_t launch_qei_cov(const double* Ps, int dp, const double* Z, int64_t M, int64_t Mp, int d, int T, int family, double s,
+                          double sigma_f2, double* C, hipStream_t st);
+// out[j] = blk[j] − Σ_{i<nchain} gam[i]·chain[i][j] ;  var[j] −= out[j]²/s  (var == nullptr: the column only)
+struct QeiPickArgs {
+    const double* blk;      // [M]   base covariances of the picked point (a row of the block)
+    const double* chain;    // [nchain][Mp]
+    double* out;            // [M]   usually chain + nchain·Mp
+    double* var;            // [M] or nullptr
+    int64_t M, Mp;
+    int nchain;
+    double s;
+    double gam[QEI_MAXQ];
+};
+hipError_t launch_qei_pick(const QeiPickArgs& a, hipStream_t st);
+// rec[e] = {tv[e], (double)ti[e], mu, var, Z[0..d), chain_0 … chain_{nchain−1}} of the candidate ti[e] − idx_base (zeros behind a
+// negative index), e < k; 4 + d + nchain doubles per record
+hipError_t launch_qei_record(const double* tv, const int64_t* ti, int k, int64_t idx_base, const double* Z, const double* mu,
+                             const double* var, const double* chain, int64_t Mp, int nchain, int d, double* rec, hipStream_t st);
+
 // Z[(j−j0)·d + c] for j in [j0, j0+count): Latin-hypercube points of an n-point design (device lower/upper)
 hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                       int64_t count, hipStream_t s);

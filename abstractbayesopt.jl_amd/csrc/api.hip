@@ -11,7 +11,9 @@
 // [Np/128][Mc], mu chunk [Mc], full-length mu/var/score arrays, top-k scratch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -22,6 +24,7 @@
 #include <mutex>
 #include <set>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/abo_hip.h"
@@ -374,15 +377,38 @@ struct abo_cand {
     // N·M kernel values; kzx_ld = 0 → not resident, the down-date recomputes
     DevBuf Kzx;
     int64_t kzx_ld = 0;
+    // block form of greedy q-EI (qei.hip).  Base = the model the set was synced with at abo_cand_qei_begin (gen, N).
+    //   qblk   [nblk_cap][T16][Mp]  base covariances Cov₀(z, x_t) of the block points (ring of blocks)
+    //   qchain [QEI_MAXQ][Mp]       c_i(z) = Cov_{i−1}(z, x_i) of the picks made since the base, in order
+    // The chain outlives abo_cand_qei_end: appending the picks for real, in order, finds its down-date column here
+    // (abo_cand_downdate) instead of streaming K_ZX again — c_i does not depend on the observed value.
+    struct Qei {
+        bool open = false;
+        uint64_t gen = 0;
+        int64_t N = -1, Mp = 0;
+        int T16 = 0, nblk_cap = 0, next_blk = 0, qmax = 0;
+        std::vector<int64_t> slot_gidx;           // global candidate index per block row (−1: empty)
+        std::vector<double> slot_x;               // [rows][d] the block points
+        int nchain = 0;
+        std::vector<double> chain_x;              // [nchain][d] the picked points
+        std::vector<double> chain_s;              // [nchain] s_i = σ²_{i−1}(x_i) + σ²_n
+        // statistics of the current / last batch
+        int builds = 0, hits = 0;
+        double block_ms = 0.0, pass_ms = 0.0, pass_bytes = 0.0, pass_flop = 0.0;
+    } qei;
+    DevBuf qblk, qchain, qwork, qrec, qmu, qvar;
     void set_device(int dev) {
         device = dev;
-        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak, &Kzx};
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak, &Kzx,
+                         &qblk, &qchain, &qwork, &qrec, &qmu, &qvar};
         for (DevBuf* b : all) b->dev = dev;
     }
     void free_all() {
-        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak, &Kzx};
+        DevBuf* all[] = {&Z, &mu, &var, &score, &cdot, &tk_keys0, &tk_keys1, &tk_idx0, &tk_idx1, &top_val, &top_idx, &mu_bak, &var_bak, &Kzx,
+                         &qblk, &qchain, &qwork, &qrec, &qmu, &qvar};
         for (DevBuf* b : all) b->release();
         kzx_ld = 0;
+        qei = Qei();
     }
 };
 
@@ -1885,6 +1911,7 @@ int32_t abo_cand_refresh(abo_gp* g, abo_cand* c) {
     }
     c->synced_gen = g->st->gen;
     c->synced_N = g->N;
+    c->qei = abo_cand::Qei();                             // blocks and chain of an earlier q-EI batch belong to the old posterior
     return ABO_OK;
 }
 
@@ -1932,9 +1959,31 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
         HIPCHK(c->cdot.ensure(sizeof(double) * pad_up(c->M, 16)));
         const bool resident = c->kzx_ld > 0 && c->kzx_ld == g->st->cap;
         HIPCHK(g->events(8));
+        // A pick of the set's last block-form q-EI batch appended for real, in the batch's order: its column c_i(z) is in the chain
+        // (it does not depend on the observed value) — no pass over K_ZX.  The model's rows since the batch's base must be the
+        // chain's points, bit for bit.
+        int chain_i = -1;
+        const abo_cand::Qei& Q = c->qei;
+        if (P == 1 && resident && !Q.open && Q.gen == g->st->gen && Q.N >= 0 && c->synced_N >= Q.N && c->synced_N - Q.N < Q.nchain &&
+            !getenv("ABO_QEI_NO_CHAIN")) {
+            const int i = (int)(c->synced_N - Q.N);
+            std::vector<double> rows((size_t)(i + 1) * g->d);
+            HIPCHK(hipMemcpyAsync(rows.data(), g->st->Xraw.as<double>() + Q.N * g->d, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (!memcmp(rows.data(), Q.chain_x.data(), sizeof(double) * rows.size())) chain_i = i;
+        }
+        g->tm.downdate_from_chain = chain_i >= 0 ? 1 : 0;
         HIPCHK(hipEventRecord(g->evs()[5], s));
         double pass_ms = 0.0;
-        for (int q = 0; q < P; ++q) {                      // one rank-1 down-date per appended row, in append order
+        if (chain_i >= 0) {
+            // the appended row's column keeps the resident K_ZX current for later passes
+            HIPCHK(launch_cand_newcol(g->st->Xs.as<double>(), c->Z.as<double>(), c->Kzx.as<double>(), c->kzx_ld, c->M, (int)(g->N - 1),
+                                      g->d, g->dp, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, s));
+            HIPCHK(hipEventRecord(g->evs()[6], s));
+            HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->qchain.as<double>() + (size_t)chain_i * Q.Mp, c->M,
+                                   g->ap_beta, g->ap_s2, s));
+        }
+        for (int q = 0; chain_i < 0 && q < P; ++q) {       // one rank-1 down-date per appended row, in append order
             const int64_t Rq = g->N - P + q;               // index of the appended row
             const double* vext = g->vext.as<double>() + (P > 1 ? (int64_t)q * g->st->cap : 0);
             const double s2 = P > 1 ? g->ap_s2v[q] : g->ap_s2, beta = P > 1 ? g->ap_betav[q] : g->ap_beta;
@@ -1968,7 +2017,7 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
         HIPCHK(hipStreamSynchronize(s));
         pass_ms = ev_ms(g->evs()[5], g->evs()[6]);
         g->tm.downdate_ms = pass_ms;
-        g->tm.downdate_bytes = resident ? 8.0 * (double)g->N * (double)c->M * P : 0.0;
+        g->tm.downdate_bytes = (resident && chain_i < 0) ? 8.0 * (double)g->N * (double)c->M * P : 0.0;
     }
     c->synced_N = g->N;
     return ABO_OK;
@@ -2000,6 +2049,336 @@ int32_t abo::cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double
     }
     HIPCHK(hipStreamSynchronize(s));
     return ABO_OK;
+}
+
+// ---- greedy q-EI, block form (qei.hip; include/abo_hip.h "block form"): per-shard steps + the driver ------------------------------
+namespace {
+
+// Julia's isless-descending order on scores (misc.hip: score_key): NaN first, then +Inf … −Inf with 0.0 before −0.0
+uint64_t host_score_key(double v) {
+    if (v != v) return ~0ull;
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+std::atomic<int> g_qei_block{-1};
+int qei_default_block() {
+    int v = g_qei_block.load();
+    if (v < 0) {
+        const char* e = getenv("ABO_QEI_BLOCK");
+        v = e ? atoi(e) : 32;
+        if (v < 0) v = 0;
+        if (v > QEI_MAXT) v = QEI_MAXT;
+        g_qei_block.store(v);
+    }
+    return v;
+}
+
+// chunk length of the split-k products against L⁻¹ (K⁻¹K_XT): about 16 chunks per column tile, so that the (tile, chunk) workgroups
+// of the triangular range are a few times the device's CUs — the product streams L⁻¹ once and is HBM-bound
+int qei_ksplit(int Np) {
+    int ks = Np / 16 / 128 * 128;
+    return ks < 128 ? 128 : ks;
+}
+
+struct QeiWork { double *P, *Ps, *KXT, *V, *U, *Ct; int ks, nz; size_t bytes; };
+QeiWork qei_carve(void* base, int T16, int d, int dp, int Np) {
+    QeiWork w{};
+    w.ks = qei_ksplit(Np);
+    w.nz = (Np + w.ks - 1) / w.ks;
+    char* p = static_cast<char*>(base);
+    auto take = [&](size_t n) { double* r = reinterpret_cast<double*>(p); p += (n * sizeof(double) + 255) / 256 * 256; return r; };
+    w.P = take((size_t)T16 * d);
+    w.Ps = take((size_t)T16 * dp);
+    w.KXT = take((size_t)T16 * Np);
+    w.V = take((size_t)T16 * Np);
+    w.U = take((size_t)T16 * Np);
+    w.Ct = take((size_t)w.nz * T16 * Np);
+    w.bytes = (size_t)(p - static_cast<char*>(base));
+    return w;
+}
+
+int qei_find_slot(const abo_cand* c, int64_t gidx) {
+    const std::vector<int64_t>& v = c->qei.slot_gidx;
+    for (size_t i = 0; i < v.size(); ++i) if (v[i] == gidx) return (int)i;
+    return -1;
+}
+
+}  // namespace
+
+int32_t abo::qei_eligible(abo_gp* g, abo_cand* c, int q) {
+    if (!g || !c) return fail(ABO_EINVAL, "q-EI: null argument");
+    int32_t rc = check_fitted(g, c->d);
+    if (rc) return rc;
+    if (g->prm.device != c->device) return fail(ABO_EINVAL, "candidate set lives on device %d, model on %d", c->device, g->prm.device);
+    if (g->st->gen != c->synced_gen || g->N != c->synced_N)
+        return fail(ABO_EINVAL, "q-EI: the candidate set is not in sync with this model (abo_cand_refresh / abo_cand_downdate)");
+    if (g->p_out > 1) return fail(ABO_EINVAL, "q-EI, block form: gradient-enhanced models take the plain loop");
+    if (c->M > 0 && !(c->kzx_ld > 0 && c->kzx_ld == g->st->cap)) return fail(ABO_EINVAL, "q-EI, block form: K_ZX of the set is not resident");
+    if (q < 1 || q > QEI_MAXQ) return fail(ABO_EINVAL, "q-EI, block form: q = %d outside 1..%d", q, QEI_MAXQ);
+    if (getenv("ABO_GEMM_NO_SKINNY")) return fail(ABO_EINVAL, "q-EI, block form: needs the skinny product (ABO_GEMM_NO_SKINNY is set)");
+    return ABO_OK;
+}
+
+int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T) {
+    int32_t rc = abo::qei_eligible(g, c, q);
+    if (rc) return rc;
+    if (T <= 0) T = qei_default_block();
+    if (T < 1) return fail(ABO_EINVAL, "q-EI, block form: block size 0 (the plain loop is a different call)");
+    if (T > QEI_MAXT) T = QEI_MAXT;
+    HIPCHK(hipSetDevice(g->prm.device));
+    abo_cand::Qei& Q = c->qei;
+    const int T16 = (int)pad_up(T, 16);
+    const int64_t Mp = pad_up(c->M > 0 ? c->M : 1, TB);
+    const int nblk = q < 4 ? q : 4;                       // ring of blocks: a pick outside all of them rebuilds the oldest
+    HIPCHK(c->qblk.ensure(sizeof(double) * (size_t)nblk * T16 * Mp));
+    HIPCHK(c->qchain.ensure(sizeof(double) * (size_t)q * Mp));
+    const QeiWork w = qei_carve(nullptr, T16, g->d, g->dp, (int)g->Np);
+    HIPCHK(c->qwork.ensure(w.bytes));
+    // snapshot of the stored posterior, in buffers of its own (the caller's abo_cand_save snapshot stays what it is): the batch is
+    // rolled back at _end
+    const size_t bytes = sizeof(double) * (c->M > 0 ? c->M : 1);
+    HIPCHK(c->qmu.ensure(bytes));
+    HIPCHK(c->qvar.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    Q = abo_cand::Qei();
+    Q.open = true; Q.gen = g->st->gen; Q.N = g->N; Q.Mp = Mp; Q.T16 = T16; Q.nblk_cap = nblk; Q.qmax = q;
+    Q.slot_gidx.assign((size_t)nblk * T16, -1);
+    Q.slot_x.assign((size_t)nblk * T16 * c->d, 0.0);
+    return ABO_OK;
+}
+
+// EI over the shard, its k best as records in DEVICE memory rec_d (k × (4 + d + picks so far) doubles); nothing is waited for
+int32_t abo::qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int k, double* rec_d) {
+    if (!g || !c || !rec_d) return fail(ABO_EINVAL, "abo_cand_qei_top: null argument");
+    if (!c->qei.open || c->qei.gen != g->st->gen || c->qei.N != g->N) return fail(ABO_EINVAL, "abo_cand_qei_top: no batch open on this model (abo_cand_qei_begin)");
+    if (k < 1 || k > 1024) return fail(ABO_EINVAL, "abo_cand_qei_top: k = %d outside 1..1024", k);
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    HIPCHK(c->score.ensure(sizeof(double) * (c->M > 0 ? c->M : 1)));
+    HIPCHK(c->top_val.ensure(sizeof(double) * k));
+    HIPCHK(c->top_idx.ensure(sizeof(int64_t) * k));
+    HIPCHK(launch_score(c->mu.as<double>(), c->var.as<double>(), c->score.as<double>(), c->M, ABO_ACQ_EI, xi, best_y, s));
+    int32_t rc = cand_topk(g, c, c->score.as<double>(), k, idx_base, c->top_val.as<double>(), c->top_idx.as<int64_t>(), ABO_DEVICE);
+    if (rc) return rc;
+    HIPCHK(launch_qei_record(c->top_val.as<double>(), c->top_idx.as<int64_t>(), k, idx_base, c->Z.as<double>(), c->mu.as<double>(),
+                             c->var.as<double>(), c->qchain.as<double>(), c->qei.Mp, c->qei.nchain, c->d, rec_d, s));
+    return ABO_OK;
+}
+
+// Cov₀(z, p_t) of T points for every candidate of the shard: K⁻¹K_XT by two split-k products against L⁻¹ / L⁻ᵀ, ONE product over the
+// resident K_ZX, the kernel values k(z, p_t) on top.  pts: T × d HOST doubles, gidx their global candidate indices.
+int32_t abo::qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t* gidx, int T) {
+    if (!g || !c || !pts || !gidx) return fail(ABO_EINVAL, "abo_cand_qei_block: null argument");
+    abo_cand::Qei& Q = c->qei;
+    if (!Q.open || Q.gen != g->st->gen || Q.N != g->N) return fail(ABO_EINVAL, "abo_cand_qei_block: no batch open on this model (abo_cand_qei_begin)");
+    if (T < 1 || T > Q.T16) return fail(ABO_EINVAL, "abo_cand_qei_block: T = %d outside 1..%d", T, Q.T16);
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    const int T16 = Q.T16, d = g->d, dp = g->dp, N = (int)g->N, Np = (int)g->Np;
+    const int64_t ld = g->st->cap, Mp = Q.Mp;
+    const int blk = Q.next_blk;
+    Q.next_blk = (Q.next_blk + 1) % Q.nblk_cap;
+    for (int t = 0; t < T16; ++t) Q.slot_gidx[(size_t)blk * T16 + t] = t < T ? gidx[t] : -1;
+    memcpy(&Q.slot_x[(size_t)blk * T16 * g->d], pts, sizeof(double) * (size_t)T * g->d);
+    ++Q.builds;
+    if (c->M == 0) return ABO_OK;
+    const QeiWork w = qei_carve(c->qwork.p, T16, d, dp, Np);
+    double* C = c->qblk.as<double>() + (size_t)blk * T16 * Mp;
+    HIPCHK(g->events(EV_BASE + 4));
+    hipEvent_t* ev = &g->evs()[EV_BASE];
+    HIPCHK(hipEventRecord(ev[0], s));
+    HIPCHK(hipMemsetAsync(w.P, 0, sizeof(double) * (size_t)T16 * d, s));
+    HIPCHK(hipMemcpyAsync(w.P, pts, sizeof(double) * (size_t)T * d, hipMemcpyHostToDevice, s));
+    HIPCHK(launch_scale_points(w.P, w.Ps, T, T16, d, dp, 1.0 / g->prm.ell, s));
+    HIPCHK(launch_qei_kxt(g->st->Xs.as<double>(), dp, N, Np, w.P, d, T, T16, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, w.KXT, s));
+    // V[t][i] = Σ_{k ≤ i} K_XT[t][k]·W[i][k] = (L⁻¹k_t)[i];  U[t][i] = Σ_{k ≥ i} V[t][k]·WT[i][k] = (K⁻¹k_t)[i]
+    GemmArgs g1{};
+    g1.A = w.KXT; g1.lda = Np; g1.B = g->st->W.as<double>(); g1.ldb = ld; g1.C = w.Ct; g1.ldc = Np; g1.sC = (int64_t)T16 * Np;
+    g1.M = TB; g1.N = Np; g1.K = Np; g1.kmode = K_B_LOWER; g1.lower_only = 0; g1.batch = 1; g1.alpha = 1.0; g1.beta = 0.0;
+    g1.ksplit = w.ks; g1.mrows = T16;
+    HIPCHK(launch_gemm_nt(g1, s));
+    HIPCHK(launch_splitk_reduce(w.Ct, Np, g1.sC, w.nz, T16, Np, Np, w.ks, K_B_LOWER, w.V, Np, s));
+    HIPCHK(launch_qei_zero_tail(w.V, Np, N, Np, T16, s));      // rows ≥ N of a shared factor may hold a discarded appended branch
+    GemmArgs g2 = g1;
+    g2.A = w.V; g2.B = g->st->WT.as<double>(); g2.kmode = K_B_UPPER;
+    HIPCHK(launch_gemm_nt(g2, s));
+    HIPCHK(launch_splitk_reduce(w.Ct, Np, g2.sC, w.nz, T16, Np, Np, w.ks, K_B_UPPER, w.U, Np, s));
+    HIPCHK(launch_qei_zero_tail(w.U, Np, N, Np, T16, s));
+    // C[t][z] = −Σ_k U[t][k]·K_ZX[z][k]: one pass over the resident K_ZX for all T columns (columns ≥ N of K_ZX meet U = 0)
+    HIPCHK(hipEventRecord(ev[1], s));
+    GemmArgs g3{};
+    g3.A = w.U; g3.lda = Np; g3.B = c->Kzx.as<double>(); g3.ldb = c->kzx_ld; g3.C = C; g3.ldc = Mp; g3.sC = 0;
+    g3.M = TB; g3.N = (int)Mp; g3.K = Np; g3.kmode = K_FULL; g3.lower_only = 0; g3.batch = 1; g3.alpha = -1.0; g3.beta = 0.0;
+    g3.ksplit = Np; g3.mrows = T16;
+    HIPCHK(launch_gemm_nt(g3, s));
+    HIPCHK(hipEventRecord(ev[2], s));
+    HIPCHK(launch_qei_cov(w.Ps, dp, c->Z.as<double>(), c->M, Mp, d, T, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, C, s));
+    HIPCHK(hipEventRecord(ev[3], s));
+    HIPCHK(hipStreamSynchronize(s));                          // (pts is the caller's; the events are read)
+    Q.block_ms += ev_ms(ev[0], ev[3]);
+    Q.pass_ms = ev_ms(ev[1], ev[2]);
+    Q.pass_bytes = 8.0 * (double)g->N * (double)c->M;
+    Q.pass_flop = 2.0 * (double)g->N * (double)c->M * (double)T16;
+    return ABO_OK;
+}
+
+int abo::qei_block_default() { return qei_default_block(); }
+
+size_t abo::qei_max_words(int d, int q, int T) {
+    if (T <= 0) T = qei_default_block();
+    if (T > QEI_MAXT) T = QEI_MAXT;
+    if (T < 1) T = 1;
+    return (size_t)T * (size_t)(4 + d + (q > 0 ? q : 1));
+}
+
+int32_t abo::qei_has(const abo_cand* c, int64_t gidx) { return c && qei_find_slot(c, gidx) >= 0 ? 1 : 0; }
+
+// condition the shard's stored variance on the pick `gidx` (a point of a block): chain vector n + 1, σ² −= c²/s with
+// s = var_x + σ²_n (var_x: the stored σ² at the pick, from the winner's record), γ_i = cx[i]/s_i (cx: c_1(x) … c_n(x) from the same
+// record).  s ≤ 0 is what the plain loop's bordered append reports as a failed pivot: ABO_ENOTPD, *info = N + n + 1.
+int32_t abo::qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, const double* cx, int n, int64_t excl, int64_t* info) {
+    if (info) *info = 0;
+    if (!g || !c || (n > 0 && !cx)) return fail(ABO_EINVAL, "abo_cand_qei_pick: null argument");
+    abo_cand::Qei& Q = c->qei;
+    if (!Q.open || Q.gen != g->st->gen || Q.N != g->N) return fail(ABO_EINVAL, "abo_cand_qei_pick: no batch open on this model (abo_cand_qei_begin)");
+    if (n != Q.nchain) return fail(ABO_EINVAL, "abo_cand_qei_pick: %d chain values for a chain of %d picks", n, Q.nchain);
+    if (Q.nchain >= Q.qmax) return fail(ABO_EINVAL, "abo_cand_qei_pick: the batch was opened for %d picks", Q.qmax);
+    if (excl >= c->M) return fail(ABO_EINVAL, "abo_cand_qei_pick: exclusion index %lld outside the shard", (long long)excl);
+    const int slot = qei_find_slot(c, gidx);
+    if (slot < 0) return fail(ABO_EINVAL, "abo_cand_qei_pick: candidate %lld is in no block (abo_cand_qei_block)", (long long)gidx);
+    const double sj = var_x + g->st->noise_used;
+    if (!(sj > 0.0)) {
+        if (info) *info = g->N + n + 1;
+        return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
+                    (long long)(g->N + n + 1));
+    }
+    HIPCHK(hipSetDevice(g->prm.device));
+    hipStream_t s = g->stream;
+    QeiPickArgs a{};
+    a.blk = c->qblk.as<double>() + (size_t)slot * Q.Mp;
+    a.chain = c->qchain.as<double>();
+    a.out = c->qchain.as<double>() + (size_t)Q.nchain * Q.Mp;
+    a.var = c->var.as<double>();
+    a.M = c->M; a.Mp = Q.Mp; a.nchain = Q.nchain; a.s = sj;
+    for (int i = 0; i < n; ++i) a.gam[i] = cx[i] / Q.chain_s[i];
+    HIPCHK(launch_qei_pick(a, s));
+    if (excl >= 0) {
+        const double ex[2] = {HUGE_VAL, 0.0};                // abo_cand_exclude: μ = +Inf, σ² = 0
+        HIPCHK(hipMemcpyAsync(c->mu.as<double>() + excl, &ex[0], sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->var.as<double>() + excl, &ex[1], sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));                      // (ex lives on this frame)
+    }
+    ++Q.nchain;
+    Q.chain_s.push_back(sj);
+    Q.chain_x.insert(Q.chain_x.end(), &Q.slot_x[(size_t)slot * c->d], &Q.slot_x[(size_t)slot * c->d] + c->d);
+    return ABO_OK;
+}
+
+int32_t abo::qei_end(abo_gp* g, abo_cand* c) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_qei_end: null argument");
+    if (!c->qei.open) return ABO_OK;
+    HIPCHK(hipSetDevice(g->prm.device));
+    HIPCHK(hipMemcpyAsync(c->mu.p, c->qmu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(c->var.p, c->qvar.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    c->qei.open = false;
+    return ABO_OK;
+}
+
+void abo::qei_get_stats(const abo_cand* c, int picks, double total_ms, abo_qei_stats* out) {
+    if (!out) return;
+    const abo_cand::Qei& Q = c->qei;
+    out->picks = picks; out->block = Q.T16; out->block_builds = Q.builds; out->block_hits = Q.hits;
+    out->total_ms = total_ms; out->block_ms = Q.block_ms; out->pass_ms = Q.pass_ms; out->pass_bytes = Q.pass_bytes; out->pass_flop = Q.pass_flop;
+}
+
+
+// The batch over n shards of one set.  S.run(f): f(i) on every shard (mgpu: the shard's worker thread); S.rec(i): the shard's
+// record block in DEVICE memory (room for S.max_words doubles); S.gather(words, out): all shards' blocks → host, n × words doubles.
+int32_t abo::qei_drive(const QeiShards& S, int q, double xi, double best_y, int distinct, int T, double* x_out, int64_t* idx_out,
+                       double* ei_out, int64_t* info) {
+    const int n = S.n, d = gp_dim(S.gp[0]);
+    if (T <= 0) T = qei_default_block();
+    if (T > QEI_MAXT) T = QEI_MAXT;
+    int64_t Mtot = 0;
+    for (int i = 0; i < n; ++i) Mtot += S.cd[i]->M;
+    if (Mtot < 1) return fail(ABO_EINVAL, "q-EI: the candidate set is empty");
+    const int Tk = (int64_t)T < Mtot ? T : (int)Mtot;
+    int32_t rc = S.run([&](int i) -> int32_t { return abo::qei_begin(S.gp[i], S.cd[i], q, T); });
+    std::string keep;
+    if (rc) keep = g_err;
+    std::vector<double> blocks;
+    int nch_done = 0;
+    std::vector<double> pts((size_t)Tk * d);
+    std::vector<int64_t> gix(Tk);
+    for (int j = 0; j < q && !rc; ++j) {
+        const int nch = nch_done, words = 4 + d + nch;
+        rc = S.run([&](int i) -> int32_t { return abo::qei_top(S.gp[i], S.cd[i], xi, best_y, S.lo[i], 1, S.rec(i)); });
+        if (rc) break;
+        blocks.resize((size_t)n * words);
+        rc = S.gather((size_t)words, blocks.data());
+        if (rc) break;
+        int win = -1;
+        for (int i = 0; i < n; ++i) {                          // sortperm(scores; rev=true)[1] over the shards' winners
+            const double* r = &blocks[(size_t)i * words];
+            if (r[1] < 0) continue;                            // empty shard
+            if (win < 0) { win = i; continue; }
+            const double* w = &blocks[(size_t)win * words];
+            const uint64_t kr = host_score_key(r[0]), kw = host_score_key(w[0]);
+            if (kr > kw || (kr == kw && r[1] < w[1])) win = i;
+        }
+        if (win < 0) { rc = fail(ABO_EINVAL, "q-EI: the candidate set is empty"); break; }
+        const std::vector<double> w(blocks.begin() + (size_t)win * words, blocks.begin() + (size_t)(win + 1) * words);
+        const int64_t gidx = (int64_t)w[1];
+        ei_out[j] = w[0];
+        idx_out[j] = gidx;
+        memcpy(x_out + (size_t)j * d, &w[4], sizeof(double) * d);
+        if (j == q - 1) break;                                 // the last pick conditions nothing (the batch is rolled back)
+        if (!abo::qei_has(S.cd[0], gidx)) {
+            // a new block: the best T of the current scores over all shards (the pick is the first of them)
+            const int wt = Tk * words;
+            rc = S.run([&](int i) -> int32_t { return abo::qei_top(S.gp[i], S.cd[i], xi, best_y, S.lo[i], Tk, S.rec(i)); });
+            if (rc) break;
+            blocks.resize((size_t)n * wt);
+            rc = S.gather((size_t)wt, blocks.data());
+            if (rc) break;
+            struct Ent { uint64_t key; int64_t idx; const double* r; };
+            std::vector<Ent> ents;
+            for (int e = 0; e < n * Tk; ++e) {
+                const double* r = &blocks[(size_t)e * words];
+                if (r[1] >= 0) ents.push_back({host_score_key(r[0]), (int64_t)r[1], r});
+            }
+            std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key > b.key || (a.key == b.key && a.idx < b.idx); });
+            const int Tb = (int)ents.size() < Tk ? (int)ents.size() : Tk;
+            bool found = false;
+            for (int t = 0; t < Tb; ++t) {
+                gix[t] = ents[t].idx;
+                memcpy(&pts[(size_t)t * d], ents[t].r + 4, sizeof(double) * d);
+                found = found || ents[t].idx == gidx;
+            }
+            if (!found) { rc = fail(ABO_EINVAL, "q-EI: internal error: the pick is not among the best %d", Tb); break; }
+            rc = S.run([&](int i) -> int32_t { return abo::qei_block(S.gp[i], S.cd[i], pts.data(), gix.data(), Tb); });
+            if (rc) break;
+        } else {
+            for (int i = 0; i < n; ++i) ++S.cd[i]->qei.hits;
+        }
+        rc = S.run([&](int i) -> int32_t {
+            const int64_t ex = (distinct && gidx >= S.lo[i] && gidx < S.lo[i] + S.cd[i]->M) ? gidx - S.lo[i] : -1;
+            int64_t inf = 0;
+            const int32_t r = abo::qei_pick(S.gp[i], S.cd[i], gidx, w[3], &w[4 + d], nch, ex, &inf);
+            if (inf && info && i == 0) *info = inf;
+            return r;
+        });
+        if (rc) break;
+        ++nch_done;
+    }
+    if (rc && keep.empty()) keep = g_err;
+    const int32_t r2 = S.run([&](int i) -> int32_t { return abo::qei_end(S.gp[i], S.cd[i]); });
+    if (rc) return fail(rc, "%s", keep.c_str());
+    return r2;
 }
 
 // ---- optimize_acquisition on the device (acq_utils.jl:33-73): refinement launch + the one-call driver -----------------
@@ -2440,6 +2819,136 @@ int32_t abo_cand_exclude(abo_gp* g, abo_cand* c, int64_t idx) {
     HIPCHK(hipMemcpyAsync(c->var.as<double>() + idx, &excl[1], sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     return ABO_OK;
+}
+
+// ---- greedy q-EI on one handle (include/abo_hip.h: "block form") ----------------------------------------------------------------
+int32_t abo_set_qei_block(int32_t block) {
+    if (block < 0 || block > QEI_MAXT) return fail(ABO_EINVAL, "abo_set_qei_block: block = %d outside 0..%d", block, QEI_MAXT);
+    g_qei_block.store(block);
+    return ABO_OK;
+}
+
+int32_t abo_cand_qei_begin(abo_gp* g, abo_cand* c, int32_t q, int32_t block) { return abo::qei_begin(g, c, q, block); }
+
+int32_t abo_cand_qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int32_t k, double* rec) {
+    if (!g || !c || !rec) return fail(ABO_EINVAL, "abo_cand_qei_top: null argument");
+    if (k < 1 || k > 1024) return fail(ABO_EINVAL, "abo_cand_qei_top: k = %d outside 1..1024", k);
+    const size_t words = (size_t)k * (4 + c->d + c->qei.nchain);
+    HIPCHK(hipSetDevice(g->prm.device));
+    HIPCHK(c->qrec.ensure(sizeof(double) * words));
+    int32_t rc = abo::qei_top(g, c, xi, best_y, idx_base, k, c->qrec.as<double>());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(rec, c->qrec.p, sizeof(double) * words, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return ABO_OK;
+}
+
+int32_t abo_cand_qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t* gidx, int32_t T) {
+    return abo::qei_block(g, c, pts, gidx, T);
+}
+
+int32_t abo_cand_qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, const double* cx, int32_t n, int64_t excl, int64_t* info) {
+    return abo::qei_pick(g, c, gidx, var_x, cx, n, excl, info);
+}
+
+int32_t abo_cand_qei_end(abo_gp* g, abo_cand* c) { return abo::qei_end(g, c); }
+
+int32_t abo_cand_qei_stats(abo_gp* g, abo_cand* c, abo_qei_stats* out) {
+    if (!g || !c || !out) return fail(ABO_EINVAL, "abo_cand_qei_stats: null argument");
+    abo::qei_get_stats(c, c->qei.nchain + (c->qei.nchain > 0 || c->qei.builds > 0 ? 1 : 0), 0.0, out);
+    return ABO_OK;
+}
+
+// the plain loop on one handle: q × [EI + arg-max, fantasy append, O(N·M) down-date], rolled back (what abo_mgpu_cand_qei's plain
+// loop does per device)
+static int32_t qei_plain(abo_gp* g, abo_cand* c, int q, double xi, double best_y, int distinct, int64_t idx_base, double* x_out,
+                         int64_t* idx_out, double* ei_out, int64_t* info) {
+    int32_t rc = check_fitted(g, c->d);
+    if (rc) return rc;
+    if (g->st->gen != c->synced_gen || g->N != c->synced_N)
+        return fail(ABO_EINVAL, "abo_cand_qei: the candidate set is not in sync with this model (abo_cand_refresh / abo_cand_downdate)");
+    HIPCHK(hipSetDevice(g->prm.device));
+    const int d = c->d;
+    const size_t bytes = sizeof(double) * (c->M > 0 ? c->M : 1);
+    HIPCHK(c->qmu.ensure(bytes));
+    HIPCHK(c->qvar.ensure(bytes));
+    HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    const uint64_t gen0 = c->synced_gen;
+    const int64_t N0 = c->synced_N;
+    c->qei = abo_cand::Qei();
+    abo_gp* cur = g;
+    std::string keep;
+    for (int j = 0; j < q && !rc; ++j) {
+        double tv = 0.0, mu = 0.0;
+        int64_t ti = -1;
+        rc = abo::cand_acq_ex(cur, c, ABO_ACQ_EI, xi, best_y, idx_base, nullptr, ABO_DEVICE, 1, &tv, &ti, ABO_HOST);
+        if (rc) break;
+        if (ti < 0) { rc = fail(ABO_EINVAL, "abo_cand_qei: the candidate set is empty"); break; }
+        double* x = x_out + (size_t)j * d;
+        rc = abo_cand_point(cur, c, ti - idx_base, x, &mu, nullptr);
+        if (rc) break;
+        ei_out[j] = tv; idx_out[j] = ti;
+        if (j == q - 1) break;
+        abo_gp* nw = nullptr;
+        if (cur->p_out > 1) {
+            double yv[MAX_P];
+            rc = abo_predict_grad(cur, x, 1, d, ABO_HOST, yv, nullptr, ABO_HOST);
+            if (!rc) rc = abo_append_grad(cur, x, d, yv, info, &nw);
+        } else {
+            rc = abo_append(cur, x, d, mu, info, &nw);
+        }
+        if (rc) break;
+        rc = abo_cand_downdate(nw, c);
+        if (!rc && distinct) rc = abo_cand_exclude(nw, c, ti - idx_base);
+        if (cur != g) abo_destroy(cur);
+        cur = nw;
+    }
+    if (rc) keep = g_err;
+    if (cur != g) abo_destroy(cur);
+    hipError_t e = hipMemcpyAsync(c->mu.p, c->qmu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->var.p, c->qvar.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    c->synced_gen = gen0; c->synced_N = N0;
+    if (rc) return fail(rc, "%s", keep.c_str());
+    HIPCHK(e);
+    return ABO_OK;
+}
+
+int32_t abo_cand_qei(abo_gp* g, abo_cand* c, int32_t q, double xi, double best_y, int32_t distinct, int64_t idx_base, int32_t block,
+                     double* x_out, int64_t* idx_out, double* ei_out, abo_qei_stats* stats) {
+    if (!g || !c || !x_out || !idx_out || !ei_out) return fail(ABO_EINVAL, "abo_cand_qei: null argument");
+    if (q < 1) return fail(ABO_EINVAL, "abo_cand_qei: q = %d", q);
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t info = 0;
+    int T = block == 0 ? qei_default_block() : block;
+    int32_t rc;
+    if (T > 0 && abo::qei_eligible(g, c, q) == ABO_OK) {
+        abo_gp* gp1[1] = {g};
+        abo_cand* cd1[1] = {c};
+        const int64_t lo1[1] = {idx_base};
+        HIPCHK(hipSetDevice(g->prm.device));
+        HIPCHK(c->qrec.ensure(sizeof(double) * abo::qei_max_words(c->d, q, T)));
+        abo::QeiShards S;
+        S.n = 1; S.gp = gp1; S.cd = cd1; S.lo = lo1;
+        S.run = [](const std::function<int32_t(int)>& f) { return f(0); };
+        S.rec = [c](int) { return c->qrec.as<double>(); };
+        S.gather = [g, c](size_t words, double* out) -> int32_t {
+            HIPCHK(hipMemcpyAsync(out, c->qrec.p, sizeof(double) * words, hipMemcpyDeviceToHost, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));
+            return ABO_OK;
+        };
+        rc = abo::qei_drive(S, q, xi, best_y, distinct, T, x_out, idx_out, ei_out, &info);
+    } else {
+        (void)hipGetLastError();
+        rc = qei_plain(g, c, q, xi, best_y, distinct, idx_base, x_out, idx_out, ei_out, &info);
+    }
+    if (stats) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        abo::qei_get_stats(c, q, ms, stats);
+    }
+    return rc;
 }
 
 int32_t abo_pool_trim(int32_t device) {

@@ -326,6 +326,7 @@ struct abo_mcand {
     int64_t M = 0;
     int64_t lo[MAXDEV + 1] = {0};
     abo_cand* c[MAXDEV] = {nullptr};
+    abo_qei_stats qei_last{};           // abo_mgpu_cand_qei_stats
 };
 
 namespace {
@@ -896,6 +897,31 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
     const int n = mg->ndev, d = mc->d;
     CommSet* cs = mg->cs;
     std::lock_guard<std::mutex> lk(cs->mu);
+    const auto t0 = std::chrono::steady_clock::now();
+    mc->qei_last = abo_qei_stats{};
+    mc->qei_last.picks = q;
+    // Block form (include/abo_hip.h, api.hip: qei_drive): the covariance columns of the T best candidates from ONE pass over each
+    // shard's resident K_ZX, no fantasy appends; what the shards exchange are pick records {EI, index, μ, σ², x[d], c_1(x) … c_n(x)}
+    // (one per pick) and, when a block is built, T of them per shard.  Every shard applies the same exchanged numbers, so the
+    // sharded batch repeats the single handle's arithmetic bit for bit.  Falls back to the plain loop below when a shard does not
+    // qualify (gradient-enhanced model, K_ZX not resident, q > 64, block size 0).
+    if (abo::qei_max_words(d, q, 0) > 0 && abo::qei_block_default() > 0 &&
+        run_all(cs->wk, n, [&](int i) -> int32_t { return abo::qei_eligible(mg->gp[i], mc->c[i], q); }) == ABO_OK) {
+        const size_t maxw = abo::qei_max_words(d, q, 0);
+        rc = run_all(cs->wk, n, [&](int i) -> int32_t { return ensure_exchange_buffers(mg, i, maxw); });
+        if (rc) return rc;
+        abo::QeiShards S;
+        S.n = n; S.gp = mg->gp; S.cd = mc->c; S.lo = mc->lo;
+        S.run = [&](const std::function<int32_t(int)>& f) { return run_all(cs->wk, n, f); };
+        S.rec = [&](int i) { return static_cast<double*>(cs->pack[i]); };
+        S.gather = [&](size_t words, double* out) { return exchange(mg, words, reinterpret_cast<uint64_t*>(out)); };
+        int64_t info = 0;
+        rc = abo::qei_drive(S, q, xi, best_y, distinct, 0, x_out, idx_out, ei_out, &info);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        abo::qei_get_stats(mc->c[0], q, ms, &mc->qei_last);
+        return rc;
+    }
+    (void)hipGetLastError();
     // exchange block per shard: the pick record {score, index, μ, x[d]}; the (score, index) pair of the device top-1 is
     // parked behind it in the same buffer
     const size_t words = 3 + (size_t)d;
@@ -977,8 +1003,15 @@ int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, dou
     for (int i = 0; i < n; ++i)
         if (cur[i] != mg->gp[i]) abo_destroy(cur[i]);
     rc = run_all(mg->cs->wk, n, [&](int i) -> int32_t { return abo_cand_restore(mg->gp[i], mc->c[i]); });
+    mc->qei_last.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (status) return abo::set_error(status, keep.c_str());
     return rc;
+}
+
+int32_t abo_mgpu_cand_qei_stats(abo_mgpu* mg, abo_mcand* mc, abo_qei_stats* out) {
+    if (!mg || !mc || !out) return failf(ABO_EINVAL, "abo_mgpu_cand_qei_stats: null argument");
+    *out = mc->qei_last;
+    return ABO_OK;
 }
 
 }  // extern "C"

@@ -98,6 +98,16 @@ class ResidentCandidates:
                                              C.byref(mu), C.byref(var)))
         return x, mu.value, var.value
 
+    def qei(self, q: int, xi: float, best_y: float, distinct: bool = False, idx_base: int = 0, block: int = 0):
+        """abo_cand_qei: the whole greedy q-EI batch in ONE library call (block form: T = `block` points per block, 0 = the
+        library default, < 0 = the plain loop); model and stored posterior are unchanged on return.
+        Returns (points (q, d), global indices, EI values, statistics)."""
+        X, idx, ei = np.empty((q, self.d)), np.empty(q, dtype=np.int64), np.empty(q)
+        st = _lib.AboQeiStats()
+        _lib.check(_lib.lib().abo_cand_qei(self.model._require(), self._h.ptr, int(q), float(xi), float(best_y), int(bool(distinct)),
+                                           int(idx_base), int(block), X.ctypes.data, idx.ctypes.data, ei.ctypes.data, C.byref(st)))
+        return X, idx, ei, st.as_dict()
+
     def evaluate(self, acq: AbstractAcquisition, k: int = 0, idx_base: int = 0, return_scores: bool = False,
                  device_out: bool = False):
         """Acquisition epilogue + top-k on the stored posterior (no kernel evaluations)."""
@@ -121,19 +131,151 @@ class ResidentCandidates:
         return scores, tv, ti
 
 
+def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, distinct, block):
+    """The picks of a greedy q-EI batch in the BLOCK form (include/abo_hip.h "block form"; csrc/qei.hip): the posterior covariances
+    of the T best candidates to every candidate from ONE pass over the resident K_ZX, rank-1 corrections between picks, no fantasy
+    appends.  n_cond picks are conditioned on (q − 1 suffice for the picks themselves).  The set's stored posterior is rolled back
+    before this returns; the chain of down-date columns stays with the set, so that appending the picks afterwards — as fantasies or
+    with their real observations, in order — costs no further pass (abo_cand_downdate).  Sharded (torch.distributed): every rank makes
+    the same calls with the same all-gathered records, so the picks equal the single-handle batch bit for bit.
+    Returns (points, global indices, EI values, μ at the picks, statistics)."""
+    L = _lib.lib()
+    d, h, c = cands.d, model._require(), cands._h.ptr
+    dist, world = None, 1
+    if group is not None or _dist_ready():
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+    m_tot = cands.M
+    if world > 1:
+        m_tot = int(_allgather_rows(np.array([[float(cands.M)]]), dist, group).sum())
+    if m_tot < 1:
+        raise ValueError("q-EI: the candidate set is empty")
+    _lib.check(L.abo_cand_qei_begin(h, c, q, int(block or 0)))
+    st = _lib.AboQeiStats()
+    try:
+        _lib.check(L.abo_cand_qei_stats(h, c, C.byref(st)))
+        T = min(int(st.block), m_tot)
+        picks, idxs, vals, mus, n_chain, in_block = [], [], [], [], 0, set()
+        for j in range(q):
+            words = 4 + d + n_chain
+            rec = np.empty((1, words))
+            _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, 1, rec.ctypes.data))
+            recs = _allgather_rows(rec, dist, group) if world > 1 else rec
+            recs = _sorted_valid(recs)
+            if len(recs) == 0:
+                raise ValueError("q-EI: the candidate set is empty")
+            w = recs[0]
+            gidx = int(w[1])
+            picks.append(w[4:4 + d].copy()); idxs.append(gidx); vals.append(w[0]); mus.append(w[2])
+            if j >= n_cond:
+                break
+            if gidx not in in_block:
+                rt = np.empty((T, words))
+                _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, T, rt.ctypes.data))
+                rt = _sorted_valid(_allgather_rows(rt, dist, group) if world > 1 else rt)[:T]
+                pts = np.ascontiguousarray(rt[:, 4:4 + d])
+                gix = np.ascontiguousarray(rt[:, 1].astype(np.int64))
+                if gidx not in set(gix.tolist()):
+                    raise _lib.AboError("q-EI: internal error: the pick is not among the block's points")
+                _lib.check(L.abo_cand_qei_block(h, c, pts.ctypes.data, gix.ctypes.data, len(gix)))
+                in_block = _ring_update(in_block, gix, q, cands)
+            cx = np.ascontiguousarray(w[4 + d:4 + d + n_chain]) if n_chain else np.zeros(1)
+            excl = gidx - idx_base if (distinct and idx_base <= gidx < idx_base + cands.M) else -1
+            info = C.c_int64(0)
+            _lib.check(L.abo_cand_qei_pick(h, c, gidx, float(w[3]), cx.ctypes.data, n_chain, excl, C.byref(info)), info.value)
+            n_chain += 1
+    finally:
+        _lib.check(L.abo_cand_qei_end(h, c))
+    _lib.check(L.abo_cand_qei_stats(h, c, C.byref(st)))
+    return np.array(picks), np.array(idxs, dtype=np.int64), np.array(vals), np.array(mus), st.as_dict()
+
+
+def _ring_update(in_block, gix, q, cands):
+    """global indices currently covered by a block: the library keeps a ring of min(q, 4) blocks, the oldest is overwritten"""
+    ring = getattr(cands, "_qei_ring", None)
+    if ring is None or not in_block:
+        ring = []
+    ring.append(set(gix.tolist()))
+    ring = ring[-min(q, 4):]
+    cands._qei_ring = ring
+    return set().union(*ring)
+
+
+def _sorted_valid(recs: np.ndarray) -> np.ndarray:
+    """records {score, global index, …} in the reference's order (score descending with NaN first, ties → lowest index); records of
+    empty shards (index −1) dropped"""
+    v = recs[recs[:, 1] >= 0]
+    if len(v) == 0:
+        return v
+    b = v[:, 0].copy().view(np.uint64)
+    neg = (b >> np.uint64(63)).astype(bool)
+    key = np.where(neg, ~b, b | np.uint64(0x8000000000000000))
+    key = np.where(np.isnan(v[:, 0]), np.uint64(0xFFFFFFFFFFFFFFFF), key)
+    order = np.lexsort((v[:, 1], np.iinfo(np.uint64).max - key))
+    return v[order]
+
+
+def _allgather_rows(rows: np.ndarray, dist, group) -> np.ndarray:
+    """all_gather a (k, words) block of records per rank → (world·k, words)"""
+    import torch
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(rows))
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.cat(out).cpu().numpy()
+
+
 def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: float, best_y: float, idx_base: int = 0,
-               group=None, distinct: bool = False, condition_last: bool = True):
+               group=None, distinct: bool = False, condition_last: bool = True, block=None, rollback: bool = False,
+               stats: dict = None):
     """Greedy q-EI (Kriging believer): for j = 1..q  pick argmax EI over the resident grid, condition on the
-    fantasy (z_j, μ(z_j)) with a bordered append, down-date the grid's posterior, repeat.
+    fantasy (z_j, μ(z_j)), repeat.
     With torch.distributed initialised (`group`), every rank holds a shard of the grid: the arg-max is the
-    only exchange (one all_gather of (score, global index, μ, x[d]) per pick) and every rank applies the
-    same append.  Returns (batch points (q, d), their global indices, their EI values, the final model).
+    only exchange (one all_gather of a pick record per pick) and every rank applies the same conditioning.
+    Returns (batch points (q, d), their global indices, their EI values, the final model).
     `cands` must be in sync with `model`; on return it is in sync with the returned model.
     distinct=True takes every picked candidate out of the running (abo_cand_exclude): with observation noise the
     fantasy does not collapse the variance at a picked point, and the plain rule may return it again.
     condition_last=False leaves the q-th pick unconditioned (the batch does not depend on it): model and `cands` then hold
-    q − 1 fantasies on return — for callers that roll the fantasies back anyway (`cands.save()` … `cands.restore()`), it
-    saves one bordered append and one O(N·M) down-date pass per batch."""
+    q − 1 fantasies on return.
+    rollback=True: the batch only — model and `cands` are as before on return (what a BO step wants: the points go to the real
+    objective, and the real observations are appended afterwards; in the block form those appends find their down-date columns in
+    the chain the batch left with the set).
+    block: None = the library's default (block form with T = 32 when the model and the set qualify), 0 / False = the plain loop
+    (one bordered append and one O(N·M) pass over the resident K_ZX per pick), T = block form with T points per block.
+    stats (a dict, optional) receives the batch's statistics (abo_qei_stats)."""
+    use_block = (block is None or bool(block)) and not hasattr(model, "p") and 1 <= q <= 64
+    if use_block:
+        n_cond = q - 1 if (rollback or not condition_last) else q
+        try:
+            pts, idxs, vals, mus, st = _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, distinct,
+                                                        0 if block is None or block is True else int(block))
+        except ValueError as e:
+            if "block form" not in str(e) and "block size 0" not in str(e):
+                raise
+            use_block = False                  # the set or the model does not qualify: the plain loop below
+    if use_block:
+        if stats is not None:
+            stats.update(st)
+        if rollback:
+            return pts, idxs, vals, model
+        for j in range(n_cond):                # materialise the fantasies: each down-date finds its column in the chain
+            model = append(model, pts[j], float(mus[j]))
+            cands.downdate(model)
+            if distinct and idx_base <= idxs[j] < idx_base + cands.M:
+                cands.exclude(int(idxs[j]) - idx_base)
+        return pts, idxs, vals, model
+    if stats is not None:
+        stats.update({"block": 0, "picks": q})
+    if rollback:
+        cands.save()
+        try:
+            pts, idxs, vals, _ = greedy_qei(model, cands, q, xi, best_y, idx_base, group, distinct, False, 0, False)
+        finally:
+            cands.restore()
+        return pts, idxs, vals, model
     acq = ExpectedImprovement(xi, best_y)
     picks, idxs, vals = [], [], []
     dist = None

@@ -245,6 +245,12 @@ class ShardedCandidates:
                                                 int(bool(distinct)), X.ctypes.data, idx.ctypes.data, ei.ctypes.data))
         return X, idx, ei
 
+    def qei_stats(self, model: HipShardedGP) -> dict:
+        """statistics of the last greedy_qei on this set (abo_qei_stats; block = 0: the plain loop ran)"""
+        st = _lib.AboQeiStats()
+        _lib.check(_lib.lib().abo_mgpu_cand_qei_stats(model._require_group(), self._h.ptr, C.byref(st)))
+        return st.as_dict()
+
 
 def append(model: HipShardedGP, x, y, cands: ShardedCandidates | None = None) -> HipShardedGP:
     """Bordered append of one observation on every device (returns a new model; `model` stays valid); a sharded

@@ -217,7 +217,7 @@ def contraction_label(abo, med):
     return (f"int8-residue, {int(med['oz_nmod'])} moduli: exact integer products and sums of fixed-point images of the fp64 operands "
             "(K_XZ kept to 2^-52 of sigma_f2; each row of L^-1 kept to >= 50 bits below that row's L1 norm, i.e. an entry far below its "
             "row's L1 norm keeps fewer of its own bits - at most log2(N) fewer than 53 for a dense equal-magnitude row); results fp64, "
-            "parity vs the oracle recorded in profiles/parity_r04.json")
+            "parity vs the oracle recorded in profiles/parity_r05.json")
 
 
 def dominant_kernel_roofline(abo, med, config, N, M_per):

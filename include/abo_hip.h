@@ -27,13 +27,16 @@
 extern "C" {
 #endif
 
-#define ABO_ABI_VERSION 5   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
+#define ABO_ABI_VERSION 6   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
                                3: abo_set_contraction, abo_timings grew (contraction engine and its phases)
                                4: abo_refine, abo_optimize_acquisition, abo_mgpu_optimize_acquisition, abo_fit_acq, abo_mgpu_create_grad,
                                   abo_mgpu_append_grad; abo_timings grew (refinement stage)
                                5: abo_mgpu_cand_get; abo_acq_lhs (the grid stage on a single handle); weighted-sum objectives and
                                   gradient-enhanced handles in the refinement stage (abo_acq_term, abo_refine_terms,
-                                  abo_optimize_acquisition_terms, abo_mgpu_optimize_acquisition_terms, ABO_ACQ_GRADNORM_UCB) */
+                                  abo_optimize_acquisition_terms, abo_mgpu_optimize_acquisition_terms, ABO_ACQ_GRADNORM_UCB)
+                               6: block form of greedy q-EI: abo_cand_qei (+ _begin / _top / _block / _pick / _end for hosts that
+                                  shard the set themselves), abo_qei_stats, abo_set_qei_block, abo_mgpu_cand_qei_stats;
+                                  abo_cand_downdate finds the down-date column of a pick appended for real in the batch's chain */
 
 /* status codes */
 enum {
@@ -127,6 +130,9 @@ typedef struct abo_timings {
      * refined and the acquisition evaluations (value + analytic gradient each) all starts took together */
     double refine_ms;
     int64_t refine_starts, refine_evals;
+    /* ABI 6: 1 when the last abo_cand_downdate on this handle took its column from the chain of the set's last block-form q-EI
+     * batch (no pass over K_ZX: downdate_bytes = 0, downdate_ms = the new K_ZX column only) */
+    int64_t downdate_from_chain;
 } abo_timings;
 
 /* --- lifetime -------------------------------------------------------------------------------
@@ -311,6 +317,55 @@ int32_t abo_cand_point(abo_gp* gp, abo_cand* c, int64_t idx, double* x, double* 
  * observation noise the Kriging-believer fantasy does not collapse the variance at a picked point. */
 int32_t abo_cand_exclude(abo_gp* gp, abo_cand* c, int64_t idx);
 
+/* --- greedy (Kriging-believer) q-EI on a resident set, block form (ABI 6) -----------------------------------------
+ * No reference counterpart (the reference's EI is single-point, src/acquisition_functions/ExpectedImprovement.jl:40-66, and its
+ * update always refits, src/surrogates/StandardGP.jl:79-83): q × [EI over the grid → arg-max → condition the grid's posterior on
+ * the fantasy observation (x_j, μ(x_j))] — each sub-step exactly `update` + EI semantics.  What a pick needs of
+ * the resident K_ZX is one column of posterior covariances c_j(z) = Cov_{j−1}(z, x_j):
+ *     Cov₀(z, x) = k(z, x) − k_zᵀK⁻¹k_x                                     under the model the set is synced with (the base),
+ *     c_j(z) = Cov₀(z, x_j) − Σ_{i<j} c_i(z)·c_i(x_j)/s_i,   s_i = σ²_{i−1}(x_i) + σ²_n,   σ²_j(z) = σ²_{j−1}(z) − c_j(z)²/s_j
+ * (μ is not touched: the fantasy value is the mean).  Cov₀ for a BLOCK of T points is ONE pass over K_ZX (a T-column product
+ * on the fp64 matrix pipe under the 8·N·M-byte stream) where the plain loop (abo_append + abo_cand_downdate per pick) streams
+ * K_ZX once per pick.  The block is the T best candidates of the current scores; a pick outside every block builds a new block
+ * from the scores of that moment.  Nothing is appended to the model: on return model and set are as before (the batch is
+ * rolled back), and the chain c_1 … c_{q−1} stays with the set — appending the picks for real, in order
+ * (abo_append(gp, x_1, y_1) → abo_cand_downdate, …), finds each down-date column there instead of streaming K_ZX again
+ * (c_j does not depend on the observed value).
+ *   abo_cand_qei: the whole batch on one handle.  x_out q × d, idx_out / ei_out q (idx = idx_base + local index);
+ *     distinct != 0 excludes every picked candidate for the rest of the call; block = T (16 … 64, rounded up to a multiple of
+ *     16; 0 = the process default, abo_set_qei_block / ABO_QEI_BLOCK, initially 32; < 0 = the plain loop).  The plain loop
+ *     is also what runs for a gradient-enhanced model, for a set whose K_ZX is not resident, and for q > 64.  stats may be NULL.
+ *   For a host that shards the set itself (one process per GPU: abstractbayesopt.jl_amd/incremental.py over torch.distributed)
+ *   the same batch in steps; every shard makes the same calls with the same exchanged numbers, so a sharded set repeats the
+ *   single set's arithmetic bit for bit:
+ *     _begin(gp, c, q, block)                         snapshot σ², μ; empty chain and blocks
+ *     _top(gp, c, xi, best_y, idx_base, k, rec)       EI over the shard and its k best as records of 4 + d + n doubles
+ *                                                     {EI, global index (−1: none), μ, σ², x[0..d), c_1(x) … c_n(x)}, n = picks so far
+ *     _block(gp, c, pts, gidx, T)                     Cov₀ columns of T points (the merged best T of all shards) in one pass
+ *     _pick(gp, c, gidx, var_x, cx, n, excl, info)    condition on the pick (its point must be in a block): var_x = σ²(x) and
+ *                                                     cx[i] = c_{i+1}(x), i < n, both from the winner's record; excl ≥ 0: local index
+ *                                                     to exclude; σ²(x) + noise ≤ 0 → ABO_ENOTPD, *info = N + n + 1 (the failed pivot
+ *                                                     of the plain loop's bordered append)
+ *     _end(gp, c)                                     roll σ², μ back; the chain stays for abo_cand_downdate */
+typedef struct abo_qei_stats {
+    int32_t picks, block, block_builds, block_hits;   /* block = T (0: the plain loop ran); hits: picks found in an existing block */
+    double total_ms;                /* host wall clock of the call */
+    double block_ms;                /* HIP events: all block builds of the batch (K⁻¹K_XT + the pass over K_ZX + kernel values) */
+    double pass_ms;                 /* HIP events: the product over the resident K_ZX of the LAST block build */
+    double pass_bytes, pass_flop;   /* algorithmic: 8·N·M bytes of K_ZX streamed once, 2·N·M·T flop */
+} abo_qei_stats;
+int32_t abo_set_qei_block(int32_t block);
+int32_t abo_cand_qei(abo_gp* gp, abo_cand* c, int32_t q, double xi, double best_y, int32_t distinct, int64_t idx_base, int32_t block,
+                     double* x_out, int64_t* idx_out, double* ei_out, abo_qei_stats* stats);
+int32_t abo_cand_qei_begin(abo_gp* gp, abo_cand* c, int32_t q, int32_t block);
+int32_t abo_cand_qei_top(abo_gp* gp, abo_cand* c, double xi, double best_y, int64_t idx_base, int32_t k, double* rec);
+int32_t abo_cand_qei_block(abo_gp* gp, abo_cand* c, const double* pts, const int64_t* gidx, int32_t T);
+int32_t abo_cand_qei_pick(abo_gp* gp, abo_cand* c, int64_t gidx, double var_x, const double* cx, int32_t n, int64_t excl,
+                          int64_t* info);
+int32_t abo_cand_qei_end(abo_gp* gp, abo_cand* c);
+/* statistics of the set's current / last block-form batch (abo_cand_qei fills its own `stats` from the same numbers) */
+int32_t abo_cand_qei_stats(abo_gp* gp, abo_cand* c, abo_qei_stats* out);
+
 /* --- grid generation and stand-alone epilogue (DEVICE buffers) --------------------------------------
  * abo_lhs: points j0 .. j0+count−1 of an n-point Latin-hypercube design in the box [lower, upper]
  * (QuasiMonteCarlo.sample(n, lower, upper, LatinHypercubeSample()), src/acquisition_functions/acq_utils.jl:44-47)
@@ -432,6 +487,9 @@ int32_t abo_mgpu_cand_acq(abo_mgpu* mg, abo_mcand* mc, int32_t kind, double p0, 
 int32_t abo_mgpu_cand_get(abo_mgpu* mg, abo_mcand* mc, double* mu, double* var);
 int32_t abo_mgpu_cand_qei(abo_mgpu* mg, abo_mcand* mc, int32_t q, double xi, double best_y, int32_t distinct, double* x_out,
                           int64_t* idx_out, double* ei_out);
+/* statistics of the last abo_mgpu_cand_qei on this set (shard 0's; block = 0 when the plain loop ran).  ABI 6: abo_mgpu_cand_qei
+ * runs the block form (abo_cand_qei's; block size = the process default) whenever every shard qualifies, the plain loop else. */
+int32_t abo_mgpu_cand_qei_stats(abo_mgpu* mg, abo_mcand* mc, abo_qei_stats* out);
 
 /* --- memory -----------------------------------------------------------------------------------
  * Device buffers of destroyed handles are cached per device (update() makes a new model every BO

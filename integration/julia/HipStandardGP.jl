@@ -31,7 +31,7 @@ const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
 else
     macro abocall(ex) esc(:(@ccall $ex)) end
 end
-const ABO_ABI = Int32(5)                 # ABO_ABI_VERSION of the header this file was written against
+const ABO_ABI = Int32(6)                 # ABO_ABI_VERSION of the header this file was written against
 const _abi_checked = Ref(false)
 # a stale libabo_hip.so on the load path would otherwise fail at the first missing symbol, somewhere inside a BO step
 function _ensure_abi()
@@ -427,33 +427,27 @@ function top_k(acqf::Union{ExpectedImprovement,UpperConfidenceBound,ProbabilityI
     tv, ti .+ 1
 end
 
-# Greedy (Kriging-believer) q-EI over the grid: q × (EI + arg-max) with a fantasy append y = μ(x) and a down-date between
-# picks; model and grid are as before on return.  (points d × q, 1-based grid indices, EI values)
-function greedy_qei(c::HipCandidates, q::Int; ξ::Float64=0.01, best_y::Float64, distinct::Bool=false)
+# Greedy (Kriging-believer) q-EI over the grid: q × (EI + arg-max over the grid, condition the grid's posterior on the fantasy
+# observation y = μ(x) at the pick); model and grid are as before on return.  One library call: the block form (include/abo_hip.h —
+# the posterior covariances of the `block` best candidates to every candidate from ONE pass over the resident K_ZX, rank-1
+# corrections between picks, no fantasy appends; block = 0: the library default, < 0: one bordered append and one pass per pick).
+# Appending the picks afterwards with their real observations, in order (`append_observation!`), finds each down-date column in
+# the chain the batch left with the grid.  (points d × q, 1-based grid indices, EI values)
+struct AboQeiStats          # must match `struct abo_qei_stats`
+    picks::Int32; block::Int32; block_builds::Int32; block_hits::Int32
+    total_ms::Float64; block_ms::Float64; pass_ms::Float64; pass_bytes::Float64; pass_flop::Float64
+end
+function greedy_qei(c::HipCandidates, q::Int; ξ::Float64=0.01, best_y::Float64, distinct::Bool=false, block::Int=0)
     X = Matrix{Float64}(undef, c.d, q); idx = Vector{Int64}(undef, q); ei = Vector{Float64}(undef, q)
+    st = Ref(AboQeiStats(0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0.0))
     if c.multi
         GC.@preserve X idx ei _check(@abocall LIBABO.abo_mgpu_cand_qei(c.model.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, q::Int32, ξ::Float64,
                                                                         best_y::Float64, Int32(distinct)::Int32, X::Ptr{Float64},
                                                                         idx::Ptr{Int64}, ei::Ptr{Float64})::Int32)
         return X, idx .+ 1, ei
     end
-    base = c.model
-    _check(@abocall LIBABO.abo_cand_save(base.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
-    cur = base; tv = Ref{Float64}(); ti = Ref{Int64}(); mu = Ref{Float64}(); x = Vector{Float64}(undef, c.d)
-    try
-        for j in 1:q
-            _check(@abocall LIBABO.abo_cand_acq(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, 0::Int32, ξ::Float64, best_y::Float64, 0::Int64,
-                                                 C_NULL::Ptr{Float64}, 1::Int32, tv::Ptr{Float64}, ti::Ptr{Int64}, 0::Int32)::Int32)
-            GC.@preserve x _check(@abocall LIBABO.abo_cand_point(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, ti[]::Int64, x::Ptr{Float64},
-                                                                  mu::Ptr{Float64}, C_NULL::Ptr{Float64})::Int32)
-            X[:, j] .= x; idx[j] = ti[] + 1; ei[j] = tv[]
-            j == q && break                                     # the last pick conditions nothing
-            cur = append(cur, copy(x), mu[])                    # fantasy observation y = μ(x)
-            _check(@abocall LIBABO.abo_cand_downdate(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
-            distinct && _check(@abocall LIBABO.abo_cand_exclude(cur.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, ti[]::Int64)::Int32)
-        end
-    finally
-        _check(@abocall LIBABO.abo_cand_restore(base.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid})::Int32)
-    end
-    X, idx, ei
+    GC.@preserve X idx ei _check(@abocall LIBABO.abo_cand_qei(c.model.gpx.ptr::Ptr{Cvoid}, c.ptr::Ptr{Cvoid}, q::Int32, ξ::Float64,
+                                                               best_y::Float64, Int32(distinct)::Int32, 0::Int64, block::Int32,
+                                                               X::Ptr{Float64}, idx::Ptr{Int64}, ei::Ptr{Float64}, st::Ptr{AboQeiStats})::Int32)
+    X, idx .+ 1, ei            # (st[]: block size, blocks built, picks found in a block, the pass over K_ZX in ms)
 end

@@ -290,3 +290,108 @@ def test_greedy_qei_distinct_batch_under_noise():
     mu1, var1 = cands.mean_and_var()
     np.testing.assert_array_equal(mu1, mu0)
     np.testing.assert_array_equal(var1, var0)
+
+
+def _oracle_greedy(fam, ell, sf2, noise, X, y, Z, q, xi, best):
+    """the batch from scratch: refit on the N + j points, EI over the grid, arg-max, Kriging-believer value"""
+    Xo, yo, idx, val = X.copy(), y.copy(), [], []
+    for j in range(q):
+        st = O.fit(fam, ell, sf2, noise, 0.0, Xo, yo)
+        mu, var = O.predict(st, Z)
+        v, i = O.top_k(O.expected_improvement(mu, var, best, xi), 1)
+        idx.append(int(i[0])); val.append(float(v[0]))
+        Xo = np.vstack([Xo, Z[i[0]]]); yo = np.append(yo, mu[i[0]])
+    return np.array(idx), np.array(val)
+
+
+@pytest.mark.parametrize("fam,d,N0,M,q,ell,noise,block", [
+    (O.MATERN52, 4, 200, 3000, 6, 0.6, 1e-6, 0),       # default block (32), near-noiseless
+    (O.MATERN52, 16, 500, 5000, 8, 2.0, 1e-2, 16),     # the C5 shape: noisy, long length scale
+    (O.SE, 2, 130, 2500, 12, 0.25, 1e-4, 16),          # short length scale: the picks leave the first block (new blocks are built)
+    (O.MATERN72, 3, 40, 37, 5, 0.7, 1e-3, 64),         # fewer candidates than a block holds
+])
+def test_block_qei_equals_the_plain_loop_and_the_from_scratch_batch(fam, d, N0, M, q, ell, noise, block):
+    """The block form of greedy q-EI (covariance columns of T points from one pass over K_ZX, rank-1 corrections between picks, no
+    fantasy appends) against (a) the plain loop (bordered append + one pass per pick) and (b) the oracle's from-scratch batch: same
+    picks, EI values to rounding.  The one-call C driver (abo_cand_qei) and the Python driver over the step calls agree bit for bit."""
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    best, xi = float(y.min()), 0.01
+    m = abo.update(make_model(fam, ell, 1.0, noise, n_max=N0 + 64), X, y)
+    cands = abo.ResidentCandidates(m, Z)
+    mu0, var0 = cands.mean_and_var()
+    pts_c, idx_c, val_c, st = cands.qei(q, xi, best, block=block)
+    assert st["block"] == (32 if block == 0 else block) and st["picks"] == q
+    assert st["block_builds"] >= 1 and st["block_builds"] + st["block_hits"] == q - 1
+    if fam == O.SE:
+        assert st["block_builds"] > 1, st                      # this case exists for the rebuild path
+    np.testing.assert_array_equal(cands.mean_and_var()[0], mu0)   # rolled back
+    np.testing.assert_array_equal(cands.mean_and_var()[1], var0)
+    stats = {}
+    pts_p, idx_p, val_p, m_same = abo.greedy_qei(m, cands, q, xi, best, block=block or None, rollback=True, stats=stats)
+    assert m_same is m and stats["block_builds"] == st["block_builds"]
+    np.testing.assert_array_equal(idx_p, idx_c)
+    np.testing.assert_array_equal(val_p, val_c)
+    np.testing.assert_array_equal(pts_p, pts_c)
+    pts_l, idx_l, val_l, _ = cands.qei(q, xi, best, block=-1)[:4]   # the plain loop, same call
+    np.testing.assert_array_equal(idx_l, idx_c)
+    np.testing.assert_array_equal(pts_l, Z[idx_c])
+    case = f"qei_block/fam{fam}_d{d}_N{N0}_M{M}_q{q}_T{block}"
+    check(case, "ei_vs_plain_loop", np.max(np.abs(val_l - val_c) / np.maximum(1e-3 * val_l[0], np.abs(val_l))), 1e-9)
+    idx_o, val_o = _oracle_greedy(fam, ell, 1.0, noise, X, y, Z, q, xi, best)
+    np.testing.assert_array_equal(idx_c, idx_o)
+    check(case, "ei_vs_from_scratch", np.max(np.abs(val_o - val_c) / np.maximum(1e-3 * val_o[0], np.abs(val_o))), 1e-8)
+    np.testing.assert_array_equal(cands.mean_and_var()[1], var0)
+
+
+def test_real_appends_after_a_block_batch_take_their_columns_from_the_chain(monkeypatch):
+    """After a block-form batch the picks are appended for real, in order: every down-date finds its column c_i(z) in the chain the
+    batch left with the set (abo_timings.downdate_from_chain) instead of streaming K_ZX — same posterior as the streaming pass to
+    rounding, and as the oracle's refit; the appended K_ZX columns are written either way (a later streaming pass is right)."""
+    d, N0, M, q = 6, 300, 4000, 5
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    fam, ell, noise, best = O.MATERN52, 0.9, 1e-3, float(y.min())
+    out = {}
+    for mode in ("chain", "stream"):
+        if mode == "stream":
+            monkeypatch.setenv("ABO_QEI_NO_CHAIN", "1")
+        m = abo.update(make_model(fam, ell, 1.0, noise, n_max=N0 + 64), X, y)
+        cands = abo.ResidentCandidates(m, Z)
+        pts, idx, val, _ = cands.qei(q, 0.01, best)
+        Xo, yo, flags = X.copy(), y.copy(), []
+        for j in range(q):                                   # q − 1 chain columns; the q-th pick was never conditioned on
+            y_real = float(np.sin(3.0 * pts[j]).sum())
+            m = abo.append(m, pts[j], y_real)
+            cands.downdate(m)
+            flags.append(m.timings()["downdate_from_chain"])
+            Xo = np.vstack([Xo, pts[j]]); yo = np.append(yo, y_real)
+        assert flags == ([1] * (q - 1) + [0] if mode == "chain" else [0] * q), flags
+        m = abo.append(m, X[0] + 0.01, 0.3)                  # not a pick: the streaming pass over K_ZX incl. the q new columns
+        cands.downdate(m)
+        Xo = np.vstack([Xo, X[0] + 0.01]); yo = np.append(yo, 0.3)
+        out[mode] = cands.mean_and_var()
+    st = O.fit(fam, ell, 1.0, noise, 0.0, Xo, yo)
+    mu_o, var_o = O.predict(st, Z)
+    case = f"qei_chain/d{d}_N{N0}_M{M}_q{q}"
+    check(case, "mu_chain_vs_stream", np.max(np.abs(out["chain"][0] - out["stream"][0])), 1e-10)
+    check(case, "var_chain_vs_stream", np.max(np.abs(out["chain"][1] - out["stream"][1])), 1e-10)
+    check(case, "mu", np.max(np.abs(out["chain"][0] - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
+    check(case, "var", np.max(np.abs(out["chain"][1] - var_o)), 1e-8)
+
+
+def test_block_batch_refuses_what_it_cannot_do_and_falls_back():
+    d, N0 = 3, 60
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, 500, d)
+    m = abo.update(make_model(O.MATERN52, 0.7, 1.0, 1e-3, n_max=N0 + 128), X, y)
+    cands = abo.ResidentCandidates(m, Z)
+    L = abo._lib.lib()
+    with pytest.raises(ValueError):                          # no batch open
+        abo._lib.check(L.abo_cand_qei_pick(m._require(), cands._h.ptr, 0, 1.0, None, 0, -1, None))
+    m2 = abo.append(m, Z[0], 0.1)                            # the set is not in sync with m2
+    with pytest.raises(ValueError):
+        abo._lib.check(L.abo_cand_qei_begin(m2._require(), cands._h.ptr, 4, 0))
+    del m2
+    pts, idx, val, st = cands.qei(66, 0.01, float(y.min()))  # q > 64: the plain loop
+    assert st["block"] == 0 and len(idx) == 66 and np.all(idx >= 0)

@@ -18,7 +18,8 @@ SHIMS = [os.path.join(ROOT, "integration", "julia", f) for f in ("HipStandardGP.
 OPAQUE = {"abo_gp", "abo_cand", "abo_mgpu", "abo_mcand", "void"}
 SCALARS = {"Int32": "int32_t", "Int64": "int64_t", "UInt64": "uint64_t", "Float64": "double", "Csize_t": "size_t"}
 POINTEES = {"Float64": "double", "Int64": "int64_t", "Int32": "int32_t", "UInt8": "char", "AboParams": "abo_params",
-            "AboRefineOpts": "abo_refine_opts", "AboAcqTerm": "abo_acq_term", "AboTimings": "abo_timings"}
+            "AboRefineOpts": "abo_refine_opts", "AboAcqTerm": "abo_acq_term", "AboTimings": "abo_timings",
+            "AboQeiStats": "abo_qei_stats"}
 
 
 def _strip_c_comments(text):
@@ -162,7 +163,7 @@ def test_every_ccall_matches_its_prototype():
 
 
 @pytest.mark.parametrize("jl_name,c_name", [("AboParams", "abo_params"), ("AboRefineOpts", "abo_refine_opts"),
-                                            ("AboAcqTerm", "abo_acq_term")])
+                                            ("AboAcqTerm", "abo_acq_term"), ("AboQeiStats", "abo_qei_stats")])
 def test_mirrored_structs_have_the_header_layout(jl_name, c_name):
     jl = julia_struct(SHIMS[0], jl_name)
     c = c_struct(c_name)
