@@ -277,6 +277,12 @@ hipError_t launch_qei_zero_tail(double* V, int64_t ld, int N, int Np, int rows, 
 // C[t][j] += sigma_f2·kappa(‖Ps_t − s·z_j‖²) for t < T, j < M   (Ps: the block points pre-scaled, [T][dp]; C: [T][Mp])
 hipError_t launch_qei_cov(const double* Ps, int dp, const double* Z, int64_t M, int64_t Mp, int d, int T, int family, double s,
                           double sigma_f2, double* C, hipStream_t st);
+// C[r][j] = alpha·Σ_{k<K} A[r][k]·B[j][k], r < rows16 (16 … 64, a multiple of 16), j < nB (a multiple of 128), K a multiple of 128:
+// the one pass over a long B (gemm.hip: qei_pass_kernel; same bits as the skinny split-k kernel with one chunk)
+// kmode K_B_LOWER / K_B_UPPER with ksplit (a multiple of 128): the split-k form against a triangular B — chunk z of the k range of B's row
+// block tj → the partial product C + z·sC (launch_splitk_reduce sums them)
+hipError_t launch_qei_pass(const double* A, int64_t lda, int rows16, const double* B, int64_t ldb, int64_t nB, int K, double alpha,
+                           double* C, int64_t ldc, hipStream_t s, int kmode = K_FULL, int ksplit = 0, int64_t sC = 0);
 // out[j] = blk[j] − Σ_{i<nchain} gam[i]·chain[i][j] ;  var[j] −= out[j]²/s  (var == nullptr: the column only)
 struct QeiPickArgs {
     const double* blk;      // [M]   base covariances of the picked point (a row of the block)

@@ -393,7 +393,7 @@ struct abo_cand {
         std::vector<double> chain_x;              // [nchain][d] the picked points
         std::vector<double> chain_s;              // [nchain] s_i = σ²_{i−1}(x_i) + σ²_n
         // statistics of the current / last batch
-        int builds = 0, hits = 0;
+        int builds = 0;
         double block_ms = 0.0, pass_ms = 0.0, pass_bytes = 0.0, pass_flop = 0.0;
     } qei;
     DevBuf qblk, qchain, qwork, qrec, qmu, qvar;
@@ -2118,6 +2118,7 @@ int32_t abo::qei_eligible(abo_gp* g, abo_cand* c, int q) {
     if (c->M > 0 && !(c->kzx_ld > 0 && c->kzx_ld == g->st->cap)) return fail(ABO_EINVAL, "q-EI, block form: K_ZX of the set is not resident");
     if (q < 1 || q > QEI_MAXQ) return fail(ABO_EINVAL, "q-EI, block form: q = %d outside 1..%d", q, QEI_MAXQ);
     if (getenv("ABO_GEMM_NO_SKINNY")) return fail(ABO_EINVAL, "q-EI, block form: needs the skinny product (ABO_GEMM_NO_SKINNY is set)");
+    if ((size_t)QEI_MAXT * c->d * sizeof(double) > 65536) return fail(ABO_EINVAL, "q-EI, block form: d = %d > 128 takes the plain loop", c->d);
     return ABO_OK;
 }
 
@@ -2195,25 +2196,33 @@ int32_t abo::qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t*
     HIPCHK(launch_scale_points(w.P, w.Ps, T, T16, d, dp, 1.0 / g->prm.ell, s));
     HIPCHK(launch_qei_kxt(g->st->Xs.as<double>(), dp, N, Np, w.P, d, T, T16, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, w.KXT, s));
     // V[t][i] = Σ_{k ≤ i} K_XT[t][k]·W[i][k] = (L⁻¹k_t)[i];  U[t][i] = Σ_{k ≥ i} V[t][k]·WT[i][k] = (K⁻¹k_t)[i]
+    const bool via_skinny = getenv("ABO_QEI_PASS_SKINNY") != nullptr;      // A/B runs and the bit-equality test: gemm.hip's split-k kernel
+    const int64_t sC = (int64_t)T16 * Np;
     GemmArgs g1{};
-    g1.A = w.KXT; g1.lda = Np; g1.B = g->st->W.as<double>(); g1.ldb = ld; g1.C = w.Ct; g1.ldc = Np; g1.sC = (int64_t)T16 * Np;
+    g1.A = w.KXT; g1.lda = Np; g1.B = g->st->W.as<double>(); g1.ldb = ld; g1.C = w.Ct; g1.ldc = Np; g1.sC = sC;
     g1.M = TB; g1.N = Np; g1.K = Np; g1.kmode = K_B_LOWER; g1.lower_only = 0; g1.batch = 1; g1.alpha = 1.0; g1.beta = 0.0;
     g1.ksplit = w.ks; g1.mrows = T16;
-    HIPCHK(launch_gemm_nt(g1, s));
-    HIPCHK(launch_splitk_reduce(w.Ct, Np, g1.sC, w.nz, T16, Np, Np, w.ks, K_B_LOWER, w.V, Np, s));
+    if (via_skinny) HIPCHK(launch_gemm_nt(g1, s));
+    else HIPCHK(launch_qei_pass(w.KXT, Np, T16, g->st->W.as<double>(), ld, Np, Np, 1.0, w.Ct, Np, s, K_B_LOWER, w.ks, sC));
+    HIPCHK(launch_splitk_reduce(w.Ct, Np, sC, w.nz, T16, Np, Np, w.ks, K_B_LOWER, w.V, Np, s));
     HIPCHK(launch_qei_zero_tail(w.V, Np, N, Np, T16, s));      // rows ≥ N of a shared factor may hold a discarded appended branch
     GemmArgs g2 = g1;
     g2.A = w.V; g2.B = g->st->WT.as<double>(); g2.kmode = K_B_UPPER;
-    HIPCHK(launch_gemm_nt(g2, s));
-    HIPCHK(launch_splitk_reduce(w.Ct, Np, g2.sC, w.nz, T16, Np, Np, w.ks, K_B_UPPER, w.U, Np, s));
+    if (via_skinny) HIPCHK(launch_gemm_nt(g2, s));
+    else HIPCHK(launch_qei_pass(w.V, Np, T16, g->st->WT.as<double>(), ld, Np, Np, 1.0, w.Ct, Np, s, K_B_UPPER, w.ks, sC));
+    HIPCHK(launch_splitk_reduce(w.Ct, Np, sC, w.nz, T16, Np, Np, w.ks, K_B_UPPER, w.U, Np, s));
     HIPCHK(launch_qei_zero_tail(w.U, Np, N, Np, T16, s));
     // C[t][z] = −Σ_k U[t][k]·K_ZX[z][k]: one pass over the resident K_ZX for all T columns (columns ≥ N of K_ZX meet U = 0)
     HIPCHK(hipEventRecord(ev[1], s));
-    GemmArgs g3{};
-    g3.A = w.U; g3.lda = Np; g3.B = c->Kzx.as<double>(); g3.ldb = c->kzx_ld; g3.C = C; g3.ldc = Mp; g3.sC = 0;
-    g3.M = TB; g3.N = (int)Mp; g3.K = Np; g3.kmode = K_FULL; g3.lower_only = 0; g3.batch = 1; g3.alpha = -1.0; g3.beta = 0.0;
-    g3.ksplit = Np; g3.mrows = T16;
-    HIPCHK(launch_gemm_nt(g3, s));
+    if (via_skinny) {
+        GemmArgs g3{};
+        g3.A = w.U; g3.lda = Np; g3.B = c->Kzx.as<double>(); g3.ldb = c->kzx_ld; g3.C = C; g3.ldc = Mp; g3.sC = 0;
+        g3.M = TB; g3.N = (int)Mp; g3.K = Np; g3.kmode = K_FULL; g3.lower_only = 0; g3.batch = 1; g3.alpha = -1.0; g3.beta = 0.0;
+        g3.ksplit = Np; g3.mrows = T16;
+        HIPCHK(launch_gemm_nt(g3, s));
+    } else {
+        HIPCHK(launch_qei_pass(w.U, Np, T16, c->Kzx.as<double>(), c->kzx_ld, Mp, Np, -1.0, C, Mp, s));
+    }
     HIPCHK(hipEventRecord(ev[2], s));
     HIPCHK(launch_qei_cov(w.Ps, dp, c->Z.as<double>(), c->M, Mp, d, T, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, C, s));
     HIPCHK(hipEventRecord(ev[3], s));
@@ -2291,7 +2300,8 @@ int32_t abo::qei_end(abo_gp* g, abo_cand* c) {
 void abo::qei_get_stats(const abo_cand* c, int picks, double total_ms, abo_qei_stats* out) {
     if (!out) return;
     const abo_cand::Qei& Q = c->qei;
-    out->picks = picks; out->block = Q.T16; out->block_builds = Q.builds; out->block_hits = Q.hits;
+    out->picks = picks; out->block = Q.T16; out->block_builds = Q.builds;
+    out->block_hits = Q.nchain > Q.builds ? Q.nchain - Q.builds : 0;      // every conditioned pick either found its point in a block or had one built
     out->total_ms = total_ms; out->block_ms = Q.block_ms; out->pass_ms = Q.pass_ms; out->pass_bytes = Q.pass_bytes; out->pass_flop = Q.pass_flop;
 }
 
@@ -2362,8 +2372,6 @@ int32_t abo::qei_drive(const QeiShards& S, int q, double xi, double best_y, int 
             if (!found) { rc = fail(ABO_EINVAL, "q-EI: internal error: the pick is not among the best %d", Tb); break; }
             rc = S.run([&](int i) -> int32_t { return abo::qei_block(S.gp[i], S.cd[i], pts.data(), gix.data(), Tb); });
             if (rc) break;
-        } else {
-            for (int i = 0; i < n; ++i) ++S.cd[i]->qei.hits;
         }
         rc = S.run([&](int i) -> int32_t {
             const int64_t ex = (distinct && gidx >= S.lo[i] && gidx < S.lo[i] + S.cd[i]->M) ? gidx - S.lo[i] : -1;

@@ -407,6 +407,127 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs p) {
             }
 }
 
+// C[r][j] = alpha·Σ_{k<K} A[r][k]·B[j][k] for FEW rows of A (16·RG ≤ 64) against a LONG B that is read exactly once — the block form of
+// greedy q-EI (qei.hip): A = K⁻¹K_XT (T rows, a few MB: L2 / MALL resident), B = the resident K_ZX (M rows of N doubles, 17 GB at
+// config 5).  HBM-bound on B: 8·K·N bytes against 2·K·N·16RG flop.  The arithmetic of gemm_skinny_kernel — the same lane ↔ k map, the
+// same k order per accumulator, hence the same bits — with what that kernel leaves on the table for a stream of this length:
+//   * A goes through LDS once per workgroup (the skinny kernel's four waves each re-read their A fragments from L2: as many bytes
+//     as the wave's own share of B at RG = 2); row stride 68 doubles: the ds_read_b128 of the MFMA fragment map is conflict-free
+//     (16-byte slot (2·row + k-group) mod 16 is distinct over each of the instruction's four 16-lane groups);
+//   * B fragments of the NEXT 64-k chunk are in flight (32 VGPRs a lane, 16 KB a wave) under the 64 MFMAs of the current one.
+// One workgroup = 128 rows of B (wave w: rows 32w … 32w+31, two 16-row MFMA groups), 2 workgroups per CU.
+constexpr int QP_LDA = 68;                 // LDS row stride of the A chunk, doubles
+template <int RG>
+__global__ void __launch_bounds__(256, 2) qei_pass_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                                           double* __restrict__ Cbase, int64_t ldc, int K, double alpha, int kmode, int ksplit,
+                                                           int64_t sC) {
+    __shared__ __attribute__((aligned(16))) double sa[2][16 * RG * QP_LDA];
+    // the split-k form of gemm_skinny_kernel: chunk blockIdx.z of the (triangular) k range of B's row block tj → the partial product
+    // Cbase + z·sC; one chunk covering all of K (ksplit ≥ K, K_FULL) is the pass over K_ZX
+    const int tj = kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, bz = blockIdx.z;
+    int kbeg = 0, kend = K;
+    if (kmode == K_B_LOWER) kend = min(K, (tj + 1) * BN);
+    if (kmode == K_B_UPPER) kbeg = min(K, tj * BN);
+    kbeg = max(kbeg, bz * ksplit);
+    kend = min(kend, (bz + 1) * ksplit);
+    if (kbeg >= kend) return;                              // uniform over the workgroup
+    double* C = Cbase + (int64_t)bz * sC;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)tj * 128 + wave * 32;
+    const double* Bp = B + (row0 + r16) * ldb + 2 * g;
+    // A chunk → LDS: 16·RG rows × 64 doubles = RG·512 d2 elements, 256 threads → 2·RG elements each (element e: row e/32, pair e%32)
+    d2_t areg[2 * RG];
+    auto load_a = [&](int k) {
+#pragma unroll
+        for (int i = 0; i < 2 * RG; ++i) {
+            const int e = t + 256 * i;
+            areg[i] = *reinterpret_cast<const d2_t*>(A + (int64_t)(e >> 5) * lda + k + 2 * (e & 31));
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2 * RG; ++i) {
+            const int e = t + 256 * i;
+            *reinterpret_cast<d2_t*>(&sa[buf][(e >> 5) * QP_LDA + 2 * (e & 31)]) = areg[i];
+        }
+    };
+    d2_t x0[8], x1[8], y0[8], y1[8];                       // two register sets of B fragments, used alternately (no copies between them)
+    auto load_b = [&](d2_t* u0, d2_t* u1, int k) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            u0[q] = *reinterpret_cast<const d2_t*>(Bp + k + 8 * q);
+            u1[q] = *reinterpret_cast<const d2_t*>(Bp + 16 * ldb + k + 8 * q);
+        }
+    };
+    d4_t acc[RG][2];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) { acc[r][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[r][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
+    auto mfmas = [&](const d2_t* u0, const d2_t* u1, int buf) {
+        const double* ap = &sa[buf][r16 * QP_LDA + 2 * g];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            d2_t a[RG];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) a[r] = *reinterpret_cast<const d2_t*>(ap + r * 16 * QP_LDA + 8 * q);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][0], u0[q][0], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][0], u1[q][0], acc[r][1], 0, 0, 0);
+                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][1], u0[q][1], acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][1], u1[q][1], acc[r][1], 0, 0, 0);
+            }
+        }
+    };
+    load_a(kbeg);
+    load_b(x0, x1, kbeg);
+    store_a(0);
+    __syncthreads();
+    for (int k = kbeg; k < kend; k += 128) {               // kbeg, kend are multiples of 128: chunks k (set x, LDS 0) and k + 64 (set y, LDS 1)
+        // (sched_barrier: the scheduler otherwise sinks the loads below the MFMAs they are meant to fly under)
+        load_b(y0, y1, k + 64);
+        load_a(k + 64);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(x0, x1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(1);
+        __syncthreads();
+        const bool more = k + 128 < kend;
+        if (more) { load_b(x0, x1, k + 128); load_a(k + 128); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(y0, y1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) store_a(0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = 16 * r + g + 4 * e;                                   // C/D map: lane l, reg e → row (l>>4) + 4e, col l&15
+                C[row * ldc + row0 + 16 * h + r16] = alpha * acc[r][h][e];
+            }
+}
+
+hipError_t launch_qei_pass(const double* A, int64_t lda, int rows16, const double* B, int64_t ldb, int64_t nB, int K, double alpha,
+                           double* C, int64_t ldc, hipStream_t s, int kmode, int ksplit, int64_t sC) {
+    if (nB <= 0) return hipSuccess;
+    if (rows16 < 16 || rows16 > 64 || rows16 % 16 || nB % 128 || K <= 0 || K % 128 || (lda & 1) || (ldb & 1)) return hipErrorInvalidValue;
+    if (kmode != K_FULL && kmode != K_B_LOWER && kmode != K_B_UPPER) return hipErrorInvalidValue;
+    if (ksplit <= 0) ksplit = K;
+    if (ksplit % 128) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(nB / 128), 1, (unsigned)((K + ksplit - 1) / ksplit)), block(256);
+    switch (rows16 / 16) {
+        case 1: hipLaunchKernelGGL((qei_pass_kernel<1>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
+        case 2: hipLaunchKernelGGL((qei_pass_kernel<2>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
+        case 3: hipLaunchKernelGGL((qei_pass_kernel<3>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
+        default: hipLaunchKernelGGL((qei_pass_kernel<4>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.batch <= 0) return hipSuccess;
     const int64_t Tm = a.M / BM, Tn = a.N / BN;

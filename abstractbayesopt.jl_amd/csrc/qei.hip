@@ -51,20 +51,26 @@ __global__ void qei_zero_tail_kernel(double* V, int64_t ld, int N, int Np, int r
     if (e < w * rows) V[(int64_t)(e / w) * ld + N + e % w] = 0.0;
 }
 
+// one thread per candidate, the block points (pre-scaled) in LDS: z is read once per thread and stays in L1 over the T points; the
+// writes of a wave are 64 consecutive candidates of one block row
 template <int FAM>
 __global__ void __launch_bounds__(256) qei_cov_kernel(const double* __restrict__ Ps, int dp, const double* __restrict__ Z, int64_t M,
-                                                       int64_t Mp, int d, double s, double sigma_f2, double* __restrict__ C) {
+                                                       int64_t Mp, int d, int T, double s, double sigma_f2, double* __restrict__ C) {
+    extern __shared__ double ps[];                        // [T][d]
+    for (int e = threadIdx.x; e < T * d; e += 256) ps[e] = Ps[(int64_t)(e / d) * dp + e % d];
+    __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int t = blockIdx.y;
     if (j >= M) return;
-    const double* p = Ps + (int64_t)t * dp;               // pre-scaled, as a training row of Xs is
     const double* z = Z + j * d;
-    double r = 0.0;
-    for (int c = 0; c < d; ++c) {                         // as cand_newcol_kernel writes the column of p_t once it is a training row
-        const double e = p[c] - z[c] * s;
-        r = fma(e, e, r);
+    for (int t = 0; t < T; ++t) {
+        const double* p = ps + t * d;                     // pre-scaled, as a training row of Xs is
+        double r = 0.0;
+        for (int c = 0; c < d; ++c) {                     // as cand_newcol_kernel writes the column of p_t once it is a training row
+            const double e = p[c] - z[c] * s;
+            r = fma(e, e, r);
+        }
+        C[(int64_t)t * Mp + j] += sigma_f2 * kappa_eval<FAM>(r);
     }
-    C[(int64_t)t * Mp + j] += sigma_f2 * kappa_eval<FAM>(r);
 }
 
 __global__ void __launch_bounds__(256) qei_pick_kernel(QeiPickArgs a) {
@@ -116,12 +122,14 @@ hipError_t launch_qei_zero_tail(double* V, int64_t ld, int N, int Np, int rows, 
 hipError_t launch_qei_cov(const double* Ps, int dp, const double* Z, int64_t M, int64_t Mp, int d, int T, int family, double s,
                           double sigma_f2, double* C, hipStream_t st) {
     if (M <= 0 || T <= 0) return hipSuccess;
-    dim3 grid((unsigned)((M + 255) / 256), (unsigned)T), block(256);
+    dim3 grid((unsigned)((M + 255) / 256)), block(256);
+    const size_t lds = sizeof(double) * (size_t)T * d;
+    if (lds > 65536) return hipErrorInvalidValue;         // (T ≤ 64 points of d ≤ 128 coordinates)
     switch (family) {
-        case ABO_KERNEL_SE: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_SE>), grid, block, 0, st, Ps, dp, Z, M, Mp, d, s, sigma_f2, C); break;
-        case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_MATERN52>), grid, block, 0, st, Ps, dp, Z, M, Mp, d, s, sigma_f2, C); break;
-        case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_MATERN72>), grid, block, 0, st, Ps, dp, Z, M, Mp, d, s, sigma_f2, C); break;
-        case ABO_KERNEL_MATERN32: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_MATERN32>), grid, block, 0, st, Ps, dp, Z, M, Mp, d, s, sigma_f2, C); break;
+        case ABO_KERNEL_SE: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_SE>), grid, block, lds, st, Ps, dp, Z, M, Mp, d, T, s, sigma_f2, C); break;
+        case ABO_KERNEL_MATERN52: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_MATERN52>), grid, block, lds, st, Ps, dp, Z, M, Mp, d, T, s, sigma_f2, C); break;
+        case ABO_KERNEL_MATERN72: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_MATERN72>), grid, block, lds, st, Ps, dp, Z, M, Mp, d, T, s, sigma_f2, C); break;
+        case ABO_KERNEL_MATERN32: hipLaunchKernelGGL((qei_cov_kernel<ABO_KERNEL_MATERN32>), grid, block, lds, st, Ps, dp, Z, M, Mp, d, T, s, sigma_f2, C); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -393,32 +393,39 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     refresh_ms = float(np.median(refresh_all[1:]))
     fit_t = model.timings()
     best_y = float(y.min())
-    ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "restore_ms": [], "downdate_pass_ms": [], "downdate_pass_bytes": []}
+    ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "downdate_pass_ms": [], "downdate_pass_bytes": [], "block_ms": [],
+          "block_pass_ms": [], "block_pass_bytes": [], "block_pass_flop": []}
+    counts = {"block_builds": 0, "block_hits": 0, "downdates_from_chain": 0, "block": 0}
     picks = None
+    blk = None if args.qei_block is None else int(args.qei_block)
     for step in range(n_warm + n_steps):
         if step == n_warm:
             sync()
             t_start = time.perf_counter()
         ta = time.perf_counter()
-        cands.save()
-        pts, idxs, vals, m_q = abo.greedy_qei(model, cands, Q, xi, best_y, idx_base=lo, condition_last=False)   # rolled back below
-        del m_q
+        st = {}
+        # the batch only: model and grid are as before on return (block form: no fantasy appends, one pass over K_ZX per block)
+        pts, idxs, vals, _ = abo.greedy_qei(model, cands, Q, xi, best_y, idx_base=lo, rollback=True, block=blk, stats=st)
         tb = time.perf_counter()
-        cands.restore()
-        tc = time.perf_counter()
         x_new = pts[0]
         y_new = ((np.sin(2 * np.pi * x_new).sum() / np.sqrt(d)) - y_mean) / y_std      # noise-free draw is fine here
         model = abo.append(model, x_new, float(y_new))
         td = time.perf_counter()
-        cands.downdate(model)
+        cands.downdate(model)                              # block form: the column of pick 1 is in the batch's chain — no pass
         te = time.perf_counter()
         dd = model.timings()
         best_y = min(best_y, float(y_new))
         picks = (idxs, vals)
         if step >= n_warm:
-            ph["qei_ms"].append((tb - ta) * 1e3); ph["restore_ms"].append((tc - tb) * 1e3)
-            ph["append_ms"].append((td - tc) * 1e3); ph["downdate_ms"].append((te - td) * 1e3)
+            ph["qei_ms"].append((tb - ta) * 1e3)
+            ph["append_ms"].append((td - tb) * 1e3); ph["downdate_ms"].append((te - td) * 1e3)
             ph["downdate_pass_ms"].append(dd["downdate_ms"]); ph["downdate_pass_bytes"].append(dd["downdate_bytes"])
+            counts["downdates_from_chain"] += int(dd.get("downdate_from_chain", 0))
+            counts["block"] = int(st.get("block", 0))
+            if st.get("block", 0):
+                counts["block_builds"] += int(st["block_builds"]); counts["block_hits"] += int(st["block_hits"])
+                ph["block_ms"].append(st["block_ms"]); ph["block_pass_ms"].append(st["pass_ms"])
+                ph["block_pass_bytes"].append(st["pass_bytes"]); ph["block_pass_flop"].append(st["pass_flop"])
     sync()
     elapsed = time.perf_counter() - t_start
     if use_dist:
@@ -429,35 +436,52 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     out = None
     del cands, model
     if rank == 0:
-        med = {k: float(np.median(v)) for k, v in ph.items()}
+        med = {k: (float(np.median(v)) if len(v) else 0.0) for k, v in ph.items()}
         n_now = N + n_warm + n_steps
         append_bytes = 8.0 * n_now * n_now                 # W (lower) + WT (upper), read once each
         ach = append_bytes / (med["append_ms"] * 1e-3) / 1e9
-        # dominant kernel of the step: the O(N*M) down-date pass, 8 launches per step (7 fantasies — the last pick of a batch that
-        # is rolled back conditions nothing — + the real point)
-        if med["downdate_pass_bytes"] > 0:
+        tr, tr_src = pmc_traffic("c5", M_per)              # committed rocprofv3 FETCH_SIZE pass (null when stale)
+        tsrc = {k: tr_src.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if tr_src and k in tr_src}
+        if counts["block"] and med["block_pass_ms"] > 0:
+            # dominant kernel of the step: the ONE product over the resident K_ZX that gives the covariance columns of a whole block
+            # (gemm_skinny_kernel: T rows of K^-1 K_XT against the streamed K_ZX) — HBM-bound; its flop ride under the stream
+            gbs = med["block_pass_bytes"] / (med["block_pass_ms"] * 1e-3) / 1e9
+            roof = {"kernel": f"gemm_skinny_kernel<{counts['block'] // 16}> (C0 = -K_ZX . K^-1 K_XT: T = {counts['block']} covariance "
+                              f"columns from ONE pass over the resident K_ZX)", "bound": "hbm",
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr, "traffic_source": tsrc,
+                    "algorithmic_bytes_per_launch": med["block_pass_bytes"], "avg_launch_ms": med["block_pass_ms"],
+                    "launches_per_step": counts["block_builds"] / n_steps,
+                    "mfma_tflops_under_the_stream": med["block_pass_flop"] / (med["block_pass_ms"] * 1e-3) / 1e12,
+                    "note": "algorithmic bytes = 8*N*M (K_ZX read once per block of T picks' columns; the plain loop reads it once "
+                            "per pick); duration = HIP events on the library stream"}
+        elif med["downdate_pass_bytes"] > 0:
+            # the plain loop (--qei-block 0): one O(N*M) down-date pass per pick, 8 launches per step (7 fantasies + the real point)
             gbs = med["downdate_pass_bytes"] / (med["downdate_pass_ms"] * 1e-3) / 1e9
-            tr, tr_src = pmc_traffic("c5", M_per)                        # committed rocprofv3 FETCH_SIZE pass (null when stale)
             roof = {"kernel": "cand_gemv_kernel (c = K_ZX . [-v; 1] over the resident K_ZX) + new-column kernel", "bound": "hbm",
-                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr,
-                    "traffic_source": {k: tr_src.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if tr_src and k in tr_src},
+                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr, "traffic_source": tsrc,
                     "algorithmic_bytes_per_launch": med["downdate_pass_bytes"], "avg_launch_ms": med["downdate_pass_ms"],
                     "launches_per_step": Q,
                     "note": "algorithmic bytes = 8*N*M (K_ZX read once); duration = HIP events on the library stream"}
         else:
-            pairs = n_now * M_per / (med["downdate_pass_ms"] * 1e-3)
+            pairs = n_now * M_per / (max(med["downdate_pass_ms"], 1e-9) * 1e-3)
             roof = {"kernel": "kgen_kernel, dot-only mode (K_ZX re-evaluated: ABO_CAND_KZX_GIB budget too small)", "bound": "valu",
                     "achieved": pairs / 1e9, "peak": None, "unit": "Gpair/s", "frac": None, "traffic": None,
                     "avg_launch_ms": med["downdate_pass_ms"], "launches_per_step": Q}
+        form = (f"block form, T={counts['block']}: covariance columns of the T best candidates from one pass over K_ZX, rank-1 "
+                f"corrections between picks, no fantasy appends; the real append's column from the batch's chain") if counts["block"] \
+            else "plain loop: fantasy append + O(N*M) down-date per pick"
         out = {
             "metric": "GP-update+acq-eval ms per BO step at N train pts x M candidates",
             "value": ms, "unit": "ms", "n_gpus": world, "steps": n_steps, "warmup": n_warm, "ms_per_step": ms,
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C5: d={d} {fam_name} ell={ell} noise={noise}, N={N}(+1 per step) train, resident grid "
-                                   f"M={M_per} per GPU ({M_total} total), greedy q-EI q={Q} (fantasy append + O(N*M) down-date "
-                                   f"per pick) + 1 real bordered append per step",
+                                   f"M={M_per} per GPU ({M_total} total), greedy q-EI q={Q} ({form}) + 1 real bordered append per step",
                        "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "q": Q,
-                       "sharding": f"grid x{world}, all_gather of (score, index, mu, x) per pick"},
+                       "sharding": f"grid x{world}, all_gather of one pick record per pick (+ T records per block)"},
+            "qei": {"block": counts["block"], "block_builds_per_step": counts["block_builds"] / n_steps,
+                    "picks_found_in_a_block": counts["block_hits"], "picks_conditioned": (Q - 1) * n_steps,
+                    "block_hit_rate": counts["block_hits"] / max(1, counts["block_hits"] + counts["block_builds"]),
+                    "real_appends_from_chain": counts["downdates_from_chain"], "real_appends": n_steps},
             "refresh_ms": refresh_ms, "refresh_ms_all": refresh_all, "value_amortized": ms + refresh_ms / 16.0,
             "refresh_phases_ms": {k: v for k, v in fit_t.items() if k.endswith("_ms")},
             "roofline": roof,
@@ -465,7 +489,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
                                    "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                                    "note": "algorithmic bytes 8*N^2 per append; duration = host wall-clock of the synchronous "
                                            "abo_append call (includes the k-row kernel, two tiny kernels and two host syncs)"},
-            "phases_ms": med, "pairs_per_s_downdate": n_now * M_per / (med["downdate_ms"] * 1e-3),
+            "phases_ms": med,
             "last_batch": {"indices": [int(i) for i in picks[0]], "ei": [float(v) for v in picks[1]]},
         }
     return out
@@ -584,8 +608,9 @@ def run_single_process(args):
 
 def run_single_process_c5(args):
     """BASELINE config 5 through the multi-device handle: a step = abo_mgpu_cand_qei (q = 8 greedy picks, each: EI + arg-max per
-    device, ONE all-gather of the devices' pick records, the same fantasy append + O(N·M) down-date on every device, rolled back at
-    the end) + abo_mgpu_append of the real observation with the grid's down-date in the same call."""
+    device, ONE all-gather of the devices' pick records; block form: the covariance columns of the T best candidates from one pass
+    over every device's K_ZX, no fantasy appends — or, --qei-block 0, the same fantasy append + O(N·M) down-date on every device per
+    pick) + abo_mgpu_append of the real observation with the grid's down-date in the same call (its column from the batch's chain)."""
     import abstractbayesopt.jl_amd as abo
     from abstractbayesopt.jl_amd import multigpu, synth
 
@@ -593,6 +618,8 @@ def run_single_process_c5(args):
     G, Q = args.gpus, 8
     M_total = M_per * G
     devices = [0] * G if args.share_device else list(range(G))
+    if args.qei_block is not None:
+        abo._lib.check(abo._lib.lib().abo_set_qei_block(int(args.qei_block)))
     X = synth.points(1, N, d)
     y_raw = synth.objective(X, noise_std=float(np.sqrt(noise)))
     y_mean, y_std = y_raw.mean(), y_raw.std(ddof=1)
@@ -614,6 +641,7 @@ def run_single_process_c5(args):
             t_all = time.perf_counter()
         t0 = time.perf_counter()
         pts, idxs, vals = cands.greedy_qei(model, Q, xi, best_y)
+        qst = cands.qei_stats(model)
         x_new = pts[0]
         y_new = ((np.sin(2 * np.pi * x_new).sum() / np.sqrt(d)) - y_mean) / y_std
         model = multigpu.append(model, x_new, float(y_new), cands)
@@ -628,7 +656,7 @@ def run_single_process_c5(args):
         "value": ms, "unit": "ms", "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"C5: d={d} {fam_name} ell={ell} noise={noise}, N={N}(+1 per step) train, resident grid M={M_per} per "
-                               f"GPU ({M_total} total), greedy q-EI q={Q} (fantasy append + O(N*M) down-date per pick) + 1 real "
+                               f"GPU ({M_total} total), greedy q-EI q={Q} (abo_mgpu_cand_qei; block form unless qei_last_step.block = 0) + 1 real "
                                f"bordered append per step",
                    "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "q": Q,
                    "host": "one process, library-owned worker thread per device (abo_mgpu_cand_qei / abo_mgpu_append)",
@@ -640,6 +668,7 @@ def run_single_process_c5(args):
         "median_ms_per_step": float(np.median(step_ms)), "min_ms_per_step": float(np.min(step_ms)),
         "max_ms_per_step": float(np.max(step_ms)),
         "last_batch": {"indices": [int(i) for i in picks[0]], "ei": [float(v) for v in picks[1]]},
+        "qei_last_step": qst,
     }
     if len(set(devices)) < G:
         out["rehearsal"] = f"{G} shards share {len(set(devices))} physical device(s): NOT a scaling measurement"
@@ -663,6 +692,9 @@ def main():
                          "RCCL all-gather inside the library); the default for a plain `python bench.py --gpus N` with N > 1 — "
                          "under torchrun (WORLD_SIZE set) every rank drives its own GPU instead")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
+    ap.add_argument("--qei-block", type=int, default=None,
+                    help="config 5: points per block of the block-form greedy q-EI (default: the library's, 32; 0 = the plain loop "
+                         "with one pass over K_ZX per pick, for A/B runs)")
     ap.add_argument("--contraction", default=None,
                     help="engine of the N^2*M variance contraction: auto (library default), fp64, int8 or int8:<moduli>")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -395,3 +395,27 @@ def test_block_batch_refuses_what_it_cannot_do_and_falls_back():
     del m2
     pts, idx, val, st = cands.qei(66, 0.01, float(y.min()))  # q > 64: the plain loop
     assert st["block"] == 0 and len(idx) == 66 and np.all(idx >= 0)
+
+
+@pytest.mark.parametrize("block", [16, 32, 48, 64])
+def test_block_pass_kernel_repeats_the_split_k_kernels_bits(monkeypatch, block):
+    """The one pass over the resident K_ZX runs on a kernel of its own (gemm.hip: qei_pass_kernel — A through LDS, B fragments of
+    the next chunk in flight under the MFMAs); it keeps the lane ↔ k map and the k order of the skinny split-k kernel, so the
+    covariance columns — and with them every EI value of the batch and the chain's down-dated posterior — are the same bits."""
+    d, N0, M, q = 5, 700, 3001, 6
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    out = {}
+    for mode in ("pass", "skinny"):
+        if mode == "skinny":
+            monkeypatch.setenv("ABO_QEI_PASS_SKINNY", "1")
+        m = abo.update(make_model(O.MATERN52, 0.8, 1.0, 1e-3, n_max=N0 + 64), X, y)
+        cands = abo.ResidentCandidates(m, Z)
+        pts, idx, val, st = cands.qei(q, 0.01, float(y.min()), block=block)
+        assert st["block"] == block
+        m2 = abo.append(m, pts[0], 0.25)
+        cands.downdate(m2)
+        assert m2.timings()["downdate_from_chain"] == 1
+        out[mode] = (idx, val) + cands.mean_and_var()
+    for a, b in zip(out["pass"], out["skinny"]):
+        np.testing.assert_array_equal(a, b)
