@@ -432,15 +432,19 @@ def _refine_starts_fd(acqf: AbstractAcquisition, surrogate: HipStandardGP, start
         return np.where(((xa <= lower) & (ga < 0)) | ((xa >= upper) & (ga > 0)), 0.0, ga)
 
     x_prev = pg_prev = None
-    for _ in range(max_iter):
+    x_run, f_run = x.copy(), f.copy()                  # where the current inner run of every start began
+    fresh_start = np.zeros(S, dtype=bool)              # starts whose next pair spans a restart: skipped
+    for _ in range(2 * max_iter + 2):
         idx = np.flatnonzero(active)
         if idx.size == 0:
             break
         pg = np.zeros((S, d))
         pg[idx] = project(x[idx], gradient(x[idx]))
         if x_prev is not None:                                 # curvature pair of the last accepted step
-            s_k = np.where(active[:, None], x - x_prev, 0.0)   # (maximisation: y = g_old − g_new)
-            y_k = np.where(active[:, None], pg_prev - pg, 0.0)
+            keep = active & ~fresh_start                       # (a fresh inner run starts without one)
+            s_k = np.where(keep[:, None], x - x_prev, 0.0)     # (maximisation: y = g_old − g_new)
+            y_k = np.where(keep[:, None], pg_prev - pg, 0.0)
+            fresh_start[:] = False
             Sh.append(s_k); Yh.append(y_k)
             if len(Sh) > history:
                 Sh.pop(0); Yh.pop(0)
@@ -485,8 +489,20 @@ def _refine_starts_fd(acqf: AbstractAcquisition, surrogate: HipStandardGP, start
             x_new[acc], f_new[acc] = cand[ok], fc[ok]
             todo[acc] = False
             t[j[~ok]] *= 0.5
-        done = todo | (np.max(np.abs(x_new - x), axis=1) <= x_abstol) | (np.abs(f_new - f) <= f_abstol)
-        x_prev, pg_prev = x, pg
+        # Fminbox's two levels (csrc/refine.hip: outer_converged): an inner run ends when one of its steps moves x by ≤ x_abstol or f
+        # by ≤ f_abstol, or when its line search finds no step; the refinement ends when a WHOLE inner run moved no further than
+        # that, else a fresh inner run (that start's curvature pairs dropped) begins where the last one ended
+        moved = ~todo
+        run_ends = todo | (moved & ((np.max(np.abs(x_new - x), axis=1) <= x_abstol) | (np.abs(f_new - f) <= f_abstol)))
+        outer = (np.max(np.abs(x_new - x_run), axis=1) <= x_abstol) | (np.abs(f_new - f_run) <= f_abstol)
+        done = run_ends & outer
+        fresh = run_ends & ~outer & active
+        for s_k, y_k in zip(Sh, Yh):
+            s_k[fresh] = 0.0; y_k[fresh] = 0.0
+        x_run = np.where(run_ends[:, None], x_new, x_run)
+        f_run = np.where(run_ends, f_new, f_run)
+        x_prev, pg_prev = np.where(fresh[:, None], x_new, x), np.where(fresh[:, None], 0.0, pg)
+        fresh_start |= fresh
         x, f = x_new, f_new
         active &= ~done
     return x, f

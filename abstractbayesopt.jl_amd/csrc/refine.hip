@@ -287,10 +287,24 @@ __device__ __forceinline__ int lbfgs_direction(int d, int m, const double* x, co
     return 0;
 }
 
-// LDS layout (doubles): x, g, pg, p, xprev, pgprev, cand, gc, lo, up [d each]; xs [dp]; Sh, Yh [m·d each]; rho, al [m each];
+// LDS layout (doubles): x, g, pg, p, xprev, pgprev, cand, gc, lo, up, xrun [d each]; xs [dp]; Sh, Yh [m·d each]; rho, al [m each];
 // red [RW·2·RCH]; out [2·RCH]; fres [4]; ctrl [4 ints → 2 doubles]
 size_t refine_lds_bytes(int d, int dp, int m) {
-    return sizeof(double) * ((size_t)10 * d + dp + (size_t)2 * m * d + 2 * m + RW * 2 * RCH + 2 * RCH + 4 + 2);
+    return sizeof(double) * ((size_t)11 * d + dp + (size_t)2 * m * d + 2 * m + RW * 2 * RCH + 2 * RCH + 4 + 2);
+}
+
+// The reference's optimiser is Fminbox(LBFGS) (acq_utils.jl:9-13): an OUTER loop of inner L-BFGS runs.  An inner run ends when one of
+// its iterations moves x by ≤ x_abstol or f by ≤ f_abstol (or its line search finds no step); the outer loop then starts a fresh inner
+// run (new L-BFGS state) from where that one ended, and stops only when a WHOLE inner run has moved x by ≤ x_abstol or f by ≤ f_abstol
+// (or the gradient test holds).  The stage below keeps that structure — the same two tolerances on both levels, one shared budget of
+// max_iter accepted steps: a run that ends (rule or failed search) is followed by a fresh one from the same point unless it as a
+// whole made no progress beyond the tolerances.  (Round 4 stopped at the end of the FIRST inner run: a quasi-Newton step shortened by
+// a curvature pair taken across a change of the active set ended the whole refinement 0.07 short of the maximiser;
+// profiles/r05_refine_diag.txt.)
+__device__ __forceinline__ int outer_converged(int d, const double* x, const double* xrun, double f, double frun, double x_abstol, double f_abstol) {
+    double dx = 0.0;
+    for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(x[c] - xrun[c]));
+    return (dx <= x_abstol || fabs(f - frun) <= f_abstol) ? 1 : 0;
 }
 
 template <int FAM>
@@ -307,7 +321,8 @@ __global__ void __launch_bounds__(RT) refine_kernel(RefineArgs a) {
     double* gc = cand + d;
     double* lo = gc + d;
     double* up = lo + d;
-    double* xs = up + d;
+    double* xrun = up + d;
+    double* xs = xrun + d;
     double* Sh = xs + dp;
     double* Yh = Sh + (size_t)m * d;
     double* rho = Yh + (size_t)m * d;
@@ -323,15 +338,20 @@ __global__ void __launch_bounds__(RT) refine_kernel(RefineArgs a) {
         lo[c] = a.lower[c]; up[c] = a.upper[c];
         const double v = a.starts[(int64_t)sidx * d + c];
         x[c] = v == v ? fmin(fmax(v, a.lower[c]), a.upper[c]) : v;         // a NaN coordinate stays NaN (→ non-finite value → returned as is)
+        xrun[c] = x[c];
     }
     __syncthreads();
     eval_point<FAM>(a, x, xs, scr, red, out, fres, g);
     double f = fres[0];
+    double frun = f;                                                       // value at the beginning of the current inner run
     int nev = 1, it = 0, nh = 0;
     bool have_prev = false;
     double tstep = 1.0;
     if (f == f && fabs(f) < 1.0e300) {                                   // a non-finite start value: nothing to refine
-        for (it = 0; it < a.max_iter; ++it) {
+        // `it` counts accepted steps.  A pass of this loop ends in one, or in a failed line search — which ends the inner run, and
+        // a fresh run's first search failing ends the refinement (nothing has moved since the run began): two failures never
+        // follow each other, so 2·max_iter + 2 passes bound the loop
+        for (int pass = 0; pass < 2 * a.max_iter + 2 && it < a.max_iter; ++pass) {
             if (t == 0) {
                 const int stop = lbfgs_direction(d, m, x, g, pg, p, xprev, pgprev, lo, up, Sh, Yh, rho, al, have_prev, nh, a.g_tol, fres[3]);
                 ctrl[0] = stop;
@@ -356,17 +376,32 @@ __global__ void __launch_bounds__(RT) refine_kernel(RefineArgs a) {
                 if (ctrl[1]) { accepted = true; break; }
                 tstep *= 0.5;
             }
-            if (!accepted) break;
-            if (t == 0) {
-                double dx = 0.0;
-                for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(cand[c] - x[c]));
-                ctrl[2] = (dx <= a.x_abstol || fabs(fc - f) <= a.f_abstol) ? 1 : 0;
-                for (int c = 0; c < d; ++c) { xprev[c] = x[c]; pgprev[c] = pg[c]; x[c] = cand[c]; g[c] = gc[c]; }
+            bool run_ends = !accepted;                                   // no acceptable step: the inner run ends where it stands
+            if (accepted) {
+                if (t == 0) {
+                    double dx = 0.0;
+                    for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(cand[c] - x[c]));
+                    ctrl[2] = (dx <= a.x_abstol || fabs(fc - f) <= a.f_abstol) ? 1 : 0;
+                    for (int c = 0; c < d; ++c) { xprev[c] = x[c]; pgprev[c] = pg[c]; x[c] = cand[c]; g[c] = gc[c]; }
+                }
+                __syncthreads();
+                f = fc;
+                have_prev = true;
+                ++it;
+                run_ends = ctrl[2] != 0;
             }
-            __syncthreads();
-            f = fc;
-            have_prev = true;
-            if (ctrl[2]) { ++it; break; }
+            if (run_ends) {
+                // the outer level (outer_converged): stop when the whole inner run moved x or f by no more than the tolerances,
+                // else a fresh inner run — no curvature pairs, cautious first step — from this point
+                if (t == 0) {
+                    ctrl[3] = outer_converged(d, x, xrun, f, frun, a.x_abstol, a.f_abstol);
+                    for (int c = 0; c < d; ++c) xrun[c] = x[c];
+                }
+                __syncthreads();
+                if (ctrl[3]) break;
+                frun = f;
+                have_prev = false; nh = 0;
+            }
         }
     }
     for (int c = t; c < d; c += RT) a.x_out[(int64_t)sidx * d + c] = x[c];
@@ -410,12 +445,13 @@ __global__ void __launch_bounds__(RT) acq_grad_kernel(RefineArgs a) {
 // when no start is active.  Same algorithm as refine_kernel; v and u come out of the MFMA tile core in another summation order, so the
 // two variants agree to rounding, not bit for bit (tests/test_gpu_refine.py).
 struct RlState {                 // per-start scalars
-    double f, tstep;
+    double f, tstep, frun;
     int phase, it, ls, nh, nev, have_prev;      // phase 0 = waiting for the start's value, 1 = in a line search, 2 = finished
 };
 
-// doubles of vector state per start: x, g, pg, p, xprev, pgprev [6·d], Sh, Yh [2·m·d], rho, al [2·m]
-__host__ __device__ inline size_t rl_vec_doubles(int d, int m) { return (size_t)6 * d + (size_t)2 * m * d + 2 * m; }
+// doubles of vector state per start: x, g, pg, p, xprev, pgprev [6·d], Sh, Yh [2·m·d], rho, al [2·m], xrun [d] (x at the beginning of
+// the current inner run: refine_kernel's outer level)
+__host__ __device__ inline size_t rl_vec_doubles(int d, int m) { return (size_t)7 * d + (size_t)2 * m * d + 2 * m; }
 
 template <int FAM>
 // Rows of a round's batch are COMPACT: row c belongs to the c-th still-active start, start_of[c] (ascending start index; built by
@@ -552,7 +588,7 @@ __global__ void __launch_bounds__(64) rl_step_kernel(RefineArgs a, int S, int fi
         }
         if (t == 0) {
             RlState& s = st[j];
-            s.f = 0.0; s.tstep = 1.0; s.phase = 0; s.it = 0; s.ls = 0; s.nh = 0; s.nev = 0; s.have_prev = 0;
+            s.f = 0.0; s.tstep = 1.0; s.frun = 0.0; s.phase = 0; s.it = 0; s.ls = 0; s.nh = 0; s.nev = 0; s.have_prev = 0;
             active[j] = 1;
             atomicAdd(reinterpret_cast<unsigned long long*>(&counters[0]), 1ull);
         }
@@ -570,6 +606,7 @@ __global__ void __launch_bounds__(64) rl_step_kernel(RefineArgs a, int S, int fi
     double* Yh = Sh + (size_t)m * d;
     double* rho = Yh + (size_t)m * d;
     double* al = rho + m;
+    double* xrun = al + m;
     double* lo = sv + nv;
     double* up = lo + d;
     double* ev = up + d;                           // [d + 1]
@@ -583,10 +620,10 @@ __global__ void __launch_bounds__(64) rl_step_kernel(RefineArgs a, int S, int fi
         RlState s = st[j];
         const double fc = ev[0];
         ++s.nev;
-        bool begin_iteration = false, finished = false;
+        bool begin_iteration = false, finished = false, run_ends = false;
         if (s.phase == 0) {                              // the start's own value and gradient
-            s.f = fc;
-            for (int c = 0; c < d; ++c) g[c] = ev[1 + c];
+            s.f = fc; s.frun = fc;
+            for (int c = 0; c < d; ++c) { g[c] = ev[1 + c]; xrun[c] = x[c]; }
             if (!(fc == fc && fabs(fc) < 1.0e300)) finished = true;      // a non-finite start value: nothing to refine
             else begin_iteration = true;
         } else {                                         // a line-search trial came back
@@ -596,15 +633,22 @@ __global__ void __launch_bounds__(64) rl_step_kernel(RefineArgs a, int S, int fi
             if (ok) {
                 double dx = 0.0;
                 for (int c = 0; c < d; ++c) dx = fmax(dx, fabs(cd[c] - x[c]));
-                const bool done = dx <= a.x_abstol || fabs(fc - s.f) <= a.f_abstol;
+                run_ends = dx <= a.x_abstol || fabs(fc - s.f) <= a.f_abstol;
                 for (int c = 0; c < d; ++c) { xprev[c] = x[c]; pgprev[c] = pg[c]; x[c] = cd[c]; g[c] = ev[1 + c]; }
                 s.f = fc; s.have_prev = 1; ++s.it;
-                if (done || s.it >= a.max_iter) finished = true;
-                else begin_iteration = true;
+                if (!run_ends) { if (s.it >= a.max_iter) finished = true; else begin_iteration = true; }
             } else {
                 s.tstep *= 0.5;
-                if (++s.ls >= a.ls_max) finished = true;                 // no acceptable step: keep x
+                if (++s.ls >= a.ls_max) run_ends = true;                 // no acceptable step: the inner run ends where it stands
             }
+        }
+        if (run_ends) {
+            // refine_kernel's outer level: stop when the whole inner run moved x or f by no more than the tolerances, else a fresh
+            // inner run (no curvature pairs, cautious first step) from this point
+            const int conv = outer_converged(d, x, xrun, s.f, s.frun, a.x_abstol, a.f_abstol);
+            for (int c = 0; c < d; ++c) xrun[c] = x[c];
+            if (conv || s.it >= a.max_iter) finished = true;
+            else { s.frun = s.f; s.have_prev = 0; s.nh = 0; begin_iteration = true; }
         }
         if (begin_iteration) {
             double t0 = 1.0;
@@ -703,7 +747,9 @@ hipError_t launch_refine_lockstep(const RefineArgs& a, int S, void* work, hipStr
     hipLaunchKernelGGL(rl_compact_kernel, dim3(1), dim3(256), 0, s, active, S, start_of, nact);
     // every loop of the one-launch kernel is bounded by the same product (64-bit: the caller's limits are clamped in
     // api.hip: refine_defaults, but the product of two ints is not an int)
-    const int64_t max_rounds = 1 + (int64_t)a.max_iter * (int64_t)a.ls_max;
+    // evaluations a start can take: its own, ≤ ls_max per accepted step, ≤ ls_max per failed search — and two failed searches never
+    // follow each other (refine_kernel)
+    const int64_t max_rounds = 1 + (2 * (int64_t)a.max_iter + 2) * (int64_t)a.ls_max;
     const size_t lds = sizeof(double) * ((size_t)a.dp + RW * 2 * RCH + 2 * RCH);
     long long left = -1;
     // what the host knows of the active count: S at first, then what the last counter read said (it only falls) — an upper bound that
@@ -820,7 +866,9 @@ __global__ void rl_grad_ev_kernel(RefineArgs a, const double* __restrict__ mean_
 size_t refine_lockstep_grad_bytes(int S, int d, int history, bool stencil) {
     const size_t npp = stencil ? 2 * (size_t)d + 1 : 1, p = (size_t)d + 1;
     return sizeof(double) * ((size_t)S * d * 2 + (size_t)S * npp * (d + p + p * p) + (size_t)S * (d + 1) +
-                             (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S + sizeof(int) * S + 64 + 64;
+                             (size_t)S * rl_vec_doubles(d, history)) + sizeof(RlState) * S + (sizeof(int) * S + 63) / 64 * 64 + 64 + 64;
+    // (the int array is the last carve: rounded up to 64 bytes, so that whatever the caller places behind this block — api.hip puts
+    // the prior means of the gradient outputs there, read with 8-byte loads — is aligned for any number of starts)
 }
 
 namespace {
@@ -861,7 +909,9 @@ hipError_t launch_refine_lockstep_grad(const RefineArgs& a, int S, const double*
     if ((e = hipMemsetAsync(w.active, 0, sizeof(int) * S, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(w.P, 0, sizeof(double) * (size_t)S * d, s)) != hipSuccess) return e;
     hipLaunchKernelGGL(rl_step_kernel, dim3(S), dim3(64), rl_step_lds(d, m), s, a, S, 1, w.P, w.active, w.EV, w.vec, w.st, w.counters);
-    const int64_t max_rounds = 1 + (int64_t)a.max_iter * (int64_t)a.ls_max;
+    // evaluations a start can take: its own, ≤ ls_max per accepted step, ≤ ls_max per failed search — and two failed searches never
+    // follow each other (refine_kernel)
+    const int64_t max_rounds = 1 + (2 * (int64_t)a.max_iter + 2) * (int64_t)a.ls_max;
     long long left = -1;
     for (int64_t r = 0; r < max_rounds; ++r) {
         if (stencil) hipLaunchKernelGGL(rl_stencil_kernel, dim3((S * d + 127) / 128), dim3(128), 0, s, w.P, S, d, w.npp, w.PTS, w.H);

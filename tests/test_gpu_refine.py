@@ -27,6 +27,51 @@ def _oracle_acq(acq, st):
     return lambda z: O.acquisition(kind, *O.predict(st, z), acq.xi, acq.best_y)
 
 
+BASIN_RADIUS = 0.25      # max-norm distance beyond which two end points are different local maximisers (boxes of width 1.4 … 2,
+                         # length scales 0.5 …: the other-maximiser cases measured on an MI355X lie 0.57 … 1.5 apart, tools/refine_diag.py)
+
+
+def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper):
+    """The refinement's end points against an INDEPENDENT optimiser on INDEPENDENT arithmetic: SciPy L-BFGS-B on the oracle's
+    acquisition from the same starts.  A start passes when the device's value reaches SciPy's (to 1e-5 relative), or when the two
+    end points are different local maximisers (more than BASIN_RADIUS apart — SciPy's first line-search step is long and often leaves
+    the start's basin); for those the device's end point must be a stationary point of the ORACLE's acquisition: a device run with
+    the stopping rules tightened ends at the same value, and the oracle's projected central-difference gradient there is zero to
+    1e-4 of the box-scale slope.  A start that ends below SciPy INSIDE SciPy's basin fails — the count is recorded and must be 0
+    (round 4 found 5 of 12 such starts in one case: failed line searches along quasi-Newton directions, since then retried along
+    the projected gradient; profiles/r05_refine_diag.txt has the per-start table before and after)."""
+    from scipy.optimize import minimize
+    xt, ft = refine(max_iter=1000, g_tol=1e-9, f_abstol=1e-300, x_abstol=1e-12)
+    below_in_basin, other, gaps = 0, 0, []
+    for i in range(len(starts)):
+        res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
+                       options={"ftol": 1e-14, "gtol": 1e-8})
+        fs = -res.fun
+        tol = 1e-5 * max(1.0, abs(fs))
+        gaps.append(min(0.0, float(fr[i] - fs)))
+        if fr[i] >= fs - tol:
+            continue
+        if np.max(np.abs(xr[i] - res.x)) <= BASIN_RADIUS and np.max(np.abs(xt[i] - res.x)) <= BASIN_RADIUS:
+            below_in_basin += 1
+            continue
+        other += 1
+        if ft[i] >= fs - tol:
+            continue                               # the reference's own rules (f_abstol on a plateau of EI / PI) ended the run: the
+                                                   # tightened run climbs to SciPy's maximiser
+        # another local maximiser: the tightened run stays there, and it is a stationary point of the oracle's acquisition
+        assert abs(ft[i] - fr[i]) <= 1e-3 * max(1.0, abs(ft[i])), (name, i, fr[i], ft[i])
+        g = _fd4(oracle, xt[i][None, :], 1e-5)[0]
+        # (a bound counts as active within 1e-8: the tightened run creeps to within an ulp of a face without landing on it)
+        pg = np.where(((xt[i] <= lower + 1e-8) & (g < 0)) | ((xt[i] >= upper - 1e-8) & (g > 0)), 0.0, g)
+        if np.max(np.abs(pg)) > 1e-4 * max(1.0, abs(ft[i])):
+            # not stationary after 1000 iterations: only a start on a plateau may do that (|∇| ≤ g_tol at the start itself)
+            g0 = _fd4(oracle, np.clip(starts[i], lower, upper)[None, :], 1e-5)[0]
+            assert np.max(np.abs(g0)) <= 1e-4, (name, i, np.max(np.abs(pg)), np.max(np.abs(g0)))
+    check(case, f"{name}_starts_below_scipy_inside_its_basin", float(below_in_basin), 0.0)
+    check(case, f"{name}_fraction_of_starts_at_another_maximiser", other / len(starts), 0.75)    # (measured ≤ 0.57: GradientNormUCB, d = 3)
+    check(case, f"{name}_median_shortfall_vs_scipy", -float(np.median(gaps)), 1e-6)
+
+
 @pytest.mark.parametrize("family,d,N", [(O.SE, 1, 30), (O.MATERN52, 3, 200), (O.MATERN72, 8, 500), (O.MATERN32, 2, 64),
                                         (O.MATERN52, 40, 150), (O.SE, 5, 1100)])
 def test_analytic_acquisition_gradient_against_central_differences(family, d, N):
@@ -83,7 +128,6 @@ def test_gradient_on_the_small_variance_branch_and_at_training_points():
 
 @pytest.mark.parametrize("family,d,N", [(O.MATERN52, 3, 60), (O.SE, 2, 100), (O.MATERN72, 6, 400)])
 def test_refinement_against_scipy_on_the_oracle_and_against_the_finite_difference_loop(family, d, N):
-    from scipy.optimize import minimize
     X, y = synth.standardized_problem(N, d, 0.02)
     ell, sf2, noise = 0.5, 1.0, 0.05                        # (noisy on purpose, as in the gradient test)
     m = abo.update(make_model(family, ell, sf2, noise), X, y)
@@ -97,20 +141,12 @@ def test_refinement_against_scipy_on_the_oracle_and_against_the_finite_differenc
         assert np.all(fr >= f0 - 1e-15), "a refined start lost against its start"
         assert np.all(xr >= lower) and np.all(xr <= upper)
         np.testing.assert_allclose(acq(m, xr), fr, rtol=1e-9, atol=1e-10)       # the reported value is the score of the reported point
-        assert np.all(it[:, 0] <= 100) and np.all(it[:, 1] <= 1 + 100 * 20)
+        assert np.all(it[:, 0] <= 100) and np.all(it[:, 1] <= 1 + (2 * 100 + 2) * 20)
         assert it[:, 1].sum() > 3 * len(starts) and np.median(fr - f0) > 1e-4, (type(acq).__name__, it[:, 1].sum(), np.median(fr - f0))
-        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)
         oracle = _oracle_acq(acq, st)
-        worse = 0
-        for i in range(len(starts)):
-            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
-                           options={"ftol": 1e-14, "gtol": 1e-8})
-            tol = 1e-5 * max(1.0, abs(res.fun))
-            # the same basin is not guaranteed for every start: count the starts that end below SciPy's optimum AND below the
-            # finite-difference loop's
-            if fr[i] < -res.fun - tol and fr[i] < ff[i] - tol:
-                worse += 1
-        assert worse <= 1, (type(acq).__name__, worse)
+        _against_scipy(f"refine/quality_fam{family}_d{d}_N{N}", type(acq).__name__, oracle,
+                       lambda **kw: refine_starts(acq, m, starts, lower, upper, **kw), starts, xr, fr, lower, upper)
+        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)
         # the analytic-gradient run is at least as good as the finite-difference one on (nearly) every start
         assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
 
@@ -268,7 +304,6 @@ def test_ensemble_objective_gradient_and_refinement_on_the_device(family, d, N, 
     """EnsembleAcquisition (EnsembleAcq.jl:53-55) as ONE objective of the refinement stage: value = Σ wᵢ·acqᵢ on one posterior
     evaluation, ∇ = Σ wᵢ ∇acqᵢ — against the oracle's weighted sum and its central differences; refinement vs SciPy on the
     oracle; the one-launch kernel (N = 200) and the lockstep variant (N = 1100 ≥ 1024 rows)."""
-    from scipy.optimize import minimize
     _no_host_loop(monkeypatch)
     X, y = synth.standardized_problem(N, d, 0.03)
     ell, sf2, noise = 0.7 * np.sqrt(d), 1.3, 0.1
@@ -300,18 +335,11 @@ def test_ensemble_objective_gradient_and_refinement_on_the_device(family, d, N, 
     assert np.all(fr >= f0 - 1e-12) and np.all(xr >= lower) and np.all(xr <= upper)
     np.testing.assert_allclose(ens(m, xr), fr, rtol=1e-9, atol=1e-10)
     assert np.median(fr - f0) > 1e-4
-    # as in the single-acquisition test: the same basin is not guaranteed for every start, and the reference's stopping rules
-    # (x_abstol = 1e-4, f_abstol = 2.2e-9) end a run earlier than SciPy's ftol = 1e-14 — count the starts that end below SciPy's
-    # optimum AND below the finite-difference host loop's (the same algorithm under the same rules, round 2's path)
-    xf, ff = _refine_starts_fd(ens, m, starts, lower, upper)
-    worse, gap = 0, []
-    for i in range(len(starts)):
-        res = minimize(lambda z: -float(oracle(z[None, :], ens)[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
-                       options={"ftol": 1e-14, "gtol": 1e-8})
-        tol = 1e-5 * max(1.0, abs(res.fun))
-        worse += fr[i] < -res.fun - tol and fr[i] < ff[i] - tol
-        gap.append(fr[i] + res.fun)
-    assert worse <= 1 and np.median(gap) >= -1e-6, (worse, np.median(gap))
+    # against SciPy on the oracle's weighted sum (independent optimiser, independent arithmetic); the finite-difference host loop —
+    # the same algorithm under the same rules on the library's own values — is compared separately
+    _against_scipy(f"refine/quality_ensemble_fam{family}_d{d}_N{N}", "ensemble", lambda z: oracle(z, ens),
+                   lambda **kw: refine_starts(ens, m, starts, lower, upper, **kw), starts, xr, fr, lower, upper)
+    xf, ff = _refine_starts_fd(ens, m, starts, lower, upper)      # (the imported function itself: the patch guards the device paths)
     assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
     # the whole optimize_acquisition in one call, and the sharded group returns the same bits
     dom = abo.ContinuousDomain(lower, upper)
@@ -381,7 +409,6 @@ def test_gradient_enhanced_refinement_and_optimize_acquisition_on_the_device(fam
     """optimize_acquisition(acqf, ::GradientGP, domain) — what the reference's tutorials run (gradNormUCB.jl:39-51 on a
     GradientGP) — as one C-ABI call: refinement never below the start, inside the box, ≥ SciPy L-BFGS-B on the oracle's
     acquisition; the finite-difference host loop is not reached; the sharded group returns the single handle's bits."""
-    from scipy.optimize import minimize
     from oracle import grad_oracle as G
     from tests.test_gpu_gradient_gp import make_grad
     _no_host_loop(monkeypatch)
@@ -405,14 +432,9 @@ def test_gradient_enhanced_refinement_and_optimize_acquisition_on_the_device(fam
         assert np.all(fr >= f0 - 1e-9) and np.all(xr >= lower) and np.all(xr <= upper)
         np.testing.assert_allclose(oracle(xr), fr, rtol=1e-8, atol=1e-9)          # the reported value is the oracle's value there
         assert it[:, 1].sum() > 2 * len(starts) and np.all(it[:, 0] <= 100)
-        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)    # (the host loop itself, called directly: the reference point)
-        worse = 0
-        for i in range(len(starts)):
-            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
-                           options={"ftol": 1e-14, "gtol": 1e-8})
-            tol = 1e-5 * max(1.0, abs(res.fun))
-            worse += fr[i] < -res.fun - tol and fr[i] < ff[i] - tol
-        assert worse <= 1, (type(acq).__name__, worse)
+        _against_scipy(f"refine/quality_gradgp_fam{family}_d{d}_N{N}", type(acq).__name__, oracle,
+                       lambda **kw: refine_starts(acq, m, starts, lower, upper, **kw), starts, xr, fr, lower, upper)
+        xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)    # (the host loop itself, called directly: the same algorithm on stencils)
         assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
         # deterministic
         xr2, fr2 = refine_starts(acq, m, starts, lower, upper)
