@@ -272,6 +272,15 @@ struct Storage {
     void add_view(int64_t n) { std::lock_guard<std::mutex> lk(mu); live.insert(n); }
     void drop_view(int64_t n) { std::lock_guard<std::mutex> lk(mu); auto it = live.find(n); if (it != live.end()) live.erase(it); }
     int64_t max_live() { std::lock_guard<std::mutex> lk(mu); return live.empty() ? 0 : *live.rbegin(); }
+    // An append in place writes rows [n_old, n_new): allowed only while no live view reaches beyond n_old — decided AND claimed
+    // (the new view registered) under one lock, so that two host threads appending to copies of one model cannot both take the
+    // rows (the loser refits into storage of its own: copy-on-write).  A failed append gives the claim back (drop_view).
+    bool claim_rows(int64_t n_old, int64_t n_new) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!live.empty() && *live.rbegin() > n_old) return false;
+        live.insert(n_new);
+        return true;
+    }
     DevBuf Xraw, Xs, ybuf, delta, K, W, WT;
     void set_device(int dv) {
         dev = dv;
@@ -1126,7 +1135,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     const int d = g->d;
     const int64_t N = g->N;
     hipStream_t s = n->stream;
-    if (N + 1 > st->cap || st->max_live() > N) {
+    if (N + 1 > st->cap || !st->claim_rows(N, N + 1)) {
         // gather this view's data on the device and refit with room to grow
         ScratchBuf xs(g->prm.device, s), ys(g->prm.device, s);
         DevBuf& xb = xs.b;
@@ -1141,6 +1150,8 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
         if (n->prm.n_max < 2 * (N + 1)) n->prm.n_max = 2 * (N + 1);
         return fit_impl(n, xb.as<double>(), N + 1, d, yb.as<double>(), ABO_DEVICE, info);
     }
+    // rows [N, N + 1) are claimed: every failure below gives them back
+    struct Claim { Storage* st; int64_t n; bool keep = false; ~Claim() { if (!keep) st->drop_view(n); } } claim{st, N + 1};
     const int64_t ld = st->cap;
     const int64_t Np = g->Np;                       // padded size of the OLD view
     const int64_t Np1 = pad_up(N + 1, TB);
@@ -1175,7 +1186,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     HIPCHK(launch_append(aa, s));
     double sc[4];
     int64_t inf = 0;
-    PinStage pin(g->ctx);
+    PinStage pin(n->ctx);                            // the NEW handle's staging block: `g` may be in use by another thread (a copy of it)
     HIPCHK(pin.d2h(sc, n->scal.p, sizeof sc, s));
     HIPCHK(pin.d2h(&inf, n->info.p, sizeof inf, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1188,7 +1199,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     storage_unref(n->st);
     st->refs.fetch_add(1);
     n->st = st;
-    st->add_view(N + 1);
+    claim.keep = true;                               // (registered by claim_rows)
     n->N = N + 1; n->npts = N + 1; n->Np = Np1; n->d = d; n->dp = st->dp;
     n->from_append = true;
     n->ap_s2 = sc[0]; n->ap_beta = sc[1];
@@ -1207,7 +1218,7 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
     const int d = g->d, P = g->p_out;
     const int64_t R = g->N, npts = g->npts;
     hipStream_t s = n->stream;
-    if (R + P > st->cap || st->max_live() > R) {
+    if (R + P > st->cap || !st->claim_rows(R, R + P)) {
         ScratchBuf xs(g->prm.device, s), ys(g->prm.device, s);
         DevBuf& xb = xs.b;
         DevBuf& yb = ys.b;
@@ -1221,6 +1232,7 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
         if (n->prm.n_max < 2 * (npts + 1)) n->prm.n_max = 2 * (npts + 1);
         return fit_impl(n, xb.as<double>(), npts + 1, d, yb.as<double>(), ABO_DEVICE, info, /*y_point_major=*/1);
     }
+    struct Claim { Storage* st; int64_t n; bool keep = false; ~Claim() { if (!keep) st->drop_view(n); } } claim{st, R + P};
     const int64_t ld = st->cap;
     HIPCHK(n->alpha.ensure(sizeof(double) * ld));
     HIPCHK(n->T.ensure(sizeof(double) * ld));              // second alpha buffer (the rows alternate between the two)
@@ -1262,7 +1274,7 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
     }
     double sc[4 * MAX_P];
     int64_t inf = 0;
-    PinStage pin(g->ctx);
+    PinStage pin(n->ctx);
     HIPCHK(pin.d2h(sc, n->scal.p, sizeof(double) * 4 * P, s));
     HIPCHK(pin.d2h(&inf, n->info.p, sizeof inf, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1275,7 +1287,7 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
     storage_unref(n->st);
     st->refs.fetch_add(1);
     n->st = st;
-    st->add_view(R + P);
+    claim.keep = true;
     n->N = R + P; n->npts = npts + 1; n->Np = pad_up(R + P, TB); n->d = d; n->dp = st->dp;
     n->from_append = true;
     n->logdet = g->logdet; n->quad = g->quad;

@@ -817,6 +817,28 @@ def main():
         torch.cuda.synchronize(dev)
         variants = {"topk_only_ms": ms_per_step, "scores_to_host_ms": (time.perf_counter() - t1) * 1e3 / 3,
                     "scores_bytes_d2h": 8 * M_per}
+        # The reference's call shape end to end (acq_utils.jl:47-50: `scores = acqf(surrogate, grid_points)` on host arrays; update(model,
+        # xs, ys) on host arrays, StandardGP.jl:79-83): X, y and the candidate grid handed over as PAGEABLE host arrays on every step
+        # (what a Julia `Matrix` is), the M scores returned to a host array — measured, not estimated.  Never `value`.
+        Xh, yh = np.ascontiguousarray(X), np.ascontiguousarray(y)
+        Zh = synth.points(2, hi - lo, d, first=lo)
+        t3 = 0.0
+        for it in range(4):
+            if it == 1:
+                torch.cuda.synchronize(dev)
+                t3 = time.perf_counter()
+            model = abo.update(gp, Xh, yh)
+            st = abo._lib.lib().abo_acq(model._require(), Zh.ctypes.data, M_per, d, abo._lib.HOST, acq.kind, acq._p0(),
+                                        acq._best(), lo, host_scores.ctypes.data, K_TOP, htv.ctypes.data,
+                                        hti.ctypes.data, abo._lib.HOST)
+            abo._lib.check(st)
+        torch.cuda.synchronize(dev)
+        variants["host_arrays_ms"] = (time.perf_counter() - t3) * 1e3 / 3
+        variants["host_arrays_bytes_h2d"] = 8 * (N * d + N + M_per * d)
+        variants["host_arrays_bytes_d2h"] = 8 * M_per + 16 * K_TOP
+        variants["host_arrays_note"] = ("X, y, Z pageable host arrays every step, all M scores + top-100 back to host arrays: the "
+                                        "reference's call shape (acq_utils.jl:47-50); value keeps the inputs resident in HBM")
+        del Zh
         # the same step on the library's other contraction engine (two untimed-for-`value` steps), and how far the two
         # engines' selections and scores are apart on this very workload
         used = int(phases[0]["contraction_engine"])

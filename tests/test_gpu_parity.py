@@ -36,7 +36,7 @@ def _load(name):
 
 # ------------------------------------------------------------------------------------------------
 def test_library_loaded_and_version():
-    assert abo._lib.lib().abo_abi_version() == abo._lib.ABI_VERSION == 5
+    assert abo._lib.lib().abo_abi_version() == abo._lib.ABI_VERSION == 6
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 128), (128, 256, 272)])
@@ -192,6 +192,7 @@ CASES = [
     (O.MATERN72, 3, 640, 513, 0.8, 2.5, 1e-3, 0.0),
     (O.MATERN32, 2, 1000, 4096, 0.6, 0.5, 1e-2, -1.2),
     (O.SE, 4, 1024, 8192, 0.5, 1.0, 1e-4, 0.0),          # C2 training shape
+    (O.SE, 4, 1024, 65536, 0.5, 1.0, 1e-4, 0.0),         # C2 at its own size (BASELINE config 2: M = 65 536, UCB in the epilogue checks)
     (O.MATERN52, 16, 1152, 2048, 2.0, 1.0, 1e-2, 0.0),   # C5 dimension, 9 blocks
     (O.MATERN52, 5, 1664, 700, 0.9, 1.0, 1e-3, 0.3),     # 13 blocks: three 512-wide Cholesky strips + a 128 remainder
     (O.SE, 7, 2304, 600, 1.2, 1.5, 1e-3, 0.0),           # 18 blocks: both GEMM variants (small-launch and LDS-tiled) in one fit
@@ -219,7 +220,7 @@ def test_against_oracle(family, d, N, M, ell, sf2, noise, mean_c):
     cond = 1.0 + N * sf2 / noise                 # crude bound on cond(K)
     tol = max(1e-11, 4e-16 * cond)
     assert tol <= 1e-6
-    case = f"oracle/fam{family}_d{d}_N{N}"
+    case = f"oracle/fam{family}_d{d}_N{N}" + (f"_M{M}" if M >= 65536 else "")
     check(case, "L", np.max(np.abs(L - st.L)) / np.sqrt(sf2 + noise), tol)
     check(case, "LinvL_minus_I", np.max(np.abs(Linv @ st.L - np.eye(N))), tol * 10)
     check(case, "alpha_rel", np.max(np.abs(alpha - st.alpha)) / max(1.0, np.max(np.abs(st.alpha))), min(1e-6, tol * 1e3))
