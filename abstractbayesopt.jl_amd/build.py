@@ -31,6 +31,17 @@ def _manifest():
     return h.hexdigest()
 
 
+def _lib_digest():
+    """sha256 of the linked library itself: the manifest's second line — a file copied over lib/libabo_hip.so while the manifest
+    stays (an A/B build put back) no longer matches it"""
+    import hashlib
+    h = hashlib.sha256()
+    with open(LIB, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
 def _newer_than_lib():
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in _deps())
@@ -42,7 +53,8 @@ def _stale():
     if not os.path.exists(LIB) or not os.path.exists(MANIFEST):
         return True
     with open(MANIFEST) as f:
-        return f.read().strip() != _manifest()
+        lines = f.read().split()
+    return len(lines) != 2 or lines[0] != _manifest() or lines[1] != _lib_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -80,7 +92,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     with open(MANIFEST, "w") as f:
-        f.write(_manifest() + "\n")
+        f.write(_manifest() + "\n" + _lib_digest() + "\n")
     return LIB
 
 

@@ -219,6 +219,9 @@ hipError_t ensure_dev(void** p, size_t* cap, size_t bytes) {
     return e;
 }
 
+long exchange_timeout_ms();
+int wait_stream_bounded(hipStream_t s, std::atomic<int>& abort, std::chrono::steady_clock::time_point deadline);
+
 CommSet* comm_set(const int* dev, int ndev) {
     static std::mutex mu;
     static std::map<std::vector<int>, CommSet*> sets;
@@ -235,11 +238,17 @@ CommSet* comm_set(const int* dev, int ndev) {
     bool distinct = true;
     for (int i = 0; i < ndev; ++i)
         for (int j = 0; j < i; ++j) distinct = distinct && dev[i] != dev[j];
+    // the list's distinct devices, ascending: the order their collective locks are taken in — needed NOW: communicator creation and the
+    // warm-up below enqueue on these devices, and a collective of another list that shares one of them must not interleave
+    cs->lock_order.assign(dev, dev + ndev);
+    std::sort(cs->lock_order.begin(), cs->lock_order.end());
+    cs->lock_order.erase(std::unique(cs->lock_order.begin(), cs->lock_order.end()), cs->lock_order.end());
     if (force_host) cs->why = "ABO_MGPU_EXCHANGE=host";
     else if (!distinct) cs->why = "a device is listed twice (RCCL needs distinct devices)";
     else if (ndev == 1 && !force_rccl) cs->why = "one shard: nothing to exchange";
     else if (!rccl().handle) cs->why = rccl().why;
     else {
+        DeviceLocks dl(cs->lock_order);
         const ncclResult_t r = rccl().CommInitAll(cs->comm, ndev, dev);
         if (r == ncclSuccess) cs->rccl_ok = cs->rccl_ever = true;
         else cs->why = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
@@ -248,32 +257,44 @@ CommSet* comm_set(const int* dev, int ndev) {
         // connections up lazily inside the first collective — a host-side exchange between the ranks — and the bounded wait of
         // exchange() only bounds what has been ENQUEUED.  After this warm-up a collective call is an asynchronous kernel launch, so a
         // rank that never arrives later costs the others a time-out, not a host call that never returns.
+        // The warm-up itself runs on a non-blocking stream of its own per device (the NULL stream would order it against every
+        // other stream of the process) and is waited for WITH the exchange's bound: on expiry the communicators are aborted and
+        // the list falls back to the host exchange, like any later collective that does not complete.
         if (cs->rccl_ok) {
             bool ok = true;
+            hipStream_t ws[MAXDEV] = {nullptr};
             for (int i = 0; ok && i < ndev; ++i)
                 ok = hipSetDevice(dev[i]) == hipSuccess && ensure_dev(&cs->pack[i], &cs->pack_cap[i], 8) == hipSuccess &&
-                     ensure_dev(&cs->gath[i], &cs->gath_cap[i], 8 * (size_t)ndev) == hipSuccess;
+                     ensure_dev(&cs->gath[i], &cs->gath_cap[i], 8 * (size_t)ndev) == hipSuccess &&
+                     hipStreamCreateWithFlags(&ws[i], hipStreamNonBlocking) == hipSuccess;
             ncclResult_t w = ok ? rccl().GroupStart() : ncclSystemError;
             for (int i = 0; w == ncclSuccess && i < ndev; ++i) {
                 (void)hipSetDevice(dev[i]);
-                w = rccl().AllGather(cs->pack[i], cs->gath[i], 1, ncclUint64, cs->comm[i], nullptr);
+                w = rccl().AllGather(cs->pack[i], cs->gath[i], 1, ncclUint64, cs->comm[i], ws[i]);
             }
             if (ok) { const ncclResult_t e = rccl().GroupEnd(); if (w == ncclSuccess) w = e; }
-            for (int i = 0; w == ncclSuccess && i < ndev; ++i)
-                if (hipSetDevice(dev[i]) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) w = ncclUnhandledCudaError;
+            bool timed_out = false;
+            if (w == ncclSuccess) {
+                std::atomic<int> abort{0};
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(exchange_timeout_ms());
+                for (int i = 0; w == ncclSuccess && i < ndev; ++i) {
+                    const int q = hipSetDevice(dev[i]) == hipSuccess ? wait_stream_bounded(ws[i], abort, deadline) : -1;
+                    if (q != 0) { w = ncclUnhandledCudaError; timed_out = q == 1; }
+                }
+            }
             if (w != ncclSuccess) {
                 for (int i = 0; i < ndev; ++i)
                     if (cs->comm[i]) { (void)hipSetDevice(dev[i]); (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
                 cs->rccl_ok = false;
-                cs->why = std::string("RCCL warm-up all-gather failed: ") + (ok ? rccl().GetErrorString(w) : "device buffers");
+                cs->why = timed_out ? std::string("RCCL warm-up all-gather timed out: communicators released, host exchange")
+                                    : std::string("RCCL warm-up all-gather failed: ") + (ok ? rccl().GetErrorString(w) : "device buffers");
             }
+            for (int i = 0; i < ndev; ++i)
+                if (ws[i]) { (void)hipSetDevice(dev[i]); (void)hipStreamSynchronize(ws[i]); (void)hipStreamDestroy(ws[i]); }   // (after an abort the kernel has exited)
             (void)hipGetLastError();
         }
     }
     if (ndev > 1) for (int i = 0; i < ndev; ++i) cs->wk[i] = new_worker();
-    cs->lock_order.assign(dev, dev + ndev);
-    std::sort(cs->lock_order.begin(), cs->lock_order.end());
-    cs->lock_order.erase(std::unique(cs->lock_order.begin(), cs->lock_order.end()), cs->lock_order.end());
     sets[key] = cs;
     return cs;
 }

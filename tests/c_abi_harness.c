@@ -481,6 +481,53 @@ int main(int argc, char** argv) {
     ok_or_die(abo_destroy(g2), "abo_destroy (appended)");
     printf("ok retain / append / rollback\n");
 
+    /* --- greedy q-EI on a resident candidate set (ABI 6): the block form against the plain loop, then the first pick appended for
+     * real — its down-date column comes from the batch's chain (abo_timings.downdate_from_chain) ------------------------------ */
+    {
+        enum { Q = 5 };
+        abo_cand* cs = NULL;
+        ok_or_die(abo_cand_create(g, Z->v, M, d, ABO_HOST, &cs), "abo_cand_create");
+        double xb[Q * 64], xp[Q * 64], eb[Q], ep[Q];
+        int64_t ib[Q], ip[Q];
+        abo_qei_stats qs;
+        CHECK(d <= 64, "q-EI section: d = %d", d);
+        ok_or_die(abo_cand_qei(g, cs, Q, a[1], a[2], 0, 0, 0, xb, ib, eb, &qs), "abo_cand_qei (block form)");
+        CHECK(qs.block == 32 && qs.block_builds >= 1 && qs.block_builds + qs.block_hits == Q - 1 && qs.picks == Q,
+              "q-EI stats: block %d builds %d hits %d picks %d", qs.block, qs.block_builds, qs.block_hits, qs.picks);
+        ok_or_die(abo_cand_qei(g, cs, Q, a[1], a[2], 0, 0, -1, xp, ip, ep, &qs), "abo_cand_qei (plain loop)");
+        CHECK(qs.block == 0, "q-EI: block = -1 must run the plain loop (stats say block %d)", qs.block);
+        int sameq = 1;
+        double dei = 0.0;
+        for (int j = 0; j < Q; ++j) {
+            sameq = sameq && ib[j] == ip[j] && memcmp(xb + j * d, xp + j * d, sizeof(double) * d) == 0 && ib[j] >= 0 && ib[j] < M;
+            const double den = fabs(ep[j]) > 1e-3 * fabs(ep[0]) ? fabs(ep[j]) : 1e-3 * fabs(ep[0]);
+            if (fabs(eb[j] - ep[j]) / den > dei) dei = fabs(eb[j] - ep[j]) / den;
+        }
+        CHECK(sameq, "q-EI: the block form and the plain loop picked different candidates");
+        CHECK(dei <= 1e-9, "q-EI: EI values of the two forms differ by %.3e (relative)", dei);
+        abo_gp* g3 = NULL;
+        ok_or_die(abo_cand_qei(g, cs, Q, a[1], a[2], 0, 0, 0, xb, ib, eb, NULL), "abo_cand_qei (block form, again)");
+        ok_or_die(abo_append(g, xb, d, 0.25, &info, &g3), "abo_append (pick 1, real value)");
+        ok_or_die(abo_cand_downdate(g3, cs), "abo_cand_downdate (from the chain)");
+        abo_timings tq;
+        ok_or_die(abo_get_timings(g3, &tq), "abo_get_timings");
+        CHECK(tq.downdate_from_chain == 1 && tq.downdate_bytes == 0.0, "down-date after the batch: from_chain %lld, bytes %.0f",
+              (long long)tq.downdate_from_chain, tq.downdate_bytes);
+        double* muc = (double*)malloc(sizeof(double) * M);
+        double* vac = (double*)malloc(sizeof(double) * M);
+        double* mur = (double*)malloc(sizeof(double) * M);
+        double* var_ = (double*)malloc(sizeof(double) * M);
+        ok_or_die(abo_cand_get(g3, cs, muc, vac, ABO_HOST), "abo_cand_get");
+        ok_or_die(abo_predict(g3, Z->v, M, d, ABO_HOST, mur, var_, ABO_HOST), "abo_predict (appended, all candidates)");
+        CHECK(maxabs(muc, mur, M) <= 1e-9 && maxabs(vac, var_, M) <= 1e-9, "chain down-date off the appended model's own posterior: mu %.3e var %.3e",
+              maxabs(muc, mur, M), maxabs(vac, var_, M));
+        printf("ok greedy q-EI (block form = plain loop: %d picks, max rel dEI %.2e; chain down-date vs re-evaluation: mu %.2e var %.2e)\n", Q, dei,
+               maxabs(muc, mur, M), maxabs(vac, var_, M));
+        free(muc); free(vac); free(mur); free(var_);
+        ok_or_die(abo_destroy(g3), "abo_destroy (appended)");
+        ok_or_die(abo_cand_destroy(cs), "abo_cand_destroy");
+    }
+
     /* --- multi-device handle: two shards on this device = the single handle, bit for bit ------------------------- */
     {
         int32_t devs[2] = {device, device};

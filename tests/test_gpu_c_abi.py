@@ -23,7 +23,7 @@ def test_c_host_runs_the_reference_closed_forms_and_the_sharded_path(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "all checks passed" in r.stdout
     for name in ("kat1", "kat3", "kat4", "kat5", "kat6", "nlml_grad kat1", "nlml_grad acq", "acq", "optimize_acquisition", "objectives as terms", "gradient-enhanced model",
-                 "retain / append / rollback", "mgpu"):
+                 "retain / append / rollback", "greedy q-EI", "mgpu"):
         assert f"ok {name}" in r.stdout
     # the process ran on the system HIP runtime, not on PyTorch's bundled copy
     hip = [ln for ln in r.stdout.splitlines() if ln.startswith("hip_runtime=")][0]

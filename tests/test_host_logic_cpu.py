@@ -281,7 +281,8 @@ def test_flattening_an_objective_leaves_no_reference_cycle_on_the_surrogate():
 
 def test_build_staleness_is_decided_by_content_not_by_time_stamps(monkeypatch, tmp_path):
     """A library file copied over lib/libabo_hip.so (an A/B build put back, older sources checked out) is newer than every source:
-    a time-stamp test would keep it.  build() compares a manifest (sha256 over csrc/, the public header and the flags)."""
+    a time-stamp test would keep it.  build() compares a manifest: sha256 over csrc/, the public header and the flags, and the sha256
+    of the linked library file itself (round 5: a copied-in library with the old manifest beside it was still trusted)."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -301,4 +302,8 @@ def test_build_staleness_is_decided_by_content_not_by_time_stamps(monkeypatch, t
     (tmp_path / "libabo_hip.manifest").write_text("0" * 64 + "\n")
     assert b._stale()                                            # … nor one whose manifest names other sources
     (tmp_path / "libabo_hip.manifest").write_text(m0 + "\n")
+    assert b._stale()                                            # … nor one that does not say which library file it describes
+    (tmp_path / "libabo_hip.manifest").write_text(m0 + "\n" + b._lib_digest() + "\n")
     assert not b._stale()
+    lib.write_bytes(b"another library copied over it")           # the motivating case: the file is replaced, the manifest stays
+    assert b._stale()
