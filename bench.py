@@ -79,6 +79,51 @@ def usable_cores():
     return n
 
 
+def pin_threads(cores):
+    """Pin every thread of this process to `cores` CPUs of the allowed set, one per physical core where the topology files say which
+    logical CPUs share one.  Returns what was done (and the masks to restore)."""
+    info = {"requested": cores, "pinned": False, "saved": {}}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        info["allowed_logical_cpus"] = len(allowed)
+        seen, pick = set(), []
+        for c in allowed:
+            try:
+                with open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id") as f:
+                    core = int(f.read())
+                with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as f:
+                    core = (int(f.read()), core)
+            except (OSError, ValueError):
+                core = ("cpu", c)
+            if core in seen:
+                continue
+            seen.add(core)
+            pick.append(c)
+            if len(pick) == cores:
+                break
+        if len(pick) < cores:
+            pick = allowed[:cores]
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                info["saved"][int(tid)] = os.sched_getaffinity(int(tid))
+                os.sched_setaffinity(int(tid), pick)
+            except OSError:
+                pass
+        info["pinned"] = True
+        info["cpus"] = pick
+    except (OSError, AttributeError) as e:
+        info["error"] = f"{type(e).__name__}: {e}"
+    return info
+
+
+def unpin_threads(info):
+    for tid, mask in info.get("saved", {}).items():
+        try:
+            os.sched_setaffinity(tid, mask)
+        except OSError:
+            pass
+
+
 def cpu_baseline(cfg, sample_m=21846, reps=3):
     """Median of `reps` repetitions of the bounded CPU sample (median of ≥ 3 steps, up to 65 536
     candidates timed and scaled linearly in M): by default 3 × 21 846 = 65 538 candidates in all, ≈ 80 s of host time
@@ -91,10 +136,19 @@ def cpu_baseline(cfg, sample_m=21846, reps=3):
     import scipy.linalg  # noqa: F401
     from oracle import gp_oracle  # noqa: F401
     cores = usable_cores()
-    with threadpool_limits(limits=cores):
-        runs = [_cpu_baseline(cfg, sample_m) for _ in range(max(1, reps))]
+    # Round 5: the baseline's threads are PINNED to `cores` distinct physical cores for its duration (every thread of the process —
+    # the BLAS pools exist since NumPy was imported — through /proc/self/task): on a 256-logical-CPU host a 16-core cgroup share
+    # otherwise lets the scheduler spread 16 BLAS threads over SMT siblings and NUMA nodes.  Whether dpotrf leaves its ≈ 30 GFLOP/s
+    # that way is recorded either way (`affinity`).
+    aff = pin_threads(cores)
+    try:
+        with threadpool_limits(limits=cores):
+            runs = [_cpu_baseline(cfg, sample_m) for _ in range(max(1, reps))]
+    finally:
+        unpin_threads(aff)
     runs.sort(key=lambda r: r["value"])
     out = runs[len(runs) // 2]
+    out["affinity"] = {k: v for k, v in aff.items() if k != "saved"}
     out["repetitions"] = len(runs)
     out["all_values"] = [r["value"] for r in runs]
     out["sample"] += f"; median of {len(runs)} repetitions"
@@ -183,7 +237,7 @@ def source_sha(names):
 
 # every file the dominant kernel of a config is compiled from (tools/pmc_traffic_json.py records the same hash)
 PMC_SOURCES = {"c3": ["gemm.hip", "abo_kernels.h"], "c3_int8": ["ozaki.hip", "abo_oz_dev.h", "abo_kernels.h"],
-               "c5": ["misc.hip", "abo_kernels.h", "abo_kappa.h"]}
+               "c5": ["gemm.hip", "abo_kernels.h"]}        # qei_pass_kernel (the block pass of greedy q-EI over the resident K_ZX)
 
 
 def pmc_traffic(config, mc_per_launch):
@@ -193,7 +247,7 @@ def pmc_traffic(config, mc_per_launch):
     traffic of that pass scaled to this run's candidates per launch.  The pass records the hash of the kernel's
     source file; when the file has changed since, the figure is STALE and `traffic` is reported as null."""
     key = config.replace("c4", "c3")                         # C4 = C3 per launch
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc_traffic.json")
         if os.path.exists(path):
             break
