@@ -511,6 +511,106 @@ __global__ void __launch_bounds__(256, 2) qei_pass_kernel(const double* __restri
             }
 }
 
+// The same product with BOTH operands going global → LDS by DMA (global_load_lds_dwordx4, no staging registers), in stages of 32 k:
+// what qei_pass_kernel's register path cannot have is a memory access shaped for the memory system — the MFMA fragment map makes a
+// load instruction touch 16 rows × 64 bytes (half a 128-byte line per row), and a 17 GB stream read that way tops out at 4.9 – 5.5
+// TB/s whatever the prefetch depth (profiles/r05_qei_pass_variants_ab.txt).  Here a DMA wave-instruction reads 4 rows × 256
+// CONTIGUOUS bytes (whole lines), lane-linearly into LDS; the 16-byte chunks of a row are XOR-swizzled through the per-lane SOURCE
+// address (chunk c of row r sits at position c ^ (r & 15)), which makes the fragment reads — lane (r16, g) wants chunk 4q + g of row
+// r16 — conflict-free: over each of ds_read_b128's four 16-lane groups (4q + g) ^ r16 takes 16 distinct values.
+// Workgroup = 4 waves × 16 rows of B (a wave fetches and reads ITS OWN rows: no barrier for B), A shared (one barrier per stage);
+// ring of three stages, two in flight; same lane ↔ k map and k order per accumulator as the kernels above: same bits.
+typedef __attribute__((address_space(3))) void* qp_lds_ptr;
+template <int RG, int BAUX>
+__global__ void __launch_bounds__(256, 2) qei_passd_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+                                                            double* __restrict__ Cbase, int64_t ldc, int K, double alpha, int kmode, int ksplit,
+                                                            int64_t sC) {
+    constexpr int SB_ = 64 * 256;                          // bytes of B per stage: 64 rows × 32 k
+    constexpr int SA_ = 16 * RG * 256;                     // bytes of A per stage
+    constexpr int SLOT = SB_ + SA_;
+    __shared__ __attribute__((aligned(1024))) char lds[3 * SLOT];       // ONE LDS object (ozaki.hip: a second one makes the compiler
+                                                                        // order every fragment read behind every DMA piece in flight)
+    const int tj = kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, bz = blockIdx.z;
+    int kbeg = 0, kend = K;
+    if (kmode == K_B_LOWER) kend = min(K, (tj / 2 + 1) * BN);          // row blocks of 64: block tj lies in the 128-row block tj/2
+    if (kmode == K_B_UPPER) kbeg = min(K, (tj / 2) * BN);
+    kbeg = max(kbeg, bz * ksplit);
+    kend = min(kend, (bz + 1) * ksplit);
+    if (kbeg >= kend) return;                              // uniform over the workgroup
+    double* C = Cbase + (int64_t)bz * sC;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)tj * 64 + wave * 16;
+    // DMA source addresses: lane L of a piece fills position L % 16 of sub-row L / 16 (4 rows × 256 bytes per piece)
+    const int sub = lane >> 4, pos = lane & 15;
+    const char* bsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rw = 4 * j + sub;                        // row inside the wave's 16
+        bsrc[j] = reinterpret_cast<const char*>(B + (row0 + rw) * ldb) + 16 * (pos ^ (rw & 15));
+    }
+    const char* asrc[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const int ra = 4 * (wave + 4 * i) + sub;           // A rows 4a … 4a+3 of piece a = wave + 4i
+        asrc[i] = reinterpret_cast<const char*>(A + (int64_t)ra * lda) + 16 * (pos ^ (ra & 15));
+    }
+    const int ns = (kend - kbeg) / 32;                     // stages (a multiple of 4)
+    auto issue = [&](int st) {                             // stage st (clamped: past the end a harmless re-fetch keeps the counts uniform)
+        const int sc = st < ns ? st : ns - 1;
+        const int64_t kb = ((int64_t)kbeg + 32 * sc) * 8;
+        char* slot = lds + (st % 3) * SLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[j] + kb),
+                                             (qp_lds_ptr)(slot + (16 * wave + 4 * j) * 256), 16, 0, BAUX);
+#pragma unroll
+        for (int i = 0; i < RG; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kb),
+                                             (qp_lds_ptr)(slot + SB_ + 4 * (wave + 4 * i) * 256), 16, 0, 0);
+    };
+    d4_t acc[RG];
+#pragma unroll
+    for (int r = 0; r < RG; ++r) acc[r] = d4_t{0.0, 0.0, 0.0, 0.0};
+    issue(0);
+    issue(1);
+    for (int st = 0; st < ns; ++st) {
+        // this wave's pieces of stage st have landed (those of stage st + 1 may still fly); its fragment reads of stage st − 1 are done
+        if constexpr (RG == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if constexpr (RG == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (RG == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // A of stage st complete for all waves; nobody still reads the slot of stage st + 2
+        __builtin_amdgcn_sched_barrier(0);
+        issue(st + 2);
+        const char* slot = lds + (st % 3) * SLOT;
+        const char* bp = slot + (16 * wave + r16) * 256;
+        const char* ap = slot + SB_ + r16 * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                     // (fragments pinned one k-group ahead of their MFMAs measured 3 % slower at T = 32)
+            const int off = 16 * ((4 * q + g) ^ r16);
+            const d2_t b = *reinterpret_cast<const d2_t*>(bp + off);
+            d2_t a[RG];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) a[r] = *reinterpret_cast<const d2_t*>(ap + r * 16 * 256 + off);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][0], b[0], acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][1], b[1], acc[r], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail's re-fetches have landed before the workgroup's LDS goes away
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t row = 16 * r + g + 4 * e;
+            C[row * ldc + row0 + r16] = alpha * acc[r][e];
+        }
+}
+
 hipError_t launch_qei_pass(const double* A, int64_t lda, int rows16, const double* B, int64_t ldb, int64_t nB, int K, double alpha,
                            double* C, int64_t ldc, hipStream_t s, int kmode, int ksplit, int64_t sC) {
     if (nB <= 0) return hipSuccess;
@@ -518,6 +618,21 @@ hipError_t launch_qei_pass(const double* A, int64_t lda, int rows16, const doubl
     if (kmode != K_FULL && kmode != K_B_LOWER && kmode != K_B_UPPER) return hipErrorInvalidValue;
     if (ksplit <= 0) ksplit = K;
     if (ksplit % 128) return hipErrorInvalidValue;
+    const bool regpath = getenv("ABO_QEI_PASS_REG") != nullptr;              // A/B runs: the register-staged kernel
+    if (!regpath) {
+        dim3 gridd((unsigned)(nB / 64), 1, (unsigned)((K + ksplit - 1) / ksplit));
+        // the B stream is read exactly once: its DMA carries the non-temporal hint (aux bit 1) — 5.7 → 6.3 TB/s at T = 16, 5.4 → 5.8 at
+        // T = 32 (profiles/r05_qei_pass_variants_ab.txt); A stays cacheable (every workgroup re-reads it)
+#define QP_LAUNCH(RG_) hipLaunchKernelGGL((qei_passd_kernel<RG_, 2>), gridd, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC)
+        switch (rows16 / 16) {
+            case 1: QP_LAUNCH(1); break;
+            case 2: QP_LAUNCH(2); break;
+            case 3: QP_LAUNCH(3); break;
+            default: QP_LAUNCH(4); break;
+        }
+#undef QP_LAUNCH
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)(nB / 128), 1, (unsigned)((K + ksplit - 1) / ksplit)), block(256);
     switch (rows16 / 16) {
         case 1: hipLaunchKernelGGL((qei_pass_kernel<1>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;

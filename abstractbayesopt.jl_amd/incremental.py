@@ -243,7 +243,7 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
     rollback=True: the batch only — model and `cands` are as before on return (what a BO step wants: the points go to the real
     objective, and the real observations are appended afterwards; in the block form those appends find their down-date columns in
     the chain the batch left with the set).
-    block: None = the library's default (block form with T = 32 when the model and the set qualify), 0 / False = the plain loop
+    block: None = the library's default (block form with T = 16 when the model and the set qualify), 0 / False = the plain loop
     (one bordered append and one O(N·M) pass over the resident K_ZX per pick), T = block form with T points per block.
     stats (a dict, optional) receives the batch's statistics (abo_qei_stats)."""
     use_block = (block is None or bool(block)) and not hasattr(model, "p") and 1 <= q <= 64

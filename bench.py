@@ -747,7 +747,7 @@ def main():
                          "under torchrun (WORLD_SIZE set) every rank drives its own GPU instead")
     ap.add_argument("--chunk", type=int, default=0, help="candidate chunk size override (0 = library default)")
     ap.add_argument("--qei-block", type=int, default=None,
-                    help="config 5: points per block of the block-form greedy q-EI (default: the library's, 32; 0 = the plain loop "
+                    help="config 5: points per block of the block-form greedy q-EI (default: the library's, 16; 0 = the plain loop "
                          "with one pass over K_ZX per pick, for A/B runs)")
     ap.add_argument("--contraction", default=None,
                     help="engine of the N^2*M variance contraction: auto (library default), fp64, int8 or int8:<moduli>")

@@ -321,7 +321,7 @@ def test_block_qei_equals_the_plain_loop_and_the_from_scratch_batch(fam, d, N0, 
     cands = abo.ResidentCandidates(m, Z)
     mu0, var0 = cands.mean_and_var()
     pts_c, idx_c, val_c, st = cands.qei(q, xi, best, block=block)
-    assert st["block"] == (32 if block == 0 else block) and st["picks"] == q
+    assert st["block"] == (16 if block == 0 else block) and st["picks"] == q
     assert st["block_builds"] >= 1 and st["block_builds"] + st["block_hits"] == q - 1
     if fam == O.SE:
         assert st["block_builds"] > 1, st                      # this case exists for the rebuild path

@@ -23,7 +23,7 @@ gp = abo.HipStandardGP(1.0 * abo.with_lengthscale(abo.Matern52Kernel(), 2.0), 1e
 m = abo.update(gp, X, y)
 c = abo.ResidentCandidates(m, Z)
 best = float(y.min())
-variants = [("pass", {}), ("skinny", {"ABO_QEI_PASS_SKINNY": "1"})]
+variants = [("pass", {}), ("reg", {"ABO_QEI_PASS_REG": "1"}), ("skinny", {"ABO_QEI_PASS_SKINNY": "1"})]
 ref = {}
 only = os.environ.get("QEI_AB_VARIANTS")
 if only:
@@ -31,7 +31,7 @@ if only:
 Ts = [int(t) for t in os.environ.get("QEI_AB_T", "16,32,48,64").split(",")]
 for T in Ts:
     for name, env in variants:
-        for k in ("ABO_QEI_PASS", "ABO_QEI_PASS_SKINNY"):
+        for k in ("ABO_QEI_PASS_REG", "ABO_QEI_PASS_SKINNY"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ts = []
