@@ -19,7 +19,7 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
            "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms", "abo_test_acq_grad_terms",
            "abo_set_qei_block", "abo_cand_qei", "abo_cand_qei_begin", "abo_cand_qei_top", "abo_cand_qei_block", "abo_cand_qei_pick",
-           "abo_cand_qei_end", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats"]
+           "abo_cand_qei_end", "abo_cand_qei_has", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats"]
 ABI_VERSION = 6
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
@@ -165,6 +165,7 @@ def lib():
     L.abo_cand_qei_block.argtypes = [vp, vp, vp, vp, i32]
     L.abo_cand_qei_pick.argtypes = [vp, vp, i64, f64, vp, i32, i64, C.POINTER(i64)]
     L.abo_cand_qei_end.argtypes = [vp, vp]
+    L.abo_cand_qei_has.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]
     L.abo_cand_qei_stats.argtypes = [vp, vp, C.POINTER(AboQeiStats)]
     L.abo_refine.argtypes = [vp, i32, f64, f64, vp, vp, i32, vp, i32, C.POINTER(AboRefineOpts), vp, vp, vp]
     L.abo_optimize_acquisition.argtypes = [vp, i32, f64, f64, vp, vp, i32, i64, i32, C.c_uint64, C.POINTER(AboRefineOpts),

@@ -283,14 +283,14 @@ hipError_t launch_qei_cov(const double* Ps, int dp, const double* Z, int64_t M, 
 // block tj → the partial product C + z·sC (launch_splitk_reduce sums them)
 hipError_t launch_qei_pass(const double* A, int64_t lda, int rows16, const double* B, int64_t ldb, int64_t nB, int K, double alpha,
                            double* C, int64_t ldc, hipStream_t s, int kmode = K_FULL, int ksplit = 0, int64_t sC = 0);
-// out[j] = blk[j] − Σ_{i<nchain} gam[i]·chain[i][j] ;  var[j] −= out[j]²/s  (var == nullptr: the column only)
+// out[j] = blk[j] − Σ_{first ≤ i < nchain} gam[i]·chain[i][j] ;  var[j] −= out[j]²/s  (var == nullptr: the column only)
 struct QeiPickArgs {
     const double* blk;      // [M]   base covariances of the picked point (a row of the block)
     const double* chain;    // [nchain][Mp]
     double* out;            // [M]   usually chain + nchain·Mp
     double* var;            // [M] or nullptr
     int64_t M, Mp;
-    int nchain;
+    int first, nchain;      // chain entries first … nchain − 1 correct the block's column
     double s;
     double gam[QEI_MAXQ];
 };

@@ -386,11 +386,14 @@ struct abo_cand {
     // N·M kernel values; kzx_ld = 0 → not resident, the down-date recomputes
     DevBuf Kzx;
     int64_t kzx_ld = 0;
-    // block form of greedy q-EI (qei.hip).  Base = the model the set was synced with at abo_cand_qei_begin (gen, N).
-    //   qblk   [nblk_cap][T16][Mp]  base covariances Cov₀(z, x_t) of the block points (ring of blocks)
-    //   qchain [QEI_MAXQ][Mp]       c_i(z) = Cov_{i−1}(z, x_i) of the picks made since the base, in order
-    // The chain outlives abo_cand_qei_end: appending the picks for real, in order, finds its down-date column here
-    // (abo_cand_downdate) instead of streaming K_ZX again — c_i does not depend on the observed value.
+    // block form of greedy q-EI (qei.hip).  Base = the model the set was synced with when the state was last reset (gen, N).
+    //   qblk   [nblk_cap][T16][Mp]  covariances Cov(z, x_t) of the block points under the model of the block's build (ring of blocks)
+    //   qchain [rows][Mp]           c_i(z) = Cov_{i−1}(z, x_i) of every conditioning since the base, in order: entries [0, nreal) are
+    //                               REAL appends (abo_cand_downdate), entries [nreal, nchain) the fantasies of the open / last batch
+    // Blocks and real entries OUTLIVE a batch: the next batch on the appended model keeps them (a BO step's picks are mostly the
+    // previous step's runners-up: their columns exist already), a block column is corrected by the chain entries made since the
+    // block's build (slot_base).  The fantasies of the last batch stay until the next one begins: appending its picks for real, in
+    // order, finds each down-date column there (c_i does not depend on the observed value).
     struct Qei {
         bool open = false;
         uint64_t gen = 0;
@@ -398,11 +401,12 @@ struct abo_cand {
         int T16 = 0, nblk_cap = 0, next_blk = 0, qmax = 0;
         std::vector<int64_t> slot_gidx;           // global candidate index per block row (−1: empty)
         std::vector<double> slot_x;               // [rows][d] the block points
-        int nchain = 0;
-        std::vector<double> chain_x;              // [nchain][d] the picked points
+        std::vector<int> blk_base;                // [nblk_cap] chain entries that existed when the block was built (already in its columns)
+        int nreal = 0, nchain = 0, chain_rows = 0;
+        std::vector<double> chain_x;              // [nchain][d] the conditioned points
         std::vector<double> chain_s;              // [nchain] s_i = σ²_{i−1}(x_i) + σ²_n
         // statistics of the current / last batch
-        int builds = 0;
+        int builds = 0, batch0 = 0;               // batch0: nchain when the batch began
         double block_ms = 0.0, pass_ms = 0.0, pass_bytes = 0.0, pass_flop = 0.0;
     } qei;
     DevBuf qblk, qchain, qwork, qrec, qmu, qvar;
@@ -1860,6 +1864,33 @@ int32_t abo_get_data(abo_gp* g, double* X, double* y) {
 }
 
 // ---- resident candidate sets (C5: greedy q-EI on a fixed grid with O(N·M) down-dates) ------------
+// Bring the set's block-form q-EI state (abo_cand::Qei) in line with a model of `rows_now` factor rows on the same storage: the rows
+// appended since the state's base must be the chain's first points, bit for bit.  A model with FEWER appended rows than the chain
+// has real entries (the caller rolled the set back — abo_cand_restore — and continues from an earlier point of the same lineage)
+// keeps the chain: the entries beyond become fantasies again (a conditioning sequence in that order), and the blocks built on the
+// longer model (their columns hold those conditionings) are dropped.  Anything else resets the state.  *ok: the state is usable.
+static int32_t qei_resync(abo_gp* g, abo_cand* c, int64_t rows_now, bool* ok) {
+    abo_cand::Qei& Q = c->qei;
+    *ok = false;
+    if (Q.N < 0) return ABO_OK;
+    const int64_t i = rows_now - Q.N;
+    if (Q.open || Q.gen != g->st->gen || i < 0 || i > Q.nreal) { Q = abo_cand::Qei(); return ABO_OK; }
+    if (i > 0) {
+        std::vector<double> rows((size_t)i * g->d);
+        HIPCHK(hipMemcpyAsync(rows.data(), g->st->Xraw.as<double>() + Q.N * g->d, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (memcmp(rows.data(), Q.chain_x.data(), sizeof(double) * rows.size())) { Q = abo_cand::Qei(); return ABO_OK; }
+    }
+    if (i < Q.nreal) {
+        Q.nreal = (int)i;
+        for (int b = 0; b < Q.nblk_cap; ++b)
+            if (Q.blk_base[b] > Q.nreal)
+                for (int t = 0; t < Q.T16; ++t) Q.slot_gidx[(size_t)b * Q.T16 + t] = -1;
+    }
+    *ok = true;
+    return ABO_OK;
+}
+
 static int32_t cand_topk(abo_gp* g, abo_cand* c, const double* sc_d, int32_t k, int64_t idx_base, double* top_val,
                          int64_t* top_idx, int32_t out_space) {
     hipStream_t s = g->stream;
@@ -1971,18 +2002,25 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
         HIPCHK(c->cdot.ensure(sizeof(double) * pad_up(c->M, 16)));
         const bool resident = c->kzx_ld > 0 && c->kzx_ld == g->st->cap;
         HIPCHK(g->events(8));
-        // A pick of the set's last block-form q-EI batch appended for real, in the batch's order: its column c_i(z) is in the chain
-        // (it does not depend on the observed value) — no pass over K_ZX.  The model's rows since the batch's base must be the
-        // chain's points, bit for bit.
-        int chain_i = -1;
-        const abo_cand::Qei& Q = c->qei;
-        if (P == 1 && resident && !Q.open && Q.gen == g->st->gen && Q.N >= 0 && c->synced_N >= Q.N && c->synced_N - Q.N < Q.nchain &&
-            !getenv("ABO_QEI_NO_CHAIN")) {
-            const int i = (int)(c->synced_N - Q.N);
-            std::vector<double> rows((size_t)(i + 1) * g->d);
-            HIPCHK(hipMemcpyAsync(rows.data(), g->st->Xraw.as<double>() + Q.N * g->d, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, s));
+        // The set's block-form q-EI state (blocks + chain) follows the model through real appends.  Entry i = number of rows appended
+        // since the state's base.  If the appended point is the next FANTASY of the last batch (the picks appended for real, in
+        // order), its column c_i(z) is in the chain already (it does not depend on the observed value): no pass over K_ZX.  Otherwise
+        // the pass below runs and its column joins the chain as real entry i (the fantasies behind it are dropped).  The model's rows
+        // since the base must be the chain's points, bit for bit; anything else resets the state.
+        int chain_i = -1, chain_put = -1;
+        abo_cand::Qei& Q = c->qei;
+        std::vector<double> newx;
+        if (Q.N >= 0 && (P != 1 || !resident || getenv("ABO_QEI_NO_CHAIN"))) Q = abo_cand::Qei();
+        bool qok = false;
+        { const int32_t r = qei_resync(g, c, c->synced_N, &qok); if (r) return r; }
+        if (qok) {
+            const int i = Q.nreal;
+            std::vector<double> row(g->d);
+            HIPCHK(hipMemcpyAsync(row.data(), g->st->Xraw.as<double>() + (Q.N + i) * g->d, sizeof(double) * g->d, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (!memcmp(rows.data(), Q.chain_x.data(), sizeof(double) * rows.size())) chain_i = i;
+            if (i < Q.nchain && !memcmp(row.data(), &Q.chain_x[(size_t)i * g->d], sizeof(double) * g->d)) chain_i = i;
+            else if (i < Q.chain_rows) { chain_put = i; newx = row; }
+            else Q = abo_cand::Qei();                                                                                  // no room: start over
         }
         g->tm.downdate_from_chain = chain_i >= 0 ? 1 : 0;
         HIPCHK(hipEventRecord(g->evs()[5], s));
@@ -1994,6 +2032,8 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
             HIPCHK(hipEventRecord(g->evs()[6], s));
             HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->qchain.as<double>() + (size_t)chain_i * Q.Mp, c->M,
                                    g->ap_beta, g->ap_s2, s));
+            Q.chain_s[chain_i] = g->ap_s2;                         // what the stored variance was down-dated with
+            Q.nreal = chain_i + 1;                                 // (the fantasies behind it stay: the next picks of the batch)
         }
         for (int q = 0; chain_i < 0 && q < P; ++q) {       // one rank-1 down-date per appended row, in append order
             const int64_t Rq = g->N - P + q;               // index of the appended row
@@ -2025,6 +2065,14 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
             }
             if (q == P - 1) HIPCHK(hipEventRecord(g->evs()[6], s));
             HIPCHK(launch_downdate(c->mu.as<double>(), c->var.as<double>(), c->cdot.as<double>(), c->M, beta, s2, s));
+            if (chain_put >= 0) {                                  // the pass's column joins the chain as real entry chain_put
+                HIPCHK(hipMemcpyAsync(c->qchain.as<double>() + (size_t)chain_put * Q.Mp, c->cdot.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
+                Q.chain_x.resize((size_t)chain_put * g->d);
+                Q.chain_x.insert(Q.chain_x.end(), newx.begin(), newx.end());
+                Q.chain_s.resize(chain_put);
+                Q.chain_s.push_back(s2);
+                Q.nreal = Q.nchain = chain_put + 1;
+            }
         }
         HIPCHK(hipStreamSynchronize(s));
         pass_ms = ev_ms(g->evs()[5], g->evs()[6]);
@@ -2144,9 +2192,37 @@ int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T) {
     abo_cand::Qei& Q = c->qei;
     const int T16 = (int)pad_up(T, 16);
     const int64_t Mp = pad_up(c->M > 0 ? c->M : 1, TB);
-    const int nblk = q < 4 ? q : 4;                       // ring of blocks: a pick outside all of them rebuilds the oldest
-    HIPCHK(c->qblk.ensure(sizeof(double) * (size_t)nblk * T16 * Mp));
-    HIPCHK(c->qchain.ensure(sizeof(double) * (size_t)q * Mp));
+    hipStream_t s = g->stream;
+    // a continuation: the state's base plus (some of) its real entries IS this model (rows compared bit for bit: qei_resync), same
+    // shapes, room for q more
+    bool cont = false;
+    if (Q.N >= 0 && (Q.T16 != T16 || Q.Mp != Mp || getenv("ABO_QEI_NO_REUSE"))) Q = abo_cand::Qei();
+    { const int32_t r = qei_resync(g, c, g->N, &cont); if (r) return r; }
+    if (cont && Q.nreal + q > QEI_MAXQ) cont = false;
+    if (!cont) {
+        Q = abo_cand::Qei();
+        Q.gen = g->st->gen; Q.N = g->N; Q.Mp = Mp; Q.T16 = T16;
+        Q.nblk_cap = 4;                                    // ring of blocks: a pick outside all of them rebuilds the oldest
+        Q.slot_gidx.assign((size_t)Q.nblk_cap * T16, -1);
+        Q.slot_x.assign((size_t)Q.nblk_cap * T16 * c->d, 0.0);
+        Q.blk_base.assign(Q.nblk_cap, 0);
+    }
+    HIPCHK(c->qblk.ensure(sizeof(double) * (size_t)Q.nblk_cap * T16 * Mp));
+    // chain rows: the real entries so far + this batch's picks, and room for the real appends that follow it
+    const int want = Q.nreal + q + 8 < QEI_MAXQ ? Q.nreal + q + 8 : QEI_MAXQ;
+    if (want > Q.chain_rows) {
+        if (Q.nreal > 0) {                                 // grow, keeping the real entries
+            ScratchBuf keep(g->prm.device, s);
+            HIPCHK(keep.b.ensure(sizeof(double) * (size_t)Q.nreal * Mp));
+            HIPCHK(hipMemcpyAsync(keep.b.p, c->qchain.p, sizeof(double) * (size_t)Q.nreal * Mp, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(c->qchain.ensure(sizeof(double) * (size_t)want * Mp));
+            HIPCHK(hipMemcpyAsync(c->qchain.p, keep.b.p, sizeof(double) * (size_t)Q.nreal * Mp, hipMemcpyDeviceToDevice, s));
+        } else {
+            HIPCHK(c->qchain.ensure(sizeof(double) * (size_t)want * Mp));
+        }
+        Q.chain_rows = want;
+    }
     const QeiWork w = qei_carve(nullptr, T16, g->d, g->dp, (int)g->Np);
     HIPCHK(c->qwork.ensure(w.bytes));
     // snapshot of the stored posterior, in buffers of its own (the caller's abo_cand_save snapshot stays what it is): the batch is
@@ -2154,19 +2230,21 @@ int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T) {
     const size_t bytes = sizeof(double) * (c->M > 0 ? c->M : 1);
     HIPCHK(c->qmu.ensure(bytes));
     HIPCHK(c->qvar.ensure(bytes));
-    HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
-    Q = abo_cand::Qei();
-    Q.open = true; Q.gen = g->st->gen; Q.N = g->N; Q.Mp = Mp; Q.T16 = T16; Q.nblk_cap = nblk; Q.qmax = q;
-    Q.slot_gidx.assign((size_t)nblk * T16, -1);
-    Q.slot_x.assign((size_t)nblk * T16 * c->d, 0.0);
+    HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
+    // the fantasies of the last batch go; blocks and real entries stay
+    Q.nchain = Q.nreal;
+    Q.chain_x.resize((size_t)Q.nreal * c->d);
+    Q.chain_s.resize(Q.nreal);
+    Q.open = true; Q.qmax = q; Q.batch0 = Q.nreal; Q.builds = 0;
+    Q.block_ms = Q.pass_ms = Q.pass_bytes = Q.pass_flop = 0.0;
     return ABO_OK;
 }
 
 // EI over the shard, its k best as records in DEVICE memory rec_d (k × (4 + d + picks so far) doubles); nothing is waited for
 int32_t abo::qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int k, double* rec_d) {
     if (!g || !c || !rec_d) return fail(ABO_EINVAL, "abo_cand_qei_top: null argument");
-    if (!c->qei.open || c->qei.gen != g->st->gen || c->qei.N != g->N) return fail(ABO_EINVAL, "abo_cand_qei_top: no batch open on this model (abo_cand_qei_begin)");
+    if (!c->qei.open || c->qei.gen != g->st->gen || c->qei.N + c->qei.nreal != g->N) return fail(ABO_EINVAL, "abo_cand_qei_top: no batch open on this model (abo_cand_qei_begin)");
     if (k < 1 || k > 1024) return fail(ABO_EINVAL, "abo_cand_qei_top: k = %d outside 1..1024", k);
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
@@ -2186,7 +2264,7 @@ int32_t abo::qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t i
 int32_t abo::qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t* gidx, int T) {
     if (!g || !c || !pts || !gidx) return fail(ABO_EINVAL, "abo_cand_qei_block: null argument");
     abo_cand::Qei& Q = c->qei;
-    if (!Q.open || Q.gen != g->st->gen || Q.N != g->N) return fail(ABO_EINVAL, "abo_cand_qei_block: no batch open on this model (abo_cand_qei_begin)");
+    if (!Q.open || Q.gen != g->st->gen || Q.N + Q.nreal != g->N) return fail(ABO_EINVAL, "abo_cand_qei_block: no batch open on this model (abo_cand_qei_begin)");
     if (T < 1 || T > Q.T16) return fail(ABO_EINVAL, "abo_cand_qei_block: T = %d outside 1..%d", T, Q.T16);
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
@@ -2196,6 +2274,7 @@ int32_t abo::qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t*
     Q.next_blk = (Q.next_blk + 1) % Q.nblk_cap;
     for (int t = 0; t < T16; ++t) Q.slot_gidx[(size_t)blk * T16 + t] = t < T ? gidx[t] : -1;
     memcpy(&Q.slot_x[(size_t)blk * T16 * g->d], pts, sizeof(double) * (size_t)T * g->d);
+    Q.blk_base[blk] = Q.nreal;                             // the model of this build holds the real entries so far: they are in its columns
     ++Q.builds;
     if (c->M == 0) return ABO_OK;
     const QeiWork w = qei_carve(c->qwork.p, T16, d, dp, Np);
@@ -2252,7 +2331,8 @@ size_t abo::qei_max_words(int d, int q, int T) {
     if (T <= 0) T = qei_default_block();
     if (T > QEI_MAXT) T = QEI_MAXT;
     if (T < 1) T = 1;
-    return (size_t)T * (size_t)(4 + d + (q > 0 ? q : 1));
+    (void)q;
+    return (size_t)T * (size_t)(4 + d + QEI_MAXQ);        // a record carries one value per chain entry: real ones carried over + the batch's
 }
 
 int32_t abo::qei_has(const abo_cand* c, int64_t gidx) { return c && qei_find_slot(c, gidx) >= 0 ? 1 : 0; }
@@ -2264,17 +2344,17 @@ int32_t abo::qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, const 
     if (info) *info = 0;
     if (!g || !c || (n > 0 && !cx)) return fail(ABO_EINVAL, "abo_cand_qei_pick: null argument");
     abo_cand::Qei& Q = c->qei;
-    if (!Q.open || Q.gen != g->st->gen || Q.N != g->N) return fail(ABO_EINVAL, "abo_cand_qei_pick: no batch open on this model (abo_cand_qei_begin)");
+    if (!Q.open || Q.gen != g->st->gen || Q.N + Q.nreal != g->N) return fail(ABO_EINVAL, "abo_cand_qei_pick: no batch open on this model (abo_cand_qei_begin)");
     if (n != Q.nchain) return fail(ABO_EINVAL, "abo_cand_qei_pick: %d chain values for a chain of %d picks", n, Q.nchain);
-    if (Q.nchain >= Q.qmax) return fail(ABO_EINVAL, "abo_cand_qei_pick: the batch was opened for %d picks", Q.qmax);
+    if (Q.nchain - Q.batch0 >= Q.qmax || Q.nchain >= Q.chain_rows) return fail(ABO_EINVAL, "abo_cand_qei_pick: the batch was opened for %d picks", Q.qmax);
     if (excl >= c->M) return fail(ABO_EINVAL, "abo_cand_qei_pick: exclusion index %lld outside the shard", (long long)excl);
     const int slot = qei_find_slot(c, gidx);
     if (slot < 0) return fail(ABO_EINVAL, "abo_cand_qei_pick: candidate %lld is in no block (abo_cand_qei_block)", (long long)gidx);
     const double sj = var_x + g->st->noise_used;
     if (!(sj > 0.0)) {
-        if (info) *info = g->N + n + 1;
-        return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld",
-                    (long long)(g->N + n + 1));
+        const long long at = (long long)(g->N + (Q.nchain - Q.nreal) + 1);
+        if (info) *info = at;
+        return fail(ABO_ENOTPD, "PosDefException: matrix is not positive definite; Cholesky factorization failed at %lld", at);
     }
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
@@ -2284,6 +2364,7 @@ int32_t abo::qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, const 
     a.out = c->qchain.as<double>() + (size_t)Q.nchain * Q.Mp;
     a.var = c->var.as<double>();
     a.M = c->M; a.Mp = Q.Mp; a.nchain = Q.nchain; a.s = sj;
+    a.first = Q.blk_base[slot / Q.T16];                    // entries before it are already in the block's columns
     for (int i = 0; i < n; ++i) a.gam[i] = cx[i] / Q.chain_s[i];
     HIPCHK(launch_qei_pick(a, s));
     if (excl >= 0) {
@@ -2313,7 +2394,8 @@ void abo::qei_get_stats(const abo_cand* c, int picks, double total_ms, abo_qei_s
     if (!out) return;
     const abo_cand::Qei& Q = c->qei;
     out->picks = picks; out->block = Q.T16; out->block_builds = Q.builds;
-    out->block_hits = Q.nchain > Q.builds ? Q.nchain - Q.builds : 0;      // every conditioned pick either found its point in a block or had one built
+    const int cond = Q.nchain - Q.batch0;                                  // picks of the batch that were conditioned on
+    out->block_hits = cond > Q.builds ? cond - Q.builds : 0;               // each of them either found its point in a block or had one built
     out->total_ms = total_ms; out->block_ms = Q.block_ms; out->pass_ms = Q.pass_ms; out->pass_bytes = Q.pass_bytes; out->pass_flop = Q.pass_flop;
 }
 
@@ -2333,7 +2415,7 @@ int32_t abo::qei_drive(const QeiShards& S, int q, double xi, double best_y, int 
     std::string keep;
     if (rc) keep = g_err;
     std::vector<double> blocks;
-    int nch_done = 0;
+    int nch_done = rc ? 0 : S.cd[0]->qei.nchain;           // the real entries the state carries over
     std::vector<double> pts((size_t)Tk * d);
     std::vector<int64_t> gix(Tk);
     for (int j = 0; j < q && !rc; ++j) {
@@ -2873,9 +2955,16 @@ int32_t abo_cand_qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, co
 
 int32_t abo_cand_qei_end(abo_gp* g, abo_cand* c) { return abo::qei_end(g, c); }
 
+int32_t abo_cand_qei_has(abo_gp* g, abo_cand* c, int64_t gidx, int32_t* has, int32_t* nchain) {
+    if (!g || !c) return fail(ABO_EINVAL, "abo_cand_qei_has: null argument");
+    if (has) *has = (c->qei.N >= 0 && gidx >= 0) ? abo::qei_has(c, gidx) : 0;
+    if (nchain) *nchain = c->qei.N >= 0 ? c->qei.nchain : 0;
+    return ABO_OK;
+}
+
 int32_t abo_cand_qei_stats(abo_gp* g, abo_cand* c, abo_qei_stats* out) {
     if (!g || !c || !out) return fail(ABO_EINVAL, "abo_cand_qei_stats: null argument");
-    abo::qei_get_stats(c, c->qei.nchain + (c->qei.nchain > 0 || c->qei.builds > 0 ? 1 : 0), 0.0, out);
+    abo::qei_get_stats(c, c->qei.nchain - c->qei.batch0 + 1, 0.0, out);
     return ABO_OK;
 }
 

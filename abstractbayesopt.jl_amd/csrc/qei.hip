@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) qei_pick_kernel(QeiPickArgs a) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= a.M) return;
     double c = a.blk[j];
-    for (int i = 0; i < a.nchain; ++i) c = fma(-a.gam[i], a.chain[(int64_t)i * a.Mp + j], c);     // fixed order: pick 1, 2, …
+    for (int i = a.first; i < a.nchain; ++i) c = fma(-a.gam[i], a.chain[(int64_t)i * a.Mp + j], c);     // fixed order: entry first, first + 1, …
     a.out[j] = c;
     if (a.var) a.var[j] = a.var[j] - c * c / a.s;         // the expression of downdate_kernel
 }

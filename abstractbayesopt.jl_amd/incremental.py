@@ -155,7 +155,10 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
     try:
         _lib.check(L.abo_cand_qei_stats(h, c, C.byref(st)))
         T = min(int(st.block), m_tot)
-        picks, idxs, vals, mus, n_chain, in_block = [], [], [], [], 0, set()
+        picks, idxs, vals, mus = [], [], [], []
+        nch, has = C.c_int32(0), C.c_int32(0)
+        _lib.check(L.abo_cand_qei_has(h, c, -1, None, C.byref(nch)))
+        n_chain = int(nch.value)                       # real appends the set's state carries over from earlier batches
         for j in range(q):
             words = 4 + d + n_chain
             rec = np.empty((1, words))
@@ -169,7 +172,8 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
             picks.append(w[4:4 + d].copy()); idxs.append(gidx); vals.append(w[0]); mus.append(w[2])
             if j >= n_cond:
                 break
-            if gidx not in in_block:
+            _lib.check(L.abo_cand_qei_has(h, c, gidx, C.byref(has), None))
+            if not has.value:
                 rt = np.empty((T, words))
                 _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, T, rt.ctypes.data))
                 rt = _sorted_valid(_allgather_rows(rt, dist, group) if world > 1 else rt)[:T]
@@ -178,7 +182,6 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
                 if gidx not in set(gix.tolist()):
                     raise _lib.AboError("q-EI: internal error: the pick is not among the block's points")
                 _lib.check(L.abo_cand_qei_block(h, c, pts.ctypes.data, gix.ctypes.data, len(gix)))
-                in_block = _ring_update(in_block, gix, q, cands)
             cx = np.ascontiguousarray(w[4 + d:4 + d + n_chain]) if n_chain else np.zeros(1)
             excl = gidx - idx_base if (distinct and idx_base <= gidx < idx_base + cands.M) else -1
             info = C.c_int64(0)
@@ -188,17 +191,6 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
         _lib.check(L.abo_cand_qei_end(h, c))
     _lib.check(L.abo_cand_qei_stats(h, c, C.byref(st)))
     return np.array(picks), np.array(idxs, dtype=np.int64), np.array(vals), np.array(mus), st.as_dict()
-
-
-def _ring_update(in_block, gix, q, cands):
-    """global indices currently covered by a block: the library keeps a ring of min(q, 4) blocks, the oldest is overwritten"""
-    ring = getattr(cands, "_qei_ring", None)
-    if ring is None or not in_block:
-        ring = []
-    ring.append(set(gix.tolist()))
-    ring = ring[-min(q, 4):]
-    cands._qei_ring = ring
-    return set().union(*ring)
 
 
 def _sorted_valid(recs: np.ndarray) -> np.ndarray:

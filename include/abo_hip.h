@@ -330,7 +330,10 @@ int32_t abo_cand_exclude(abo_gp* gp, abo_cand* c, int64_t idx);
  * from the scores of that moment.  Nothing is appended to the model: on return model and set are as before (the batch is
  * rolled back), and the chain c_1 … c_{q−1} stays with the set — appending the picks for real, in order
  * (abo_append(gp, x_1, y_1) → abo_cand_downdate, …), finds each down-date column there instead of streaming K_ZX again
- * (c_j does not depend on the observed value).
+ * (c_j does not depend on the observed value).  Blocks and chain FOLLOW the model through real appends (any abo_cand_downdate puts
+ * its column into the chain): the next batch, on the appended model, still finds the columns of the earlier blocks — a BO step's
+ * picks are mostly the previous step's runners-up — corrected by the chain entries made since each block was built; a refresh,
+ * another lineage of the model or 64 chain entries start the state afresh.
  *   abo_cand_qei: the whole batch on one handle.  x_out q × d, idx_out / ei_out q (idx = idx_base + local index);
  *     distinct != 0 excludes every picked candidate for the rest of the call; block = T (16 … 64, rounded up to a multiple of
  *     16; 0 = the process default, abo_set_qei_block / ABO_QEI_BLOCK, initially 16; < 0 = the plain loop).  The plain loop
@@ -340,7 +343,8 @@ int32_t abo_cand_exclude(abo_gp* gp, abo_cand* c, int64_t idx);
  *   single set's arithmetic bit for bit:
  *     _begin(gp, c, q, block)                         snapshot σ², μ; empty chain and blocks
  *     _top(gp, c, xi, best_y, idx_base, k, rec)       EI over the shard and its k best as records of 4 + d + n doubles
- *                                                     {EI, global index (−1: none), μ, σ², x[0..d), c_1(x) … c_n(x)}, n = picks so far
+ *                                                     {EI, global index (−1: none), μ, σ², x[0..d), c_1(x) … c_n(x)}, n = entries of the
+ *                                                     chain (abo_cand_qei_has: real appends carried over + the batch's picks so far)
  *     _block(gp, c, pts, gidx, T)                     Cov₀ columns of T points (the merged best T of all shards) in one pass
  *     _pick(gp, c, gidx, var_x, cx, n, excl, info)    condition on the pick (its point must be in a block): var_x = σ²(x) and
  *                                                     cx[i] = c_{i+1}(x), i < n, both from the winner's record; excl ≥ 0: local index
@@ -363,6 +367,9 @@ int32_t abo_cand_qei_block(abo_gp* gp, abo_cand* c, const double* pts, const int
 int32_t abo_cand_qei_pick(abo_gp* gp, abo_cand* c, int64_t gidx, double var_x, const double* cx, int32_t n, int64_t excl,
                           int64_t* info);
 int32_t abo_cand_qei_end(abo_gp* gp, abo_cand* c);
+/* *has = 1 when candidate gidx is a point of one of the set's blocks; *nchain = entries of the set's chain (a record of _top carries
+ * that many values behind x).  Either output may be NULL. */
+int32_t abo_cand_qei_has(abo_gp* gp, abo_cand* c, int64_t gidx, int32_t* has, int32_t* nchain);
 /* statistics of the set's current / last block-form batch (abo_cand_qei fills its own `stats` from the same numbers) */
 int32_t abo_cand_qei_stats(abo_gp* gp, abo_cand* c, abo_qei_stats* out);
 

@@ -327,6 +327,12 @@ def test_block_qei_equals_the_plain_loop_and_the_from_scratch_batch(fam, d, N0, 
         assert st["block_builds"] > 1, st                      # this case exists for the rebuild path
     np.testing.assert_array_equal(cands.mean_and_var()[0], mu0)   # rolled back
     np.testing.assert_array_equal(cands.mean_and_var()[1], var0)
+    # the same batch again on the same model: the blocks are still there — no pass over K_ZX — and give the same bits
+    pts_r, idx_r, val_r, st_r = cands.qei(q, xi, best, block=block)
+    assert st_r["block_builds"] == 0 and st_r["block_hits"] == q - 1, st_r
+    np.testing.assert_array_equal(idx_r, idx_c)
+    np.testing.assert_array_equal(val_r, val_c)
+    cands.refresh(m)                                           # (a refresh starts the set's q-EI state afresh)
     stats = {}
     pts_p, idx_p, val_p, m_same = abo.greedy_qei(m, cands, q, xi, best, block=block or None, rollback=True, stats=stats)
     assert m_same is m and stats["block_builds"] == st["block_builds"]
@@ -419,3 +425,51 @@ def test_block_pass_kernel_repeats_the_split_k_kernels_bits(monkeypatch, block):
         out[mode] = (idx, val) + cands.mean_and_var()
     for a, b in zip(out["pass"], out["skinny"]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_blocks_and_chain_follow_the_model_through_bo_steps(monkeypatch):
+    """A BO loop: batch → the first pick appended for real (its column from the chain) → next batch on the appended model → … .  The
+    set's blocks and chain follow the model: later batches find most of their picks' columns in the earlier blocks (no pass over
+    K_ZX at all in such a step), corrected by the chain entries made since.  A real append that is NOT a pick (its column comes
+    from the streaming pass) joins the chain too.  Every step's picks equal the plain loop's (one pass per pick) and the oracle's
+    from-scratch batch; the grid's posterior after the loop equals the oracle's refit."""
+    d, N0, M, q, steps = 5, 400, 6000, 5, 6
+    X, y = synth.standardized_problem(N0, d, 0.05)
+    Z = synth.points(2, M, d)
+    fam, ell, noise, xi = O.MATERN52, 0.9, 1e-2, 0.01
+    runs = {}
+    for mode in ("reuse", "fresh", "plain"):
+        if mode == "fresh":
+            monkeypatch.setenv("ABO_QEI_NO_REUSE", "1")
+        m = abo.update(make_model(fam, ell, 1.0, noise, n_max=N0 + 64), X, y)
+        cands = abo.ResidentCandidates(m, Z)
+        Xo, yo, best, log, builds, chain = X.copy(), y.copy(), float(y.min()), [], [], []
+        for step in range(steps):
+            pts, idx, val, st = cands.qei(q, xi, best, block=(-1 if mode == "plain" else 16))
+            if mode == "reuse" and step < 3:
+                idx_o, val_o = _oracle_greedy(fam, ell, 1.0, noise, Xo, yo, Z, q, xi, best)
+                np.testing.assert_array_equal(idx, idx_o)
+                assert np.max(np.abs(val - val_o) / np.maximum(1e-3 * val_o[0], np.abs(val_o))) <= 1e-8
+            log.append((idx.copy(), val.copy()))
+            builds.append(st["block_builds"])
+            x_new = pts[0] if step != 3 else Z[17] + 1e-3          # step 3: a real observation that is not a pick
+            y_new = float(np.sin(3.0 * x_new).sum() - 0.5)
+            m = abo.append(m, x_new, y_new)
+            cands.downdate(m)
+            chain.append(m.timings()["downdate_from_chain"])
+            Xo = np.vstack([Xo, x_new]); yo = np.append(yo, y_new)
+            best = min(best, y_new)
+        runs[mode] = (log, builds, chain, cands.mean_and_var())
+    for mode in ("fresh", "plain"):
+        for (ia, va), (ib, vb) in zip(runs["reuse"][0], runs[mode][0]):
+            np.testing.assert_array_equal(ia, ib)
+            assert np.max(np.abs(va - vb) / np.maximum(1e-3 * vb[0], np.abs(vb))) <= 1e-8, mode
+    assert runs["reuse"][2] == [1, 1, 1, 0, 1, 1] and runs["plain"][2] == [0] * steps
+    assert runs["fresh"][1][0] >= 1 and all(b >= 1 for b in runs["fresh"][1])      # without reuse every batch builds its block
+    assert sum(runs["reuse"][1]) < sum(runs["fresh"][1]), (runs["reuse"][1], runs["fresh"][1])   # … with it, later batches find theirs
+    st = O.fit(fam, ell, 1.0, noise, 0.0, Xo, yo)
+    mu_o, var_o = O.predict(st, Z)
+    case = f"qei_steps/d{d}_N{N0}_M{M}_q{q}x{steps}"
+    check(case, "mu_after_loop", np.max(np.abs(runs["reuse"][3][0] - mu_o)) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
+    check(case, "var_after_loop", np.max(np.abs(runs["reuse"][3][1] - var_o)), 1e-8)
+    check(case, "var_reuse_vs_plain", np.max(np.abs(runs["reuse"][3][1] - runs["plain"][3][1])), 1e-10)
