@@ -1351,6 +1351,9 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256; g.sU = (int64_t)Np256 * Mc256;
     g.Ti = Np256 / OZ_T; g.Tj = Mc256 / OZ_T; g.n = pl.n;
     g.tjg = g.Tj >= 64 ? 64 : (int)pad_up(g.Tj, 8);
+    // A/B runs (profiles/r05_notes.md): column blocks per tile group — an XCD's patch is 4 row blocks × tjg/8 column blocks
+    static const int tjg_env = [] { const char* e = getenv("ABO_OZ_TJG"); const int v = e ? atoi(e) : 0; return (v >= 8 && v <= 2040 && v % 8 == 0) ? v : 0; }();
+    if (tjg_env && g.Tj >= tjg_env) g.tjg = tjg_env;
     for (int l = 0; l < pl.n; ++l) {
         g.invp[l] = pl.invp[l]; g.p[l] = pl.p[l];
     }
