@@ -184,7 +184,9 @@ hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, con
 // places in W / WT), the panel solve below the block as a blocked triangular solve on L (rows r0+128 … r0+128+nrows), and —
 // once, after the factorisation — the 128×128 inverses of ALL diagonal blocks in one batched launch
 hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
-hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s);
+// the same step in 78 KB of LDS on 8 waves (fits beside a running trailing update: the look-ahead chain of api.hip: factorise); same bits
+hipError_t launch_potf2_lite(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
+hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s, int lite = 0);
 hipError_t launch_trtri_diag_batched(double* K, double* W, double* WT, int64_t ld, int nblocks, int64_t* info, hipStream_t s);
 // out[i] = Σ_{k ≤ i} Wm[i][k]·v[k]   (lower == 1)   or   Σ_{k ≥ i} Wm[i][k]·v[k]   (lower == 0)
 hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* out, int Np, int lower, hipStream_t s);

@@ -176,6 +176,7 @@ struct DevBuf {
 constexpr size_t PIN_BYTES = 32768, PIN_OUT = 64;      // [0,16) fit scalars, [16,24) info, [PIN_OUT, …) selected pairs
 struct ExecCtx {
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;      // the trailing updates of the factorisation's look-ahead (created on first use)
     std::vector<hipEvent_t> ev;
     char* pin = nullptr;
 };
@@ -485,6 +486,10 @@ void fit_collect(abo_gp* g) {
     g->tm.fit_total_ms = ev_ms(g->evs()[0], g->evs()[4]);
 }
 
+constexpr size_t EV_BASE = 10;        // 0-4 fit phases, 5-7 acquisition call, 8-9 residue planes of W; from EV_BASE: per-chunk events of a
+                                      // posterior call, or (inside a fit) the strip events of the factorisation's look-ahead
+constexpr size_t EV_PER_CHUNK = 8;   // kgen 0-1, contraction 2-3, epilogue 4-5, int8 pipeline: end of quantisation 6, end of GEMM 7
+
 // Right-looking blocked Cholesky, 128-wide panels, then L⁻¹ by recursive doubling.
 // info_host == nullptr: launches only — the caller synchronises later and then looks at g->h_info / calls fit_collect().
 int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
@@ -541,7 +546,73 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // in one kernel, panel solve as a product with the inverse) for A/B runs.
     const char* spe = getenv("ABO_CHOL_SPLIT");
     const bool split = (!spe || atoi(spe) != 0) && Np > TB;     // a single block has no chain: factor + inverse in one launch
-    for (int S0 = 0, SS = SW; S0 < Np; S0 += SS) {
+    // Look-ahead (round 5): the panel chain of strip s + 1 runs WHILE the trailing update behind strip s is still going.  The update
+    // behind a strip is cut in two — (a) the next strip's columns, which the next chain needs, stays on this stream; (b) everything
+    // beyond goes to a second stream — and the chain's kernels are built to take the place of ONE departed workgroup of (b)
+    // (potf2_lite_kernel, trsm_panel_kernel: ≤ 80 KB of LDS; tools/prio_probe.hip).  Every tile still receives its updates in strip
+    // order — (b)(s − 1) before (a)(s), event-ordered — so the factor keeps its bits.  Strips only (no super-strips) in this mode.
+    const char* lae = getenv("ABO_CHOL_LOOKAHEAD");
+    // MEASURED AND OFF BY DEFAULT (profiles/r05_notes.md D): same bits, but no gain — the chain's wide kernels (the triangular solve of all
+    // rows below, the in-strip update: up to 190 workgroups) get their slots only as workgroups of (b) retire, one K = 512 tile
+    // (110 – 190 µs) at a time: Cholesky 8.32 → 8.53 ms at N = 8192, 2.81 → 3.19 at 4096, 33.0 (super-strips) → 33.2 at 16384.
+    const bool lookahead = split && lae && atoi(lae) != 0;
+    if (lookahead) {
+        ExecCtx* cx = g->ctx;
+        if (!cx->stream2) HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
+        hipStream_t lo = cx->stream2;
+        const int ns = (Np + SW - 1) / SW;
+        HIPCHK(g->events(EV_BASE + 2 * (size_t)ns + 2));
+        hipEvent_t* ec = &g->evs()[EV_BASE];               // ec[s]: chain of strip s done;  eb[s]: update (b) behind strip s done
+        hipEvent_t* eb = ec + ns;
+        int last_b = -1;
+        for (int si = 0, s0 = 0; s0 < Np; ++si, s0 += SW) {
+            const int sw = (Np - s0) < SW ? (Np - s0) : SW;
+            for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
+                const int rem = Np - r0 - TB;
+                HIPCHK(launch_potf2_lite(K, W, WT, ld, r0, info, s));
+                if (rem <= 0) break;
+                HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s, 1));
+                const int ncol = s0 + sw - r0 - TB;
+                if (ncol > 0) {
+                    GemmArgs u{};
+                    u.A = K + (int64_t)(r0 + TB) * ld + r0; u.lda = ld;
+                    u.B = u.A; u.ldb = ld;
+                    u.C = K + (int64_t)(r0 + TB) * ld + (r0 + TB); u.ldc = ld;
+                    u.M = rem; u.N = ncol; u.K = TB; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+                    u.alpha = -1.0; u.beta = 1.0; u.info = info;
+                    HIPCHK(launch_gemm_nt(u, s));
+                }
+            }
+            const int rows = Np - s0 - sw;                 // rows below the strip
+            if (rows <= 0) break;
+            const int swn = rows < SW ? rows : SW;         // the next strip's width
+            const int rest = rows - swn;                   // rows / columns beyond the next strip
+            if (rest > 0) {
+                HIPCHK(hipEventRecord(ec[si], s));
+                HIPCHK(hipStreamWaitEvent(lo, ec[si], 0));
+                GemmArgs u{};                              // (b): A[r,c] −= L[r,strip]·L[c,strip]ᵀ for r, c beyond the next strip
+                u.A = K + (int64_t)(s0 + sw + swn) * ld + s0; u.lda = ld;
+                u.B = u.A; u.ldb = ld;
+                u.C = K + (int64_t)(s0 + sw + swn) * ld + (s0 + sw + swn); u.ldc = ld;
+                u.M = rest; u.N = rest; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+                u.alpha = -1.0; u.beta = 1.0; u.info = info;
+                HIPCHK(launch_gemm_nt(u, lo));
+                HIPCHK(hipEventRecord(eb[si], lo));
+            }
+            // (a): the next strip's columns, all rows below this strip — behind (b) of the strip before, which updates the same tiles
+            if (last_b >= 0) HIPCHK(hipStreamWaitEvent(s, eb[last_b], 0));
+            if (rest > 0) last_b = si;
+            GemmArgs u{};
+            u.A = K + (int64_t)(s0 + sw) * ld + s0; u.lda = ld;
+            u.B = u.A; u.ldb = ld;
+            u.C = K + (int64_t)(s0 + sw) * ld + (s0 + sw); u.ldc = ld;
+            u.M = rows; u.N = swn; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
+            u.alpha = -1.0; u.beta = 1.0; u.info = info;
+            HIPCHK(launch_gemm_nt(u, s));
+        }
+        if (last_b >= 0) HIPCHK(hipStreamWaitEvent(s, eb[last_b], 0));
+    }
+    for (int S0 = lookahead ? Np : 0, SS = SW; S0 < Np; S0 += SS) {
         SS = (Np - S0) >= super_rows ? SSmax : SW;
         const int ss = (Np - S0) < SS ? (Np - S0) : SS;
         for (int s0 = S0; s0 < S0 + ss; s0 += SW) {
@@ -688,8 +759,6 @@ double grad_prior_var(const abo_gp* g) {
     return c * g->prm.sigma_f2 / (g->prm.ell * g->prm.ell);
 }
 
-constexpr size_t EV_BASE = 10;        // 0-4 fit phases, 5-7 acquisition call, 8-9 residue planes of W
-constexpr size_t EV_PER_CHUNK = 8;   // kgen 0-1, contraction 2-3, epilogue 4-5, int8 pipeline: end of quantisation 6, end of GEMM 7
 
 // exponent of the row scaling of a gradient-enhanced model's derivative outputs: 2^t ≈ √(prior variance of a derivative output / σ_f²)
 int oz_grad_exp(const abo_gp* g) {

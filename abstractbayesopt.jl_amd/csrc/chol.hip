@@ -390,6 +390,159 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
 }
 #undef AA
 
+// ---- the potf2 step in a footprint that fits BESIDE a trailing update ---------------------------------------------------------------
+// chol_diag_kernel<1> keeps the whole 128×128 block in LDS (129 KB, 1024 threads): it needs an empty CU, and a CU is never empty
+// while a trailing update (two 80 KB workgroups per CU) is running — tools/prio_probe.hip: a chain of 132 KB kernels waits for
+// the bulk kernel to END, a chain of 66 KB kernels slots in with ≈ 9 µs per kernel, whatever the streams' priorities.  This build
+// of the same phases holds only the 36 LOWER 16×16 sub-blocks (rows of 17 doubles: 78.3 KB) and runs on 8 waves, so that it takes
+// the place of ONE departed workgroup of the update and the panel chain of strip s + 1 can run while the update behind strip s is
+// still going (api.hip: factorise, look-ahead).  Same operations in the same order on every element as chol_diag_kernel<1>: same bits.
+constexpr int SBL = SB + 1;                       // sub-block row stride (odd: the one-row-per-lane walks spread over the banks)
+constexpr int SBSZ = SB * SBL;
+constexpr int LT = 512;
+#define LA(r, c) a[(((r) >> 4) * (((r) >> 4) + 1) / 2 + ((c) >> 4)) * SBSZ + ((r) & 15) * SBL + ((c) & 15)]      // sub-block (r/16 ≥ c/16)
+__global__ void __launch_bounds__(LT, 4) potf2_lite_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info) {
+    __shared__ double a[36 * SBSZ];
+    __shared__ double dinv[NB];
+    __shared__ int fail;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    if (*info != 0) return;
+    if (t == 0) fail = 0;
+    double* Kb = K + (int64_t)r0 * ld + r0;
+    for (int idx = t; idx < NB * NB; idx += LT) {
+        const int i = idx >> 7, j = idx & 127;
+        if ((i >> 4) >= (j >> 4)) LA(i, j) = Kb[(int64_t)i * ld + j];
+    }
+    __syncthreads();
+    for (int p = 0; p < NSB; ++p) {
+        const int o = SB * p;
+        const int below = NB - o - SB;
+        if (wave * 48 < below || wave == 0) {
+            const int row = lane < SB ? o + lane : o + SB + wave * 48 + (lane - SB);
+            const bool valid = row < NB;
+            double x[SB];
+#pragma unroll
+            for (int c = 0; c < SB; ++c) x[c] = valid ? LA(row, o + c) : 0.0;
+            int failcol = SB;
+            double myrp = 0.0;
+            double d = readlane_f64(x[0], 0);
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {                 // the instruction stream of chol_diag_kernel (see there)
+                const int jp = j > 0 ? j - 1 : 0;
+                int kq = j + 1;
+#define ABO_FILL() do { if (j > 0 && kq < SB) { x[kq] = fma(-x[jp], readlane_f64(x[jp], kq), x[kq]); ++kq; } \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+                failcol = (failcol == SB && !(d >= 2.3e-308)) ? j : failcol;
+                const double y = __builtin_amdgcn_rsq(d);
+                ABO_FILL();
+                double gg = d * y, h = 0.5 * y;
+                ABO_FILL();
+                double r = fma(-h, gg, 0.5);
+                ABO_FILL();
+                gg = fma(gg, r, gg);
+                h = fma(h, r, h);
+                ABO_FILL();
+                r = fma(-h, gg, 0.5);
+                ABO_FILL();
+                gg = fma(gg, r, gg);
+                h = fma(h, r, h);
+                ABO_FILL();
+                const double e = fma(-gg, gg, d);
+                ABO_FILL();
+                const double piv = fma(e, h, gg);
+                const double q = h + h;
+                ABO_FILL();
+                const double u = fma(-piv, q, 1.0);
+                ABO_FILL();
+                const double rp = fma(u, q, q);
+                ABO_FILL();
+                const double xs = x[j] * rp;
+                ABO_FILL();
+                x[j] = (lane == j) ? piv : xs;
+                myrp = (lane == j) ? rp : myrp;
+                ABO_FILL();
+#pragma unroll
+                for (int rest = 0; rest < SB; ++rest) ABO_FILL();
+#undef ABO_FILL
+                if (j + 1 < SB) {
+                    x[j + 1] = fma(-x[j], readlane_f64(x[j], j + 1), x[j + 1]);
+                    d = readlane_f64(x[j + 1], j + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (failcol < SB) {
+                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
+            } else if (valid) {
+                if (lane >= SB) {
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) LA(row, o + c) = x[c];
+                } else if (wave == 0) {
+                    dinv[o + lane] = myrp;
+#pragma unroll
+                    for (int c = 0; c < SB; ++c)
+                        if (c <= lane) LA(row, o + c) = x[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (fail) return;
+        {
+            const int nb = NSB - 1 - p;
+            const int total = nb * (nb + 1) / 2;
+            for (int e = wave; e < total; e += LT / 64) {
+                int bi = 0, rem = e;
+                while (rem > bi) { rem -= bi + 1; ++bi; }
+                const int bj = rem;
+                const int ri = SB * (p + 1 + bi), rj = SB * (p + 1 + bj);
+                d4_t c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[r] = LA(ri + g + 4 * r, rj + r16);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-LA(ri + r16, o + g + 4 * s4), LA(rj + r16, o + g + 4 * s4), c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) LA(ri + g + 4 * r, rj + r16) = c[r];
+            }
+        }
+        __syncthreads();
+    }
+    // the eight 16×16 diagonal sub-block inverses: column n of X_cc into ROW n of the sub-block's strict upper triangle
+    if (t < NB) {
+        const int o = SB * (t >> 4), n = t & 15;
+        double x[SB];
+#pragma unroll
+        for (int m = 0; m < SB; ++m) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < m; ++k) sacc = fma(LA(o + m, o + k), x[k], sacc);
+            x[m] = (m < n) ? 0.0 : (m == n ? dinv[o + m] : -sacc * dinv[o + m]);
+        }
+#pragma unroll
+        for (int m = 0; m < SB; ++m)
+            if (m > n) LA(o + n, o + m) = x[m];
+    }
+    __syncthreads();
+    double* Wd = W + (int64_t)r0 * ld + r0;
+    double* WTd = WT + (int64_t)r0 * ld + r0;
+    for (int idx = t; idx < NB * NB; idx += LT) {
+        const int i = idx >> 7, j = idx & 127;
+        Kb[(int64_t)i * ld + j] = i >= j ? LA(i, j) : 0.0;
+        if ((i >> 4) == (j >> 4)) {
+            const double w = i > j ? LA(j, i) : (i == j ? dinv[i] : 0.0);
+            Wd[(int64_t)i * ld + j] = w;
+            WTd[(int64_t)j * ld + i] = w;
+        }
+    }
+}
+#undef LA
+
+hipError_t launch_potf2_lite(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
+    hipLaunchKernelGGL(potf2_lite_kernel, dim3(1), dim3(LT), 0, s, K, W, WT, ld, r0, info);
+    return hipGetLastError();
+}
+
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
     hipLaunchKernelGGL(chol_diag_kernel<0>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
     return hipGetLastError();
@@ -420,10 +573,14 @@ hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, con
 // conflict-free 8-byte read per lane), the Y_k are previous MFMA results, whose C/D register r is exactly the B operand
 // of k-step r.  176 MFMAs per wave (64 of them on the dependent path); no 128×128 inverse is needed — only the eight 16×16 diagonal inverses the
 // potf2 kernel leaves in W.  (The GEMM form X = A·W_ppᵀ needed the full inverse first: 12 µs more on the panel chain.)
+// Round 5, WREG: the eight diagonal inverses live in REGISTERS (32 doubles a lane, read straight from W: L2 hits), not in LDS — 78 KB
+// instead of 96: the workgroup fits the slot of ONE departed trailing-update workgroup (see potf2_lite_kernel), same operands, same bits.
+// (WREG = true, the look-ahead chain only; the plain chain keeps them in LDS: 3 % faster when nothing else is on the CU)
 constexpr int TRSM_BLK = 36 + 8;          // 36 lower sub-blocks of L_pp (j ≥ k) + 8 diagonal inverses
+template <bool WREG>
 __global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double* W, int64_t ld, int r0, int nrows,
                                                          const int64_t* info) {
-    __shared__ double lt[TRSM_BLK][16][16 + 1];            // [block][kk][m] (+1: the transposing fill stays conflict-poor)
+    __shared__ double lt[WREG ? 36 : TRSM_BLK][16][16 + 1];            // [block][kk][m] (+1: the transposing fill stays conflict-poor)
     if (*info != 0) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = lane & 15, g = lane >> 4;
@@ -432,16 +589,26 @@ __global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double
     // fill: 64 + 8 independent loads per thread (fully unrolled: they are all in flight together), coalesced along rows
     // (the loads are unconditional — every address lies inside the block — so that all of them are issued before the first
     // one is waited for; a load under the `lower sub-block` condition would be waited for one at a time)
-    double v[64], w[8];
+    double v[64];
 #pragma unroll
     for (int e = 0; e < 64; ++e) {
         const int idx = t + 256 * e;
         v[e] = Lb[(int64_t)(idx >> 7) * ld + (idx & 127)];
     }
+    // WREG: this lane's A-operand values of the diagonal inverses, W_kk[m = n][kk = 4·s4 + g] for k = 0 … 7, s4 = 0 … 3; else the
+    // inverses go to LDS with the sub-blocks
+    double wd[8][4], w[8];
+    if constexpr (WREG) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int idx = t + 256 * e;                       // 8 blocks × 16 rows × 16 columns
-        w[e] = Wb[(int64_t)(16 * (idx >> 8) + ((idx >> 4) & 15)) * ld + 16 * (idx >> 8) + (idx & 15)];
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) wd[k][s4] = Wb[(int64_t)(16 * k + n) * ld + 16 * k + 4 * s4 + g];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = t + 256 * e;                       // 8 blocks × 16 rows × 16 columns
+            w[e] = Wb[(int64_t)(16 * (idx >> 8) + ((idx >> 4) & 15)) * ld + 16 * (idx >> 8) + (idx & 15)];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 64; ++e) {
@@ -450,10 +617,12 @@ __global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double
         const int bj = i >> 4, bk = c >> 4;
         if (bk <= bj) lt[bj * (bj + 1) / 2 + bk][c & 15][i & 15] = v[e];
     }
+    if constexpr (!WREG) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int idx = t + 256 * e;
-        lt[36 + (idx >> 8)][idx & 15][(idx >> 4) & 15] = w[e];
+        for (int e = 0; e < 8; ++e) {
+            const int idx = t + 256 * e;
+            lt[36 + (idx >> 8)][idx & 15][(idx >> 4) & 15] = w[e];
+        }
     }
     __syncthreads();
     const int rb = blockIdx.x * 4 + wave;
@@ -471,7 +640,8 @@ __global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double
     for (int k = 0; k < 8; ++k) {
         d4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[36 + k][4 * s4 + g][n], Y[k][s4], y, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; ++s4)
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(WREG ? wd[k][s4] : lt[WREG ? 0 : 36 + k][4 * s4 + g][n], Y[k][s4], y, 0, 0, 0);
         Y[k] = y;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
@@ -485,9 +655,10 @@ __global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double
         for (int r = 0; r < 4; ++r) Arow[16 * j + 4 * r + g] = Y[j][r];
 }
 
-hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s) {
+hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s, int lite) {
     if (nrows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trsm_panel_kernel, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
+    if (lite) hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
+    else hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
     return hipGetLastError();
 }
 

@@ -100,6 +100,33 @@ def test_lower_tiles_only_syrk_launch_is_bit_identical_to_the_2d_one(monkeypatch
             np.testing.assert_array_equal(Lg, L0)
 
 
+@pytest.mark.parametrize("N", [640, 2304, 2700, 4500])
+def test_look_ahead_factorisation_keeps_the_bits(monkeypatch, N):
+    """Round 5: the panel chain of strip s + 1 runs on the handle's stream while the trailing update behind strip s runs on a second
+    one (api.hip: factorise; chain kernels in a footprint that fits beside the update: potf2_lite_kernel, trsm_panel_kernel with its
+    diagonal inverses in registers).  Every tile still takes its updates in strip order and every kernel does the same arithmetic
+    as in the plain chain: L, L⁻¹ and α equal the plain chain's bit for bit — also with a ragged last strip, with a failed pivot
+    (same `info`), and for a model that is refitted many times on one handle (the second stream is re-used)."""
+    X = synth.points(1, N, 5)
+    y = synth.objective(X, 0.05)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ABO_CHOL_LOOKAHEAD", mode)
+        gp = make_model(O.MATERN52, 1.0, 1.0, 1e-3)
+        m = abo.update(gp, X, y)
+        for _ in range(2):
+            m = abo.update(gp, X, y)
+        out[mode] = abo.get_factor(m)
+        Xb = X.copy()
+        Xb[N - 7] = Xb[3]                                      # a duplicate point, no noise: the factorisation fails at row N − 6
+        with pytest.raises(abo.PosDefException) as e:
+            abo.update(make_model(O.MATERN52, 1.0, 1.0, 0.0), Xb, y)
+        out[mode] += (e.value.info,)
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(a, b)
+    assert out["1"][3] == N - 6
+
+
 @pytest.mark.parametrize("name", ["kat1", "kat3", "kat4", "kat5"])
 def test_kat_closed_forms(name):
     """test/test_surrogates.jl:59-105,:145-170; test/test_acquisition.jl; test/test_bayesian_opt.jl:
