@@ -26,12 +26,14 @@ except (OSError, ValueError):
 _recorded = {}
 
 
-def check(case: str, metric: str, err: float, bar: float):
+def check(case: str, metric: str, err: float, bar: float, tighten: bool = True):
+    """tighten=False: recorded and held against the hard bar only — for counts and fractions (starts of a refinement that end at
+    another local maximiser …), where 100 × a recorded 0 would be a bar of 1e-13 on a quantity that moves in steps"""
     err = float(err)
     _recorded.setdefault(case, {})[metric] = err
     limit = bar
     prev = BOUNDS.get(case, {}).get(metric)
-    if prev is not None:
+    if prev is not None and tighten:
         limit = min(bar, max(MARGIN * prev, FLOOR))
     assert err <= limit, f"{case}.{metric}: achieved {err:.3e} exceeds {limit:.3e} (hard bar {bar:.1e}, recorded {prev})"
 

@@ -67,10 +67,10 @@ def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper):
             # not stationary after 1000 iterations: only a start on a plateau may do that (|∇| ≤ g_tol at the start itself)
             g0 = _fd4(oracle, np.clip(starts[i], lower, upper)[None, :], 1e-5)[0]
             assert np.max(np.abs(g0)) <= 1e-4, (name, i, np.max(np.abs(pg)), np.max(np.abs(g0)))
-    check(case, f"{name}_starts_below_scipy_inside_its_basin", float(below_in_basin), 0.0)
-    check(case, f"{name}_fraction_of_starts_at_another_maximiser", other / len(starts), 0.75)    # (measured ≤ 0.57: GradientNormUCB, d = 3)
+    check(case, f"{name}_starts_below_scipy_inside_its_basin", float(below_in_basin), 0.0, tighten=False)
+    check(case, f"{name}_fraction_of_starts_at_another_maximiser", other / len(starts), 0.75, tighten=False)    # (measured ≤ 0.57: GradientNormUCB, d = 3)
     # what optimize_acquisition returns is the BEST over the starts (acq_utils.jl:66-72): the device's against SciPy's
-    check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 0.05)
+    check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 0.05, tighten=False)
 
 
 @pytest.mark.parametrize("family,d,N", [(O.SE, 1, 30), (O.MATERN52, 3, 200), (O.MATERN72, 8, 500), (O.MATERN32, 2, 64),
