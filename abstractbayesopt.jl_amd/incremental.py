@@ -239,6 +239,17 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
     (one bordered append and one O(N·M) pass over the resident K_ZX per pick), T = block form with T points per block.
     stats (a dict, optional) receives the batch's statistics (abo_qei_stats)."""
     use_block = (block is None or bool(block)) and not hasattr(model, "p") and 1 <= q <= 64
+    sharded = False
+    if group is not None or _dist_ready():
+        import torch.distributed as _d
+        sharded = _d.get_world_size(group) > 1
+    if use_block and rollback and not sharded:
+        # one shard, the batch only: the library's one-call driver (abo_cand_qei — the same steps, same bits, no interpreter between them)
+        pts, idxs, vals, st = cands.qei(q, xi, best_y, distinct=distinct, idx_base=idx_base,
+                                        block=0 if block is None or block is True else int(block))
+        if stats is not None:
+            stats.update(st)
+        return pts, idxs, vals, model
     if use_block:
         n_cond = q - 1 if (rollback or not condition_last) else q
         try:

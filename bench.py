@@ -38,19 +38,21 @@ PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X fp64 matrix peak: 256 CU × 4 SIMD × 20
 PEAK_INT8_MFMA_TOPS = 5033.0
 
 
-def sustained_int8_tops():
+def sustained_int8_tops(with_source=False):
     """what v_mfma_i32_16x16x64_i8 sustains on random operands from registers (tools/mfma_i8_power_probe.hip), read from the
-    committed probe output; None when the file is missing"""
+    NEWEST committed probe output; None when no file is there.  with_source: (value, the file it came from)"""
     import re
-    for tag in ("r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
+        rel = os.path.join("profiles", f"{tag}_mfma_i8_power_probe.txt")
         try:
-            with open(os.path.join(ROOT, "profiles", f"{tag}_mfma_i8_power_probe.txt")) as f:
+            with open(os.path.join(ROOT, rel)) as f:
                 for line in f:
                     if line.startswith("random operands") and "16x16x64" in line:
-                        return float(re.search(r"([0-9.]+) TOP/s", line).group(1))
+                        v = float(re.search(r"([0-9.]+) TOP/s", line).group(1))
+                        return (v, rel) if with_source else v
         except OSError:
             pass
-    return None
+    return (None, None) if with_source else None
                                # (v_mfma_f64_16x16x4_f64 measured at 64 clk/SIMD: profiles/r01_mfma_f64_probe.txt)
 
 CONFIGS = {
@@ -312,7 +314,7 @@ def dominant_kernel_roofline(abo, med, config, N, M_per):
             "note": "achieved = algorithmic int8 operations (moduli x N^2 x M) of the residue GEMM launches / their HIP-event duration "
                     "(library stream, median over timed steps); peak = dense int8 MFMA at 2.4 GHz; sustained_peak = the same "
                     "instruction on random operands from registers, clock as the chip holds it "
-                    "(profiles/r02_mfma_i8_power_probe.txt); fp64_equivalent = N^2*M / time of the whole contraction pipeline",
+                    f"({sustained_int8_tops(True)[1]}); fp64_equivalent = N^2*M / time of the whole contraction pipeline",
         }
     return {
         "kernel": "var_gemm256s_kernel (V = L^-1 K_XZ triangular contraction + column sum of squares)",

@@ -333,9 +333,10 @@ def test_block_qei_equals_the_plain_loop_and_the_from_scratch_batch(fam, d, N0, 
     np.testing.assert_array_equal(idx_r, idx_c)
     np.testing.assert_array_equal(val_r, val_c)
     cands.refresh(m)                                           # (a refresh starts the set's q-EI state afresh)
-    stats = {}
-    pts_p, idx_p, val_p, m_same = abo.greedy_qei(m, cands, q, xi, best, block=block or None, rollback=True, stats=stats)
-    assert m_same is m and stats["block_builds"] == st["block_builds"]
+    # the Python driver over the step calls (what a host that shards the set itself runs: incremental.py over torch.distributed)
+    from abstractbayesopt.jl_amd.incremental import _qei_block_batch
+    pts_p, idx_p, val_p, _, stats = _qei_block_batch(m, cands, q, q - 1, xi, best, 0, None, False, block)
+    assert stats["block_builds"] == st["block_builds"]
     np.testing.assert_array_equal(idx_p, idx_c)
     np.testing.assert_array_equal(val_p, val_c)
     np.testing.assert_array_equal(pts_p, pts_c)

@@ -1,5 +1,5 @@
 # copy what tools/run_final.sh left under gpurun_out/ into profiles/ (run here, after the gpurun call): bash tools/collect_final.sh r04
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd gpurun_out
 cp final_bench_default.json ../profiles/${TAG}_bench_default.json
 cp final_bench_c2.json ../profiles/${TAG}_c2_bench.json

@@ -9,7 +9,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 STAGE=${2:-all}
 want() { [ "$STAGE" = all ] || [ "$STAGE" = "$1" ]; }
 if want tests; then
@@ -37,7 +37,7 @@ if want bench; then
 timeout -k 10 900 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --contraction fp64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c3_fp64_engine.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c2 --steps 30 --warmup 5 --cpu-sample-m 65536 --cpu-reps 3 > gpurun_out/final_bench_c2.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
-timeout -k 10 300 python bench.py --config c5 --steps 5 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --config c5 --steps 20 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 600 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 > gpurun_out/final_bench_c3_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 --config c5 > gpurun_out/final_bench_c5_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 # BASELINE config 4 at its own size through the 8-shard path, all shards on this one GPU (a rehearsal of the fan-out, NOT a scaling figure)
