@@ -30,6 +30,7 @@
 #include <thread>
 #include <vector>
 
+#include "abo_exchange.h"
 #include "abo_internal.h"
 #include "abo_kernels.h"
 
@@ -461,60 +462,65 @@ int32_t exchange(abo_mgpu* mg, size_t words, uint64_t* out) {
         return ABO_OK;
     });
     if (rc) return rc;                       // nothing was enqueued anywhere
-    // 2. gather, bounded
-    std::atomic<int> abort{0};               // 1 = a shard failed after the vote, 2 = deadline
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(exchange_timeout_ms());
-    int* stall_word = nullptr;
-    std::string first_fault;
-    std::mutex fmu;
-    auto give_up = [&](int i, const char* what) {
-        abort.store(1, std::memory_order_release);
-        std::lock_guard<std::mutex> lk(fmu);
-        if (first_fault.empty()) { char b[256]; snprintf(b, sizeof b, "shard %d: %s", i, what); first_fault = b; }
-    };
-    rc = run_all(cs->wk, n, [&](int i) -> int32_t {
-        hipStream_t s = abo::gp_stream(mg->gp[i]);
-        bool enqueued = false;
-        if (hipSetDevice(mg->dev[i]) != hipSuccess) give_up(i, "hipSetDevice failed after the vote");
-        else if (fault.where == 2 && fault.shard == i) give_up(i, "failed before its all-gather (injected: ABO_MGPU_FAULT)");
-        else if (fault.where == 3 && fault.shard == i) {
-            if (hipMalloc(reinterpret_cast<void**>(&stall_word), sizeof(int)) == hipSuccess && hipMemsetAsync(stall_word, 0, sizeof(int), s) == hipSuccess) {
-                hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, s, stall_word, 20ll * 100000000ll);
-                enqueued = true;
-            } else give_up(i, "stall injection could not allocate");
-        } else {
+    // 2. gather, bounded: the protocol of abo_exchange.h (driven on a CPU with a stubbed transport by tests/exchange_stub.cpp) over
+    // RCCL and the shards' streams
+    struct RcclTransport {
+        abo_mgpu* mg; CommSet* cs; size_t words; uint64_t* out; Fault fault; int* stall_word = nullptr;
+        bool enqueue(int i, std::string* err) {
+            hipStream_t s = abo::gp_stream(mg->gp[i]);
+            if (hipSetDevice(mg->dev[i]) != hipSuccess) { *err = "hipSetDevice failed after the vote"; return false; }
+            if (fault.where == 2 && fault.shard == i) { *err = "failed before its all-gather (injected: ABO_MGPU_FAULT)"; return false; }
+            if (fault.where == 3 && fault.shard == i) {
+                if (hipMalloc(reinterpret_cast<void**>(&stall_word), sizeof(int)) == hipSuccess && hipMemsetAsync(stall_word, 0, sizeof(int), s) == hipSuccess) {
+                    hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(64), 0, s, stall_word, 20ll * 100000000ll);
+                    return true;
+                }
+                *err = "stall injection could not allocate";
+                return false;
+            }
             const ncclResult_t r = rccl().AllGather(cs->pack[i], cs->gath[i], words, ncclUint64, cs->comm[i], s);
-            if (r != ncclSuccess) give_up(i, rccl().GetErrorString(r));
-            else if (i == 0 && hipMemcpyAsync(out, cs->gath[0], n * words * 8, hipMemcpyDeviceToHost, s) != hipSuccess)
-                give_up(i, "device-to-host copy of the gathered block failed");
-            else enqueued = true;
+            if (r != ncclSuccess) { *err = rccl().GetErrorString(r); return false; }
+            if (i == 0 && hipMemcpyAsync(out, cs->gath[0], mg->ndev * words * 8, hipMemcpyDeviceToHost, s) != hipSuccess) {
+                *err = "device-to-host copy of the gathered block failed";
+                return false;
+            }
+            return true;
         }
-        int w = enqueued ? wait_stream_bounded(s, abort, deadline) : 1;
-        if (w == 0) return ABO_OK;
-        if (w < 0) give_up(i, "its stream reported an error during the collective");
-        // aborted, timed out or failed: take this shard's communicator down so that whatever it has in flight exits
-        if (cs->comm[i]) { (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
-        if (stall_word && fault.shard == i) {        // release the stand-in kernel (on a stream of its own: s is busy with it)
-            const int one = 1;
-            hipStream_t t = nullptr;
-            if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) == hipSuccess) {
-                (void)hipMemcpyAsync(stall_word, &one, sizeof one, hipMemcpyHostToDevice, t);
-                (void)hipStreamSynchronize(t);
-                (void)hipStreamDestroy(t);
+        int poll(int i) {
+            const hipError_t q = hipStreamQuery(abo::gp_stream(mg->gp[i]));
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); return -1; }
+            return 1;
+        }
+        void abort(int i) {
+            if (cs->comm[i]) { (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
+            if (stall_word && fault.shard == i) {        // release the stand-in kernel (on a stream of its own: the shard's is busy with it)
+                const int one = 1;
+                hipStream_t t = nullptr;
+                if (hipStreamCreateWithFlags(&t, hipStreamNonBlocking) == hipSuccess) {
+                    (void)hipMemcpyAsync(stall_word, &one, sizeof one, hipMemcpyHostToDevice, t);
+                    (void)hipStreamSynchronize(t);
+                    (void)hipStreamDestroy(t);
+                }
             }
         }
-        (void)hipStreamSynchronize(s);       // returns: the collective kernel exits on the abort, the stand-in on its word or its clock
-        (void)hipGetLastError();
-        return failf(ABO_EHIP, "exchange: collective aborted");
+        void drain(int i) {
+            (void)hipStreamSynchronize(abo::gp_stream(mg->gp[i]));   // returns: the collective kernel exits on the abort, the stand-in on its word or its clock
+            (void)hipGetLastError();
+        }
+    } tr{mg, cs, words, out, fault};
+    const abo::GatherVerdict gv = abo::bounded_gather(tr, n, exchange_timeout_ms(), [&](const std::function<void(int)>& f) {
+        (void)run_all(cs->wk, n, [&](int i) -> int32_t { f(i); return ABO_OK; });
     });
-    if (stall_word) { (void)hipFree(stall_word); stall_word = nullptr; }
-    if (!rc) return ABO_OK;
+    if (tr.stall_word) { (void)hipFree(tr.stall_word); tr.stall_word = nullptr; }
+    if (!gv.aborted) return ABO_OK;
+    const std::string first_fault = gv.first_fault;
     // 3. fall-back: no thread is inside RCCL any more; the set's remaining communicators go too
     for (int i = 0; i < n; ++i)
         if (cs->comm[i]) { (void)hipSetDevice(mg->dev[i]); (void)rccl().CommAbort(cs->comm[i]); cs->comm[i] = nullptr; }
     (void)hipGetLastError();
     cs->rccl_ok = false;
-    cs->why = std::string(abort.load() == 2 ? "RCCL exchange timed out" : "RCCL exchange aborted") +
+    cs->why = std::string(gv.aborted == 2 ? "RCCL exchange timed out" : "RCCL exchange aborted") +
               (first_fault.empty() ? "" : " (" + first_fault + ")") + ": communicators released, host exchange from now on";
     return exchange_host(mg, words, out);
 }

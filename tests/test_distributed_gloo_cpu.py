@@ -100,3 +100,20 @@ def test_qei_pick_exchange_prefers_lowest_index_on_ties():
         assert p.exitcode == 0
     for rank, rec in res:
         assert rec[1] == 41.0 and rec[0] == 0.7 and rec[2] == -0.3 and rec[3:].tolist() == [0.1, 0.2, 0.3]
+
+
+def test_bounded_gather_protocol_with_a_stubbed_transport(tmp_path):
+    """The part of the in-library exchange that must never hang — every shard enqueues its all-gather, polls its stream, an abort
+    word and a deadline, and takes its OWN communicator down when any of them says so (csrc/abo_exchange.h, used by mgpu.hip) —
+    driven on the CPU with a stubbed transport (tests/exchange_stub.cpp): n = 2, 3, 8 shards on one thread each; a peer that never
+    enqueues (the others are released by their own aborts, at once), a collective that never completes (released at the deadline),
+    a stream error.  The one-GPU box can only ever run this at one rank (tests/test_gpu_multigpu.py: fault injection)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "exchange_stub")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-I", os.path.join(root, "abstractbayesopt.jl_amd", "csrc"),
+                           os.path.join(root, "tests", "exchange_stub.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout

@@ -17,10 +17,10 @@ for f in glob.glob("gpurun_out/pmc_c5_fetch/**/*kernel_trace.csv", recursive=Tru
         dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size_X", r.get("Grid_Size", ""))))
 lines = ["rocprofv3 --kernel-trace --pmc FETCH_SIZE (tools/run_pmc_c5.sh), C5: N = 16384(+), grid 131072, means per dispatch;",
          "bytes = FETCH_SIZE (KB) x 1024 x 2 (gfx950: 64 B counted per 128-B request of a 16-B/lane stream)",
-         "qei_pass_kernel<2> is launched three times per block: two split-k products against L^-1 / L^-T (grid z > 1, ~1.1 GB each) and the pass over K_ZX (the largest)"]
+         "qei_passd_kernel<T/16> is launched three times per block: two split-k products against L^-1 / L^-T (grid z > 1, ~1.1 GB each) and the pass over K_ZX (the largest)"]
 out = {}
 for k in sorted(acc):
-    if "qei_pass_kernel" in k or "trmv_kernel" in k or "cand_gemv" in k:
+    if "qei_pass" in k or "trmv_kernel" in k or "cand_gemv" in k:
         vals = sorted(v for v, _ in acc[k])
         ds = sorted(d for d, _ in dur.get(k, []))
         big = [v for v in vals if v > 0.5 * vals[-1]]               # the pass over K_ZX: the launches with the most traffic
@@ -30,11 +30,11 @@ for k in sorted(acc):
         out[k] = (kb, dm)
 open("gpurun_out/pmc_c5_fetch_summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
-key = [k for k in out if "qei_pass_kernel" in k]
+key = [k for k in out if "qei_passd_kernel" in k]
 if key:
     kb, dm = out[key[0]]
     srcs = ("gemm.hip", "abo_kernels.h")            # = bench.py PMC_SOURCES["c5"]
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE, tools/run_pmc_c5.sh", "kernel": "qei_pass_kernel (the pass over the resident K_ZX)",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE, tools/run_pmc_c5.sh", "kernel": "qei_passd_kernel (the pass over the resident K_ZX)",
                "N": 16384, "M": 131072, "kernel_sources": list(srcs),
                "kernel_source_sha": hashlib.sha256(b"".join(open("abstractbayesopt.jl_amd/csrc/" + n, "rb").read() for n in srcs)).hexdigest()[:16],
                "FETCH_SIZE_KB_mean": kb, "correction": "gfx950: x2 (64 B counted per 128-B request of a 16-B/lane stream)",
