@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -128,15 +129,27 @@ hipError_t pool_alloc(int dev, size_t bytes, void** p, size_t* cap) {
 void pool_free(int dev, void* p, size_t cap) {
     if (g_exiting.load()) return;        // the process is going away: the driver reclaims device memory, the runtime may be gone
     Pool& pl = g_pool[dev & 15];
+    std::vector<void*> evict;
+    bool kept = false;
     {
         std::lock_guard<std::mutex> lk(pl.mu);
+        // A full pool gives up its LARGEST blocks to keep a smaller one (round 5: after a config-5 model — 17 GB of K_ZX and its
+        // factors held — the few-KB buffers of a small model that followed it were hipFree'd and hipMalloc'ed on every BO step,
+        // 0.17 → 0.35 ms per step; a large block is the one whose next hipMalloc is amortised over the most work)
+        while (pl.held + cap > pool_limit() && !pl.blocks.empty() && std::prev(pl.blocks.end())->first > cap) {
+            auto it = std::prev(pl.blocks.end());
+            evict.push_back(it->second);
+            pl.held -= it->first;
+            pl.blocks.erase(it);
+        }
         if (pl.held + cap <= pool_limit()) {
             pl.blocks.emplace(cap, p);
             pl.held += cap;
-            return;
+            kept = true;
         }
     }
-    (void)hipFree(p);
+    for (void* q : evict) (void)hipFree(q);
+    if (!kept) (void)hipFree(p);
 }
 
 void pool_trim(int dev) {
