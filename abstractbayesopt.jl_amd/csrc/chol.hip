@@ -8,6 +8,7 @@
 // (gemm.hip) does the panel solve, the trailing SYRK and the blocked L⁻¹.
 #include "abo_kernels.h"
 #include "abo_kappa.h"
+#include <cstdlib>
 
 // tools/chol_diag_probe.hip defines ABO_CHOL_PROBE to time the phases of chol_diag_kernel with the 100 MHz
 // constant clock; in the library build the macro is empty.
@@ -59,6 +60,71 @@ __device__ __forceinline__ void sqrt_and_reciprocal(double d, double& piv, doubl
     piv = fma(fma(-g, g, d), h, g);
     const double q = h + h;
     rp = fma(fma(-piv, q, 1.0), q, q);
+}
+
+// The register step of a 16-column sub-step (phase 1, (1)+(2) below), shared by every build of the diagonal-block kernel: lanes 0-15
+// of the wave hold the 16 rows of the diagonal sub-block, lanes 16-63 rows below it, one row (16 doubles) per lane, in x[].
+// Right-looking, and scheduled that way: column j's pivot chain (v_rsq_f64 + 14 dependent fp64 operations, the steps of
+// sqrt_and_reciprocal) is the serial spine, its update of column j+1 is the only update the next pivot waits for, and the
+// 14 − j updates column j owes to the columns beyond are independent filler.  Left to itself the compiler either sinks
+// every update of a column to just before that column's pivot (left-looking: j more dependent operations on the spine) or
+// issues the chain back to back with nothing in its latency; here one owed update of column j−1 is issued behind every
+// step of column j's chain, and the scheduling fences pin that order.  Every element sees the same operations in the same
+// order as in the plain loop: same bits.
+// Returns the first column whose pivot is not a positive normal number (SB if none; wave-uniform); myrp = 1/pivot of the lane's own
+// column (lanes 0-15).
+__device__ __forceinline__ int register_potf2_step(double (&x)[16], int lane, double& myrp) {
+    constexpr int SBX = 16;
+    int failcol = SBX;
+    myrp = 0.0;
+    double d = readlane_f64(x[0], 0);
+#pragma unroll
+    for (int j = 0; j < SBX; ++j) {                    // straight-line: a failed pivot poisons what follows (never
+                                                       // stored) instead of branching out of the dependent chain
+        const int jp = j > 0 ? j - 1 : 0;              // the column whose owed updates fill this chain
+        int kq = j + 1;
+#define ABO_FILL() do { if (j > 0 && kq < SBX) { x[kq] = fma(-x[jp], readlane_f64(x[jp], kq), x[kq]); ++kq; } \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+        failcol = (failcol == SBX && !(d >= 2.3e-308)) ? j : failcol;       // also catches NaN; wave-uniform
+        const double y = __builtin_amdgcn_rsq(d);
+        ABO_FILL();
+        double g = d * y, h = 0.5 * y;
+        ABO_FILL();
+        double r = fma(-h, g, 0.5);
+        ABO_FILL();
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+        ABO_FILL();
+        r = fma(-h, g, 0.5);
+        ABO_FILL();
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+        ABO_FILL();
+        const double e = fma(-g, g, d);
+        ABO_FILL();
+        const double piv = fma(e, h, g);
+        const double q = h + h;
+        ABO_FILL();
+        const double u = fma(-piv, q, 1.0);
+        ABO_FILL();
+        const double rp = fma(u, q, q);
+        ABO_FILL();
+        const double xs = x[j] * rp;
+        ABO_FILL();
+        x[j] = (lane == j) ? piv : xs;
+        myrp = (lane == j) ? rp : myrp;
+        ABO_FILL();
+#pragma unroll
+        for (int rest = 0; rest < SBX; ++rest) ABO_FILL();          // what column j−1 still owes (none once kq reaches SB)
+#undef ABO_FILL
+        if (j + 1 < SBX) {
+            x[j + 1] = fma(-x[j], readlane_f64(x[j], j + 1), x[j + 1]);
+            d = readlane_f64(x[j + 1], j + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // (column 15 owes nothing)
+    return failcol;
 }
 
 // One workgroup (16 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
@@ -184,62 +250,8 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
-            int failcol = SB;                              // first column whose pivot is not a positive normal number
-            double myrp = 0.0;
-            // Right-looking, and scheduled that way: column j's pivot chain (v_rsq_f64 + 14 dependent fp64 operations, the steps of
-            // sqrt_and_reciprocal) is the serial spine, its update of column j+1 is the only update the next pivot waits for, and the
-            // 14 − j updates column j owes to the columns beyond are independent filler.  Left to itself the compiler either sinks
-            // every update of a column to just before that column's pivot (left-looking: j more dependent operations on the spine) or
-            // issues the chain back to back with nothing in its latency; here one owed update of column j−1 is issued behind every
-            // step of column j's chain, and the scheduling fences pin that order.  Every element sees the same operations in the same
-            // order as in the plain loop: same bits.
-            double d = readlane_f64(x[0], 0);
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {                 // straight-line: a failed pivot poisons what follows (never
-                                                           // stored) instead of branching out of the dependent chain
-                const int jp = j > 0 ? j - 1 : 0;          // the column whose owed updates fill this chain
-                int kq = j + 1;
-#define ABO_FILL() do { if (j > 0 && kq < SB) { x[kq] = fma(-x[jp], readlane_f64(x[jp], kq), x[kq]); ++kq; } \
-                        __builtin_amdgcn_sched_barrier(0); } while (0)
-                failcol = (failcol == SB && !(d >= 2.3e-308)) ? j : failcol;       // also catches NaN; wave-uniform
-                const double y = __builtin_amdgcn_rsq(d);
-                ABO_FILL();
-                double g = d * y, h = 0.5 * y;
-                ABO_FILL();
-                double r = fma(-h, g, 0.5);
-                ABO_FILL();
-                g = fma(g, r, g);
-                h = fma(h, r, h);
-                ABO_FILL();
-                r = fma(-h, g, 0.5);
-                ABO_FILL();
-                g = fma(g, r, g);
-                h = fma(h, r, h);
-                ABO_FILL();
-                const double e = fma(-g, g, d);
-                ABO_FILL();
-                const double piv = fma(e, h, g);
-                const double q = h + h;
-                ABO_FILL();
-                const double u = fma(-piv, q, 1.0);
-                ABO_FILL();
-                const double rp = fma(u, q, q);
-                ABO_FILL();
-                const double xs = x[j] * rp;
-                ABO_FILL();
-                x[j] = (lane == j) ? piv : xs;
-                myrp = (lane == j) ? rp : myrp;
-                ABO_FILL();
-#pragma unroll
-                for (int rest = 0; rest < SB; ++rest) ABO_FILL();          // what column j−1 still owes (none once kq reaches SB)
-#undef ABO_FILL
-                if (j + 1 < SB) {
-                    x[j + 1] = fma(-x[j], readlane_f64(x[j], j + 1), x[j + 1]);
-                    d = readlane_f64(x[j + 1], j + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // (column 15 owes nothing)
+            double myrp;
+            const int failcol = register_potf2_step(x, lane, myrp);
             if (failcol < SB) {
                 if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
             } else if (valid) {
@@ -388,6 +400,232 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         }
     }
 }
+// Order in which the inverse of a 16×16 lower-triangular sub-block (potf2_pipe_kernel: inverse) uses the factor's strictly-lower entries,
+// two rows at a time: for the pair (m, m + 1) the entries (m, k), (m + 1, k) for k < m alternate, then (m + 1, m).  Entry = row·16 + column.
+struct InvSeq { int e[120]; };
+constexpr InvSeq make_inv_seq() {
+    InvSeq t{};
+    int c = 0;
+    for (int m = 1; m < 16; m += 2) {
+        for (int k = 0; k < m; ++k) {
+            t.e[c++] = m * 16 + k;
+            if (m + 1 < 16) t.e[c++] = (m + 1) * 16 + k;
+        }
+        if (m + 1 < 16) t.e[c++] = (m + 1) * 16 + m;
+    }
+    return t;
+}
+
+// ---- potf2 with its side work taken off the panel chain (round 5) ----------------------------------------------------------------------
+// chol_diag_kernel<1> runs its steps one after the other: load the block (4.0 µs), eight times [register step 2.6 µs, trailing update of
+// ALL remaining sub-blocks 1.5 … 0.2 µs], the eight 16×16 inverses (2.0 µs), write-back (2.6 µs) — tools/chol_diag_probe.  Only the register
+// steps and the update of the NEXT sub-block column are a dependent chain; here everything else runs beside a register step, on waves
+// of the SIMDs the spine waves do not use (a wave that shares a SIMD with a spine wave takes issue slots from it: the register step
+// is issue-bound):
+//   before step 0       sub-block column 0 is loaded (2 of the 16 loads a thread made) — the loads of everything else are in flight
+//   beside step 0       the rest of the block's lower sub-blocks arrives and goes to LDS
+//   after step p        F(p): panel p's update of sub-block column p + 1 — all the next register step waits for
+//   beside step p ≥ 1   D(p−1): panel p−1's update of the sub-block columns beyond p;  column block p−1 of L (final) is written back
+//   beside steps 4 … 7  (one spine wave left) the inverses of diagonal sub-blocks 0 … 6 are formed and written to W / WT, two a step;
+//                       the last one follows the last step
+// Every element still receives the same operations in the same order (F / D are the MFMA chain of chol_diag_kernel's step (3), panel by
+// panel, barrier-ordered): same bits as chol_diag_kernel<1>.
+__global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    __shared__ double a[NB * LDA];
+    __shared__ double dinv[NB];
+    __shared__ int fail;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    if (t == 0) fail = 0;
+    double* Kb = K + (int64_t)r0 * ld + r0;
+    double* Wd = W + (int64_t)r0 * ld + r0;
+    double* WTd = WT + (int64_t)r0 * ld + r0;
+    PROBE(0);
+    // every load of the block is issued before anything is waited for (the status word included): sub-block column 0 first — the counter
+    // of outstanding loads is in order, the first register step waits for these two only — then, on the 13 waves without a spine row at
+    // step 0, the 28 lower sub-blocks beyond it, whole sub-blocks per wave (at most three each: six 16-byte loads a lane)
+    const double c0a = Kb[(int64_t)(t >> 4) * ld + (t & 15)];
+    const double c0b = Kb[(int64_t)(64 + (t >> 4)) * ld + (t & 15)];
+    const int hw = wave - 3, rr = lane >> 3, c2 = lane & 7;
+    d2_t v[3][2];
+    if (wave >= 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int sb = hw + 13 * u;
+            if (sb < 28) {
+                int bi = 0, rem = sb;
+                while (rem > bi) { rem -= bi + 1; ++bi; }
+                const double* src = Kb + (int64_t)(SB * (bi + 1) + rr) * ld + SB * (rem + 1) + 2 * c2;
+                v[u][0] = *reinterpret_cast<const d2_t*>(src);
+                v[u][1] = *reinterpret_cast<const d2_t*>(src + 8 * ld);
+            }
+        }
+    }
+    const int64_t failed_before = *info;
+    AA(t >> 4, t & 15) = c0a;
+    AA(64 + (t >> 4), t & 15) = c0b;
+    if (failed_before != 0) return;                                        // uniform
+    __syncthreads();
+    if (wave >= 3) {                                                       // beside register step 0
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int sb = hw + 13 * u;
+            if (sb < 28) {
+                int bi = 0, rem = sb;
+                while (rem > bi) { rem -= bi + 1; ++bi; }
+                const int i = SB * (bi + 1) + rr, j = SB * (rem + 1) + 2 * c2;
+                AA(i, j) = v[u][0][0];
+                AA(i, j + 1) = v[u][0][1];
+                AA(i + 8, j) = v[u][1][0];
+                AA(i + 8, j + 1) = v[u][1][1];
+            }
+        }
+    }
+    PROBE(1);
+    // panel q's MFMA update of sub-block (bi, bj) of the block that remains behind it (chol_diag_kernel's step (3)); three LDS addresses
+    // per lane, every read and write at a constant offset from them (all twelve reads are issued before the first MFMA)
+    typedef __attribute__((address_space(3))) double lds_double;
+    auto update = [&](int q, int bi, int bj) {
+        const int o = SB * q;
+        const int ri = SB * (q + 1 + bi), rj = SB * (q + 1 + bj);
+        lds_double* cp = (lds_double*)&AA(ri + g, rj + r16);
+        lds_double* ap = (lds_double*)&AA(ri + r16, o + g);
+        lds_double* bp = (lds_double*)&AA(rj + r16, o + g);
+        d4_t c;
+        double av[4], bv[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { av[s4] = ap[4 * s4]; bv[s4] = bp[4 * s4]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = cp[4 * r * LDA];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[s4], bv[s4], c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cp[4 * r * LDA] = c[r];
+    };
+    // inverse of diagonal sub-block q by lanes 0-15 of ONE wave (column n of X_qq into ROW n of the sub-block's strict upper
+    // triangle: phase 2(a) of chol_diag_kernel), then that sub-block's entries of W and WT by the whole wave
+    auto inverse = [&](int q) {
+        const int o = SB * q;
+        if (lane < SB) {
+            const int n = lane;
+            constexpr int D = 12;                                          // reads in flight ahead of the chains that use them
+            constexpr InvSeq seq = make_inv_seq();
+            lds_double* ab = (lds_double*)&AA(o, o);                       // the sub-block's corner: every read below is `ab + constant`
+            double x[SB], win[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) win[i] = ab[(seq.e[i] >> 4) * LDA + (seq.e[i] & 15)];
+            x[0] = (0 < n) ? 0.0 : dinv[o];
+            // Rows m and m + 1 run as two interleaved chains (row m + 1 needs x[m] only in its last step); each row's own sum keeps its
+            // order k = 0, 1, …: same bits as the one-row-at-a-time loop.  The read that refills a window slot is made to depend on the
+            // sum just formed: left alone, instruction selection puts all 120 reads in front of the first multiply-add and spills them
+            // (a scheduling fence does not hold pure arithmetic back).
+            int i = 0;
+#define ABO_REFILL(acc) do { if (i + D < 120) { asm volatile("" : "+v"(ab), "+v"(acc)); \
+                             win[i % D] = ab[(seq.e[i + D] >> 4) * LDA + (seq.e[i + D] & 15)]; } ++i; } while (0)
+#pragma unroll
+            for (int m = 1; m < SB; m += 2) {
+                const double da = dinv[o + m], db = m + 1 < SB ? dinv[o + m + 1] : 0.0;
+                double sa = 0.0, sb = 0.0;
+#pragma unroll
+                for (int k = 0; k < m; ++k) {
+                    sa = fma(win[i % D], x[k], sa);
+                    ABO_REFILL(sa);
+                    if (m + 1 < SB) {
+                        sb = fma(win[i % D], x[k], sb);
+                        ABO_REFILL(sb);
+                    }
+                }
+                x[m] = (m < n) ? 0.0 : (m == n ? da : -sa * da);
+                if (m + 1 < SB) {
+                    sb = fma(win[i % D], x[m], sb);
+                    ABO_REFILL(sb);
+                    x[m + 1] = (m + 1 < n) ? 0.0 : (m + 1 == n ? db : -sb * db);
+                }
+            }
+#undef ABO_REFILL
+#pragma unroll
+            for (int m = 0; m < SB; ++m)
+                if (m > n) AA(o + n, o + m) = x[m];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = (lane + 64 * e) >> 4, j = lane & 15;
+            const double w = i > j ? AA(o + j, o + i) : (i == j ? dinv[o + i] : 0.0);          // X[i][j] lives at a[j][i]
+            Wd[(int64_t)(o + i) * ld + o + j] = w;
+            WTd[(int64_t)(o + j) * ld + o + i] = w;
+        }
+    };
+    for (int p = 0; p < NSB; ++p) {
+        const int o = SB * p;
+        const int below = NB - o - SB;
+        const int nspine = below > 96 ? 3 : (below > 48 ? 2 : 1);          // the waves `wave * 48 < below || wave == 0`
+        if (wave < nspine) {
+            const int row = lane < SB ? o + lane : o + SB + wave * 48 + (lane - SB);
+            const bool valid = row < NB;
+            double x[SB];
+#pragma unroll
+            for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
+            double myrp;
+            const int failcol = register_potf2_step(x, lane, myrp);
+            if (failcol < SB) {
+                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
+            } else if (valid) {
+                if (lane >= SB) {
+#pragma unroll
+                    for (int c = 0; c < SB; ++c) AA(row, o + c) = x[c];
+                } else if (wave == 0) {
+                    dinv[o + lane] = myrp;
+#pragma unroll
+                    for (int c = 0; c < SB; ++c)
+                        if (c <= lane) AA(row, o + c) = x[c];
+                }
+            }
+        } else if (p >= 4 && (wave & 3) >= 2) {
+            // steps 4 … 7 have one spine wave: SIMDs 2 and 3 take the seven inverses that are due, one wave alone on its SIMD each
+            // (beside a wave that issues MFMA updates an inverse takes 3.4 µs instead of 2.1 — longer than the register step)
+            const int qi = 2 * (p - 4) + (wave == 15 ? 0 : 1);
+            if ((wave == 15 || wave == 14) && qi < NSB - 1) inverse(qi);
+        } else if (p > 0 && (wave & 3) >= nspine) {
+            // D(p−1) and the write-back of column block p−1, over the waves of ALL SIMDs without a spine wave (at p < 4: 2 and 3, then
+            // SIMD 1): an update is four dependent MFMAs, 256 cycles of ONE SIMD's matrix pipe — 21 of them on one SIMD outlast the step
+            const int lo = nspine, hi = p >= 4 ? 2 : 4;                     // SIMDs lo … hi−1
+            const int per = hi - lo;
+            const int hid = (wave >> 2) * per + ((wave & 3) - lo), Hd = 4 * per;
+            const int q = p - 1;
+            const int nb = NSB - 1 - q;                                    // sub-block rows / columns behind panel q; column 0 is done (F)
+            const int total = (nb - 1) * nb / 2;
+            for (int e = hid; e < total; e += Hd) {
+                int bi = 0, rem = e;
+                while (rem > bi) { rem -= bi + 1; ++bi; }
+                update(q, bi + 1, rem + 1);
+            }
+            for (int idx = hid * 64 + lane; idx < NB * SB; idx += Hd * 64) {            // column block q of L: final
+                const int i = idx >> 4, j = SB * q + (idx & 15);
+                Kb[(int64_t)i * ld + j] = i >= j ? AA(i, j) : 0.0;
+            }
+        }
+        __syncthreads();
+        if (p < 4) PROBE(6 + 2 * p);
+        if (fail) return;                                                  // uniform (LDS flag after the barrier)
+        if (p + 1 < NSB) {
+            for (int e = wave; e < NSB - 1 - p; e += DT / 64) update(p, e, 0);          // F(p)
+            __syncthreads();
+        }
+        if (p < 4) PROBE(7 + 2 * p);
+    }
+    PROBE(2);
+    for (int idx = t; idx < NB * SB; idx += DT) {                          // the last column block; D(7) is empty
+        const int i = idx >> 4, j = SB * (NSB - 1) + (idx & 15);
+        Kb[(int64_t)i * ld + j] = i >= j ? AA(i, j) : 0.0;
+    }
+    PROBE(3);
+    if (wave == 0) inverse(NSB - 1);
+    PROBE(4);
+    PROBE(5);
+}
 #undef AA
 
 // ---- the potf2 step in a footprint that fits BESIDE a trailing update ---------------------------------------------------------------
@@ -425,53 +663,8 @@ __global__ void __launch_bounds__(LT, 4) potf2_lite_kernel(double* K, double* W,
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? LA(row, o + c) : 0.0;
-            int failcol = SB;
-            double myrp = 0.0;
-            double d = readlane_f64(x[0], 0);
-#pragma unroll
-            for (int j = 0; j < SB; ++j) {                 // the instruction stream of chol_diag_kernel (see there)
-                const int jp = j > 0 ? j - 1 : 0;
-                int kq = j + 1;
-#define ABO_FILL() do { if (j > 0 && kq < SB) { x[kq] = fma(-x[jp], readlane_f64(x[jp], kq), x[kq]); ++kq; } \
-                        __builtin_amdgcn_sched_barrier(0); } while (0)
-                failcol = (failcol == SB && !(d >= 2.3e-308)) ? j : failcol;
-                const double y = __builtin_amdgcn_rsq(d);
-                ABO_FILL();
-                double gg = d * y, h = 0.5 * y;
-                ABO_FILL();
-                double r = fma(-h, gg, 0.5);
-                ABO_FILL();
-                gg = fma(gg, r, gg);
-                h = fma(h, r, h);
-                ABO_FILL();
-                r = fma(-h, gg, 0.5);
-                ABO_FILL();
-                gg = fma(gg, r, gg);
-                h = fma(h, r, h);
-                ABO_FILL();
-                const double e = fma(-gg, gg, d);
-                ABO_FILL();
-                const double piv = fma(e, h, gg);
-                const double q = h + h;
-                ABO_FILL();
-                const double u = fma(-piv, q, 1.0);
-                ABO_FILL();
-                const double rp = fma(u, q, q);
-                ABO_FILL();
-                const double xs = x[j] * rp;
-                ABO_FILL();
-                x[j] = (lane == j) ? piv : xs;
-                myrp = (lane == j) ? rp : myrp;
-                ABO_FILL();
-#pragma unroll
-                for (int rest = 0; rest < SB; ++rest) ABO_FILL();
-#undef ABO_FILL
-                if (j + 1 < SB) {
-                    x[j + 1] = fma(-x[j], readlane_f64(x[j], j + 1), x[j + 1]);
-                    d = readlane_f64(x[j + 1], j + 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            double myrp;
+            const int failcol = register_potf2_step(x, lane, myrp);
             if (failcol < SB) {
                 if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
             } else if (valid) {
@@ -549,7 +742,10 @@ hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0
 }
 
 hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
-    hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
+    const char* pe = getenv("ABO_POTF2_PIPE");                       // 0: chol_diag_kernel<1> (A/B runs, the bit-equality test)
+    const bool pipe = !(pe && atoi(pe) == 0);
+    if (pipe) hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    else hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
     return hipGetLastError();
 }
 

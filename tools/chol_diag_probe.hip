@@ -11,7 +11,10 @@
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-int main() {
+int main(int argc, char** argv) {
+    // mode 0: chol_diag_kernel<0> (factor + inverse);  1: the potf2 step of the panel chain (launch_potf2_diag: potf2_pipe_kernel, or
+    // chol_diag_kernel<1> under ABO_POTF2_PIPE=0) — the two must print the same hash
+    const int mode = argc > 1 ? atoi(argv[1]) : 0;
     const int n = 128;
     std::vector<double> K(n * n);
     for (int i = 0; i < n; ++i)
@@ -26,9 +29,11 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 5; ++rep) {
         CK(hipMemcpy(dK, dK0, n * n * 8, hipMemcpyDeviceToDevice));
+        CK(hipMemset(dW, 0, n * n * 8)); CK(hipMemset(dWT, 0, n * n * 8));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        CK(abo::launch_chol_diag(dK, dW, dWT, n, 0, info, 0));
+        if (mode == 0) CK(abo::launch_chol_diag(dK, dW, dWT, n, 0, info, 0));
+        else CK(abo::launch_potf2_diag(dK, dW, dWT, n, 0, info, 0));
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
