@@ -127,6 +127,88 @@ __device__ __forceinline__ int register_potf2_step(double (&x)[16], int lane, do
     return failcol;
 }
 
+// The same register step with the owed updates fed from LDS (round 5; potf2_pipe_kernel): the step is bound by the ≈ 76 issue slots a
+// column takes, not by its dependent chain (tools/dp_latency_probe: a dependent v_fma_f64 issues every 5.2 cycles, the chain and its
+// v_readlane round trips come to ≈ 130 of a column's 390 cycles), and 26 of the slots are the v_readlane pairs that broadcast
+// L[k][j−1] for the 13 owed updates.  Here every lane writes its entry of column j to a 64-double buffer of its wave when the column is
+// final (lanes 0-15: L[lane][j]) and reads the entries it owes updates with back as broadcasts, two per ds_read_b128, at the top of
+// the next column's chain — the LDS queue of a wave is in order, no synchronisation.  The update of column j + 1 (the next pivot
+// waits for it) keeps its v_readlane.  The pivot test is one select per column (the pivot's argument kept in its own lane) and one
+// ballot at the end instead of six scalar instructions per column.  Same values, same operations in the same order: same bits.
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ int register_potf2_step_lds(double (&x)[16], int lane, double& myrp, lds_f64* cb) {
+    constexpr int SBX = 16;
+    myrp = 0.0;
+    double dsave = 1.0;
+    double d = readlane_f64(x[0], 0);
+#pragma unroll
+    for (int j = 0; j < SBX; ++j) {
+        const int jp = j > 0 ? j - 1 : 0;              // the column whose owed updates fill this chain
+        // the entries of column j−1 this column's chain owes updates with come from the wave's buffer; NRL > 0: the NRL nearest
+        // columns by v_readlane instead, their updates first (the LDS round trip, 72 cycles, is half a chain) — measured with NRL = 3:
+        // 2.44 µs a step against 2.40, the column is bound by its issue slots and a v_readlane pair costs two more than a read
+        constexpr int NRL = 0;
+        double w[SBX];
+        if (j > 0) {
+#pragma unroll
+            for (int k = j + 1 + NRL; k < SBX; ++k) w[k] = cb[k];       // L[k][j−1] (written at the end of column j−1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int kq = j + 1;
+#define ABO_FILL() do { if (j > 0 && kq < SBX) { x[kq] = fma(-x[jp], kq <= j + NRL ? readlane_f64(x[jp], kq) : w[kq], x[kq]); ++kq; } \
+                        __builtin_amdgcn_sched_barrier(0); } while (0)
+#define ABO_FILL_RL() do { if (NRL > 0) ABO_FILL(); else __builtin_amdgcn_sched_barrier(0); } while (0)
+        dsave = (lane == j) ? d : dsave;
+        const double y = __builtin_amdgcn_rsq(d);
+        ABO_FILL_RL();
+        double g = d * y, h = 0.5 * y;
+        ABO_FILL_RL();
+        double r = fma(-h, g, 0.5);
+        ABO_FILL_RL();                                 // (the reads are back about six instructions on)
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+        __builtin_amdgcn_sched_barrier(0);
+        r = fma(-h, g, 0.5);
+        __builtin_amdgcn_sched_barrier(0);
+        g = fma(g, r, g);
+        h = fma(h, r, h);
+        __builtin_amdgcn_sched_barrier(0);
+        const double e = fma(-g, g, d);
+        ABO_FILL();
+        ABO_FILL();
+        const double piv = fma(e, h, g);
+        const double q = h + h;
+        ABO_FILL();
+        ABO_FILL();
+        const double u = fma(-piv, q, 1.0);
+        ABO_FILL();
+        ABO_FILL();
+        const double rp = fma(u, q, q);
+        ABO_FILL();
+        ABO_FILL();
+        const double xs = x[j] * rp;
+        ABO_FILL();
+        x[j] = (lane == j) ? piv : xs;
+        myrp = (lane == j) ? rp : myrp;
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < SBX) {
+            if (j + 2 + NRL < SBX) cb[lane] = x[j];               // column j for the updates it owes through the buffer
+            const double lnext = readlane_f64(x[j], j + 1);
+            ABO_FILL();                                            // (two more in the latency of the v_readlane round trips)
+            x[j + 1] = fma(-x[j], lnext, x[j + 1]);
+            ABO_FILL();
+            d = readlane_f64(x[j + 1], j + 1);
+        }
+#pragma unroll
+        for (int rest = 0; rest < SBX; ++rest) ABO_FILL();          // (none left: 14 slots above)
+#undef ABO_FILL
+#undef ABO_FILL_RL
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const unsigned long long bad = __ballot(!(dsave >= 2.3e-308)) & 0xffffull;      // lanes 0-15: column = lane; also catches NaN
+    return bad ? __builtin_ctzll(bad) : SBX;
+}
+
 // One workgroup (16 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
 // as an 8×8 grid of 16×16 sub-blocks so that everything but the 16×16 diagonal factorisations runs
 // on the fp64 MFMA (v_mfma_f64_16x16x4_f64) with 16 + 8 workgroup barriers in total:
@@ -434,6 +516,7 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
     typedef double d2_t __attribute__((ext_vector_type(2)));
     __shared__ double a[NB * LDA];
     __shared__ double dinv[NB];
+    __shared__ __attribute__((aligned(16))) double colbuf[3][64];          // per spine wave: the column just finished (register_potf2_step_lds)
     __shared__ int fail;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -486,7 +569,7 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
     PROBE(1);
     // panel q's MFMA update of sub-block (bi, bj) of the block that remains behind it (chol_diag_kernel's step (3)); three LDS addresses
     // per lane, every read and write at a constant offset from them (all twelve reads are issued before the first MFMA)
-    typedef __attribute__((address_space(3))) double lds_double;
+    typedef lds_f64 lds_double;
     auto update = [&](int q, int bi, int bj) {
         const int o = SB * q;
         const int ri = SB * (q + 1 + bi), rj = SB * (q + 1 + bj);
@@ -569,7 +652,7 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
             double myrp;
-            const int failcol = register_potf2_step(x, lane, myrp);
+            const int failcol = register_potf2_step_lds(x, lane, myrp, (lds_f64*)colbuf[wave]);
             if (failcol < SB) {
                 if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
             } else if (valid) {
