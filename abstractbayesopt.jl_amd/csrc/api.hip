@@ -569,6 +569,10 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // rows below, the in-strip update: up to 190 workgroups) get their slots only as workgroups of (b) retire, one K = 512 tile
     // (110 – 190 µs) at a time: Cholesky 8.32 → 8.53 ms at N = 8192, 2.81 → 3.19 at 4096, 33.0 (super-strips) → 33.2 at 16384.
     const bool lookahead = split && lae && atoi(lae) != 0;
+    // Panel solve from the operand stream the diagonal-block kernel leaves (trsm_stream_kernel; ABO_TRSM_STREAM=0: the LDS-staged
+    // trsm_panel_kernel): the stream lives in T, which the factorisation does not use (the blocked inverse behind it does)
+    const char* tse = getenv("ABO_TRSM_STREAM");
+    double* trsm_ops = (split && potf2_pipe_enabled() && !(tse && atoi(tse) == 0) && g->T.cap >= TRSM_STREAM_BYTES) ? g->T.as<double>() : nullptr;
     if (lookahead) {
         ExecCtx* cx = g->ctx;
         if (!cx->stream2) HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
@@ -633,9 +637,10 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
                 const int rem = Np - r0 - TB;
                 if (split) {
-                    HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s));
+                    HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s, trsm_ops));
                     if (rem <= 0) break;
-                    HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s));
+                    if (trsm_ops) HIPCHK(launch_trsm_stream(K, trsm_ops, ld, r0, rem, info, s));
+                    else HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s));
                 } else {
                     HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
                     if (rem <= 0) break;

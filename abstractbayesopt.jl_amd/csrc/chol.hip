@@ -498,6 +498,14 @@ constexpr InvSeq make_inv_seq() {
     return t;
 }
 
+// Operand stream of trsm_stream_kernel, written by potf2_pipe_kernel: stage k (sub-block column k of the diagonal block) holds, per
+// lane (m = lane & 15, g = lane >> 4), the A operands of the solve's MFMAs in the order they are issued — X_kk[m][4·s4 + g] for
+// s4 = 0 … 3, then −L_jk[m][4·s4 + g] for s4 = 0 … 3, j = k+1 … 7 — 4 + 4·(7 − k) doubles, 144 in all; entry i of lane l lies at
+// (i / 2)·128 + 2·l + (i & 1): a lane's 16-byte load takes two consecutive operands, a wave's load is one 1 KB run.
+constexpr int TRSM_OPS = 144;
+__host__ __device__ constexpr int trsm_stage_base(int k) { return 32 * k - 2 * k * (k - 1); }
+#define TRSM_OP(i, l) ((((i) >> 1) << 7) + 2 * (l) + ((i) & 1))
+
 // ---- potf2 with its side work taken off the panel chain (round 5) ----------------------------------------------------------------------
 // chol_diag_kernel<1> runs its steps one after the other: load the block (4.0 µs), eight times [register step 2.6 µs, trailing update of
 // ALL remaining sub-blocks 1.5 … 0.2 µs], the eight 16×16 inverses (2.0 µs), write-back (2.6 µs) — tools/chol_diag_probe.  Only the register
@@ -512,7 +520,7 @@ constexpr InvSeq make_inv_seq() {
 //                       the last one follows the last step
 // Every element still receives the same operations in the same order (F / D are the MFMA chain of chol_diag_kernel's step (3), panel by
 // panel, barrier-ordered): same bits as chol_diag_kernel<1>.
-__global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info) {
+__global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, double* P) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     __shared__ double a[NB * LDA];
     __shared__ double dinv[NB];
@@ -640,6 +648,14 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
             Wd[(int64_t)(o + i) * ld + o + j] = w;
             WTd[(int64_t)(o + j) * ld + o + i] = w;
         }
+        if (P) {                                                           // stage q of trsm_stream_kernel's operand stream: X_qq[m = r16][kk = 4·s4 + g]
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int c = 4 * s4 + g;
+                const double w = r16 > c ? AA(o + c, o + r16) : (r16 == c ? dinv[o + r16] : 0.0);
+                P[TRSM_OP(trsm_stage_base(q) + s4, lane)] = w;
+            }
+        }
     };
     for (int p = 0; p < NSB; ++p) {
         const int o = SB * p;
@@ -688,6 +704,13 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
             for (int idx = hid * 64 + lane; idx < NB * SB; idx += Hd * 64) {            // column block q of L: final
                 const int i = idx >> 4, j = SB * q + (idx & 15);
                 Kb[(int64_t)i * ld + j] = i >= j ? AA(i, j) : 0.0;
+            }
+            if (P) {                                                       // … and, negated, as stage q of the panel solve's operand stream
+                const int nj = NSB - 1 - q;
+                for (int e = hid; e < 4 * nj; e += Hd) {
+                    const int s4 = e / nj, jj = e - s4 * nj;
+                    P[TRSM_OP(trsm_stage_base(q) + 4 + e, lane)] = -AA(SB * (q + 1 + jj) + r16, SB * q + 4 * s4 + g);
+                }
             }
         }
         __syncthreads();
@@ -824,10 +847,15 @@ hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0
     return hipGetLastError();
 }
 
-hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
+bool potf2_pipe_enabled() {
     const char* pe = getenv("ABO_POTF2_PIPE");                       // 0: chol_diag_kernel<1> (A/B runs, the bit-equality test)
-    const bool pipe = !(pe && atoi(pe) == 0);
-    if (pipe) hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info);
+    return !(pe && atoi(pe) == 0);
+}
+
+// P: where the packed operands of the panel solve go (TRSM_OPS × 64 doubles; potf2_pipe_kernel only), or null
+hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P) {
+    const bool pipe = potf2_pipe_enabled();
+    if (pipe) hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, P);
     else hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
     return hipGetLastError();
 }
@@ -938,6 +966,55 @@ hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int
     if (nrows <= 0) return hipSuccess;
     if (lite) hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
     else hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
+    return hipGetLastError();
+}
+
+// The same solve with its A operands streamed from the packed copy potf2_pipe_kernel leaves (round 5): no staging of the 128×128 block
+// in LDS (64 loads a thread, a transposing fill and a barrier in front of the first MFMA: a third of trsm_panel_kernel's 16.5 µs),
+// no LDS at all — a wave is on its own: 32 loads of its right-hand sides, 72 16-byte loads of operands (one 1 KB run per wave and
+// load, L2 hits), all issued before the first MFMA, then the 144 MFMAs of trsm_panel_kernel in the same order on the same values
+// (the negation of L_jk is in the stream): same bits.  One wave per workgroup, so that a launch over few rows still spreads over
+// as many SIMDs as it has waves (N = 1024: 56 instead of 14 workgroups).
+__global__ void __launch_bounds__(64) trsm_stream_kernel(double* K, const double* __restrict__ P, int64_t ld, int r0, int nrows,
+                                                         const int64_t* info) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    const int rb = blockIdx.x;
+    if (rb * 16 >= nrows) return;
+    double* Arow = K + (int64_t)(r0 + NB + rb * 16 + n) * ld + r0;    // this lane's row, the panel's 128 columns
+    d4_t Y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[j][r] = Arow[16 * j + 4 * r + g];
+    d2_t op[TRSM_OPS / 2];
+#pragma unroll
+    for (int i = 0; i < TRSM_OPS / 2; ++i) op[i] = reinterpret_cast<const d2_t*>(P)[i * 64 + lane];
+    if (*info != 0) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int b = trsm_stage_base(k);
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) y = __builtin_amdgcn_mfma_f64_16x16x4f64(op[(b + s4) >> 1][(b + s4) & 1], Y[k][s4], y, 0, 0, 0);
+        Y[k] = y;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = k + 1; j < 8; ++j) {
+                const int i = b + 4 + s4 * (7 - k) + (j - k - 1);
+                Y[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[i >> 1][i & 1], Y[k][s4], Y[j], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Arow[16 * j + 4 * r + g] = Y[j][r];
+}
+
+hipError_t launch_trsm_stream(double* K, const double* P, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s) {
+    if (nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trsm_stream_kernel, dim3((nrows + 15) / 16), dim3(64), 0, s, K, P, ld, r0, nrows, info);
     return hipGetLastError();
 }
 
