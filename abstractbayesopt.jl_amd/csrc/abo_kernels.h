@@ -187,6 +187,9 @@ hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r
 bool potf2_pipe_enabled();
 constexpr size_t TRSM_STREAM_BYTES = 144 * 64 * sizeof(double);      // the packed operands potf2_pipe_kernel leaves for trsm_stream_kernel
 hipError_t launch_trsm_stream(double* K, const double* P, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s);
+// diagonal block + panel solve + in-strip update of one panel in one launch; flag: two ints, zero before the launch
+hipError_t launch_panel_fused(double* K, double* W, double* WT, int64_t ld, int r0, int nrows, int ncol, int64_t* info, int* flag, double* P,
+                              hipStream_t s);
 // the same step in 78 KB of LDS on 8 waves (fits beside a running trailing update: the look-ahead chain of api.hip: factorise); same bits
 hipError_t launch_potf2_lite(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
 hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s, int lite = 0);

@@ -513,10 +513,14 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     double* K = st->K.as<double>();
     double* W = st->W.as<double>();
     double* WT = st->WT.as<double>();
+    // info[0]: the LAPACK-style status; behind it one word (two flags) per panel for the hand-overs inside panel_fused_kernel
+    const size_t info_words = 1 + (size_t)(Np / TB);
+    HIPCHK(g->info.ensure(sizeof(int64_t) * info_words));
     int64_t* info = g->info.as<int64_t>();
+    int* panel_flags = reinterpret_cast<int*>(info + 1);
 
     HIPCHK(hipEventRecord(g->evs()[0], s));
-    HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
+    HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t) * info_words, s));
     // whole capacity region: zeros, identity on the padded diagonal (rows ≥ N), K on the active part
     if (ld > Np) HIPCHK(hipMemsetAsync(K, 0, sizeof(double) * ld * ld, s));
     HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
@@ -572,6 +576,12 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // Panel solve from the operand stream the diagonal-block kernel leaves (trsm_stream_kernel; ABO_TRSM_STREAM=0: the LDS-staged
     // trsm_panel_kernel): the stream lives in T, which the factorisation does not use (the blocked inverse behind it does)
     const char* tse = getenv("ABO_TRSM_STREAM");
+    // One launch per panel (panel_fused_kernel: diagonal block → solve → in-strip update, handed over through flags in device memory)
+    // while at most ABO_PANEL_FUSED rows lie below the panel.  MEASURED AND OFF BY DEFAULT (0; profiles/r05_notes.md D): same bits, but
+    // 67 µs per panel at N = 1024 against 31 + 7 + 10 µs for the three launches — what one workgroup hands another inside a launch
+    // has to travel as agent-scope (L2-bypassing) loads and stores, and a launch boundary here costs 1.3 µs plus a short ramp
+    const char* pfe = getenv("ABO_PANEL_FUSED");
+    const int fused_rows = pfe ? atoi(pfe) : 0;
     double* trsm_ops = (split && potf2_pipe_enabled() && !(tse && atoi(tse) == 0) && g->T.cap >= TRSM_STREAM_BYTES) ? g->T.as<double>() : nullptr;
     if (lookahead) {
         ExecCtx* cx = g->ctx;
@@ -636,6 +646,12 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             const int sw = (S0 + ss - s0) < SW ? (S0 + ss - s0) : SW;
             for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
                 const int rem = Np - r0 - TB;
+                const bool fused = trsm_ops != nullptr && rem <= fused_rows;
+                if (fused && rem > 0) {
+                    const int ncol = s0 + sw - r0 - TB;
+                    HIPCHK(launch_panel_fused(K, W, WT, ld, r0, rem, ncol > 0 ? ncol : 0, info, panel_flags + 2 * (r0 / TB), trsm_ops, s));
+                    continue;
+                }
                 if (split) {
                     HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s, trsm_ops));
                     if (rem <= 0) break;

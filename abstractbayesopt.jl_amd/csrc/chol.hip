@@ -498,6 +498,13 @@ constexpr InvSeq make_inv_seq() {
     return t;
 }
 
+// Accesses that are coherent across the XCDs of the device WITHOUT a cache-wide operation (agent-scope relaxed atomics: sc1 loads and
+// stores): what one workgroup of panel_fused_kernel hands to another inside a launch goes through these.  The agent-scope release /
+// acquire fences that would make ordinary stores and loads do — buffer_wbl2, a write-back of the WHOLE L2 of the XCD, and buffer_inv, an
+// invalidation of all of it — were measured first: + 16 µs per panel, every solving and updating wave paying for one.
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Operand stream of trsm_stream_kernel, written by potf2_pipe_kernel: stage k (sub-block column k of the diagonal block) holds, per
 // lane (m = lane & 15, g = lane >> 4), the A operands of the solve's MFMAs in the order they are issued — X_kk[m][4·s4 + g] for
 // s4 = 0 … 3, then −L_jk[m][4·s4 + g] for s4 = 0 … 3, j = k+1 … 7 — 4 + 4·(7 − k) doubles, 144 in all; entry i of lane l lies at
@@ -520,12 +527,17 @@ __host__ __device__ constexpr int trsm_stage_base(int k) { return 32 * k - 2 * k
 //                       the last one follows the last step
 // Every element still receives the same operations in the same order (F / D are the MFMA chain of chol_diag_kernel's step (3), panel by
 // panel, barrier-ordered): same bits as chol_diag_kernel<1>.
-__global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, double* P) {
+// LDS of the diagonal-block kernel (declared by the kernels that call potf2_pipe_body: panel_fused_kernel's other workgroups stage
+// the solve's operands in `a`)
+#define POTF2_PIPE_LDS() \
+    __shared__ __attribute__((aligned(16))) double a[NB * LDA]; \
+    __shared__ double dinv[NB]; \
+    __shared__ __attribute__((aligned(16))) double colbuf[3][64];          /* per spine wave: the column just finished (register_potf2_step_lds) */ \
+    __shared__ int fail
+
+__device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double (*colbuf)[64], int& fail,
+                                                double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, double* P) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    __shared__ double a[NB * LDA];
-    __shared__ double dinv[NB];
-    __shared__ __attribute__((aligned(16))) double colbuf[3][64];          // per spine wave: the column just finished (register_potf2_step_lds)
-    __shared__ int fail;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -653,7 +665,7 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int c = 4 * s4 + g;
                 const double w = r16 > c ? AA(o + c, o + r16) : (r16 == c ? dinv[o + r16] : 0.0);
-                P[TRSM_OP(trsm_stage_base(q) + s4, lane)] = w;
+                st_agent(&P[TRSM_OP(trsm_stage_base(q) + s4, lane)], w);
             }
         }
     };
@@ -709,7 +721,7 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
                 const int nj = NSB - 1 - q;
                 for (int e = hid; e < 4 * nj; e += Hd) {
                     const int s4 = e / nj, jj = e - s4 * nj;
-                    P[TRSM_OP(trsm_stage_base(q) + 4 + e, lane)] = -AA(SB * (q + 1 + jj) + r16, SB * q + 4 * s4 + g);
+                    st_agent(&P[TRSM_OP(trsm_stage_base(q) + 4 + e, lane)], -AA(SB * (q + 1 + jj) + r16, SB * q + 4 * s4 + g));
                 }
             }
         }
@@ -731,6 +743,164 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
     if (wave == 0) inverse(NSB - 1);
     PROBE(4);
     PROBE(5);
+}
+
+__global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, double* P) {
+    POTF2_PIPE_LDS();
+    potf2_pipe_body(a, dinv, colbuf, fail, K, W, WT, ld, r0, info, P);
+}
+
+// ---- one launch per panel: diagonal block, panel solve, in-strip update (round 5) ----------------------------------------------------
+// The three steps of a panel were three launches; a launch boundary between dependent kernels costs ≈ 1.3 µs of idle queue plus the
+// ramp of the next kernel (its first loads, its status word), and the steps of a panel at N ≤ 4096 are 7 – 30 µs long.  Here they are
+// the workgroups of ONE launch, in the order of their dependencies, handing over through flags in device memory:
+//   workgroup 0            potf2_pipe_body, then flag[0] = 1 (the packed operands of the solve were stored with agent-scope stores and
+//                          acknowledged: visible to every XCD)
+//   workgroups 1 … T       the panel solve of trsm_stream_kernel, 64 rows each (waves 0 – 3: one per SIMD — sixteen solving waves on one
+//                          CU would share four matrix pipes); right-hand sides loaded BEFORE the wait for flag[0]; the operand stream
+//                          goes through LDS, brought in by all sixteen waves in one round trip (a 1024-thread workgroup has 128
+//                          registers a lane: the 144 operands do not fit beside the 64 of the right-hand sides, and a ring of a few
+//                          in flight exposes a memory latency per piece); each wave ends with flag[1] += 1 behind its acknowledged
+//                          agent-scope stores
+//   workgroups T+1 …       the in-strip update A[r, c] −= L[r, p]·L[c, p]ᵀ, one 64 × 64 block each (16 waves × one MFMA tile, the
+//                          arithmetic of gemm_nt_small_kernel: same k order, same lane ↔ k map, C − acc rounded once), after
+//                          flag[1] has reached the number of solving waves
+// Producers come FIRST in the grid: a workgroup only ever waits for workgroups with smaller indices, and those are dispatched before
+// it — no wait can starve the one it waits for, whatever the grid size.  Every wait is bounded all the same (wall clock, 2 s): a wave
+// that gives up stores −(1000 + row) in `info` and every later launch of the fit exits on it.  Same values through the same operations as
+// the three kernels: same bits.
+constexpr long long PANEL_WAIT_TICKS = 200000000ll;                        // 2 s of the 100 MHz constant clock
+
+__device__ __forceinline__ bool panel_wait(const int* flag, int target, int64_t* info, int r0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        // a failed pivot (or a wave that gave up) ends the panel: the waves that would have counted up never do
+        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (wall_clock64() - t0 > PANEL_WAIT_TICKS) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(info, (int64_t)(-1000 - r0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    asm volatile("" ::: "memory");                                         // (the loads behind the wait are agent-scope ones: no cache to invalidate)
+    return true;
+}
+
+__global__ void __launch_bounds__(DT) panel_fused_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int nrows, int ncol,
+                                                         int64_t* info, int* flag, double* P) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    POTF2_PIPE_LDS();
+    __shared__ int go;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int T = (nrows + 63) / 64;                                       // solving workgroups
+    const int b = blockIdx.x;
+    if (b == 0) {
+        potf2_pipe_body(a, dinv, colbuf, fail, K, W, WT, ld, r0, info, P);
+        __builtin_amdgcn_s_waitcnt(0);                                     // this wave's stores of the operand stream have been acknowledged
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (b <= T) {
+        // right-hand sides first (final since the last launch), then ONE wave waits for the diagonal block, then all sixteen waves bring
+        // the operand stream into LDS (72 KB in one round trip: nine agent-scope loads a thread, all in flight), then waves 0 – 3 solve
+        const int n = lane & 15, g = lane >> 4;
+        const int rb = (b - 1) * 4 + wave;
+        const bool solver = wave < 4 && rb * 16 < nrows;                   // (nrows is a multiple of 16)
+        double* Arow = K + (int64_t)(r0 + NB + rb * 16 + n) * ld + r0;
+        d4_t Y[8];
+        if (solver) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[j][r] = Arow[16 * j + 4 * r + g];
+        }
+        if (wave == 0) {
+            const bool ok = panel_wait(flag, 1, info, r0) && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            if (lane == 0) go = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!go) return;                                                   // failed pivot (nothing to solve with) or a wait given up
+        double stg[TRSM_OPS * 64 / DT];
+#pragma unroll
+        for (int e = 0; e < TRSM_OPS * 64 / DT; ++e) stg[e] = ld_agent(P + t + DT * e);
+#pragma unroll
+        for (int e = 0; e < TRSM_OPS * 64 / DT; ++e) a[t + DT * e] = stg[e];
+        __syncthreads();
+        if (!solver) return;
+        const double* op = a + 2 * lane;                                   // operand i of this lane: op[(i / 2)·128 + (i & 1)]
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int bs = trsm_stage_base(k);
+            d4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                y = __builtin_amdgcn_mfma_f64_16x16x4f64(op[((bs + s4) >> 1) * 128 + ((bs + s4) & 1)], Y[k][s4], y, 0, 0, 0);
+            Y[k] = y;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = k + 1; j < 8; ++j) {
+                    const int i = bs + 4 + s4 * (7 - k) + (j - k - 1);
+                    Y[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[(i >> 1) * 128 + (i & 1)], Y[k][s4], Y[j], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_agent(&Arow[16 * j + 4 * r + g], Y[j][r]);
+        __builtin_amdgcn_s_waitcnt(0);                                     // the stores have been acknowledged
+        if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // in-strip update: 64 × 64 block (si, sj) of the rows below the panel × the strip's remaining columns; 128-tile (si/2, sj/2) must
+    // be a lower one (the launches this replaces worked on whole 128 × 128 tiles with tj ≤ ti)
+    const int u = b - 1 - T;
+    const int ncb = ncol / 64;
+    const int si = u / ncb, sj = u - si * ncb;
+    if ((sj >> 1) > (si >> 1)) return;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r16 = lane & 15, g = lane >> 4;
+    const double* A = K + (int64_t)(r0 + NB) * ld + r0;                   // L[r, p]: rows below the panel, the panel's 128 columns
+    const double* Ap = A + (int64_t)(si * 64 + wm * 16 + r16) * ld + 2 * g;
+    const double* Bp = A + (int64_t)(sj * 64 + wn * 16 + r16) * ld + 2 * g;
+    double* Cg = K + (int64_t)(r0 + NB) * ld + (r0 + NB);
+    double cin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)                                            // C is final since the last launch: its loads go first
+        cin[r] = Cg[(int64_t)(si * 64 + wm * 16 + g + 4 * r) * ld + sj * 64 + wn * 16 + r16];
+    if (wave == 0) {                                                       // one polling wave per workgroup
+        const bool ok = panel_wait(flag + 1, nrows / 16, info, r0) && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        if (lane == 0) go = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!go) return;
+    d2_t av[16], bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                                         // the rows the solving waves have just stored: agent-scope loads
+        av[q][0] = ld_agent(Ap + 8 * q);
+        av[q][1] = ld_agent(Ap + 8 * q + 1);
+        bv[q][0] = ld_agent(Bp + 8 * q);
+        bv[q][1] = ld_agent(Bp + 8 * q + 1);
+    }
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][0], bv[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][1], bv[q][1], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        Cg[(int64_t)(si * 64 + wm * 16 + g + 4 * r) * ld + sj * 64 + wn * 16 + r16] = fma(1.0, cin[r], -1.0 * acc[r]);
+}
+
+// flag: two ints, zero before the launch
+hipError_t launch_panel_fused(double* K, double* W, double* WT, int64_t ld, int r0, int nrows, int ncol, int64_t* info, int* flag, double* P,
+                              hipStream_t s) {
+    if (nrows <= 0 || nrows % 64 != 0 || ncol % 64 != 0 || ncol < 0) return hipErrorInvalidValue;
+    const int T = nrows / 64, U = (nrows / 64) * (ncol / 64);
+    hipLaunchKernelGGL(panel_fused_kernel, dim3(1 + T + U), dim3(DT), 0, s, K, W, WT, ld, r0, nrows, ncol, info, flag, P);
+    return hipGetLastError();
 }
 #undef AA
 

@@ -287,6 +287,15 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmArgs p) {
     const int r16 = lane & 15, g = lane >> 4;
     const double* Ap = p.A + (int64_t)bz * p.sA + (int64_t)(si * 32 + wm * 16 + r16) * p.lda + 2 * g;
     const double* Bp = p.B + (int64_t)bz * p.sB + (int64_t)(sj * 32 + wn * 16 + r16) * p.ldb + 2 * g;
+    double* Cg = p.C + (int64_t)bz * p.sC;
+    double* Ctg = p.Ct ? p.Ct + (int64_t)bz * p.sCt : nullptr;
+    // C goes first (an update's C is final before the launch): behind the MFMA chain its latency was a tenth of a K = 128 launch
+    double cin[4] = {0.0, 0.0, 0.0, 0.0};
+    if (p.beta != 0.0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            cin[r] = Cg[((int64_t)si * 32 + wm * 16 + g + 4 * r) * p.ldc + (int64_t)sj * 32 + wn * 16 + r16];
+    }
     d4_t acc = {0.0, 0.0, 0.0, 0.0};
     for (int k = kbeg; k < kend; k += 128) {               // K, kbeg, kend are multiples of 128
         d2_t a[16], b[16];
@@ -301,14 +310,12 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmArgs p) {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b[q][1], acc, 0, 0, 0);
         }
     }
-    double* Cg = p.C + (int64_t)bz * p.sC;
-    double* Ctg = p.Ct ? p.Ct + (int64_t)bz * p.sCt : nullptr;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = (int64_t)si * 32 + wm * 16 + g + 4 * r;
         const int64_t col = (int64_t)sj * 32 + wn * 16 + r16;
         double v = p.alpha * acc[r];
-        if (p.beta != 0.0) v += p.beta * Cg[row * p.ldc + col];
+        if (p.beta != 0.0) v += p.beta * cin[r];
         Cg[row * p.ldc + col] = v;
         if (Ctg) Ctg[col * p.ldct + row] = v;
     }

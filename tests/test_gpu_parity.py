@@ -132,15 +132,17 @@ def test_look_ahead_factorisation_keeps_the_bits(monkeypatch, N):
 def test_pipelined_potf2_keeps_the_bits(monkeypatch, N):
     """Round 5: the diagonal-block kernel of the panel chain with its side work (block load, deferred sub-block updates, write-back,
     16×16 inverses) moved beside the register steps and its owed column updates fed from LDS (chol.hip: potf2_pipe_kernel), and the
-    panel solve fed by the operand stream that kernel leaves (trsm_stream_kernel), against the step-by-step chol_diag_kernel<1> +
-    trsm_panel_kernel (ABO_POTF2_PIPE=0 / ABO_TRSM_STREAM=0): same operations in the same order on every element — L, L⁻¹ and α equal
+    panel solve fed by the operand stream that kernel leaves (trsm_stream_kernel), both and the in-strip update as ONE launch per panel
+    (panel_fused_kernel, ABO_PANEL_FUSED > 0: measured slower, off by default), against the step-by-step chol_diag_kernel<1> + trsm_panel_kernel
+    (ABO_POTF2_PIPE=0 / ABO_TRSM_STREAM=0): same operations in the same order on every element — L, L⁻¹ and α equal
     bit for bit, a failed pivot reports the same row (in the first, a middle and the last 16-column sub-step of a block)."""
     X = synth.points(1, N, 5)
     y = synth.objective(X, 0.05)
     out = {}
-    for mode in (("1", "1"), ("1", "0"), ("0", "1")):
+    for mode in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "1"), ("0", "1", "1")):
         monkeypatch.setenv("ABO_POTF2_PIPE", mode[0])
         monkeypatch.setenv("ABO_TRSM_STREAM", mode[1])
+        monkeypatch.setenv("ABO_PANEL_FUSED", "1000000" if mode[2] == "1" and mode[:2] == ("1", "1") else "0")
         m = abo.update(make_model(O.MATERN52, 1.0, 1.3, 1e-4), X, y)
         out[mode] = abo.get_factor(m)
         for bad in (5, 128 + 70, N - 3):
@@ -149,10 +151,10 @@ def test_pipelined_potf2_keeps_the_bits(monkeypatch, N):
             with pytest.raises(abo.PosDefException) as e:
                 abo.update(make_model(O.MATERN52, 1.0, 1.3, 0.0), Xb, y)
             out[mode] += (e.value.info,)
-    for mode in (("1", "1"), ("1", "0")):
-        for a, b in zip(out[mode], out[("0", "1")]):
+    for mode in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "1")):
+        for a, b in zip(out[mode], out[("0", "1", "1")]):
             np.testing.assert_array_equal(a, b)
-    assert out[("1", "1")][3:] == (6, 128 + 71, N - 2)
+    assert out[("1", "1", "1")][3:] == (6, 128 + 71, N - 2)
 
 
 @pytest.mark.parametrize("name", ["kat1", "kat3", "kat4", "kat5"])
