@@ -24,6 +24,7 @@ cp final_small_n_latency.txt ../profiles/${TAG}_small_n_latency.txt
 cp final_optimize_acquisition_latency.txt ../profiles/${TAG}_optimize_acquisition_latency.txt
 cp final_c_host_latency.txt ../profiles/${TAG}_c_host_latency.txt
 cp final_fit_times.txt ../profiles/${TAG}_fit_times.txt
+cp fit_trace_summary.txt ../profiles/${TAG}_fit_trace_summary.txt
 cp final_soak.txt ../profiles/${TAG}_soak.txt
 cp final_pytest_gpu.txt ../profiles/${TAG}_pytest_gpu.txt
 cp final_smoke.txt ../profiles/${TAG}_smoke.txt
