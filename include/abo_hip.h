@@ -464,9 +464,14 @@ int32_t abo_mgpu_acq_lhs(abo_mgpu* mg, int64_t n, int32_t d, const double* lower
  * same call (abo_cand_downdate).  abo_mgpu_cand_create / _lhs: shard a candidate grid over the devices and evaluate its
  * posterior; _refresh after a refit.  abo_mgpu_cand_acq: epilogue + merged top-k on the stored posterior.
  * abo_mgpu_cand_qei: greedy (Kriging-believer) q-EI — q × [EI + arg-max per device, ONE all-gather of the devices' pick
- * records {score, index, μ, x}] with the same fantasy append (y = μ(x)) and O(N·M) down-date on every device between picks
- * (q − 1 of them: the last pick conditions nothing) — then the stored posterior is rolled back and the fantasy models are
- * dropped: on return model and set are as before.  x_out q × d,
+ * records] with the grid conditioned on each pick (y = μ(x): variances only) before the next; on return model and set are as
+ * before.  ABI 6: the block form of abo_cand_qei run across the shards whenever every shard qualifies — per batch the shards'
+ * top-T are gathered, every shard forms the covariance columns of the SAME T block points in one pass over its part of K_ZX
+ * and conditions on a pick by a rank-1 correction from the chain of earlier picks' columns (records {EI, index, μ, σ², x,
+ * chain values}); no fantasy append, no pass per pick; blocks and chain stay with the set from call to call
+ * (abo_mgpu_cand_qei_stats).  Otherwise (a shard without room for the block buffers, a gradient-enhanced model, q > 64): the
+ * plain loop — the same fantasy append (y = μ(x)) and O(N·M) down-date on every device between picks (q − 1 of them: the last
+ * pick conditions nothing), rolled back at the end.  Both give the same picks as one handle over the whole set.  x_out q × d,
  * idx_out / ei_out q.  distinct != 0 excludes every picked candidate for the rest of the call. */
 int32_t abo_mgpu_append(abo_mgpu* mg, const double* x, int32_t d, double y, int64_t* info, abo_mcand* cands);
 int32_t abo_mgpu_append_grad(abo_mgpu* mg, const double* x, int32_t d, const double* y, int64_t* info, abo_mcand* cands);
