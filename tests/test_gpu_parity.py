@@ -128,7 +128,7 @@ def test_look_ahead_factorisation_keeps_the_bits(monkeypatch, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N", [256, 1100, 2304])
+@pytest.mark.parametrize("N", [256, 640, 1100, 2304, 6300])
 def test_pipelined_potf2_keeps_the_bits(monkeypatch, N):
     """Round 5: the diagonal-block kernel of the panel chain with its side work (block load, deferred sub-block updates, write-back,
     16×16 inverses) moved beside the register steps and its owed column updates fed from LDS (chol.hip: potf2_pipe_kernel), and the
