@@ -129,7 +129,9 @@ def fit(family, ell, sigma_f2, noise_var, mean_c, X, y) -> GPState:
         raise ValueError("DimensionMismatch: xs and ys differ in length")
     K = kernel_matrix(family, ell, sigma_f2, X)
     K[np.diag_indices_from(K)] += noise_var
-    L, info = sla.lapack.dpotrf(K, lower=1, clean=1)
+    # K is symmetric: its transpose view is the same matrix in Fortran order, which LAPACK factors in place without a copy — and the
+    # host OpenBLAS runs its LOWER Fortran-order dpotrf 4 × faster than what a C-ordered argument makes it do (tools/host_potrf_probe.py)
+    L, info = sla.lapack.dpotrf(K.T, lower=1, clean=1, overwrite_a=1)
     if info > 0:
         raise NotPositiveDefinite(info)
     if info < 0:
