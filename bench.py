@@ -211,17 +211,17 @@ def _cpu_baseline(cfg, sample_m):
     # the ratio against it says little — the line then flags it and does not print a speed-up
     potrf_gflops = (N ** 3 / 3.0) / (potrf_ms * 1e-3) / 1e9
     trsm_gflops = (float(N) * N * sample_m) / max(trsm_s, 1e-9) / 1e9
-    # (dtrsm is 98 % of the step's host flops; OpenBLAS's own dpotrf stays at ≈ 120 GFLOP/s on 16 threads where its dsyrk reaches 1100:
-    # half the bar for it)
-    under = trsm_gflops < 10.0 * threads or potrf_gflops < 5.0 * threads
+    # (the flag goes by dtrsm, 98 % of the step's host flops: OpenBLAS's own dpotrf delivers 60 – 125 GFLOP/s on 16 threads from box to
+    # box where its dsyrk reaches 1100 — reported, not judged)
+    under = trsm_gflops < 10.0 * threads
     return {
         "host_blas": {"libraries": [{k: p.get(k) for k in ("user_api", "internal_api", "version", "num_threads", "threading_layer")}
                                     for p in pools],
                       "dpotrf_gflops": potrf_gflops, "dtrsm_gflops": trsm_gflops, "threads": threads,
                       "under_threaded": bool(under),
                       "note": "achieved rate of LAPACK dpotrf (N x N, Fortran order, lower) and solve_triangular (N x N against the "
-                              "sample, Fortran-ordered operands) inside this baseline; under_threaded = dtrsm below 10 or dpotrf below "
-                              "5 GFLOP/s per thread"},
+                              "sample, Fortran-ordered operands) inside this baseline; under_threaded = dtrsm (98 % of the host flops) below "
+                              "10 GFLOP/s per thread"},
         "value": fit_ms + acq_ms * (M / sample_m), "unit": "ms per BO step (extrapolated)", "cores": threads,
         "kind": "port",
         "sample": f"CPU restatement (NumPy/SciPy LAPACK), not the Julia reference: full N={N} refit measured "
