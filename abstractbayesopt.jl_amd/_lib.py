@@ -19,8 +19,8 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
            "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms", "abo_test_acq_grad_terms",
            "abo_set_qei_block", "abo_cand_qei", "abo_cand_qei_begin", "abo_cand_qei_top", "abo_cand_qei_block", "abo_cand_qei_pick",
-           "abo_cand_qei_end", "abo_cand_qei_has", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats"]
-ABI_VERSION = 6
+           "abo_cand_qei_end", "abo_cand_qei_has", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats", "abo_cand_qei_eligible"]
+ABI_VERSION = 7
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
 
@@ -161,7 +161,8 @@ def lib():
     L.abo_set_qei_block.argtypes = [i32]
     L.abo_cand_qei.argtypes = [vp, vp, i32, f64, f64, i32, i64, i32, vp, vp, vp, C.POINTER(AboQeiStats)]
     L.abo_cand_qei_begin.argtypes = [vp, vp, i32, i32]
-    L.abo_cand_qei_top.argtypes = [vp, vp, f64, f64, i64, i32, vp]
+    L.abo_cand_qei_top.argtypes = [vp, vp, f64, f64, i64, i32, vp, i64]
+    L.abo_cand_qei_eligible.argtypes = [vp, vp, i32, i32, C.POINTER(i32)]
     L.abo_cand_qei_block.argtypes = [vp, vp, vp, vp, i32]
     L.abo_cand_qei_pick.argtypes = [vp, vp, i64, f64, vp, i32, i64, C.POINTER(i64)]
     L.abo_cand_qei_end.argtypes = [vp, vp]

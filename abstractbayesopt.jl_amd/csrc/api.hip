@@ -412,6 +412,7 @@ struct abo_cand {
         bool open = false;
         uint64_t gen = 0;
         int64_t N = -1, Mp = 0;
+        int64_t idx_base = -1;                    // the global index of the shard's first candidate the slots below were keyed with (−1: none yet)
         int T16 = 0, nblk_cap = 0, next_blk = 0, qmax = 0;
         std::vector<int64_t> slot_gidx;           // global candidate index per block row (−1: empty)
         std::vector<double> slot_x;               // [rows][d] the block points
@@ -2262,6 +2263,19 @@ QeiWork qei_carve(void* base, int T16, int d, int dp, int Np) {
     return w;
 }
 
+// The block slots are keyed by GLOBAL candidate index = idx_base + local index.  A caller that passes another idx_base than the one
+// the slots were keyed with (a continuation from an earlier batch, or a change inside a batch) would match a pick against another
+// candidate's covariance column: the slots are dropped (the chain is per local candidate and stays); the next pick builds a block.
+int32_t qei_rebase(abo_cand* c, int64_t idx_base) {
+    abo_cand::Qei& Q = c->qei;
+    if (idx_base < 0) return fail(ABO_EINVAL, "q-EI: idx_base = %lld", (long long)idx_base);
+    if (Q.idx_base != idx_base) {
+        if (Q.idx_base >= 0) Q.slot_gidx.assign(Q.slot_gidx.size(), -1);
+        Q.idx_base = idx_base;
+    }
+    return ABO_OK;
+}
+
 int qei_find_slot(const abo_cand* c, int64_t gidx) {
     const std::vector<int64_t>& v = c->qei.slot_gidx;
     for (size_t i = 0; i < v.size(); ++i) if (v[i] == gidx) return (int)i;
@@ -2349,6 +2363,7 @@ int32_t abo::qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t i
     if (!g || !c || !rec_d) return fail(ABO_EINVAL, "abo_cand_qei_top: null argument");
     if (!c->qei.open || c->qei.gen != g->st->gen || c->qei.N + c->qei.nreal != g->N) return fail(ABO_EINVAL, "abo_cand_qei_top: no batch open on this model (abo_cand_qei_begin)");
     if (k < 1 || k > 1024) return fail(ABO_EINVAL, "abo_cand_qei_top: k = %d outside 1..1024", k);
+    if (int32_t r = qei_rebase(c, idx_base)) return r;
     HIPCHK(hipSetDevice(g->prm.device));
     hipStream_t s = g->stream;
     HIPCHK(c->score.ensure(sizeof(double) * (c->M > 0 ? c->M : 1)));
@@ -3035,10 +3050,22 @@ int32_t abo_set_qei_block(int32_t block) {
 
 int32_t abo_cand_qei_begin(abo_gp* g, abo_cand* c, int32_t q, int32_t block) { return abo::qei_begin(g, c, q, block); }
 
-int32_t abo_cand_qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int32_t k, double* rec) {
+int32_t abo_cand_qei_eligible(abo_gp* g, abo_cand* c, int32_t q, int32_t block, int32_t* ok) {
+    if (!g || !c || !ok) return fail(ABO_EINVAL, "abo_cand_qei_eligible: null argument");
+    const int T = block <= 0 ? qei_default_block() : block;
+    *ok = 0;
+    if (T < 1) { (void)fail(ABO_EINVAL, "q-EI, block form: block size 0 (the plain loop is a different call)"); return ABO_OK; }
+    *ok = abo::qei_eligible(g, c, q) == ABO_OK ? 1 : 0;                                   // (the reason stays in abo_last_error)
+    return ABO_OK;
+}
+
+int32_t abo_cand_qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int32_t k, double* rec, int64_t cap_words) {
     if (!g || !c || !rec) return fail(ABO_EINVAL, "abo_cand_qei_top: null argument");
     if (k < 1 || k > 1024) return fail(ABO_EINVAL, "abo_cand_qei_top: k = %d outside 1..1024", k);
     const size_t words = (size_t)k * (4 + c->d + c->qei.nchain);
+    if (cap_words < 0 || (size_t)cap_words < words)
+        return fail(ABO_EINVAL, "abo_cand_qei_top: rec holds %lld doubles, %d records of 4 + d + %d chain values need %zu", (long long)cap_words, k,
+                    c->qei.nchain, words);
     HIPCHK(hipSetDevice(g->prm.device));
     HIPCHK(c->qrec.ensure(sizeof(double) * words));
     int32_t rc = abo::qei_top(g, c, xi, best_y, idx_base, k, c->qrec.as<double>());

@@ -162,7 +162,7 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
         for j in range(q):
             words = 4 + d + n_chain
             rec = np.empty((1, words))
-            _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, 1, rec.ctypes.data))
+            _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, 1, rec.ctypes.data, rec.size))
             recs = _allgather_rows(rec, dist, group) if world > 1 else rec
             recs = _sorted_valid(recs)
             if len(recs) == 0:
@@ -175,7 +175,7 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
             _lib.check(L.abo_cand_qei_has(h, c, gidx, C.byref(has), None))
             if not has.value:
                 rt = np.empty((T, words))
-                _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, T, rt.ctypes.data))
+                _lib.check(L.abo_cand_qei_top(h, c, xi, best_y, idx_base, T, rt.ctypes.data, rt.size))
                 rt = _sorted_valid(_allgather_rows(rt, dist, group) if world > 1 else rt)[:T]
                 pts = np.ascontiguousarray(rt[:, 4:4 + d])
                 gix = np.ascontiguousarray(rt[:, 1].astype(np.int64))
@@ -191,6 +191,27 @@ def _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, disti
         _lib.check(L.abo_cand_qei_end(h, c))
     _lib.check(L.abo_cand_qei_stats(h, c, C.byref(st)))
     return np.array(picks), np.array(idxs, dtype=np.int64), np.array(vals), np.array(mus), st.as_dict()
+
+
+def _local_block_eligible(model, cands, q, block=0) -> bool:
+    """abo_cand_qei_eligible: can THIS rank's shard run the block form (K_ZX resident, model in sync, q ≤ 64, …)?  No side effects."""
+    ok = C.c_int32(0)
+    _lib.check(_lib.lib().abo_cand_qei_eligible(model._require(), cands._h.ptr, int(q), int(block or 0), C.byref(ok)))
+    return bool(ok.value)
+
+
+def _block_form_agreed(model, cands, q, group, block=0) -> bool:
+    """The block form and the plain loop exchange records of different widths in different collectives: every rank must take the
+    same one.  Residency of a shard's K_ZX depends on that rank's allocations, so the ranks all-gather their own answer and take the
+    block form only if ALL can (the C multi-device path does the same: abo_mgpu_cand_qei runs qei_eligible on every shard first)."""
+    mine = _local_block_eligible(model, cands, q, block)
+    if not (group is not None or _dist_ready()):
+        return mine
+    import torch.distributed as dist
+    if dist.get_world_size(group) <= 1:
+        return mine
+    flags = _allgather_rows(np.array([[1.0 if mine else 0.0]]), dist, group)
+    return bool(np.all(flags > 0.5))
 
 
 def _sorted_valid(recs: np.ndarray) -> np.ndarray:
@@ -243,6 +264,9 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
     if group is not None or _dist_ready():
         import torch.distributed as _d
         sharded = _d.get_world_size(group) > 1
+    if use_block and sharded:
+        # agreed BEFORE the paths diverge: a rank that cannot run the block form would leave the others' all-gathers without a partner
+        use_block = _block_form_agreed(model, cands, q, group, 0 if block is None or block is True else int(block))
     if use_block and rollback and not sharded:
         # one shard, the batch only: the library's one-call driver (abo_cand_qei — the same steps, same bits, no interpreter between them)
         pts, idxs, vals, st = cands.qei(q, xi, best_y, distinct=distinct, idx_base=idx_base,
@@ -256,8 +280,8 @@ def greedy_qei(model: HipStandardGP, cands: ResidentCandidates, q: int, xi: floa
             pts, idxs, vals, mus, st = _qei_block_batch(model, cands, q, n_cond, xi, best_y, idx_base, group, distinct,
                                                         0 if block is None or block is True else int(block))
         except ValueError as e:
-            if "block form" not in str(e) and "block size 0" not in str(e):
-                raise
+            if sharded or ("block form" not in str(e) and "block size 0" not in str(e)):
+                raise                          # (sharded: the ranks agreed on the block form — falling back alone would desynchronise them)
             use_block = False                  # the set or the model does not qualify: the plain loop below
     if use_block:
         if stats is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ABO_ABI_VERSION 6   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
+#define ABO_ABI_VERSION 7   /* 2: abo_mgpu_* (multi-device handles), k and d limits lifted
                                3: abo_set_contraction, abo_timings grew (contraction engine and its phases)
                                4: abo_refine, abo_optimize_acquisition, abo_mgpu_optimize_acquisition, abo_fit_acq, abo_mgpu_create_grad,
                                   abo_mgpu_append_grad; abo_timings grew (refinement stage)
@@ -36,7 +36,10 @@ extern "C" {
                                   abo_optimize_acquisition_terms, abo_mgpu_optimize_acquisition_terms, ABO_ACQ_GRADNORM_UCB)
                                6: block form of greedy q-EI: abo_cand_qei (+ _begin / _top / _block / _pick / _end for hosts that
                                   shard the set themselves), abo_qei_stats, abo_set_qei_block, abo_mgpu_cand_qei_stats;
-                                  abo_cand_downdate finds the down-date column of a pick appended for real in the batch's chain */
+                                  abo_cand_downdate finds the down-date column of a pick appended for real in the batch's chain
+                               7: abo_cand_qei_top takes the capacity of the caller's record buffer; abo_cand_qei_eligible (what ranks
+                                  that shard a set themselves agree on before they take the block form); abo_cand_qei keeps its
+                                  pick loop on the device (one launch per pick, one read-back per batch) */
 
 /* status codes */
 enum {
@@ -362,7 +365,16 @@ int32_t abo_set_qei_block(int32_t block);
 int32_t abo_cand_qei(abo_gp* gp, abo_cand* c, int32_t q, double xi, double best_y, int32_t distinct, int64_t idx_base, int32_t block,
                      double* x_out, int64_t* idx_out, double* ei_out, abo_qei_stats* stats);
 int32_t abo_cand_qei_begin(abo_gp* gp, abo_cand* c, int32_t q, int32_t block);
-int32_t abo_cand_qei_top(abo_gp* gp, abo_cand* c, double xi, double best_y, int64_t idx_base, int32_t k, double* rec);
+/* *ok = 1 when _begin(gp, c, q, block) would open a block-form batch on this shard (model fitted and in sync with the set, K_ZX
+ * resident, q ≤ 64, block size > 0, …), 0 otherwise — the reason is then in abo_last_error.  Changes nothing.  Ranks that shard a set
+ * themselves exchange this flag and take the block form only if EVERY rank can (a rank that cannot would leave the others'
+ * all-gathers without a partner). */
+int32_t abo_cand_qei_eligible(abo_gp* gp, abo_cand* c, int32_t q, int32_t block, int32_t* ok);
+/* rec: k records of 4 + d + n doubles each, n = the chain's entries at the moment of the call (abo_cand_qei_has; it grows with
+ * every pick and with the real appends carried over from earlier batches); cap_words = doubles the caller's buffer holds — ABO_EINVAL
+ * (nothing written) when k·(4 + d + n) exceeds it.  A set's block slots are keyed by global index = idx_base + local index: every call
+ * of one set passes the same idx_base (another value drops the blocks; the next pick builds a new one). */
+int32_t abo_cand_qei_top(abo_gp* gp, abo_cand* c, double xi, double best_y, int64_t idx_base, int32_t k, double* rec, int64_t cap_words);
 int32_t abo_cand_qei_block(abo_gp* gp, abo_cand* c, const double* pts, const int64_t* gidx, int32_t T);
 int32_t abo_cand_qei_pick(abo_gp* gp, abo_cand* c, int64_t gidx, double var_x, const double* cx, int32_t n, int64_t excl,
                           int64_t* info);

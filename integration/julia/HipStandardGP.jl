@@ -31,7 +31,7 @@ const LIBABO = get(ENV, "ABO_HIP_LIB", "libabo_hip.so")
 else
     macro abocall(ex) esc(:(@ccall $ex)) end
 end
-const ABO_ABI = Int32(6)                 # ABO_ABI_VERSION of the header this file was written against
+const ABO_ABI = Int32(7)                 # ABO_ABI_VERSION of the header this file was written against
 const _abi_checked = Ref(false)
 # a stale libabo_hip.so on the load path would otherwise fail at the first missing symbol, somewhere inside a BO step
 function _ensure_abi()

@@ -40,7 +40,7 @@ def pytest_collection_modifyitems(config, items):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """achieved errors of the GPU parity tests → gpurun_out/parity_r05.json (tests/parity_record.py)"""
+    """achieved errors of the GPU parity tests → gpurun_out/parity_r06.json (tests/parity_record.py)"""
     try:
         from tests import parity_record
         parity_record.dump()

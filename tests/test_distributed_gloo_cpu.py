@@ -117,3 +117,80 @@ def test_bounded_gather_protocol_with_a_stubbed_transport(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+def _worker_agree(rank, world, port, flags, q):
+    """greedy_qei under torch.distributed with a per-rank eligibility flag (stubbed: no GPU here) and both batch forms stubbed to
+    record which one this rank takes — and to run the collective that form runs, so a disagreement would hang (the parent's timeout)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from abstractbayesopt.jl_amd import incremental as I
+
+    class _Cands:
+        M, d = 10, 3
+
+        def save(self): pass
+
+        def restore(self): pass
+
+        def evaluate(self, acq, k=0, idx_base=0, **kw):
+            return None, np.array([0.5 + rank]), np.array([idx_base + 1], dtype=np.int64)
+
+        def point(self, idx):
+            return np.full(3, float(rank)), 0.25, 0.1
+
+    class _Model:
+        pass
+
+    taken = []
+    I._local_block_eligible = lambda model, cands, q_, block=0: bool(flags[rank])
+
+    def block_batch(model, cands, q_, n_cond, xi, best_y, idx_base, group, distinct, block):
+        taken.append("block")
+        recs = I._allgather_rows(np.full((1, 7), float(rank)), dist, group)          # the block form's record width (4 + d)
+        assert recs.shape == (world, 7)
+        return np.zeros((q_, 3)), np.zeros(q_, dtype=np.int64), np.zeros(q_), np.zeros(q_), {"block": 16}
+
+    I._qei_block_batch = block_batch
+    real_best = I._allgather_best
+
+    def best(rec, d_, group):
+        taken.append("plain")
+        return real_best(rec, d_, group)
+
+    I._allgather_best = best
+    I.append = lambda model, x, y: model
+    _Cands.downdate = lambda self, model: None
+    pts, idxs, vals, _ = I.greedy_qei(_Model(), _Cands(), 2, 0.01, 0.0, idx_base=10 * rank, rollback=True)
+    q.put((rank, sorted(set(taken)), idxs.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_agree(flags):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = len(flags)
+    procs = [ctx.Process(target=_worker_agree, args=(r, world, port, flags, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def test_ranks_agree_on_the_qei_form_before_their_collectives_diverge():
+    """a rank whose K_ZX is not resident cannot run the block form; before the fix it fell back to the plain loop ALONE
+    (3 + d-word records through _allgather_best) while the others all-gathered (k, 4 + d + n)-word records — a hang or garbage.  Now
+    the ranks exchange abo_cand_qei_eligible's answer first and all take the same form."""
+    res = _run_agree([1, 0])                       # rank 1 cannot: BOTH take the plain loop
+    assert [r[1] for r in res] == [["plain"], ["plain"]], res
+    assert res[0][2] == res[1][2] == [11, 11]      # rank 1's record wins (score 1.5), global index 10·1 + 1
+    res = _run_agree([1, 1])                       # all can: the block form everywhere
+    assert [r[1] for r in res] == [["block"], ["block"]], res
+    res = _run_agree([0, 1, 1])
+    assert [r[1] for r in res] == [["plain"]] * 3, res

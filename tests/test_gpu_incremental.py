@@ -237,6 +237,78 @@ def test_full_size_parity_c5():
     check(case, "var_downdated_grid", np.max(np.abs(var_c[:1024] - var_o)) / sf2, 1e-8)
 
 
+def test_full_size_block_qei_c5_against_the_from_scratch_path_and_the_oracle():
+    """BASELINE config 5's q-EI hot path AT ITS OWN SIZE (d = 16, N = 16384, a resident grid of 131 072 candidates, q = 8, T = 16:
+    the resident K_ZX has 131 072 × 16 448 = 2.16e9 elements, beyond 2³¹) anchored on something other than itself:
+      (a) the batch replayed with the library's FROM-SCRATCH path — per pick a full refit on the N + j points (the fantasy value is
+          the refitted model's mean: Kriging believer) and one abo_acq(k = 1) over the whole grid, the path test_full_size_parity_c3 /
+          _c5 verify against the oracle at this size; it shares neither K_ZX, nor the pass kernel, nor the chain with the block form:
+          same picks, EI to 1e-8 relative;
+      (b) the INDEPENDENT oracle (O.fit: host LAPACK) on the base model: EI of 3 × 341 grid rows — the first, the middle and the LAST
+          rows of K_ZX — and of the 16 best candidates, whose oracle ordering must put pick 1 first;
+      (c) after the first pick is appended for real — its down-date column served from the batch's chain — the down-dated (μ, σ²) of
+          the same rows against an oracle refit on the N + 1 points.
+    Reference semantics per sub-step: src/surrogates/StandardGP.jl:79-83 (update), src/acquisition_functions/ExpectedImprovement.jl:40-66."""
+    import torch
+    d, N, M, q = 16, 16384, 131072, 8
+    ell, sf2, noise, xi = 2.0, 1.0, 1e-2, 0.01
+    X = synth.points(1, N, d)
+    y = synth.objective(X, 0.1)
+    y = (y - y.mean()) / y.std(ddof=1)
+    Z = synth.points(2, M, d)
+    best = float(y.min())
+    acq = abo.ExpectedImprovement(xi, best)
+    m = abo.update(make_model(O.MATERN52, ell, sf2, noise, n_max=N + 64), X, y)
+    cands = abo.ResidentCandidates(m, Z)
+    ei0, tv16, ti16 = cands.evaluate(acq, k=16, return_scores=True)
+    pts, idx, val, st = cands.qei(q, xi, best)
+    assert st["block"] == 16 and st["block_builds"] >= 1 and st["block_builds"] + st["block_hits"] == q - 1, st
+    assert st["pass_bytes"] == 8.0 * N * M                    # the block came from one pass over the resident K_ZX
+    np.testing.assert_array_equal(pts, Z[idx])
+    assert idx[0] == ti16[0] and val[0] == tv16[0]
+    rows = np.concatenate([np.arange(341), np.arange(M // 2 - 170, M // 2 + 171), np.arange(M - 341, M)])
+    case = "qei_full/N16384_d16_M131072_q8_T16"
+    # (c) first: the real append of pick 1, column from the chain
+    y_real = 0.25
+    m1 = abo.append(m, pts[0], y_real)
+    cands.downdate(m1)
+    assert m1.timings()["downdate_from_chain"] == 1
+    mu1, var1 = cands.mean_and_var()
+    del cands, m1
+    abo._lib.lib().abo_pool_trim(0)
+    # (a) the from-scratch replay on the device
+    Zd = torch.from_numpy(Z).cuda()
+    Xj, yj = X.copy(), y.copy()
+    idx_s, val_s = [], []
+    for j in range(q):
+        mj = abo.update(make_model(O.MATERN52, ell, sf2, noise), Xj, yj)
+        _, tv, ti = abo.evaluate(acq, mj, Zd, k=1, return_scores=False)
+        i = int(ti.cpu().numpy()[0])
+        idx_s.append(i); val_s.append(float(tv.cpu().numpy()[0]))
+        Xj = np.vstack([Xj, Z[i]])
+        yj = np.append(yj, abo.posterior_mean(mj, Z[i][None, :])[0])     # Kriging believer
+        del mj
+    np.testing.assert_array_equal(idx, np.array(idx_s))
+    val_s = np.array(val_s)
+    check(case, "ei_vs_from_scratch_refits_rel", np.max(np.abs(val - val_s) / np.maximum(1e-3 * val_s[0], np.abs(val_s))), 1e-8)
+    del Zd
+    # (b) the independent oracle on the base model
+    st0 = O.fit(O.MATERN52, ell, sf2, noise, 0.0, X, y)
+    sel = np.concatenate([rows, ti16])
+    mu_o, var_o = O.predict(st0, Z[sel])
+    ei_o = O.expected_improvement(mu_o, var_o, best, xi)
+    check(case, "ei_rows_first_middle_last_abs", np.max(np.abs(ei0[rows] - ei_o[:len(rows)])), 1e-9)
+    check(case, "ei_top16_rel", np.max(np.abs(tv16 - ei_o[len(rows):]) / np.abs(ei_o[len(rows):])), 1e-8)
+    assert int(np.argmax(ei_o[len(rows):])) == 0              # the oracle ranks pick 1 first among the block's candidates
+    assert abs(val[0] - ei_o[len(rows)]) <= 1e-8 * abs(ei_o[len(rows)])
+    del st0
+    # (c) the oracle's refit on the N + 1 points against the chain-served down-date
+    st1 = O.fit(O.MATERN52, ell, sf2, noise, 0.0, np.vstack([X, pts[0]]), np.append(y, y_real))
+    mu_o1, var_o1 = O.predict(st1, Z[rows])
+    check(case, "mu_downdated_from_chain", np.max(np.abs(mu1[rows] - mu_o1)) / max(1.0, np.max(np.abs(mu_o1))), 1e-8)
+    check(case, "var_downdated_from_chain", np.max(np.abs(var1[rows] - var_o1)) / sf2, 1e-8)
+
+
 def test_resident_kzx_and_recomputed_downdates_agree(monkeypatch):
     """The down-date streams a resident K_ZX when it fits the budget (ABO_CAND_KZX_GIB) and re-evaluates the kernel
     otherwise: same posterior either way, including after a rollback that re-uses the appended columns and with

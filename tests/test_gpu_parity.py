@@ -36,7 +36,7 @@ def _load(name):
 
 # ------------------------------------------------------------------------------------------------
 def test_library_loaded_and_version():
-    assert abo._lib.lib().abo_abi_version() == abo._lib.ABI_VERSION == 6
+    assert abo._lib.lib().abo_abi_version() == abo._lib.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 128), (128, 256, 272)])

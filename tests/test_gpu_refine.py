@@ -70,7 +70,8 @@ def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper):
     check(case, f"{name}_starts_below_scipy_inside_its_basin", float(below_in_basin), 0.0, tighten=False)
     check(case, f"{name}_fraction_of_starts_at_another_maximiser", other / len(starts), 0.75, tighten=False)    # (measured ≤ 0.57: GradientNormUCB, d = 3)
     # what optimize_acquisition returns is the BEST over the starts (acq_utils.jl:66-72): the device's against SciPy's
-    check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 0.05, tighten=False)
+    # held to the per-start tolerance (every recorded value is ≤ 5.4e-8): a result 1e-4 below SciPy's best fails
+    check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 1e-5, tighten=False)
 
 
 @pytest.mark.parametrize("family,d,N", [(O.SE, 1, 30), (O.MATERN52, 3, 200), (O.MATERN72, 8, 500), (O.MATERN32, 2, 64),
@@ -150,6 +151,37 @@ def test_refinement_against_scipy_on_the_oracle_and_against_the_finite_differenc
         xf, ff = _refine_starts_fd(acq, m, starts, lower, upper)
         # the analytic-gradient run is at least as good as the finite-difference one on (nearly) every start
         assert np.sum(fr >= ff - 1e-6 * np.maximum(1.0, np.abs(ff))) >= len(starts) - 2
+
+
+def test_refinement_at_config_3_size_against_the_oracle_and_scipy():
+    """The lockstep rounds at the size the headline is quoted on (N = 8192, d = 8, Matérn-5/2: split-k products over L⁻¹, compacted
+    batches — the path DESIGN §3c times at 34 ms and no quality test reached before round 6): 8 starts inside the data's box; never
+    below the start, inside the box, the reported value IS the oracle's acquisition at the reported point (1e-8), and the best of
+    the starts reaches SciPy L-BFGS-B's best on the oracle's acquisition from the same starts (acq_utils.jl:55-71)."""
+    from scipy.optimize import minimize
+    from tests.test_gpu_parity import c3_oracle
+    X, y, st = c3_oracle()
+    d = 8
+    m = abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y)
+    lower, upper = np.zeros(d), np.ones(d)
+    starts = synth.points(9, 8, d)
+    case = "refine/quality_c3_N8192_d8"
+    for acq in (abo.UpperConfidenceBound(2.0), abo.ExpectedImprovement(0.01, float(np.median(y)))):
+        name = type(acq).__name__
+        oracle = _oracle_acq(acq, st)
+        f0 = oracle(starts)
+        xr, fr, it = refine_starts(acq, m, starts, lower, upper, return_iters=True)
+        assert np.all(xr >= lower) and np.all(xr <= upper)
+        assert np.all(fr >= f0 - 1e-9 * np.maximum(1.0, np.abs(f0))), (name, "a refined start lost against its start")
+        assert it[:, 1].sum() > 3 * len(starts) and np.max(fr - f0) > 1e-4, (name, it[:, 1].sum())
+        fo = oracle(xr)
+        check(case, f"{name}_reported_value_vs_oracle_at_reported_point", np.max(np.abs(fr - fo) / np.maximum(1.0, np.abs(fo))), 1e-8)
+        fs_best = -np.inf
+        for i in range(len(starts)):
+            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
+                           options={"ftol": 1e-12, "gtol": 1e-7, "maxiter": 60})
+            fs_best = max(fs_best, -res.fun)
+        check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 1e-5, tighten=False)
 
 
 def test_refine_edge_cases():
