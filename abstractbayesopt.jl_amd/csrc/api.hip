@@ -1882,7 +1882,11 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     a.A = g->st->WT.as<double>(); a.lda = ld; a.B = g->st->WT.as<double>(); a.ldb = ld;
     a.C = g->T.as<double>(); a.ldc = Np; a.M = (int)Np; a.N = (int)Np; a.K = (int)Np;
     a.kmode = K_A_UPPER; a.lower_only = 1; a.batch = 1; a.alpha = 1.0; a.beta = 0.0;
+    HIPCHK(g->events(EV_BASE + 3));
+    hipEvent_t* ev = &g->evs()[EV_BASE];
+    HIPCHK(hipEventRecord(ev[0], s));
     HIPCHK(launch_gemm_nt(a, s));
+    HIPCHK(hipEventRecord(ev[1], s));
     NlmlGradArgs ga{};
     ga.Xs = g->st->Xs.as<double>(); ga.Kinv = g->T.as<double>(); ga.alpha = g->alpha.as<double>();
     ga.delta = g->st->delta.as<double>(); ga.partial = g->partial.as<double>(); ga.out = g->scal.as<double>() + 4;
@@ -1901,9 +1905,12 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     } else {
         HIPCHK(launch_nlml_grad(ga, s));
     }
+    HIPCHK(hipEventRecord(ev[2], s));
     double o[4];
     HIPCHK(hipMemcpyAsync(o, g->scal.as<double>() + 4, sizeof o, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    g->tm.nlml_kinv_ms = ev_ms(ev[0], ev[1]);
+    g->tm.nlml_trace_ms = ev_ms(ev[1], ev[2]);
     // ∂NLML/∂θ = ½ tr((K⁻¹ − ααᵀ) ∂K/∂θ);  ∂K/∂log σ_f² = K − noise·I  and  K α = δ
     const double noise = g->st->noise_used;
     if (nlml) *nlml = 0.5 * ((double)g->N * std::log(2.0 * M_PI) + g->logdet + g->quad);

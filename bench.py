@@ -180,15 +180,40 @@ def _cpu_baseline(cfg, sample_m):
     chunk = 4096
     mu = np.empty(sample_m)
     var = np.empty(sample_m)
-    trsm_s = 0.0
+    trsm_s = asm_s = 0.0
+    # Round 6: the kernel-matrix ASSEMBLY runs on all the cores the BLAS runs on.  The oracle's kernel_matrix is
+    # single-threaded NumPy (d passes of N x m temporaries): 9 s of the 10.4 s acquisition sample in round 5, which made the "port"
+    # ratio a measure of NumPy temporaries.  Here the chunk's candidates are dealt to `workers` threads, each assembling its rows with
+    # the oracle's own function (NumPy ufuncs release the GIL; rows of K_ZX are independent) — same values, bit for bit.  K_XZ is
+    # still built TWICE per chunk, as the reference does (posterior_mean and posterior_var each evaluate the kernel matrix,
+    # ExpectedImprovement.jl:41-42).  The fit's N x N assembly gets the same treatment through fit_threaded below.
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, usable_cores())
+    pool = ThreadPoolExecutor(max_workers=workers)
+
+    def kzx_threaded(zc):
+        out = np.empty((zc.shape[0], N))
+        step = 128          # row blocks whose temporaries (128 x N doubles each) stay cache-resident: 137 against 42 Mpair/s with 512-row
+                            # blocks on 8 threads, 2.9 for the oracle's whole-chunk call on one (measured in the build container)
+        parts = [(a, min(a + step, zc.shape[0])) for a in range(0, zc.shape[0], step)]
+
+        def one(ab):
+            out[ab[0]:ab[1]] = O.kernel_matrix(fam, ell, sf2, zc[ab[0]:ab[1]], X)
+        list(pool.map(one, parts))
+        return out
     # Round 5: operands in the layout the host BLAS is fast in (tools/host_potrf_probe.py, profiles/r05_host_potrf_probe.txt: with
     # Fortran-ordered operands solve_triangular runs at 1150 GFLOP/s on 16 threads, with C-ordered ones at 130; dpotrf 120 against
     # 33) — K_ZX is generated candidate-major and its transpose VIEW is the Fortran-ordered K_XZ, L comes Fortran-ordered out of O.fit
     Lf = st.L if st.L.flags.f_contiguous else np.asfortranarray(st.L)
     for a in range(0, sample_m, chunk):
         zc = Z[a:a + chunk]
-        mu[a:a + chunk] = O.kernel_matrix(fam, ell, sf2, zc, X) @ st.alpha             # posterior_mean
-        Kxz = O.kernel_matrix(fam, ell, sf2, zc, X).T
+        tk = time.perf_counter()
+        Kzx1 = kzx_threaded(zc)
+        asm_s += time.perf_counter() - tk
+        mu[a:a + chunk] = Kzx1 @ st.alpha                                               # posterior_mean
+        tk = time.perf_counter()
+        Kxz = kzx_threaded(zc).T                                                        # posterior_var builds it again
+        asm_s += time.perf_counter() - tk
         ta = time.perf_counter()
         V = sla.solve_triangular(Lf, Kxz, lower=True, check_finite=False)
         trsm_s += time.perf_counter() - ta
@@ -196,6 +221,7 @@ def _cpu_baseline(cfg, sample_m):
     s = O.acquisition(O.ACQ_EI if acq == "ei" else O.ACQ_UCB, mu, var, p0, float(y.min()))
     O.top_k(s, 100)
     t2 = time.perf_counter()
+    pool.shutdown()
     pools = threadpool_info()
     threads = max([p.get("num_threads", 1) for p in pools] + [1])
     fit_ms, acq_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
@@ -228,6 +254,11 @@ def _cpu_baseline(cfg, sample_m):
                   f"({fit_ms:.0f} ms) + posterior/acq over M'={sample_m} candidates measured ({acq_ms:.0f} ms), "
                   f"acq part scaled x{M / sample_m:.2f} to M={M}",
         "measured_fit_ms": fit_ms, "measured_acq_ms_sample": acq_ms, "sample_m": sample_m,
+        "acq_sample_split_s": {"kernel_matrix_assembly": asm_s, "dtrsm": trsm_s, "rest": acq_ms * 1e-3 - asm_s - trsm_s,
+                               "assembly_threads": workers,
+                               "note": "assembly = K_ZX built twice per chunk (posterior_mean and posterior_var each evaluate it, "
+                                       "ExpectedImprovement.jl:41-42) with the oracle's kernel_matrix on assembly_threads threads; rest = "
+                                       "the mean's gemv, the column sums of squares, EI and the top-100"},
         "blas3_floor": {"value": potrf_ms + trsm_s * 1e3 * (M / sample_m), "unit": "ms per BO step (extrapolated)",
                         "measured_potrf_ms": potrf_ms, "measured_trsm_ms_sample": trsm_s * 1e3,
                         "note": "dpotrf + dtrsm only, kernel-matrix assembly and epilogue excluded"},
@@ -407,6 +438,29 @@ def quick_c1_shape(abo, synth, torch, dev, local_rank, k_top=100, steps=200, war
     return out
 
 
+def exchange_record(args, use_dist, local_rank):
+    """What the collective layer itself saw: backend, world size from the process group, and the device every rank
+    runs on — gathered through the group (outside the timed region), so the first multi-GPU line can be checked for N ranks on N
+    distinct devices without reading logs."""
+    import torch
+    if not use_dist:
+        return {"backend": None, "world_size": 1, "ranks": [{"rank": 0, "device": local_rank, "host": os.uname().nodename}],
+                "note": "one process, no process group"}
+    import torch.distributed as dist
+    mine = {"rank": dist.get_rank(), "device": local_rank, "host": os.uname().nodename}
+    try:
+        mine["device_uuid"] = str(torch.cuda.get_device_properties(local_rank).uuid)
+    except Exception:                                   # noqa: BLE001 - older torch: no uuid field
+        pass
+    ranks = [None] * dist.get_world_size()
+    dist.all_gather_object(ranks, mine)
+    rec = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks,
+           "distinct_devices": len({(r["host"], r.get("device_uuid", r["device"])) for r in ranks})}
+    if args.backend == "nccl":
+        rec["library"] = "RCCL through torch.distributed (backend nccl)"
+    return rec
+
+
 def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, warmup=None):
     """BASELINE config 5.  A step = greedy q-EI over the resident grid (q = 8 picks, each: EI + arg-max,
     fantasy bordered append, O(N·M) down-date), roll the grid posterior back, append the real (noisy)
@@ -500,6 +554,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms = elapsed * 1e3 / n_steps
+    xchg = exchange_record(args, use_dist, local_rank)
     # The same step when NOTHING carries over from the step before (ABO_QEI_NO_REUSE: every batch builds its own block — one pass
     # over K_ZX per step): three untimed-for-`value` steps.  `value` is what the loop above measured — a BO loop, where the blocks and
     # the chain follow the model and a step streams K_ZX only when a pick falls outside every block; this is the step without that.
@@ -565,7 +620,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
             "config": {"workload": f"C5: d={d} {fam_name} ell={ell} noise={noise}, N={N}(+1 per step) train, resident grid "
                                    f"M={M_per} per GPU ({M_total} total), greedy q-EI q={Q} ({form}) + 1 real bordered append per step",
                        "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "q": Q,
-                       "sharding": f"grid x{world}, all_gather of one pick record per pick (+ T records per block)"},
+                       "sharding": f"grid x{world}, all_gather of one pick record per pick (+ T records per block)",
+                       "exchange": xchg},
             "qei": {"block": counts["block"], "block_builds_per_step": counts["block_builds"] / n_steps,
                     "picks_found_in_a_block": counts["block_hits"], "picks_conditioned": (Q - 1) * n_steps,
                     "block_hit_rate": counts["block_hits"] / max(1, counts["block_hits"] + counts["block_builds"]),
@@ -887,6 +943,7 @@ def main():
     if use_dist:
         elapsed = reduce_max(elapsed)
     ms_per_step = elapsed * 1e3 / args.steps
+    xchg = exchange_record(args, use_dist, local_rank)
 
     # SURVEY 8(d) asks for the metric in two shapes.  `value` above is "arg-max / top-100 only"; the reference's own
     # API shape (acq_utils.jl:50) also hands the M scores back to the host: timed here on two extra steps
@@ -963,6 +1020,7 @@ def main():
                                    f"{acq_name.upper()} p0={p0}, top-{K_TOP}, full refit every step",
                        "N": N, "M_per_gpu": M_per, "M_total": M_total, "d": d, "kernel": fam_name, "acq": acq_name,
                        "sharding": f"candidates x{world}, all_gather top-{K_TOP}",
+                       "exchange": xchg,
                        "contraction": contraction_label(abo, med)},
             "candidates_per_s": M_total / (ms_per_step * 1e-3),
             "roofline": roofline,

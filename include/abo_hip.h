@@ -136,6 +136,9 @@ typedef struct abo_timings {
     /* ABI 6: 1 when the last abo_cand_downdate on this handle took its column from the chain of the set's last block-form q-EI
      * batch (no pass over K_ZX: downdate_bytes = 0, downdate_ms = the new K_ZX column only) */
     int64_t downdate_from_chain;
+    /* ABI 7: the last abo_nlml_grad on this handle: K⁻¹ = L⁻ᵀL⁻¹ on the fp64 MFMA GEMM (N³/3 flop, lower tiles), and the
+     * sweep that generates ∂K/∂log ℓ tile by tile and reduces tr((K⁻¹ − ααᵀ)∂K/∂θ) */
+    double nlml_kinv_ms, nlml_trace_ms;
 } abo_timings;
 
 /* --- lifetime -------------------------------------------------------------------------------

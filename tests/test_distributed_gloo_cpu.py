@@ -194,3 +194,36 @@ def test_ranks_agree_on_the_qei_form_before_their_collectives_diverge():
     assert [r[1] for r in res] == [["block"], ["block"]], res
     res = _run_agree([0, 1, 1])
     assert [r[1] for r in res] == [["plain"]] * 3, res
+
+
+def _worker_xchg(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec = bench.exchange_record(argparse.Namespace(backend="gloo"), True, rank)
+    q.put((rank, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_line_records_what_the_collective_layer_saw():
+    """bench.py's config.exchange: backend, world size and the device of every rank as the process group reports
+    them — the first multi-GPU line can then be checked for N ranks on N devices without reading logs."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_xchg, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rec in res:
+        assert rec["backend"] == "gloo" and rec["world_size"] == 2
+        assert [r["rank"] for r in rec["ranks"]] == [0, 1] and [r["device"] for r in rec["ranks"]] == [0, 1]
+        assert rec["distinct_devices"] == 2

@@ -261,6 +261,7 @@ def test_full_size_block_qei_c5_against_the_from_scratch_path_and_the_oracle():
     m = abo.update(make_model(O.MATERN52, ell, sf2, noise, n_max=N + 64), X, y)
     cands = abo.ResidentCandidates(m, Z)
     ei0, tv16, ti16 = cands.evaluate(acq, k=16, return_scores=True)
+    mu0, var0 = cands.mean_and_var()
     pts, idx, val, st = cands.qei(q, xi, best)
     assert st["block"] == 16 and st["block_builds"] >= 1 and st["block_builds"] + st["block_hits"] == q - 1, st
     assert st["pass_bytes"] == 8.0 * N * M                    # the block came from one pass over the resident K_ZX
@@ -297,6 +298,9 @@ def test_full_size_block_qei_c5_against_the_from_scratch_path_and_the_oracle():
     sel = np.concatenate([rows, ti16])
     mu_o, var_o = O.predict(st0, Z[sel])
     ei_o = O.expected_improvement(mu_o, var_o, best, xi)
+    # (EI underflows on most of a random grid: the rows are held by their posterior, the EI comparison proper is the top-16's)
+    check(case, "mu_rows_first_middle_last", np.max(np.abs(mu0[rows] - mu_o[:len(rows)])) / max(1.0, np.max(np.abs(mu_o))), 1e-8)
+    check(case, "var_rows_first_middle_last", np.max(np.abs(var0[rows] - var_o[:len(rows)])) / sf2, 1e-8)
     check(case, "ei_rows_first_middle_last_abs", np.max(np.abs(ei0[rows] - ei_o[:len(rows)])), 1e-9)
     check(case, "ei_top16_rel", np.max(np.abs(tv16 - ei_o[len(rows):]) / np.abs(ei_o[len(rows):])), 1e-8)
     assert int(np.argmax(ei_o[len(rows):])) == 0              # the oracle ranks pick 1 first among the block's candidates

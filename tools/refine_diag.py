@@ -64,6 +64,19 @@ def diagnose(tag, acq, m, st, starts, lower, upper, out):
 
 
 out = {}
+if len(sys.argv) > 1 and sys.argv[1] == "c3":
+    # the lockstep path at the headline's size (tests/test_gpu_refine.py: test_refinement_at_config_3_size_…)
+    from tests.test_gpu_parity import c3_oracle
+    X, y, st = c3_oracle()
+    m = abo.update(make_model(O.MATERN52, 1.0, 1.0, 1e-3), X, y)
+    lower, upper = np.zeros(8), np.ones(8)
+    starts = synth.points(9, 8, 8)
+    for acq in (abo.UpperConfidenceBound(2.0), abo.ExpectedImprovement(0.01, float(np.median(y)))):
+        diagnose(f"c3/N8192_d8/{type(acq).__name__}", acq, m, st, starts, lower, upper, out)
+        for r in out[f"c3/N8192_d8/{type(acq).__name__}"]["rows"]:
+            print("   ", json.dumps(r))
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_refine_diag_c3.json"), "w"), indent=1)
+    sys.exit(0)
 for family, d, N in [(O.MATERN52, 3, 60), (O.SE, 2, 100), (O.MATERN72, 6, 400)]:
     X, y = synth.standardized_problem(N, d, 0.02)
     ell, sf2, noise = 0.5, 1.0, 0.05
@@ -85,4 +98,4 @@ for family, d, N in [(O.MATERN52, 3, 200), (O.SE, 2, 1100)]:
     lower, upper = np.full(d, -0.5), np.full(d, 1.5)
     starts = synth.points(7, 12, d) * 2.0 - 0.5
     diagnose(f"ensemble/fam{family}_d{d}_N{N}", ens, m, st, starts, lower, upper, out)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r05_refine_diag.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r06_refine_diag.json"), "w"), indent=1)
