@@ -38,7 +38,8 @@ class AboTimings(C.Structure):
                 ("downdate_bytes", C.c_double), ("contraction_engine", C.c_int64), ("oz_nmod", C.c_int64)] + \
                [(n, C.c_double) for n in ("oz_prepare_ms", "oz_quant_ms", "oz_gemm_ms", "oz_crt_ms", "oz_gemm_ops", "refine_ms")] + \
                [("refine_starts", C.c_int64), ("refine_evals", C.c_int64), ("downdate_from_chain", C.c_int64),
-                ("nlml_kinv_ms", C.c_double), ("nlml_trace_ms", C.c_double)]
+                ("nlml_kinv_ms", C.c_double), ("nlml_trace_ms", C.c_double), ("append_trmv_ms", C.c_double),
+                ("append_trmv_bytes", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -10,6 +10,23 @@
 
 namespace abo {
 
+// Total order of Julia's stable `sortperm(scores; rev=true)` (acq_utils.jl:51): isless-descending (NaN first, then +Inf … −Inf, with
+// 0.0 before −0.0), equal scores by ascending index.  Scores map to order-preserving u64 keys.
+__device__ __forceinline__ uint64_t score_key(double s) {
+    if (s != s) return 0xffffffffffffffffull;
+    const uint64_t b = (uint64_t)__double_as_longlong(s);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+// the score a key came from (a NaN comes back as the canonical quiet NaN)
+__device__ __forceinline__ double score_of_key(uint64_t k) {
+    if (k == 0xffffffffffffffffull) return __longlong_as_double(0x7ff8000000000000ll);
+    return __longlong_as_double((long long)((k >> 63) ? (k ^ 0x8000000000000000ull) : ~k));
+}
+// true if entry (ka, ia) must come before (kb, ib)
+__device__ __forceinline__ bool before(uint64_t ka, int64_t ia, uint64_t kb, int64_t ib) {
+    return (ka > kb) || (ka == kb && ia < ib);
+}
+
 __device__ __forceinline__ double norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440084436210485); }
 __device__ __forceinline__ double norm_pdf(double z) { return exp(-0.5 * z * z) * 0.39894228040143267793994605993438; }
 

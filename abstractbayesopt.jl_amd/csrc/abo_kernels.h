@@ -308,6 +308,44 @@ hipError_t launch_qei_pick(const QeiPickArgs& a, hipStream_t st);
 hipError_t launch_qei_record(const double* tv, const int64_t* ti, int k, int64_t idx_base, const double* Z, const double* mu,
                              const double* var, const double* chain, int64_t Mp, int nchain, int d, double* rec, hipStream_t st);
 
+// ---- the pick loop of a block-form batch on ONE handle, without the host (qei.hip: qei_step_kernel; ABI 7) -------------------------
+// Launch k of a batch of q picks (k = 0 … q) finishes pick k − 1 and selects pick k:
+//   (B) every workgroup reduces the ≤ QEI_STEP_MAXWG partial arg-maxima launch k − 1 left (strict total order: any reduction tree
+//       gives the same winner), workgroup 0 writes the pick's record, every workgroup looks the winner up in the slot table, forms
+//       s = σ²(x) + σ²_n and γ_i = c_i(x)/s_i and applies c = C₀[slot] − Σ γ_i c_i, σ² −= c²/s to its candidates (the arithmetic of
+//       qei_pick_kernel), then
+//   (C) scores its candidates (EI) and leaves its partial arg-max {key, index, μ, σ²} for launch k + 1.
+// No workgroup waits for another inside a launch (stream order is the only synchronisation): no atomics, no fences — bit-reproducible.
+// A pick outside every block, or s ≤ 0, raises st->stop: the remaining launches return at once, the host builds the block (or reports
+// the failed pivot) and resumes from launch k.
+constexpr int QEI_STEP_MAXWG = 1024;
+struct QeiStepState {                    // device memory, one per candidate set
+    int32_t stop;                        // 0: running; 1: pick stop_at is in no block; 2: s ≤ 0 at pick stop_at
+    int32_t stop_at;
+    double s_batch[QEI_MAXQ];            // s of the picks this batch conditioned on (entry t: the batch's pick t)
+};
+struct QeiStepPartial { uint64_t key; int64_t idx; double mu, var; };
+struct QeiStepArgs {
+    double* mu; double* var;             // [M] stored posterior of the set (σ² is conditioned in place; the batch rolls it back)
+    const double* Z;                     // [M][d]
+    const double* blk;                   // [slots][Mp] block columns
+    double* chain;                       // [rows][Mp]
+    QeiStepState* st;
+    QeiStepPartial* part;                // [2][QEI_STEP_MAXWG]: launch k writes half k & 1, reads half (k − 1) & 1
+    double* rec;                         // [q][wmax] records {EI, global index, μ, σ², x[d], c_1(x) … c_n(x)}
+    int64_t M, Mp, idx_base;
+    int d, T16, nslots, wmax;
+    int k, q;                            // this launch; picks of the batch
+    int n0;                              // chain entries when the batch's pick 0 was selected (real entries carried over)
+    int nwg_prev;                        // workgroups of launch k − 1 (partials to reduce)
+    int distinct;
+    double xi, best_y, noise;
+    double chain_s0[QEI_MAXQ];           // s_i of the chain entries i < n0 (host knows them)
+    int blk_base[4];                     // per block: chain entries already in its columns
+    int64_t slot_gidx[4 * QEI_MAXT];     // global candidate index per block row (−1: empty)
+};
+hipError_t launch_qei_step(const QeiStepArgs& a, int nwg, hipStream_t st);
+
 // Z[(j−j0)·d + c] for j in [j0, j0+count): Latin-hypercube points of an n-point design (device lower/upper)
 hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                       int64_t count, hipStream_t s);

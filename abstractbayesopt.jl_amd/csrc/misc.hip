@@ -275,11 +275,7 @@ constexpr int TK_T = 1024;   // threads: one compare-exchange per thread and sta
 constexpr uint64_t KEY_PAD = 0ull;
 constexpr int64_t IDX_PAD = 0x7fffffffffffffffll;
 
-__device__ __forceinline__ uint64_t score_key(double s) {
-    if (s != s) return 0xffffffffffffffffull;
-    const uint64_t b = (uint64_t)__double_as_longlong(s);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
+// (score_key / before: abo_acq_dev.h — shared with the pick loop of greedy q-EI, qei.hip)
 
 // ordering point for LDS traffic between the lanes of ONE wave (in-order LDS queue: drained counter + compiler fence)
 __device__ __forceinline__ void wave_lds_sync() {
@@ -289,10 +285,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// true if entry (ka, ia) must come before (kb, ib)
-__device__ __forceinline__ bool before(uint64_t ka, int64_t ia, uint64_t kb, int64_t ib) {
-    return (ka > kb) || (ka == kb && ia < ib);
-}
 
 // thr (FIRST pass only, may be null): {key, idx} of the last entry already selected by an earlier round of a k > 1024
 // selection — only entries strictly AFTER it in the total order take part (the order is strict, so "after the last

@@ -23,6 +23,7 @@
 #include "abo_kernels.h"
 #include "../../include/abo_hip.h"
 #include "abo_kappa.h"
+#include "abo_acq_dev.h"
 
 namespace abo {
 
@@ -97,6 +98,118 @@ __global__ void qei_record_kernel(const double* __restrict__ tv, const int64_t* 
     }
     for (int c = t; c < d; c += blockDim.x) r[4 + c] = ok ? Z[li * d + c] : 0.0;
     for (int i = t; i < nchain; i += blockDim.x) r[4 + d + i] = ok ? chain[(int64_t)i * Mp + li] : 0.0;
+}
+
+// ---- the pick loop on the device (abo_kernels.h: QeiStepArgs) --------------------------------------------------------------------------
+// wave-then-workgroup arg-max of (key, idx) in the total order of `before`; the winner's (mu, var) travel with it.  All threads return the
+// winner (broadcast through LDS).
+__device__ __forceinline__ void qei_wg_argmax(uint64_t& bk, int64_t& bi, double& bm, double& bv, uint64_t* sk, int64_t* si, double* sm,
+                                              double* sv) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint64_t ok = (uint64_t)__shfl_xor((long long)bk, o);
+        const int64_t oi = (int64_t)__shfl_xor((long long)bi, o);
+        const double om = __shfl_xor(bm, o), ov = __shfl_xor(bv, o);
+        if (before(ok, oi, bk, bi)) { bk = ok; bi = oi; bm = om; bv = ov; }
+    }
+    if (lane == 0) { sk[wave] = bk; si[wave] = bi; sm[wave] = bm; sv[wave] = bv; }
+    __syncthreads();
+    bk = sk[0]; bi = si[0]; bm = sm[0]; bv = sv[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (before(sk[w], si[w], bk, bi)) { bk = sk[w]; bi = si[w]; bm = sm[w]; bv = sv[w]; }
+    __syncthreads();                                          // (the LDS slots are reused by the caller's next reduction)
+}
+
+constexpr uint64_t QEI_KEY_PAD = 0ull;
+constexpr int64_t QEI_IDX_PAD = 0x7fffffffffffffffll;
+
+__global__ void __launch_bounds__(256) qei_step_kernel(const QeiStepArgs a) {
+    __shared__ uint64_t sk[4];
+    __shared__ int64_t si[4];
+    __shared__ double sm[4], sv[4];
+    __shared__ double gam[QEI_MAXQ];
+    __shared__ int s_slot;
+    if (a.st->stop) return;                                   // an earlier launch of the batch asked for the host
+    const int t = threadIdx.x;
+    const int k = a.k;
+    bool apply = false;
+    int n = 0, slot = -1, first = 0;
+    int64_t li = -1;
+    double s = 1.0;
+    if (k > 0) {
+        // (B) the winner of launch k − 1: pick k − 1 of the batch, selected on a chain of n entries
+        const QeiStepPartial* pp = a.part + (size_t)((k - 1) & 1) * QEI_STEP_MAXWG;
+        uint64_t bk = QEI_KEY_PAD;
+        int64_t bi = QEI_IDX_PAD;
+        double bm = 0.0, bv = 0.0;
+        for (int e = t; e < a.nwg_prev; e += 256) {
+            const QeiStepPartial p = pp[e];
+            if (before(p.key, p.idx, bk, bi)) { bk = p.key; bi = p.idx; bm = p.mu; bv = p.var; }
+        }
+        qei_wg_argmax(bk, bi, bm, bv, sk, si, sm, sv);
+        li = bi;
+        n = a.n0 + (k - 1);
+        const int64_t gidx = li + a.idx_base;
+        if (blockIdx.x == 0) {
+            double* r = a.rec + (size_t)(k - 1) * a.wmax;
+            if (t == 0) { r[0] = score_of_key(bk); r[1] = (double)gidx; r[2] = bm; r[3] = bv; }
+            for (int c = t; c < a.d; c += 256) r[4 + c] = a.Z[li * a.d + c];
+            for (int i = t; i < n; i += 256) r[4 + a.d + i] = a.chain[(int64_t)i * a.Mp + li];
+        }
+        if (k == a.q) return;                                 // the tail launch: the last pick conditions nothing
+        // the pick's block row: the FIRST slot holding its index (qei_find_slot's order)
+        if (t == 0) s_slot = 0x7fffffff;
+        __syncthreads();
+        for (int e = t; e < a.nslots; e += 256)
+            if (a.slot_gidx[e] == gidx) atomicMin(&s_slot, e);
+        s = bv + a.noise;
+        for (int i = t; i < n; i += 256) {
+            const double si_ = i < a.n0 ? a.chain_s0[i] : a.st->s_batch[i - a.n0];
+            gam[i] = a.chain[(int64_t)i * a.Mp + li] / si_;
+        }
+        __syncthreads();
+        slot = s_slot == 0x7fffffff ? -1 : s_slot;
+        if (slot < 0 || !(s > 0.0)) {
+            if (blockIdx.x == 0 && t == 0) { a.st->stop_at = k - 1; a.st->stop = slot < 0 ? 1 : 2; }
+            return;
+        }
+        if (blockIdx.x == 0 && t == 0) a.st->s_batch[k - 1] = s;
+        first = a.blk_base[slot / a.T16];
+        apply = true;
+    }
+    // (B, continued) condition this workgroup's candidates on the pick, then (C) score them: EI and the partial arg-max
+    const double* blk = a.blk + (int64_t)(slot < 0 ? 0 : slot) * a.Mp;
+    double* out = a.chain + (int64_t)n * a.Mp;
+    uint64_t bk = QEI_KEY_PAD;
+    int64_t bi = QEI_IDX_PAD;
+    double bm = 0.0, bv = 0.0;
+    for (int64_t z = (int64_t)blockIdx.x * 256 + t; z < a.M; z += (int64_t)gridDim.x * 256) {
+        double m = a.mu[z], v = a.var[z];
+        if (apply) {
+            double c = blk[z];
+            for (int i = first; i < n; ++i) c = fma(-gam[i], a.chain[(int64_t)i * a.Mp + z], c);     // fixed order: entry first, first + 1, …
+            out[z] = c;
+            v = v - c * c / s;                                // the expression of qei_pick_kernel / downdate_kernel
+            if (a.distinct && z == li) { m = HUGE_VAL; v = 0.0; a.mu[z] = m; }     // abo_cand_exclude: μ = +Inf, σ² = 0
+            a.var[z] = v;
+        }
+        const uint64_t key = score_key(acq_score(ABO_ACQ_EI, m, v, a.xi, a.best_y));
+        if (before(key, z, bk, bi)) { bk = key; bi = z; bm = m; bv = v; }
+    }
+    qei_wg_argmax(bk, bi, bm, bv, sk, si, sm, sv);
+    if (t == 0) {
+        QeiStepPartial p;
+        p.key = bk; p.idx = bi; p.mu = bm; p.var = bv;
+        a.part[(size_t)(k & 1) * QEI_STEP_MAXWG + blockIdx.x] = p;
+    }
+}
+
+hipError_t launch_qei_step(const QeiStepArgs& a, int nwg, hipStream_t st) {
+    if (nwg < 1 || nwg > QEI_STEP_MAXWG || a.M < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(qei_step_kernel, dim3((unsigned)(a.k == a.q ? 1 : nwg)), dim3(256), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_qei_kxt(const double* Xs, int dp, int N, int Np, const double* P, int d, int T, int rows, int family, double s,

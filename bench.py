@@ -465,7 +465,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     """BASELINE config 5.  A step = greedy q-EI over the resident grid (q = 8 picks, each: EI + arg-max,
     fantasy bordered append, O(N·M) down-date), roll the grid posterior back, append the real (noisy)
     observation of the first pick to the parent model, down-date.  The full refresh (refit + grid
-    re-evaluation, due every 16 steps and whenever hyper-parameters change) is timed once in setup and
+    re-evaluation: due when the factor's spare rows are used up — --refresh-every — and whenever hyper-parameters
+    change; appends alone never need one, profiles/r06_c5_refresh_drift.txt) is timed once in setup and
     reported as refresh_ms / value_amortized."""
     import torch
     import torch.distributed as dist
@@ -485,8 +486,18 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     y_mean, y_std = y_raw.mean(), y_raw.std(ddof=1)
     y = (y_raw - y_mean) / y_std
     Zd = torch.from_numpy(synth.points(2, hi - lo, d, first=lo)).to(dev)
+    # Refresh cadence (full refit + grid re-evaluation).  Round 6 MEASURED what rounds 1 - 5 assumed (16): 64 real appends with no
+    # refresh leave the appended factor and the down-dated grid where an independent oracle refit puts them — max |dL| 6.4e-14,
+    # |dmu| 7.0e-12, |dvar| 6.9e-14 after 64 appends against 5.2e-14, 5.2e-12, 6.9e-14 after 16 (profiles/r06_c5_refresh_drift.txt):
+    # there is no drift to bound, appends alone never force a refresh.  What does is the factor's capacity (n_max rows) and a change of
+    # hyper-parameters (the reference re-optimises them every 10 iterations when asked to, bayesian_opt.jl:388 — a refit either way).
+    # The cadence is therefore the capacity the caller gives the model: --refresh-every (default 64), n_max = N + cadence.
+    cadence = max(1, int(getattr(args, "refresh_every", 64) or 64))
+    if n_warm + n_steps + 3 > cadence:
+        raise SystemExit(f"bench.py --config c5: {n_warm} + {n_steps} (+ 3 untimed) appends exceed the model's capacity N + {cadence} "
+                         "(--refresh-every): a refresh inside the timed region is not what this line times")
     gp = abo.HipStandardGP(sf2 * abo.with_lengthscale(getattr(abo, fam_name)(), ell), noise, device=local_rank,
-                           n_max=N + 64, chunk=args.chunk)
+                           n_max=N + cadence, chunk=args.chunk)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -511,7 +522,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     fit_t = model.timings()
     best_y = float(y.min())
     ph = {"qei_ms": [], "append_ms": [], "downdate_ms": [], "downdate_pass_ms": [], "downdate_pass_bytes": [], "block_ms": [],
-          "block_pass_ms": [], "block_pass_bytes": [], "block_pass_flop": []}
+          "block_pass_ms": [], "block_pass_bytes": [], "block_pass_flop": [], "append_trmv_ms": [], "append_trmv_bytes": []}
+    builds_timed = 0
     counts = {"block_builds": 0, "block_hits": 0, "downdates_from_chain": 0, "block": 0}
     picks = None
     blk = None if args.qei_block is None else int(args.qei_block)
@@ -537,6 +549,7 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
             ph["qei_ms"].append((tb - ta) * 1e3)
             ph["append_ms"].append((td - tb) * 1e3); ph["downdate_ms"].append((te - td) * 1e3)
             ph["downdate_pass_ms"].append(dd["downdate_ms"]); ph["downdate_pass_bytes"].append(dd["downdate_bytes"])
+            ph["append_trmv_ms"].append(dd.get("append_trmv_ms", 0.0)); ph["append_trmv_bytes"].append(dd.get("append_trmv_bytes", 0.0))
             counts["downdates_from_chain"] += int(dd.get("downdate_from_chain", 0))
             counts["block"] = int(st.get("block", 0))
             if st.get("block", 0):
@@ -582,20 +595,38 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
         ach = append_bytes / (med["append_ms"] * 1e-3) / 1e9
         tr, tr_src = pmc_traffic("c5", M_per)              # committed rocprofv3 FETCH_SIZE pass (null when stale)
         tsrc = {k: tr_src.get(k) for k in ("file", "kernel_source_sha", "stale", "note") if tr_src and k in tr_src}
+        block_roof = None
         if counts["block"] and med["block_pass_ms"] > 0:
-            # dominant kernel of the step: the ONE product over the resident K_ZX that gives the covariance columns of a whole block
-            # (gemm_skinny_kernel: T rows of K^-1 K_XT against the streamed K_ZX) — HBM-bound; its flop ride under the stream
+            # the ONE product over the resident K_ZX that gives the covariance columns of a whole block — HBM-bound; its flop ride
+            # under the stream.  In the running loop it is RARE (blocks and chain follow the model): its own launches_per_step says
+            # how often the timed steps ran it, and it is the line's `roofline` only when they did.
             gbs = med["block_pass_bytes"] / (med["block_pass_ms"] * 1e-3) / 1e9
-            roof = {"kernel": f"qei_passd_kernel<{counts['block'] // 16}> (C0 = -K_ZX . K^-1 K_XT: T = {counts['block']} covariance "
-                              f"columns from ONE pass over the resident K_ZX)", "bound": "hbm",
-                    "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr, "traffic_source": tsrc,
-                    "algorithmic_bytes_per_launch": med["block_pass_bytes"], "avg_launch_ms": med["block_pass_ms"],
-                    "launches_per_step": counts["block_builds"] / n_steps,
-                    "mfma_tflops_under_the_stream": med["block_pass_flop"] / (med["block_pass_ms"] * 1e-3) / 1e12,
-                    "launches_timed": len(ph["block_pass_ms"]),
-                    "note": "algorithmic bytes = 8*N*M (K_ZX read once per block of T picks' columns; the plain loop reads it once "
-                            "per pick); duration = HIP events on the library stream, median over every step that built a block "
-                            "(warm-up steps included: blocks and chain follow the model, so most steps build none)"}
+            block_roof = {"kernel": f"qei_passd_kernel<{counts['block'] // 16}> (C0 = -K_ZX . K^-1 K_XT: T = {counts['block']} "
+                                    f"covariance columns from ONE pass over the resident K_ZX)", "bound": "hbm",
+                          "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": tr, "traffic_source": tsrc,
+                          "algorithmic_bytes_per_launch": med["block_pass_bytes"], "avg_launch_ms": med["block_pass_ms"],
+                          "launches_per_step": counts["block_builds"] / n_steps,
+                          "mfma_tflops_under_the_stream": med["block_pass_flop"] / (med["block_pass_ms"] * 1e-3) / 1e12,
+                          "launches_timed": len(ph["block_pass_ms"]),
+                          "note": "algorithmic bytes = 8*N*M (K_ZX read once per block of T picks' columns; the plain loop reads it "
+                                  "once per pick); duration = HIP events on the library stream, median over every step that built "
+                                  "a block, WARM-UP STEPS INCLUDED (launches_per_step counts the timed steps only)"}
+        if counts["block"] and med["append_trmv_ms"] > 0 and (block_roof is None or counts["block_builds"] < n_steps):
+            # the timed step's dominant kernel BY KERNEL TIME: the bordered append's two triangular mat-vecs (trmv_kernel: l = L^-1 k,
+            # v = L^-T l), each streaming one triangle of its N x N matrix once — 2 launches per step, HBM-bound
+            gbs = med["append_trmv_bytes"] / (med["append_trmv_ms"] * 1e-3) / 1e9
+            roof = {"kernel": "trmv_kernel x2 (bordered append: l = L^-1 k over the lower triangle of L^-1, v = L^-T l over the upper "
+                              "triangle of L^-T)", "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                    "frac": gbs / 8000.0, "traffic": None,
+                    "algorithmic_bytes_per_launch": med["append_trmv_bytes"] / 2.0, "avg_launch_ms": med["append_trmv_ms"] / 2.0,
+                    "launches_per_step": 2,
+                    "share_of_step": med["append_trmv_ms"] / ms if ms > 0 else None,
+                    "note": "algorithmic bytes = 8*N^2 for the pair (one triangle of each matrix, read once); duration = HIP events "
+                            "on the library stream around the two launches, median over the timed steps.  The q-EI batch of a timed "
+                            "step runs q + 1 = 9 launches of qei_step_kernel (pick loop on the device, no pass over K_ZX: the "
+                            "block build is block_build_roofline, with its own launches_per_step)"}
+        elif block_roof is not None:
+            roof, block_roof = block_roof, None
         elif med["downdate_pass_bytes"] > 0:
             # the plain loop (--qei-block 0): one O(N*M) down-date pass per pick, 8 launches per step (7 fantasies + the real point)
             gbs = med["downdate_pass_bytes"] / (med["downdate_pass_ms"] * 1e-3) / 1e9
@@ -630,13 +661,18 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
                     "note": "value = the BO loop as it runs: blocks and chain follow the model from step to step, a step streams "
                             "K_ZX (one pass per block) only when a pick falls outside every block; step_with_a_fresh_block_ms = "
                             "the same step with nothing carried over (every batch builds its block)"},
-            "refresh_ms": refresh_ms, "refresh_ms_all": refresh_all, "value_amortized": ms + refresh_ms / 16.0,
+            "refresh_ms": refresh_ms, "refresh_ms_all": refresh_all, "value_amortized": ms + refresh_ms / cadence,
+            "refresh": {"every_steps": cadence, "value_amortized_at_16": ms + refresh_ms / 16.0,
+                        "why": "capacity of the factor (n_max = N + every_steps) or a hyper-parameter change; NOT numerical drift: "
+                               "64 appends without a refresh stay at 7e-12 (mu) / 7e-14 (var) of an independent oracle refit, the "
+                               "same as after 16 (profiles/r06_c5_refresh_drift.txt)"},
             "refresh_phases_ms": {k: v for k, v in fit_t.items() if k.endswith("_ms")},
             "roofline": roof,
-            "secondary_roofline": {"kernel": "trmv_kernel x2 (bordered append: l = L^-1 k, v = L^-T l)", "bound": "hbm",
-                                   "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "block_build_roofline": block_roof,
+            "secondary_roofline": {"kernel": "the whole abo_append call (k-row kernel, trmv_kernel x2, two tiny kernels, host sync)",
+                                   "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                                    "note": "algorithmic bytes 8*N^2 per append; duration = host wall-clock of the synchronous "
-                                           "abo_append call (includes the k-row kernel, two tiny kernels and two host syncs)"},
+                                           "abo_append call"},
             "phases_ms": med,
             "last_batch": {"indices": [int(i) for i in picks[0]], "ei": [float(v) for v in picks[1]]},
         }
@@ -843,6 +879,9 @@ def main():
     ap.add_argument("--qei-block", type=int, default=None,
                     help="config 5: points per block of the block-form greedy q-EI (default: the library's, 16; 0 = the plain loop "
                          "with one pass over K_ZX per pick, for A/B runs)")
+    ap.add_argument("--refresh-every", type=int, default=64,
+                    help="config 5: BO steps between full refreshes = spare rows of the factor (n_max = N + this); value_amortized = "
+                         "value + refresh_ms / this.  64: what profiles/r06_c5_refresh_drift.txt supports (no drift after 64 appends)")
     ap.add_argument("--contraction", default=None,
                     help="engine of the N^2*M variance contraction: auto (library default), fp64, int8 or int8:<moduli>")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -1062,8 +1101,8 @@ def main():
 
             def c5_leg():
                 c5 = run_c5(args, CONFIGS["c5"], 1, 0, local_rank, dev, False, steps=5, warmup=2)
-                keep = {k: c5[k] for k in ("value", "unit", "steps", "warmup", "roofline", "secondary_roofline", "refresh_ms",
-                                           "value_amortized", "phases_ms", "refresh_phases_ms")}
+                keep = {k: c5[k] for k in ("value", "unit", "steps", "warmup", "roofline", "block_build_roofline", "secondary_roofline", "qei", "refresh_ms",
+                                           "value_amortized", "refresh", "phases_ms", "refresh_phases_ms") if k in c5}
                 keep["workload"] = c5["config"]["workload"]
                 return keep
 

