@@ -5,6 +5,9 @@ import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libabo_hip.so")
+# the same library with the abo_test_* building blocks compiled in (-DABO_TEST_HOOKS; include/abo_hip.h, last section): what the test
+# suite loads (tests/conftest.py sets ABO_LIB_TEST_HOOKS=1 before the package is imported).  The shipped library exports none of them.
+LIB_TEST_PATH = os.path.join(PKG, "lib", "libabo_hip_test.so")
 
 ABO_OK, ABO_ENOTPD, ABO_EDIM, ABO_EINVAL, ABO_EHIP, ABO_ENOMEM = range(6)
 HOST, DEVICE = 0, 1
@@ -12,14 +15,15 @@ HOST, DEVICE = 0, 1
 EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_grad", "abo_predict_grad_cov", "abo_retain", "abo_destroy", "abo_fit", "abo_append", "abo_append_grad", "abo_cand_create", "abo_cand_destroy",
            "abo_cand_refresh", "abo_cand_downdate", "abo_cand_save", "abo_cand_restore", "abo_cand_acq", "abo_cand_get", "abo_cand_point", "abo_cand_exclude", "abo_predict", "abo_acq", "abo_nlml", "abo_nlml_grad", "abo_lhs", "abo_score",
            "abo_get_factor", "abo_get_n", "abo_get_data", "abo_get_timings", "abo_last_error", "abo_abi_version", "abo_pool_trim",
-           "abo_test_gemm_nt", "abo_test_kappa", "abo_test_oz_plan", "abo_test_oz_contract",
            "abo_mgpu_create", "abo_mgpu_clone", "abo_mgpu_destroy", "abo_mgpu_info", "abo_mgpu_get", "abo_mgpu_fit",
            "abo_mgpu_predict", "abo_mgpu_acq", "abo_mgpu_acq_lhs", "abo_mgpu_append", "abo_mgpu_cand_create",
            "abo_mgpu_cand_create_lhs", "abo_mgpu_cand_refresh", "abo_mgpu_cand_destroy", "abo_mgpu_cand_acq",
-           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_test_acq_grad", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
-           "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms", "abo_test_acq_grad_terms",
+           "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
+           "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms",
            "abo_set_qei_block", "abo_cand_qei", "abo_cand_qei_begin", "abo_cand_qei_top", "abo_cand_qei_block", "abo_cand_qei_pick",
            "abo_cand_qei_end", "abo_cand_qei_has", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats", "abo_cand_qei_eligible"]
+TEST_EXPORTS = ["abo_test_gemm_nt", "abo_test_kappa", "abo_test_oz_plan", "abo_test_oz_contract", "abo_test_acq_grad",
+                "abo_test_acq_grad_terms"]
 ABI_VERSION = 7
 CONTRACT_AUTO, CONTRACT_FP64, CONTRACT_INT8 = 0, 1, 2
 
@@ -89,8 +93,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise AboError(f"{LIB_PATH} not found: the HIP library has not been built "
+    hooks = os.environ.get("ABO_LIB_TEST_HOOKS") == "1"
+    path = LIB_TEST_PATH if hooks else LIB_PATH
+    if not os.path.exists(path):
+        raise AboError(f"{path} not found: the HIP library has not been built "
                        "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
     # libabo_hip.so has NEEDED libamdhip64.so.7 + RUNPATH /opt/rocm-*/lib: a host without PyTorch (the Julia `ccall`
     # host; tests/c_abi_harness.c, run as a child process by tests/test_gpu_c_abi.py, which asserts that the system
@@ -101,7 +107,8 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
+    L.has_test_hooks = hooks
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.abo_create.argtypes = [C.POINTER(AboParams), C.POINTER(vp)]
     L.abo_set_contraction.argtypes = [vp, i32, i32]
@@ -136,10 +143,14 @@ def lib():
     L.abo_last_error.argtypes = [C.c_char_p, C.c_size_t]
     L.abo_abi_version.argtypes = []
     L.abo_pool_trim.argtypes = [i32]
-    L.abo_test_kappa.argtypes = [i32, i32, vp, vp, i64]
-    L.abo_test_oz_plan.argtypes = [i32, vp, vp, vp, vp]
-    L.abo_test_oz_contract.argtypes = [i32, vp, i64, i32, i32, vp, i64, i32, f64, i32, vp, i64]
-    L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
+    if hooks:
+        L.abo_test_kappa.argtypes = [i32, i32, vp, vp, i64]
+    if hooks:
+        L.abo_test_oz_plan.argtypes = [i32, vp, vp, vp, vp]
+    if hooks:
+        L.abo_test_oz_contract.argtypes = [i32, vp, i64, i32, i32, vp, i64, i32, f64, i32, vp, i64]
+    if hooks:
+        L.abo_test_gemm_nt.argtypes = [i32, vp, vp, vp, i32, i32, i32, i64, i64, i64, f64, f64]
     L.abo_mgpu_create.argtypes = [C.POINTER(AboParams), i32, C.POINTER(i32), C.POINTER(vp)]
     L.abo_mgpu_create_grad.argtypes = [C.POINTER(AboParams), i32, vp, i32, C.POINTER(i32), C.POINTER(vp)]
     L.abo_mgpu_append_grad.argtypes = [vp, vp, i32, vp, C.POINTER(i64), vp]
@@ -174,9 +185,11 @@ def lib():
     L.abo_optimize_acquisition.argtypes = [vp, i32, f64, f64, vp, vp, i32, i64, i32, C.c_uint64, C.POINTER(AboRefineOpts),
                                            vp, C.POINTER(f64), vp, vp, vp, vp]
     L.abo_mgpu_optimize_acquisition.argtypes = L.abo_optimize_acquisition.argtypes
-    L.abo_test_acq_grad.argtypes = [vp, i32, f64, f64, vp, i64, i32, vp, vp]
+    if hooks:
+        L.abo_test_acq_grad.argtypes = [vp, i32, f64, f64, vp, i64, i32, vp, vp]
     tp = C.POINTER(AboAcqTerm)
-    L.abo_test_acq_grad_terms.argtypes = [vp, tp, i32, vp, i64, i32, vp, vp]
+    if hooks:
+        L.abo_test_acq_grad_terms.argtypes = [vp, tp, i32, vp, i64, i32, vp, vp]
     L.abo_acq_terms.argtypes = [vp, vp, i64, i32, i32, tp, i32, i64, vp, i32, vp, vp, i32]
     L.abo_acq_lhs.argtypes = [vp, i64, i32, vp, vp, C.c_uint64, i32, f64, f64, i32, vp, vp, vp]
     L.abo_refine_terms.argtypes = [vp, tp, i32, vp, vp, i32, vp, i32, C.POINTER(AboRefineOpts), vp, vp, vp]
@@ -184,7 +197,7 @@ def lib():
                                                  vp, C.POINTER(f64), vp, vp, vp, vp]
     L.abo_mgpu_optimize_acquisition_terms.argtypes = L.abo_optimize_acquisition_terms.argtypes
     L.abo_fit_acq.argtypes = [vp, vp, i64, i32, vp, i32, C.POINTER(i64), vp, i64, i32, i32, f64, f64, i64, vp, i32, vp, vp, i32]
-    for name in EXPORTS:
+    for name in EXPORTS + (TEST_EXPORTS if hooks else []):
         getattr(L, name).restype = i32
     _lib = L
     return L

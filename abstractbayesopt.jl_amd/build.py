@@ -1,4 +1,6 @@
-"""Builds libabo_hip.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree."""
+"""Builds libabo_hip.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree — and libabo_hip_test.so, the same objects with api.hip
+compiled once more under -DABO_TEST_HOOKS: the abo_test_* building blocks the GPU suite drives (include/abo_hip.h, last section) are in
+the test library only; the shipped library exports the header's documented surface and nothing else."""
 import os
 import shutil
 import subprocess
@@ -6,6 +8,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib", "libabo_hip.so")
+LIB_TEST = os.path.join(PKG, "lib", "libabo_hip_test.so")
+HOOK_SOURCES = ["api.hip"]          # the translation units that hold #ifdef ABO_TEST_HOOKS code
 SOURCES = ["kgen.hip", "kgen_res.hip", "kgen_grad_res.hip", "gemm.hip", "ozaki.hip", "chol.hip", "misc.hip", "qei.hip", "refine.hip", "api.hip", "mgpu.hip"]
 # -amdgpu-mfma-vgpr-form: keep fp64 MFMA accumulators in VGPRs; the AGPR form makes hipcc shuttle
 # every accumulator through v_accvgpr_read/write each k-step (2.2x slower, profiles/r01_mfma_f64_probe.txt)
@@ -50,7 +54,7 @@ def _newer_than_lib():
 def _stale():
     # by CONTENT, not by time stamps alone: a library file copied over lib/libabo_hip.so (an A/B build put back, a checkout of
     # older sources) is newer than every source and would pass a time-stamp test while being built from something else
-    if not os.path.exists(LIB) or not os.path.exists(MANIFEST):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_TEST) or not os.path.exists(MANIFEST):
         return True
     with open(MANIFEST) as f:
         lines = f.read().split()
@@ -75,22 +79,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(PKG, "..", "include", "abo_hip.h")]
     hdr_t = max(os.path.getmtime(h) for h in hdrs)
 
-    def compile_one(src):
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+    def compile_one(job):
+        src, hooks = job
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ("_hooks.o" if hooks else ".o"))
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
             return obj
-        cmd = [hipcc] + cflags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + cflags + (["-DABO_TEST_HOOKS"] if hooks else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-pthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    jobs = [(s_, False) for s_ in SOURCES] + [(s_, True) for s_ in HOOK_SOURCES]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+        built = list(ex.map(compile_one, jobs))
+    objs, hook_objs = built[:len(SOURCES)], dict(zip(HOOK_SOURCES, built[len(SOURCES):]))
+    for lib, these in ((LIB, objs), (LIB_TEST, [hook_objs.get(s_, o) for s_, o in zip(SOURCES, objs)])):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + these + ["-ldl", "-pthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     with open(MANIFEST, "w") as f:
         f.write(_manifest() + "\n" + _lib_digest() + "\n")
     return LIB

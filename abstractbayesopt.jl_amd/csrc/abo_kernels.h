@@ -56,7 +56,6 @@ struct VarGemmArgs {
     double* partial;      // [Np/128][ldp]
     int64_t ldw, ldk, ldp;
     int Np, Mc;           // multiples of 128
-    int force128;         // 1: always use the 128×128-tile kernel (A/B comparisons)
     int nvalid;           // rows ≥ nvalid (the view's N) are excluded from the norm
 };
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s);
@@ -183,16 +182,9 @@ hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, con
 // the same split for the panel chain: potf2 (factor + the eight 16×16 diagonal sub-block inverses, which go to their final
 // places in W / WT), the panel solve below the block as a blocked triangular solve on L (rows r0+128 … r0+128+nrows), and —
 // once, after the factorisation — the 128×128 inverses of ALL diagonal blocks in one batched launch
-hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P = nullptr);
-bool potf2_pipe_enabled();
+hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P);
 constexpr size_t TRSM_STREAM_BYTES = 144 * 64 * sizeof(double);      // the packed operands potf2_pipe_kernel leaves for trsm_stream_kernel
 hipError_t launch_trsm_stream(double* K, const double* P, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s);
-// diagonal block + panel solve + in-strip update of one panel in one launch; flag: two ints, zero before the launch
-hipError_t launch_panel_fused(double* K, double* W, double* WT, int64_t ld, int r0, int nrows, int ncol, int64_t* info, int* flag, double* P,
-                              hipStream_t s);
-// the same step in 78 KB of LDS on 8 waves (fits beside a running trailing update: the look-ahead chain of api.hip: factorise); same bits
-hipError_t launch_potf2_lite(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s);
-hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s, int lite = 0);
 hipError_t launch_trtri_diag_batched(double* K, double* W, double* WT, int64_t ld, int nblocks, int64_t* info, hipStream_t s);
 // out[i] = Σ_{k ≤ i} Wm[i][k]·v[k]   (lower == 1)   or   Σ_{k ≥ i} Wm[i][k]·v[k]   (lower == 0)
 hipError_t launch_trmv(const double* Wm, int64_t ld, const double* v, double* out, int Np, int lower, hipStream_t s);

@@ -189,7 +189,6 @@ struct DevBuf {
 constexpr size_t PIN_BYTES = 32768, PIN_OUT = 64;      // [0,16) fit scalars, [16,24) info, [PIN_OUT, …) selected pairs
 struct ExecCtx {
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;      // the trailing updates of the factorisation's look-ahead (created on first use)
     std::vector<hipEvent_t> ev;
     char* pin = nullptr;
 };
@@ -514,14 +513,11 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     double* K = st->K.as<double>();
     double* W = st->W.as<double>();
     double* WT = st->WT.as<double>();
-    // info[0]: the LAPACK-style status; behind it one word (two flags) per panel for the hand-overs inside panel_fused_kernel
-    const size_t info_words = 1 + (size_t)(Np / TB);
-    HIPCHK(g->info.ensure(sizeof(int64_t) * info_words));
-    int64_t* info = g->info.as<int64_t>();
-    int* panel_flags = reinterpret_cast<int*>(info + 1);
+    HIPCHK(g->info.ensure(sizeof(int64_t)));
+    int64_t* info = g->info.as<int64_t>();              // the LAPACK-style status
 
     HIPCHK(hipEventRecord(g->evs()[0], s));
-    HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t) * info_words, s));
+    HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
     // whole capacity region: zeros, identity on the padded diagonal (rows ≥ N), K on the active part
     if (ld > Np) HIPCHK(hipMemsetAsync(K, 0, sizeof(double) * ld * ld, s));
     HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
@@ -543,133 +539,33 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // (K = 128 products on a tall, narrow block); the matrix behind the strip is updated once per strip with
     // K = SW — a quarter of the read-modify-write passes over the trailing matrix and four times longer k loops
     // per tile than a panel-by-panel SYRK.
-    const char* swe = getenv("ABO_CHOL_STRIP");
-    const int SW = swe ? atoi(swe) : 512;
-    // Third level (ABO_CHOL_SUPER = super-strip width, default 1024; 0 = off): strips grouped into super-strips, behind a strip only
-    // the rest of its super-strip is updated (K = SW), the matrix behind the super-strip once per super-strip with K = SS — half
-    // the passes over the trailing matrix and tiles twice as long.  Everywhere: Cholesky at N = 16384 35.0 → 32.8 ms (32.7 at
-    // 2048), at N = 8192 8.20 → 8.23 (round 3 had measured 38.2 → 36.6 / 8.67 → 8.76, profiles/r03_chol_super_sweep.txt).
-    // A super-strip pays while the square update behind it is large: its in-super-strip update is a launch of 4 × T tiles that
-    // lasts ≈ 150 µs whatever T is, against K = 1024 tiles at 70 TFLOP/s instead of 52 (profiles/r04_fit_trace_summary.txt) — so
-    // super-strips are used while at least ABO_CHOL_SUPER_ROWS (default 6144) rows remain, plain strips from there on.
-    const char* sse = getenv("ABO_CHOL_SUPER");
-    int SSmax = sse ? atoi(sse) : 1024;
-    if (SSmax <= SW) SSmax = SW;
-    SSmax = SSmax / SW * SW;
-    const char* sre = getenv("ABO_CHOL_SUPER_ROWS");
-    const int super_rows = sre ? atoi(sre) : 6144;
-    // Panel chain: potf2 of the diagonal block → triangular solve of the rows below it on L itself → in-strip update.  The
-    // 128×128 inverses of the diagonal blocks (the seeds of the blocked L⁻¹ below) are not on that chain: all of them are
-    // formed by ONE batched launch behind the factorisation.  ABO_CHOL_SPLIT=0 restores the round-1 chain (factor + inverse
-    // in one kernel, panel solve as a product with the inverse) for A/B runs.
-    const char* spe = getenv("ABO_CHOL_SPLIT");
-    const bool split = (!spe || atoi(spe) != 0) && Np > TB;     // a single block has no chain: factor + inverse in one launch
-    // Look-ahead (round 5): the panel chain of strip s + 1 runs WHILE the trailing update behind strip s is still going.  The update
-    // behind a strip is cut in two — (a) the next strip's columns, which the next chain needs, stays on this stream; (b) everything
-    // beyond goes to a second stream — and the chain's kernels are built to take the place of ONE departed workgroup of (b)
-    // (potf2_lite_kernel, trsm_panel_kernel: ≤ 80 KB of LDS; tools/prio_probe.hip).  Every tile still receives its updates in strip
-    // order — (b)(s − 1) before (a)(s), event-ordered — so the factor keeps its bits.  Strips only (no super-strips) in this mode.
-    const char* lae = getenv("ABO_CHOL_LOOKAHEAD");
-    // MEASURED AND OFF BY DEFAULT (profiles/r05_notes.md D): same bits, but no gain — the chain's wide kernels (the triangular solve of all
-    // rows below, the in-strip update: up to 190 workgroups) get their slots only as workgroups of (b) retire, one K = 512 tile
-    // (110 – 190 µs) at a time: Cholesky 8.32 → 8.53 ms at N = 8192, 2.81 → 3.19 at 4096, 33.0 (super-strips) → 33.2 at 16384.
-    const bool lookahead = split && lae && atoi(lae) != 0;
-    // Panel solve from the operand stream the diagonal-block kernel leaves (trsm_stream_kernel; ABO_TRSM_STREAM=0: the LDS-staged
-    // trsm_panel_kernel): the stream lives in T, which the factorisation does not use (the blocked inverse behind it does)
-    const char* tse = getenv("ABO_TRSM_STREAM");
-    // One launch per panel (panel_fused_kernel: diagonal block → solve → in-strip update, handed over through flags in device memory)
-    // while at most ABO_PANEL_FUSED rows lie below the panel.  MEASURED AND OFF BY DEFAULT (0; profiles/r05_notes.md D): same bits, but
-    // 67 µs per panel at N = 1024 against 31 + 7 + 10 µs for the three launches — what one workgroup hands another inside a launch
-    // has to travel as agent-scope (L2-bypassing) loads and stores, and a launch boundary here costs 1.3 µs plus a short ramp
-    const char* pfe = getenv("ABO_PANEL_FUSED");
-    const int fused_rows = pfe ? atoi(pfe) : 0;
-    double* trsm_ops = (split && potf2_pipe_enabled() && !(tse && atoi(tse) == 0) && g->T.cap >= TRSM_STREAM_BYTES) ? g->T.as<double>() : nullptr;
-    if (lookahead) {
-        ExecCtx* cx = g->ctx;
-        if (!cx->stream2) HIPCHK(hipStreamCreateWithFlags(&cx->stream2, hipStreamNonBlocking));
-        hipStream_t lo = cx->stream2;
-        const int ns = (Np + SW - 1) / SW;
-        HIPCHK(g->events(EV_BASE + 2 * (size_t)ns + 2));
-        hipEvent_t* ec = &g->evs()[EV_BASE];               // ec[s]: chain of strip s done;  eb[s]: update (b) behind strip s done
-        hipEvent_t* eb = ec + ns;
-        int last_b = -1;
-        for (int si = 0, s0 = 0; s0 < Np; ++si, s0 += SW) {
-            const int sw = (Np - s0) < SW ? (Np - s0) : SW;
-            for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
-                const int rem = Np - r0 - TB;
-                HIPCHK(launch_potf2_lite(K, W, WT, ld, r0, info, s));
-                if (rem <= 0) break;
-                HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s, 1));
-                const int ncol = s0 + sw - r0 - TB;
-                if (ncol > 0) {
-                    GemmArgs u{};
-                    u.A = K + (int64_t)(r0 + TB) * ld + r0; u.lda = ld;
-                    u.B = u.A; u.ldb = ld;
-                    u.C = K + (int64_t)(r0 + TB) * ld + (r0 + TB); u.ldc = ld;
-                    u.M = rem; u.N = ncol; u.K = TB; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
-                    u.alpha = -1.0; u.beta = 1.0; u.info = info;
-                    HIPCHK(launch_gemm_nt(u, s));
-                }
-            }
-            const int rows = Np - s0 - sw;                 // rows below the strip
-            if (rows <= 0) break;
-            const int swn = rows < SW ? rows : SW;         // the next strip's width
-            const int rest = rows - swn;                   // rows / columns beyond the next strip
-            if (rest > 0) {
-                HIPCHK(hipEventRecord(ec[si], s));
-                HIPCHK(hipStreamWaitEvent(lo, ec[si], 0));
-                GemmArgs u{};                              // (b): A[r,c] −= L[r,strip]·L[c,strip]ᵀ for r, c beyond the next strip
-                u.A = K + (int64_t)(s0 + sw + swn) * ld + s0; u.lda = ld;
-                u.B = u.A; u.ldb = ld;
-                u.C = K + (int64_t)(s0 + sw + swn) * ld + (s0 + sw + swn); u.ldc = ld;
-                u.M = rest; u.N = rest; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
-                u.alpha = -1.0; u.beta = 1.0; u.info = info;
-                HIPCHK(launch_gemm_nt(u, lo));
-                HIPCHK(hipEventRecord(eb[si], lo));
-            }
-            // (a): the next strip's columns, all rows below this strip — behind (b) of the strip before, which updates the same tiles
-            if (last_b >= 0) HIPCHK(hipStreamWaitEvent(s, eb[last_b], 0));
-            if (rest > 0) last_b = si;
-            GemmArgs u{};
-            u.A = K + (int64_t)(s0 + sw) * ld + s0; u.lda = ld;
-            u.B = u.A; u.ldb = ld;
-            u.C = K + (int64_t)(s0 + sw) * ld + (s0 + sw); u.ldc = ld;
-            u.M = rows; u.N = swn; u.K = sw; u.kmode = K_FULL; u.lower_only = 1; u.batch = 1;
-            u.alpha = -1.0; u.beta = 1.0; u.info = info;
-            HIPCHK(launch_gemm_nt(u, s));
-        }
-        if (last_b >= 0) HIPCHK(hipStreamWaitEvent(s, eb[last_b], 0));
-    }
-    for (int S0 = lookahead ? Np : 0, SS = SW; S0 < Np; S0 += SS) {
+    constexpr int SW = 512;
+    // Third level: strips grouped into super-strips of 1024 columns — behind a strip only the rest of its super-strip is updated
+    // (K = SW), the matrix behind the super-strip once per super-strip with K = SS: half the passes over the trailing matrix and
+    // tiles twice as long (Cholesky at N = 16384 35.0 → 32.8 ms, at N = 8192 8.20 → 8.23: profiles/r03_chol_super_sweep.txt).  A
+    // super-strip pays while the square update behind it is large — its in-super-strip update is a launch of 4 × T tiles that lasts
+    // ≈ 150 µs whatever T is, against K = 1024 tiles at 70 TFLOP/s instead of 52 (profiles/r04_fit_trace_summary.txt) — so
+    // super-strips are used while at least 6144 rows remain, plain strips from there on.
+    constexpr int SSmax = 1024, super_rows = 6144;
+    // Panel chain: potf2 of the diagonal block (potf2_pipe_kernel) → triangular solve of the rows below it from the operand stream that
+    // kernel leaves (trsm_stream_kernel; the stream lives in T, which the factorisation does not use — the blocked inverse behind it
+    // does) → in-strip update.  The 128×128 inverses of the diagonal blocks (the seeds of the blocked L⁻¹ below) are not on that chain:
+    // all of them are formed by ONE batched launch behind the factorisation.  Measured and not adopted (profiles/r05_notes.md D, removed
+    // from the library in round 6): a two-stream look-ahead, one launch per panel with in-launch hand-overs, 256 × 128 trailing tiles.
+    const bool split = Np > TB;                            // a single block has no chain: factor + inverse in one launch
+    if (split) HIPCHK(g->T.ensure(TRSM_STREAM_BYTES));
+    double* trsm_ops = g->T.as<double>();
+    for (int S0 = 0, SS = SW; S0 < Np; S0 += SS) {
         SS = (Np - S0) >= super_rows ? SSmax : SW;
         const int ss = (Np - S0) < SS ? (Np - S0) : SS;
         for (int s0 = S0; s0 < S0 + ss; s0 += SW) {
             const int sw = (S0 + ss - s0) < SW ? (S0 + ss - s0) : SW;
             for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
                 const int rem = Np - r0 - TB;
-                const bool fused = trsm_ops != nullptr && rem <= fused_rows;
-                if (fused && rem > 0) {
-                    const int ncol = s0 + sw - r0 - TB;
-                    HIPCHK(launch_panel_fused(K, W, WT, ld, r0, rem, ncol > 0 ? ncol : 0, info, panel_flags + 2 * (r0 / TB), trsm_ops, s));
-                    continue;
-                }
-                if (split) {
-                    HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s, trsm_ops));
-                    if (rem <= 0) break;
-                    if (trsm_ops) HIPCHK(launch_trsm_stream(K, trsm_ops, ld, r0, rem, info, s));
-                    else HIPCHK(launch_trsm_panel(K, W, ld, r0, rem, info, s));
-                } else {
-                    HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s));
-                    if (rem <= 0) break;
-                }
-                GemmArgs a{};
-                // panel solve  L[r,p] = A[r,p] · Linv_ppᵀ   (in place; each workgroup owns its rows)
-                a.A = K + (int64_t)(r0 + TB) * ld + r0; a.lda = ld;
-                a.B = W + (int64_t)r0 * ld + r0; a.ldb = ld;
-                a.C = K + (int64_t)(r0 + TB) * ld + r0; a.ldc = ld;
-                a.M = rem; a.N = TB; a.K = TB; a.kmode = K_FULL; a.lower_only = 0; a.batch = 1;
-                a.alpha = 1.0; a.beta = 0.0; a.info = info;
-                if (!split) HIPCHK(launch_gemm_nt(a, s));
+                if (!split) { HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s)); break; }
+                HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s, trsm_ops));
+                if (rem <= 0) break;
+                HIPCHK(launch_trsm_stream(K, trsm_ops, ld, r0, rem, info, s));
                 // in-strip update  A[r,c] −= L[r,p]·L[c,p]ᵀ  for the strip's remaining columns c, lower tiles only
                 const int ncol = s0 + sw - r0 - TB;
                 if (ncol > 0) {
@@ -919,7 +815,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         KgenArgs probe{};
         probe.pt = g->p_out; probe.dp = g->dp;
         // the fp64 chunk of K_XZ is not materialised when the generator writes the residue planes itself
-        if (!kstore && !(oz && kgen_writes_residues(probe, nm) && !getenv("ABO_OZ_UNFUSED"))) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
+        if (!kstore && !(oz && kgen_writes_residues(probe, nm))) HIPCHK(g->Kxz.ensure(sizeof(double) * Mc * Np));
     }
     HIPCHK(g->partial.ensure(sizeof(double) * T * Mc));
     HIPCHK(g->mu_c.ensure(sizeof(double) * Mc));
@@ -947,7 +843,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
         ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = g->prm.mean_c;
         // int8 engine: the generator writes the residue planes of the chunk itself (the fp64 K_XZ is then only materialised for a
         // caller that keeps it — the resident K_ZX of a candidate set)
-        const bool fused = oz && kgen_writes_residues(ka, g->oz_plan.n) && !getenv("ABO_OZ_UNFUSED");
+        const bool fused = oz && kgen_writes_residues(ka, g->oz_plan.n);
         if (fused) {
             const int64_t q = pad_up(Np, 256);
             ka.res = g->oz_KR.as<int8_t>(); ka.res_ld = q; ka.res_plane = pad_up(mcp, 256) * q;
@@ -980,7 +876,6 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             VarGemmArgs va{};
             va.W = g->st->W.as<double>(); va.Kxz = kchunk; va.partial = g->partial.as<double>();
             va.ldw = g->st->cap; va.ldk = ldk; va.ldp = Mc; va.Np = (int)Np; va.Mc = mcp; va.nvalid = (int)g->N;
-            va.force128 = getenv("ABO_TILE128") ? 1 : 0;
             PHASE_EVENT(e[2], s);
             HIPCHK(launch_var_gemm(va, s));
             PHASE_EVENT(e[3], s);
@@ -1032,7 +927,7 @@ int32_t grad_eval_device(abo_gp* g, const double* Zd, int64_t M, double beta, do
     if (oz) {
         KgenArgs probe{};
         probe.pt = P; probe.dp = g->dp;
-        fused = kgen_writes_residues(probe, g->oz_plan.n) && !getenv("ABO_OZ_UNFUSED");
+        fused = kgen_writes_residues(probe, g->oz_plan.n);
     }
     if (!fused) HIPCHK(g->Kxz.ensure(sizeof(double) * rows_pad * Np));
     HIPCHK(g->partial.ensure(sizeof(double) * rows_pad * Np));       // V
@@ -1170,7 +1065,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
     HIPCHK(g->info.ensure(sizeof(int64_t)));
     HIPCHK(g->scal.ensure(sizeof(double) * 8));
     // N ≤ 128, d ≤ 16, no spare capacity: the whole fit is one launch (chol.hip, mode 3 of the diagonal-block kernel)
-    const bool fused_small = P == 1 && cap == TB && st->dp <= 16 && !getenv("ABO_NO_FUSED_FIT");
+    const bool fused_small = P == 1 && cap == TB && st->dp <= 16;
     if (defer) {
         if (!fused_small) {
             HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
@@ -2308,7 +2203,6 @@ int32_t abo::qei_eligible(abo_gp* g, abo_cand* c, int q) {
     if (g->p_out > 1) return fail(ABO_EINVAL, "q-EI, block form: gradient-enhanced models take the plain loop");
     if (c->M > 0 && !(c->kzx_ld > 0 && c->kzx_ld == g->st->cap)) return fail(ABO_EINVAL, "q-EI, block form: K_ZX of the set is not resident");
     if (q < 1 || q > QEI_MAXQ) return fail(ABO_EINVAL, "q-EI, block form: q = %d outside 1..%d", q, QEI_MAXQ);
-    if (getenv("ABO_GEMM_NO_SKINNY")) return fail(ABO_EINVAL, "q-EI, block form: needs the skinny product (ABO_GEMM_NO_SKINNY is set)");
     if ((size_t)QEI_MAXT * c->d * sizeof(double) > 65536) return fail(ABO_EINVAL, "q-EI, block form: d = %d > 128 takes the plain loop", c->d);
     return ABO_OK;
 }
@@ -2890,6 +2784,7 @@ int32_t abo_refine(abo_gp* g, int32_t kind, double p0, double best_y, const doub
     return refine_terms_impl(g, t, lower, upper, d, starts, S, opts, x_out, f_out, iters_out);
 }
 
+#ifdef ABO_TEST_HOOKS
 int32_t abo_test_acq_grad_terms(abo_gp* g, const abo_acq_term* terms, int32_t nterms, const double* Z, int64_t M, int32_t d, double* f,
                                 double* grad) {
     if (!g) return fail(ABO_EINVAL, "abo_test_acq_grad: null handle");
@@ -2919,6 +2814,7 @@ int32_t abo_test_acq_grad(abo_gp* g, int32_t kind, double p0, double best_y, con
     const abo_acq_term one{kind, 0, p0, best_y, 1.0};
     return abo_test_acq_grad_terms(g, &one, 1, Z, M, d, f, grad);
 }
+#endif  // ABO_TEST_HOOKS
 
 }  // extern "C"
 
@@ -3347,6 +3243,7 @@ int32_t abo_score(int32_t device, const double* mu, const double* var, int64_t M
     return ABO_OK;
 }
 
+#ifdef ABO_TEST_HOOKS
 int32_t abo_test_oz_plan(int32_t n, int32_t* p, double* tables, double* scal, int32_t* eP) {
     if (!p || !tables || !scal || !eP) return fail(ABO_EINVAL, "abo_test_oz_plan: null argument");
     OzPlan pl;
@@ -3410,5 +3307,6 @@ int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, doubl
     HIPCHK(hipStreamSynchronize(nullptr));
     return ABO_OK;
 }
+#endif  // ABO_TEST_HOOKS
 
 }  // extern "C"

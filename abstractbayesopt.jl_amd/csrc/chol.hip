@@ -224,13 +224,10 @@ __device__ __forceinline__ int register_potf2_step_lds(double (&x)[16], int lane
 //                MFMA when its k-steps are taken as {g, g+4, g+8, g+12} — no data movement in between
 //   phase 3  write L back to K (lower, zeros above), X to W (lower) and Xᵀ to WT (upper).
 // The kernel comes in three builds of the same phases (MODE):
-//   0  everything (factor + full 128×128 inverse): the reference schedule, kept for A/B runs (ABO_CHOL_SPLIT=0)
-//   1  potf2 only — phase 1, the eight 16×16 diagonal sub-block inverses of phase 2(a), L written back and those
-//      sub-block inverses written to their final places in W / WT.  This is what sits on the panel chain: the 128×128
-//      inverse (a quarter of the kernel's time) is not needed there, because the panel solve is a blocked triangular
-//      solve on L itself (trsm_panel_kernel) that only wants the 16×16 diagonal inverses.
+//   0  everything (factor + full 128×128 inverse) of ONE block: a model of a single 128-row block that mode 3 does not serve
 //   2  trtri, batched — one workgroup per diagonal block (blockIdx.x): reads the finished L block back, runs phase 2 and
-//      writes W / WT.  ONE launch of N/128 workgroups after the factorisation instead of N/128 serial 12 µs phases.
+//      writes W / WT.  ONE launch of N/128 workgroups after the factorisation instead of N/128 serial 12 µs phases (the panel
+//      chain's own diagonal-block kernel is potf2_pipe_kernel below: the 128×128 inverse is not needed on the chain).
 //   3  the WHOLE fit of a model with N ≤ 128 points (the reference's own regime: its examples and tests run 5 … 50
 //      points, src/acquisition_functions/acq_utils.jl:37 scores 10 000 candidates per step) in this one launch: scaled
 //      inputs, K + σ²I generated straight into LDS (same arithmetic as kgen_kernel, same bits), factor, inverse,
@@ -395,22 +392,6 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     }
     __syncthreads();
     PROBE(3);
-    if constexpr (MODE == 1) {
-        // write back: L (lower, zeros above) and the 16×16 diagonal sub-block inverses (final values of those entries of
-        // W and WT; everything else of the W block is written by the batched trtri launch)
-        double* Wd = W + (int64_t)r0 * ld + r0;
-        double* WTd = WT + (int64_t)r0 * ld + r0;
-        for (int idx = t; idx < NB * NB; idx += DT) {
-            const int i = idx >> 7, j = idx & 127;
-            Kb[(int64_t)i * ld + j] = i >= j ? AA(i, j) : 0.0;
-            if ((i >> 4) == (j >> 4)) {
-                const double w = i > j ? AA(j, i) : (i == j ? dinv[i] : 0.0);          // X[i][j] lives at a[j][i]
-                Wd[(int64_t)i * ld + j] = w;
-                WTd[(int64_t)j * ld + i] = w;
-            }
-        }
-        return;
-    }
     for (int dl = 1; dl < nsb; ++dl) {                     // (b) sub-blocks at distance dl below the diagonal
         for (int c = wave; c + dl < nsb; c += DT / 64) {
             const int i = c + dl;
@@ -498,13 +479,6 @@ constexpr InvSeq make_inv_seq() {
     return t;
 }
 
-// Accesses that are coherent across the XCDs of the device WITHOUT a cache-wide operation (agent-scope relaxed atomics: sc1 loads and
-// stores): what one workgroup of panel_fused_kernel hands to another inside a launch goes through these.  The agent-scope release /
-// acquire fences that would make ordinary stores and loads do — buffer_wbl2, a write-back of the WHOLE L2 of the XCD, and buffer_inv, an
-// invalidation of all of it — were measured first: + 16 µs per panel, every solving and updating wave paying for one.
-__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // Operand stream of trsm_stream_kernel, written by potf2_pipe_kernel: stage k (sub-block column k of the diagonal block) holds, per
 // lane (m = lane & 15, g = lane >> 4), the A operands of the solve's MFMAs in the order they are issued — X_kk[m][4·s4 + g] for
 // s4 = 0 … 3, then −L_jk[m][4·s4 + g] for s4 = 0 … 3, j = k+1 … 7 — 4 + 4·(7 − k) doubles, 144 in all; entry i of lane l lies at
@@ -514,7 +488,7 @@ __host__ __device__ constexpr int trsm_stage_base(int k) { return 32 * k - 2 * k
 #define TRSM_OP(i, l) ((((i) >> 1) << 7) + 2 * (l) + ((i) & 1))
 
 // ---- potf2 with its side work taken off the panel chain (round 5) ----------------------------------------------------------------------
-// chol_diag_kernel<1> runs its steps one after the other: load the block (4.0 µs), eight times [register step 2.6 µs, trailing update of
+// Round 4's diagonal-block kernel ran its steps one after the other: load the block (4.0 µs), eight times [register step 2.6 µs, trailing update of
 // ALL remaining sub-blocks 1.5 … 0.2 µs], the eight 16×16 inverses (2.0 µs), write-back (2.6 µs) — tools/chol_diag_probe.  Only the register
 // steps and the update of the NEXT sub-block column are a dependent chain; here everything else runs beside a register step, on waves
 // of the SIMDs the spine waves do not use (a wave that shares a SIMD with a spine wave takes issue slots from it: the register step
@@ -525,10 +499,8 @@ __host__ __device__ constexpr int trsm_stage_base(int k) { return 32 * k - 2 * k
 //   beside step p ≥ 1   D(p−1): panel p−1's update of the sub-block columns beyond p;  column block p−1 of L (final) is written back
 //   beside steps 4 … 7  (one spine wave left) the inverses of diagonal sub-blocks 0 … 6 are formed and written to W / WT, two a step;
 //                       the last one follows the last step
-// Every element still receives the same operations in the same order (F / D are the MFMA chain of chol_diag_kernel's step (3), panel by
-// panel, barrier-ordered): same bits as chol_diag_kernel<1>.
-// LDS of the diagonal-block kernel (declared by the kernels that call potf2_pipe_body: panel_fused_kernel's other workgroups stage
-// the solve's operands in `a`)
+// (F / D are the MFMA chain of chol_diag_kernel's step (3), panel by panel, barrier-ordered.)
+// LDS of the diagonal-block kernel
 #define POTF2_PIPE_LDS() \
     __shared__ __attribute__((aligned(16))) double a[NB * LDA]; \
     __shared__ double dinv[NB]; \
@@ -665,7 +637,7 @@ __device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double 
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int c = 4 * s4 + g;
                 const double w = r16 > c ? AA(o + c, o + r16) : (r16 == c ? dinv[o + r16] : 0.0);
-                st_agent(&P[TRSM_OP(trsm_stage_base(q) + s4, lane)], w);
+                P[TRSM_OP(trsm_stage_base(q) + s4, lane)] = w;
             }
         }
     };
@@ -721,7 +693,7 @@ __device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double 
                 const int nj = NSB - 1 - q;
                 for (int e = hid; e < 4 * nj; e += Hd) {
                     const int s4 = e / nj, jj = e - s4 * nj;
-                    st_agent(&P[TRSM_OP(trsm_stage_base(q) + 4 + e, lane)], -AA(SB * (q + 1 + jj) + r16, SB * q + 4 * s4 + g));
+                    P[TRSM_OP(trsm_stage_base(q) + 4 + e, lane)] = -AA(SB * (q + 1 + jj) + r16, SB * q + 4 * s4 + g);
                 }
             }
         }
@@ -750,283 +722,17 @@ __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, do
     potf2_pipe_body(a, dinv, colbuf, fail, K, W, WT, ld, r0, info, P);
 }
 
-// ---- one launch per panel: diagonal block, panel solve, in-strip update (round 5) ----------------------------------------------------
-// The three steps of a panel were three launches; a launch boundary between dependent kernels costs ≈ 1.3 µs of idle queue plus the
-// ramp of the next kernel (its first loads, its status word), and the steps of a panel at N ≤ 4096 are 7 – 30 µs long.  Here they are
-// the workgroups of ONE launch, in the order of their dependencies, handing over through flags in device memory:
-//   workgroup 0            potf2_pipe_body, then flag[0] = 1 (the packed operands of the solve were stored with agent-scope stores and
-//                          acknowledged: visible to every XCD)
-//   workgroups 1 … T       the panel solve of trsm_stream_kernel, 64 rows each (waves 0 – 3: one per SIMD — sixteen solving waves on one
-//                          CU would share four matrix pipes); right-hand sides loaded BEFORE the wait for flag[0]; the operand stream
-//                          goes through LDS, brought in by all sixteen waves in one round trip (a 1024-thread workgroup has 128
-//                          registers a lane: the 144 operands do not fit beside the 64 of the right-hand sides, and a ring of a few
-//                          in flight exposes a memory latency per piece); each wave ends with flag[1] += 1 behind its acknowledged
-//                          agent-scope stores
-//   workgroups T+1 …       the in-strip update A[r, c] −= L[r, p]·L[c, p]ᵀ, one 64 × 64 block each (16 waves × one MFMA tile, the
-//                          arithmetic of gemm_nt_small_kernel: same k order, same lane ↔ k map, C − acc rounded once), after
-//                          flag[1] has reached the number of solving waves
-// Producers come FIRST in the grid: a workgroup only ever waits for workgroups with smaller indices, and those are dispatched before
-// it — no wait can starve the one it waits for, whatever the grid size.  Every wait is bounded all the same (wall clock, 2 s): a wave
-// that gives up stores −(1000 + row) in `info` and every later launch of the fit exits on it.  Same values through the same operations as
-// the three kernels: same bits.
-constexpr long long PANEL_WAIT_TICKS = 200000000ll;                        // 2 s of the 100 MHz constant clock
-
-__device__ __forceinline__ bool panel_wait(const int* flag, int target, int64_t* info, int r0) {
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        // a failed pivot (or a wave that gave up) ends the panel: the waves that would have counted up never do
-        if (__hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (wall_clock64() - t0 > PANEL_WAIT_TICKS) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(info, (int64_t)(-1000 - r0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    asm volatile("" ::: "memory");                                         // (the loads behind the wait are agent-scope ones: no cache to invalidate)
-    return true;
-}
-
-__global__ void __launch_bounds__(DT) panel_fused_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int nrows, int ncol,
-                                                         int64_t* info, int* flag, double* P) {
-    typedef double d2_t __attribute__((ext_vector_type(2)));
-    POTF2_PIPE_LDS();
-    __shared__ int go;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int T = (nrows + 63) / 64;                                       // solving workgroups
-    const int b = blockIdx.x;
-    if (b == 0) {
-        potf2_pipe_body(a, dinv, colbuf, fail, K, W, WT, ld, r0, info, P);
-        __builtin_amdgcn_s_waitcnt(0);                                     // this wave's stores of the operand stream have been acknowledged
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (b <= T) {
-        // right-hand sides first (final since the last launch), then ONE wave waits for the diagonal block, then all sixteen waves bring
-        // the operand stream into LDS (72 KB in one round trip: nine agent-scope loads a thread, all in flight), then waves 0 – 3 solve
-        const int n = lane & 15, g = lane >> 4;
-        const int rb = (b - 1) * 4 + wave;
-        const bool solver = wave < 4 && rb * 16 < nrows;                   // (nrows is a multiple of 16)
-        double* Arow = K + (int64_t)(r0 + NB + rb * 16 + n) * ld + r0;
-        d4_t Y[8];
-        if (solver) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Y[j][r] = Arow[16 * j + 4 * r + g];
-        }
-        if (wave == 0) {
-            const bool ok = panel_wait(flag, 1, info, r0) && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-            if (lane == 0) go = ok ? 1 : 0;
-        }
-        __syncthreads();
-        if (!go) return;                                                   // failed pivot (nothing to solve with) or a wait given up
-        double stg[TRSM_OPS * 64 / DT];
-#pragma unroll
-        for (int e = 0; e < TRSM_OPS * 64 / DT; ++e) stg[e] = ld_agent(P + t + DT * e);
-#pragma unroll
-        for (int e = 0; e < TRSM_OPS * 64 / DT; ++e) a[t + DT * e] = stg[e];
-        __syncthreads();
-        if (!solver) return;
-        const double* op = a + 2 * lane;                                   // operand i of this lane: op[(i / 2)·128 + (i & 1)]
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int bs = trsm_stage_base(k);
-            d4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-                y = __builtin_amdgcn_mfma_f64_16x16x4f64(op[((bs + s4) >> 1) * 128 + ((bs + s4) & 1)], Y[k][s4], y, 0, 0, 0);
-            Y[k] = y;
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int j = k + 1; j < 8; ++j) {
-                    const int i = bs + 4 + s4 * (7 - k) + (j - k - 1);
-                    Y[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[(i >> 1) * 128 + (i & 1)], Y[k][s4], Y[j], 0, 0, 0);
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st_agent(&Arow[16 * j + 4 * r + g], Y[j][r]);
-        __builtin_amdgcn_s_waitcnt(0);                                     // the stores have been acknowledged
-        if (lane == 0) __hip_atomic_fetch_add(flag + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    // in-strip update: 64 × 64 block (si, sj) of the rows below the panel × the strip's remaining columns; 128-tile (si/2, sj/2) must
-    // be a lower one (the launches this replaces worked on whole 128 × 128 tiles with tj ≤ ti)
-    const int u = b - 1 - T;
-    const int ncb = ncol / 64;
-    const int si = u / ncb, sj = u - si * ncb;
-    if ((sj >> 1) > (si >> 1)) return;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int r16 = lane & 15, g = lane >> 4;
-    const double* A = K + (int64_t)(r0 + NB) * ld + r0;                   // L[r, p]: rows below the panel, the panel's 128 columns
-    const double* Ap = A + (int64_t)(si * 64 + wm * 16 + r16) * ld + 2 * g;
-    const double* Bp = A + (int64_t)(sj * 64 + wn * 16 + r16) * ld + 2 * g;
-    double* Cg = K + (int64_t)(r0 + NB) * ld + (r0 + NB);
-    double cin[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)                                            // C is final since the last launch: its loads go first
-        cin[r] = Cg[(int64_t)(si * 64 + wm * 16 + g + 4 * r) * ld + sj * 64 + wn * 16 + r16];
-    if (wave == 0) {                                                       // one polling wave per workgroup
-        const bool ok = panel_wait(flag + 1, nrows / 16, info, r0) && __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-        if (lane == 0) go = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!go) return;
-    d2_t av[16], bv[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {                                         // the rows the solving waves have just stored: agent-scope loads
-        av[q][0] = ld_agent(Ap + 8 * q);
-        av[q][1] = ld_agent(Ap + 8 * q + 1);
-        bv[q][0] = ld_agent(Bp + 8 * q);
-        bv[q][1] = ld_agent(Bp + 8 * q + 1);
-    }
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][0], bv[q][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][1], bv[q][1], acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        Cg[(int64_t)(si * 64 + wm * 16 + g + 4 * r) * ld + sj * 64 + wn * 16 + r16] = fma(1.0, cin[r], -1.0 * acc[r]);
-}
-
-// flag: two ints, zero before the launch
-hipError_t launch_panel_fused(double* K, double* W, double* WT, int64_t ld, int r0, int nrows, int ncol, int64_t* info, int* flag, double* P,
-                              hipStream_t s) {
-    if (nrows <= 0 || nrows % 64 != 0 || ncol % 64 != 0 || ncol < 0) return hipErrorInvalidValue;
-    const int T = nrows / 64, U = (nrows / 64) * (ncol / 64);
-    hipLaunchKernelGGL(panel_fused_kernel, dim3(1 + T + U), dim3(DT), 0, s, K, W, WT, ld, r0, nrows, ncol, info, flag, P);
-    return hipGetLastError();
-}
 #undef AA
 
-// ---- the potf2 step in a footprint that fits BESIDE a trailing update ---------------------------------------------------------------
-// chol_diag_kernel<1> keeps the whole 128×128 block in LDS (129 KB, 1024 threads): it needs an empty CU, and a CU is never empty
-// while a trailing update (two 80 KB workgroups per CU) is running — tools/prio_probe.hip: a chain of 132 KB kernels waits for
-// the bulk kernel to END, a chain of 66 KB kernels slots in with ≈ 9 µs per kernel, whatever the streams' priorities.  This build
-// of the same phases holds only the 36 LOWER 16×16 sub-blocks (rows of 17 doubles: 78.3 KB) and runs on 8 waves, so that it takes
-// the place of ONE departed workgroup of the update and the panel chain of strip s + 1 can run while the update behind strip s is
-// still going (api.hip: factorise, look-ahead).  Same operations in the same order on every element as chol_diag_kernel<1>: same bits.
-constexpr int SBL = SB + 1;                       // sub-block row stride (odd: the one-row-per-lane walks spread over the banks)
-constexpr int SBSZ = SB * SBL;
-constexpr int LT = 512;
-#define LA(r, c) a[(((r) >> 4) * (((r) >> 4) + 1) / 2 + ((c) >> 4)) * SBSZ + ((r) & 15) * SBL + ((c) & 15)]      // sub-block (r/16 ≥ c/16)
-__global__ void __launch_bounds__(LT, 4) potf2_lite_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info) {
-    __shared__ double a[36 * SBSZ];
-    __shared__ double dinv[NB];
-    __shared__ int fail;
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
-    if (*info != 0) return;
-    if (t == 0) fail = 0;
-    double* Kb = K + (int64_t)r0 * ld + r0;
-    for (int idx = t; idx < NB * NB; idx += LT) {
-        const int i = idx >> 7, j = idx & 127;
-        if ((i >> 4) >= (j >> 4)) LA(i, j) = Kb[(int64_t)i * ld + j];
-    }
-    __syncthreads();
-    for (int p = 0; p < NSB; ++p) {
-        const int o = SB * p;
-        const int below = NB - o - SB;
-        if (wave * 48 < below || wave == 0) {
-            const int row = lane < SB ? o + lane : o + SB + wave * 48 + (lane - SB);
-            const bool valid = row < NB;
-            double x[SB];
-#pragma unroll
-            for (int c = 0; c < SB; ++c) x[c] = valid ? LA(row, o + c) : 0.0;
-            double myrp;
-            const int failcol = register_potf2_step(x, lane, myrp);
-            if (failcol < SB) {
-                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
-            } else if (valid) {
-                if (lane >= SB) {
-#pragma unroll
-                    for (int c = 0; c < SB; ++c) LA(row, o + c) = x[c];
-                } else if (wave == 0) {
-                    dinv[o + lane] = myrp;
-#pragma unroll
-                    for (int c = 0; c < SB; ++c)
-                        if (c <= lane) LA(row, o + c) = x[c];
-                }
-            }
-        }
-        __syncthreads();
-        if (fail) return;
-        {
-            const int nb = NSB - 1 - p;
-            const int total = nb * (nb + 1) / 2;
-            for (int e = wave; e < total; e += LT / 64) {
-                int bi = 0, rem = e;
-                while (rem > bi) { rem -= bi + 1; ++bi; }
-                const int bj = rem;
-                const int ri = SB * (p + 1 + bi), rj = SB * (p + 1 + bj);
-                d4_t c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c[r] = LA(ri + g + 4 * r, rj + r16);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(-LA(ri + r16, o + g + 4 * s4), LA(rj + r16, o + g + 4 * s4), c, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) LA(ri + g + 4 * r, rj + r16) = c[r];
-            }
-        }
-        __syncthreads();
-    }
-    // the eight 16×16 diagonal sub-block inverses: column n of X_cc into ROW n of the sub-block's strict upper triangle
-    if (t < NB) {
-        const int o = SB * (t >> 4), n = t & 15;
-        double x[SB];
-#pragma unroll
-        for (int m = 0; m < SB; ++m) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = 0; k < m; ++k) sacc = fma(LA(o + m, o + k), x[k], sacc);
-            x[m] = (m < n) ? 0.0 : (m == n ? dinv[o + m] : -sacc * dinv[o + m]);
-        }
-#pragma unroll
-        for (int m = 0; m < SB; ++m)
-            if (m > n) LA(o + n, o + m) = x[m];
-    }
-    __syncthreads();
-    double* Wd = W + (int64_t)r0 * ld + r0;
-    double* WTd = WT + (int64_t)r0 * ld + r0;
-    for (int idx = t; idx < NB * NB; idx += LT) {
-        const int i = idx >> 7, j = idx & 127;
-        Kb[(int64_t)i * ld + j] = i >= j ? LA(i, j) : 0.0;
-        if ((i >> 4) == (j >> 4)) {
-            const double w = i > j ? LA(j, i) : (i == j ? dinv[i] : 0.0);
-            Wd[(int64_t)i * ld + j] = w;
-            WTd[(int64_t)j * ld + i] = w;
-        }
-    }
-}
-#undef LA
-
-hipError_t launch_potf2_lite(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
-    hipLaunchKernelGGL(potf2_lite_kernel, dim3(1), dim3(LT), 0, s, K, W, WT, ld, r0, info);
-    return hipGetLastError();
-}
-
+// a model of ONE 128-row block that the whole-fit kernel does not serve (d > 16, or spare capacity): factor + inverse in one launch
 hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s) {
     hipLaunchKernelGGL(chol_diag_kernel<0>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
     return hipGetLastError();
 }
 
-bool potf2_pipe_enabled() {
-    const char* pe = getenv("ABO_POTF2_PIPE");                       // 0: chol_diag_kernel<1> (A/B runs, the bit-equality test)
-    return !(pe && atoi(pe) == 0);
-}
-
-// P: where the packed operands of the panel solve go (TRSM_OPS × 64 doubles; potf2_pipe_kernel only), or null
+// the diagonal block of a panel; P: where the packed operands of the panel solve go (TRSM_OPS × 64 doubles)
 hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P) {
-    const bool pipe = potf2_pipe_enabled();
-    if (pipe) hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, P);
-    else hipLaunchKernelGGL(chol_diag_kernel<1>, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, FitSmallArgs{});
+    hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, P);
     return hipGetLastError();
 }
 
@@ -1046,104 +752,13 @@ hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, con
 // (rows r0+128 … r0+128+nrows, columns r0 … r0+127; in place).  One wave per 16 rows, in transposed space so that every
 // product chains through the matrix pipe without data movement:  with Y_j = X_jᵀ (16 columns of block j × 16 rows),
 //     Y_j = L_jj⁻¹ · (A_jᵀ − Σ_{k<j} L_jk · Y_k)
-// L_jk / L_jj⁻¹ are A operands (staged once per workgroup in LDS, stored [block][kk][m] so that a k-step is one
-// conflict-free 8-byte read per lane), the Y_k are previous MFMA results, whose C/D register r is exactly the B operand
-// of k-step r.  176 MFMAs per wave (64 of them on the dependent path); no 128×128 inverse is needed — only the eight 16×16 diagonal inverses the
-// potf2 kernel leaves in W.  (The GEMM form X = A·W_ppᵀ needed the full inverse first: 12 µs more on the panel chain.)
-// Round 5, WREG: the eight diagonal inverses live in REGISTERS (32 doubles a lane, read straight from W: L2 hits), not in LDS — 78 KB
-// instead of 96: the workgroup fits the slot of ONE departed trailing-update workgroup (see potf2_lite_kernel), same operands, same bits.
-// (WREG = true, the look-ahead chain only; the plain chain keeps them in LDS: 3 % faster when nothing else is on the CU)
-constexpr int TRSM_BLK = 36 + 8;          // 36 lower sub-blocks of L_pp (j ≥ k) + 8 diagonal inverses
-template <bool WREG>
-__global__ void __launch_bounds__(256) trsm_panel_kernel(double* K, const double* W, int64_t ld, int r0, int nrows,
-                                                         const int64_t* info) {
-    __shared__ double lt[WREG ? 36 : TRSM_BLK][16][16 + 1];            // [block][kk][m] (+1: the transposing fill stays conflict-poor)
-    if (*info != 0) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int n = lane & 15, g = lane >> 4;
-    const double* Lb = K + (int64_t)r0 * ld + r0;
-    const double* Wb = W + (int64_t)r0 * ld + r0;
-    // fill: 64 + 8 independent loads per thread (fully unrolled: they are all in flight together), coalesced along rows
-    // (the loads are unconditional — every address lies inside the block — so that all of them are issued before the first
-    // one is waited for; a load under the `lower sub-block` condition would be waited for one at a time)
-    double v[64];
-#pragma unroll
-    for (int e = 0; e < 64; ++e) {
-        const int idx = t + 256 * e;
-        v[e] = Lb[(int64_t)(idx >> 7) * ld + (idx & 127)];
-    }
-    // WREG: this lane's A-operand values of the diagonal inverses, W_kk[m = n][kk = 4·s4 + g] for k = 0 … 7, s4 = 0 … 3; else the
-    // inverses go to LDS with the sub-blocks
-    double wd[8][4], w[8];
-    if constexpr (WREG) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) wd[k][s4] = Wb[(int64_t)(16 * k + n) * ld + 16 * k + 4 * s4 + g];
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = t + 256 * e;                       // 8 blocks × 16 rows × 16 columns
-            w[e] = Wb[(int64_t)(16 * (idx >> 8) + ((idx >> 4) & 15)) * ld + 16 * (idx >> 8) + (idx & 15)];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 64; ++e) {
-        const int idx = t + 256 * e;
-        const int i = idx >> 7, c = idx & 127;
-        const int bj = i >> 4, bk = c >> 4;
-        if (bk <= bj) lt[bj * (bj + 1) / 2 + bk][c & 15][i & 15] = v[e];
-    }
-    if constexpr (!WREG) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int idx = t + 256 * e;
-            lt[36 + (idx >> 8)][idx & 15][(idx >> 4) & 15] = w[e];
-        }
-    }
-    __syncthreads();
-    const int rb = blockIdx.x * 4 + wave;
-    if (rb * 16 >= nrows) return;
-    double* Arow = K + (int64_t)(r0 + NB + rb * 16 + n) * ld + r0;    // this lane's row, the panel's 128 columns
-    d4_t Y[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)                            // right-hand sides first: 32 independent loads per lane
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Y[j][r] = Arow[16 * j + 4 * r + g];
-    // right-looking order: as soon as Y_k is final every later block takes its update, k-step by k-step over DIFFERENT
-    // accumulators — independent MFMAs that issue back to back; the dependent path is 8 × (4 + 4) MFMAs instead of 176
-    // (each block still receives its updates in the order k = 0, 1, … : same bits as the left-looking loop)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        d4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-            y = __builtin_amdgcn_mfma_f64_16x16x4f64(WREG ? wd[k][s4] : lt[WREG ? 0 : 36 + k][4 * s4 + g][n], Y[k][s4], y, 0, 0, 0);
-        Y[k] = y;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int j = k + 1; j < 8; ++j)
-                Y[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[j * (j + 1) / 2 + k][4 * s4 + g][n], Y[k][s4], Y[j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Arow[16 * j + 4 * r + g] = Y[j][r];
-}
-
-hipError_t launch_trsm_panel(double* K, const double* W, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s, int lite) {
-    if (nrows <= 0) return hipSuccess;
-    if (lite) hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
-    else hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((nrows + 63) / 64), dim3(256), 0, s, K, W, ld, r0, nrows, info);
-    return hipGetLastError();
-}
-
-// The same solve with its A operands streamed from the packed copy potf2_pipe_kernel leaves (round 5): no staging of the 128×128 block
-// in LDS (64 loads a thread, a transposing fill and a barrier in front of the first MFMA: a third of trsm_panel_kernel's 16.5 µs),
-// no LDS at all — a wave is on its own: 32 loads of its right-hand sides, 72 16-byte loads of operands (one 1 KB run per wave and
-// load, L2 hits), all issued before the first MFMA, then the 144 MFMAs of trsm_panel_kernel in the same order on the same values
-// (the negation of L_jk is in the stream): same bits.  One wave per workgroup, so that a launch over few rows still spreads over
+// L_jk / L_jj⁻¹ are A operands, the Y_k are previous MFMA results, whose C/D register r is exactly the B operand of k-step r.
+// 176 MFMAs per wave (64 of them on the dependent path); no 128×128 inverse is needed — only the eight 16×16 diagonal inverses.
+// Right-looking order: as soon as Y_k is final every later block takes its update, k-step by k-step over DIFFERENT accumulators —
+// independent MFMAs that issue back to back; the dependent path is 8 × (4 + 4) MFMAs.
+// The A operands are streamed from the packed copy potf2_pipe_kernel leaves: no staging of the 128×128 block in LDS (64 loads a thread,
+// a transposing fill and a barrier in front of the first MFMA were a third of round 4's 16.5 µs), no LDS at all — a wave is on its own: 32 loads of its right-hand sides, 72 16-byte loads of operands (one 1 KB run per wave and
+// load, L2 hits), all issued before the first MFMA, then the 144 MFMAs (the negation of L_jk is in the stream).  One wave per workgroup, so that a launch over few rows still spreads over
 // as many SIMDs as it has waves (N = 1024: 56 instead of 14 workgroups).
 __global__ void __launch_bounds__(64) trsm_stream_kernel(double* K, const double* __restrict__ P, int64_t ld, int r0, int nrows,
                                                          const int64_t* info) {

@@ -417,109 +417,9 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs p) {
 // C[r][j] = alpha·Σ_{k<K} A[r][k]·B[j][k] for FEW rows of A (16·RG ≤ 64) against a LONG B that is read exactly once — the block form of
 // greedy q-EI (qei.hip): A = K⁻¹K_XT (T rows, a few MB: L2 / MALL resident), B = the resident K_ZX (M rows of N doubles, 17 GB at
 // config 5).  HBM-bound on B: 8·K·N bytes against 2·K·N·16RG flop.  The arithmetic of gemm_skinny_kernel — the same lane ↔ k map, the
-// same k order per accumulator, hence the same bits — with what that kernel leaves on the table for a stream of this length:
-//   * A goes through LDS once per workgroup (the skinny kernel's four waves each re-read their A fragments from L2: as many bytes
-//     as the wave's own share of B at RG = 2); row stride 68 doubles: the ds_read_b128 of the MFMA fragment map is conflict-free
-//     (16-byte slot (2·row + k-group) mod 16 is distinct over each of the instruction's four 16-lane groups);
-//   * B fragments of the NEXT 64-k chunk are in flight (32 VGPRs a lane, 16 KB a wave) under the 64 MFMAs of the current one.
-// One workgroup = 128 rows of B (wave w: rows 32w … 32w+31, two 16-row MFMA groups), 2 workgroups per CU.
-constexpr int QP_LDA = 68;                 // LDS row stride of the A chunk, doubles
-template <int RG>
-__global__ void __launch_bounds__(256, 2) qei_pass_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
-                                                           double* __restrict__ Cbase, int64_t ldc, int K, double alpha, int kmode, int ksplit,
-                                                           int64_t sC) {
-    __shared__ __attribute__((aligned(16))) double sa[2][16 * RG * QP_LDA];
-    // the split-k form of gemm_skinny_kernel: chunk blockIdx.z of the (triangular) k range of B's row block tj → the partial product
-    // Cbase + z·sC; one chunk covering all of K (ksplit ≥ K, K_FULL) is the pass over K_ZX
-    const int tj = kmode == K_B_LOWER ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x, bz = blockIdx.z;
-    int kbeg = 0, kend = K;
-    if (kmode == K_B_LOWER) kend = min(K, (tj + 1) * BN);
-    if (kmode == K_B_UPPER) kbeg = min(K, tj * BN);
-    kbeg = max(kbeg, bz * ksplit);
-    kend = min(kend, (bz + 1) * ksplit);
-    if (kbeg >= kend) return;                              // uniform over the workgroup
-    double* C = Cbase + (int64_t)bz * sC;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)tj * 128 + wave * 32;
-    const double* Bp = B + (row0 + r16) * ldb + 2 * g;
-    // A chunk → LDS: 16·RG rows × 64 doubles = RG·512 d2 elements, 256 threads → 2·RG elements each (element e: row e/32, pair e%32)
-    d2_t areg[2 * RG];
-    auto load_a = [&](int k) {
-#pragma unroll
-        for (int i = 0; i < 2 * RG; ++i) {
-            const int e = t + 256 * i;
-            areg[i] = *reinterpret_cast<const d2_t*>(A + (int64_t)(e >> 5) * lda + k + 2 * (e & 31));
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2 * RG; ++i) {
-            const int e = t + 256 * i;
-            *reinterpret_cast<d2_t*>(&sa[buf][(e >> 5) * QP_LDA + 2 * (e & 31)]) = areg[i];
-        }
-    };
-    d2_t x0[8], x1[8], y0[8], y1[8];                       // two register sets of B fragments, used alternately (no copies between them)
-    auto load_b = [&](d2_t* u0, d2_t* u1, int k) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            u0[q] = *reinterpret_cast<const d2_t*>(Bp + k + 8 * q);
-            u1[q] = *reinterpret_cast<const d2_t*>(Bp + 16 * ldb + k + 8 * q);
-        }
-    };
-    d4_t acc[RG][2];
-#pragma unroll
-    for (int r = 0; r < RG; ++r) { acc[r][0] = d4_t{0.0, 0.0, 0.0, 0.0}; acc[r][1] = d4_t{0.0, 0.0, 0.0, 0.0}; }
-    auto mfmas = [&](const d2_t* u0, const d2_t* u1, int buf) {
-        const double* ap = &sa[buf][r16 * QP_LDA + 2 * g];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            d2_t a[RG];
-#pragma unroll
-            for (int r = 0; r < RG; ++r) a[r] = *reinterpret_cast<const d2_t*>(ap + r * 16 * QP_LDA + 8 * q);
-#pragma unroll
-            for (int r = 0; r < RG; ++r) {
-                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][0], u0[q][0], acc[r][0], 0, 0, 0);
-                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][0], u1[q][0], acc[r][1], 0, 0, 0);
-                acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][1], u0[q][1], acc[r][0], 0, 0, 0);
-                acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r][1], u1[q][1], acc[r][1], 0, 0, 0);
-            }
-        }
-    };
-    load_a(kbeg);
-    load_b(x0, x1, kbeg);
-    store_a(0);
-    __syncthreads();
-    for (int k = kbeg; k < kend; k += 128) {               // kbeg, kend are multiples of 128: chunks k (set x, LDS 0) and k + 64 (set y, LDS 1)
-        // (sched_barrier: the scheduler otherwise sinks the loads below the MFMAs they are meant to fly under)
-        load_b(y0, y1, k + 64);
-        load_a(k + 64);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(x0, x1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(1);
-        __syncthreads();
-        const bool more = k + 128 < kend;
-        if (more) { load_b(x0, x1, k + 128); load_a(k + 128); }
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(y0, y1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) store_a(0);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < RG; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t row = 16 * r + g + 4 * e;                                   // C/D map: lane l, reg e → row (l>>4) + 4e, col l&15
-                C[row * ldc + row0 + 16 * h + r16] = alpha * acc[r][h][e];
-            }
-}
-
-// The same product with BOTH operands going global → LDS by DMA (global_load_lds_dwordx4, no staging registers), in stages of 32 k:
-// what qei_pass_kernel's register path cannot have is a memory access shaped for the memory system — the MFMA fragment map makes a
+// same k order per accumulator, hence the same bits (tests/test_gpu_incremental.py) — with BOTH operands going global → LDS by DMA
+// (global_load_lds_dwordx4, no staging registers), in stages of 32 k.  What a register-staged kernel cannot have (round 5 built one:
+// profiles/r05_qei_pass_variants_ab.txt, removed in round 6) is a memory access shaped for the memory system — the MFMA fragment map makes a
 // load instruction touch 16 rows × 64 bytes (half a 128-byte line per row), and a 17 GB stream read that way tops out at 4.9 – 5.5
 // TB/s whatever the prefetch depth (profiles/r05_qei_pass_variants_ab.txt).  Here a DMA wave-instruction reads 4 rows × 256
 // CONTIGUOUS bytes (whole lines), lane-linearly into LDS; the 16-byte chunks of a row are XOR-swizzled through the per-lane SOURCE
@@ -625,28 +525,17 @@ hipError_t launch_qei_pass(const double* A, int64_t lda, int rows16, const doubl
     if (kmode != K_FULL && kmode != K_B_LOWER && kmode != K_B_UPPER) return hipErrorInvalidValue;
     if (ksplit <= 0) ksplit = K;
     if (ksplit % 128) return hipErrorInvalidValue;
-    const bool regpath = getenv("ABO_QEI_PASS_REG") != nullptr;              // A/B runs: the register-staged kernel
-    if (!regpath) {
-        dim3 gridd((unsigned)(nB / 64), 1, (unsigned)((K + ksplit - 1) / ksplit));
-        // the B stream is read exactly once: its DMA carries the non-temporal hint (aux bit 1) — 5.7 → 6.3 TB/s at T = 16, 5.4 → 5.8 at
-        // T = 32 (profiles/r05_qei_pass_variants_ab.txt); A stays cacheable (every workgroup re-reads it)
+    dim3 gridd((unsigned)(nB / 64), 1, (unsigned)((K + ksplit - 1) / ksplit));
+    // the B stream is read exactly once: its DMA carries the non-temporal hint (aux bit 1) — 5.7 → 6.3 TB/s at T = 16, 5.4 → 5.8 at
+    // T = 32 (profiles/r05_qei_pass_variants_ab.txt); A stays cacheable (every workgroup re-reads it)
 #define QP_LAUNCH(RG_) hipLaunchKernelGGL((qei_passd_kernel<RG_, 2>), gridd, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC)
-        switch (rows16 / 16) {
-            case 1: QP_LAUNCH(1); break;
-            case 2: QP_LAUNCH(2); break;
-            case 3: QP_LAUNCH(3); break;
-            default: QP_LAUNCH(4); break;
-        }
-#undef QP_LAUNCH
-        return hipGetLastError();
-    }
-    dim3 grid((unsigned)(nB / 128), 1, (unsigned)((K + ksplit - 1) / ksplit)), block(256);
     switch (rows16 / 16) {
-        case 1: hipLaunchKernelGGL((qei_pass_kernel<1>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
-        case 2: hipLaunchKernelGGL((qei_pass_kernel<2>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
-        case 3: hipLaunchKernelGGL((qei_pass_kernel<3>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
-        default: hipLaunchKernelGGL((qei_pass_kernel<4>), grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, kmode, ksplit, sC); break;
+        case 1: QP_LAUNCH(1); break;
+        case 2: QP_LAUNCH(2); break;
+        case 3: QP_LAUNCH(3); break;
+        default: QP_LAUNCH(4); break;
     }
+#undef QP_LAUNCH
     return hipGetLastError();
 }
 
@@ -666,7 +555,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     if (a.ksplit) {
         if (a.batch != 1 || a.beta != 0.0 || a.ksplit % 128 != 0 || a.Ct) return hipErrorInvalidValue;
         dim3 grid(a.N / BN, a.M / BM, (a.K + a.ksplit - 1) / a.ksplit);
-        if (a.mrows >= 16 && a.mrows <= 64 && a.mrows % 16 == 0 && a.M == BM && !getenv("ABO_GEMM_NO_SKINNY")) {
+        if (a.mrows >= 16 && a.mrows <= 64 && a.mrows % 16 == 0 && a.M == BM) {
             switch (a.mrows / 16) {
                 case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, dim3(256), 0, s, a); break;
                 case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, dim3(256), 0, s, a); break;
@@ -686,9 +575,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     } else if (a.lower_only && a.kmode == K_FULL && a.M == a.N && a.batch == 1 && Tm >= 16 && !getenv("ABO_GEMM_NO_SWIZZLE")) {
         GemmArgs b = a;
         b.swz = (int)tiles;
-        const char* ge = getenv("ABO_GEMM_SWZ_G");
-        b.swz_g = ge ? atoi(ge) : 4;
-        if (b.swz_g < 1 || b.swz_g > 64) return hipErrorInvalidValue;
+        b.swz_g = 4;
         hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(((tiles + 7) / 8) * 8)), dim3(256), 0, s, b);
     } else {
         dim3 grid(a.N / BN, a.M / BM, a.batch);
@@ -771,147 +658,14 @@ __global__ void __launch_bounds__(256, 2) var_gemm_kernel(VarGemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256×128 variant: one 512-thread workgroup (8 waves as 4(m)×2(n), same 64×64 wave tile and the same
-// one-barrier interleaved pipeline) computes the two vertically adjacent 128×128 tiles that var_gemm_kernel
-// would give to two workgroups, sharing ONE candidate (B) tile in LDS: 25 % fewer operand bytes requested
-// from L2 and 25 % fewer VMEM / LDS-store instructions per MFMA.  The upper 128 rows see zeros of W in the
-// last 128 k of the tile, so their waves (wm < 2) skip the MFMAs of the last 8 stages — every SIMD hosts one
-// upper and one lower wave, the matrix pipe stays busy and no flop is added over the 128×128 tiling.
-// Writes the same two partial rows (2·ti2, 2·ti2+1) with the same summation order: results are bit-identical
-// to var_gemm_kernel.  Used when Np is a multiple of 256.
+// 256×128 tile: one 512-thread workgroup (8 waves as 4(m)×2(n), 64×64 of outputs per wave, one-barrier interleaved pipeline)
+// computes the two vertically adjacent 128×128 tiles that var_gemm_kernel gives to two workgroups, sharing ONE candidate (B) tile
+// in LDS: 25 % fewer operand bytes requested from L2 and 25 % fewer VMEM / LDS-store instructions per MFMA.  Used when Np is a
+// multiple of 256 (var_gemm_kernel serves an odd number of 128-row blocks); same summation order of the partial rows.
 constexpr int BM2 = 256;
 constexpr int STAGE2 = (BM2 + BN) * LDT;       // doubles per LDS stage: A rows 0..255, B rows 256..383
 
-__global__ void __launch_bounds__(512, 2) var_gemm256_kernel(VarGemmArgs p) {
-    __shared__ __attribute__((aligned(16))) double smem[2 * STAGE2];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r16 = lane & 15, g = lane >> 4;
-    const int Tj = p.Mc / BN;
-    const int Ti2 = p.Np / BM2;
-    const int b = blockIdx.x;
-    const int ti2 = Ti2 - 1 - b / Tj;
-    const int tj = b % Tj;
-    const double* __restrict__ Ag = p.W + (int64_t)ti2 * BM2 * p.ldw;
-    const double* __restrict__ Bg = p.Kxz + (int64_t)tj * BN * p.ldk;
-    const int nk = (ti2 + 1) * (BM2 / BK);
-    const int srow = t >> 3, skk = (t & 7) * 2;
-    const int aoff = (wm * 64 + r16) * LDT + g * 2;
-    const int boff = (BM2 + wn * 64 + r16) * LDT + g * 2;
-    d2_t sa[4], sb[2];
-    Frag f0, f1;
-    d4_t acc[4][4];
-    acc_zero(acc);
-
-#define G_LOAD(k0)                                                                                              \
-    do {                                                                                                        \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                           \
-            sa[q] = *reinterpret_cast<const d2_t*>(Ag + (int64_t)(srow + 64 * q) * p.ldw + (k0) + skk);         \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
-            sb[q] = *reinterpret_cast<const d2_t*>(Bg + (int64_t)(srow + 64 * q) * p.ldk + (k0) + skk);         \
-    } while (0)
-#define L_STORE(buf)                                                                                            \
-    do {                                                                                                        \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                           \
-            *reinterpret_cast<d2_t*>((buf) + (srow + 64 * q) * LDT + skk) = sa[q];                              \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                           \
-            *reinterpret_cast<d2_t*>((buf) + (BM2 + srow + 64 * q) * LDT + skk) = sb[q];                        \
-    } while (0)
-
-    G_LOAD(0);
-    L_STORE(smem);
-    G_LOAD(BK);                                             // nk ≥ 16
-    __syncthreads();
-    frag_read(smem + aoff, smem + boff, 0, f0);
-    int st = 0;
-    for (; st < nk - 8; ++st) {                             // every wave has MFMA work: one basic block
-        double* cur = smem + (st & 1) * STAGE2;
-        double* nxt = smem + ((st + 1) & 1) * STAGE2;
-        L_STORE(nxt);
-        frag_read(cur + aoff, cur + boff, 1, f1);
-        G_LOAD((st + 2) * BK);
-        frag_mma<0>(f0, acc);
-        frag_mma<1>(f0, acc);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        frag_read(nxt + aoff, nxt + boff, 0, f0);
-        frag_mma<0>(f1, acc);
-        frag_mma<1>(f1, acc);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 24, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    const bool mma = wm >= 2;                               // last 8 stages: W is zero for the upper 128 rows
-    for (; st < nk; ++st) {
-        double* cur = smem + (st & 1) * STAGE2;
-        double* nxt = smem + ((st + 1) & 1) * STAGE2;
-        if (mma) frag_mma<0>(f0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        frag_read(cur + aoff, cur + boff, 1, f1);
-        if (st + 1 < nk) {
-            L_STORE(nxt);
-            if (st + 2 < nk) G_LOAD((st + 2) * BK);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (mma) frag_mma<1>(f0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (st + 1 < nk) frag_read(nxt + aoff, nxt + boff, 0, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (mma) { frag_mma<0>(f1, acc); frag_mma<1>(f1, acc); }
-    }
-    __syncthreads();
-#undef G_LOAD
-#undef L_STORE
-
-    double* red = smem;                                     // [4 wm][128]
-    const int row0 = ti2 * BM2 + wm * 64 + g;
-    const bool edge = (ti2 + 1) * BM2 > p.nvalid;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        double s = 0.0;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = acc[mi][ni][r];
-                if (edge && row0 + mi * 16 + 4 * r >= p.nvalid) v = 0.0;
-                s = fma(v, v, s);
-            }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (lane < 16) red[wm * 128 + wn * 64 + ni * 16 + lane] = s;
-    }
-    __syncthreads();
-    if (t < 256) {
-        const int half = t >> 7, c = t & 127;                // the two 128-row blocks of this tile
-        p.partial[(int64_t)(2 * ti2 + half) * p.ldp + (int64_t)tj * BN + c] = red[(2 * half) * 128 + c] + red[(2 * half + 1) * 128 + c];
-    }
-}
-
-// 256×128 tile with the structural zeros of the diagonal blocks skipped at 16-row granularity (production):
-// same pipeline as var_gemm256_kernel, but wave (wm, wn) owns the 16-row sub-tiles {wm, wm+4, wm+8, wm+12} of the
+// The structural zeros of the diagonal blocks are skipped at 16-row granularity: wave (wm, wn) owns the 16-row sub-tiles {wm, wm+4, wm+8, wm+12} of the
 // 256 rows instead of 64 consecutive rows, so that every wave — and with it every SIMD — loses the same share of
 // MFMAs when the k loop runs through the two triangular diagonal blocks.  The 128-granular tiling spends a factor
 // 1 + 128/N of the credited flops (1.6 % at N = 8192, 12.5 % at N = 1024); this one 1 + 16/N.  Measured
@@ -1079,11 +833,10 @@ __global__ void __launch_bounds__(512, 2) var_gemm256s_kernel(VarGemmArgs p) {
 }
 
 hipError_t launch_var_gemm(const VarGemmArgs& a, hipStream_t s) {
-    if (a.Np % BM2 == 0 && !a.force128) {
+    if (a.Np % BM2 == 0) {
         const int tiles2 = (a.Np / BM2) * (a.Mc / BN);
         if (tiles2 <= 0) return hipSuccess;
-        if (getenv("ABO_VAR_NOSKIP")) hipLaunchKernelGGL(var_gemm256_kernel, dim3(tiles2), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL(var_gemm256s_kernel, dim3(tiles2), dim3(512), 0, s, a);
+        hipLaunchKernelGGL(var_gemm256s_kernel, dim3(tiles2), dim3(512), 0, s, a);
         return hipGetLastError();
     }
     const int tiles = (a.Np / BM) * (a.Mc / BN);

@@ -549,14 +549,13 @@ hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base,
     const int kreal = (int64_t)k < M ? k : (int)(M < 1 ? 1 : M);
     if (kreal < k) hipLaunchKernelGGL(topk_fill_kernel, dim3((k - kreal + 255) / 256), dim3(256), 0, s, top_val, top_idx, kreal, k);
     k = kreal;
-    static const int small_off = getenv("ABO_TOPK_BLOCKSORT") ? 1 : 0;       // A/B: always the block-sort path
-    if (!small_off && M >= 1 && M <= TKS_MAXM && k <= 1024) {
+    if (M >= 1 && M <= TKS_MAXM && k <= 1024) {
         int kp = pow2_at_least(k);
         if (kp < 2) kp = 2;
         hipLaunchKernelGGL(topk_small_kernel, dim3(1), dim3(TKS_T), 0, s, scores, (int)M, k, kp, idx_base, top_val, top_idx);
         return hipGetLastError();
     }
-    if (!small_off && k == 1 && M > TKS_MAXM) {       // one workspace entry per block of TK_E scores: topk_workspace_entries(M, 1) holds them
+    if (k == 1 && M > TKS_MAXM) {       // one workspace entry per block of TK_E scores: topk_workspace_entries(M, 1) holds them
         const int64_t nb = (M + TK_E - 1) / TK_E;
         hipLaunchKernelGGL(argmax_partial_kernel, dim3((unsigned)nb), dim3(AM_T), 0, s, scores, M, w.keys[0], w.idx[0]);
         hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(AM_T), 0, s, scores, w.keys[0], w.idx[0], (int)nb, M, idx_base, top_val,

@@ -20,11 +20,11 @@
 //
 // Kernels: oz_rowscale_kernel (L1 / max per row of W → s_i), oz_quant_kernel (fp64 → n residue planes: W once per model; K_XZ per
 // chunk only when the generator cannot write the planes itself — kgen.hip does for a StandardGP with d ≤ 32), the residue GEMM
-// (256×256 tile per 8-wave workgroup, triangular k-range, epilogue = symmetric mod + byte pack + LDS transpose) in three variants
-// with identical results — oz_gemm16d_kernel (shipped: v_mfma_i32_16x16x64_i8 fed by an LDS-DMA ring), oz_gemm16_kernel and
-// oz_gemm_kernel (register-staged 16×16×64 / 32×32×32, kept as A/B references: ABO_OZ_REGSTAGE, ABO_OZ_MFMA32) —, and
-// oz_crt_kernel (reconstruction + squares + per-row-block column sums).  Residue planes are stored in 16 KB blocks of 256 rows ×
-// 64 k-bytes (abo_oz_dev.h: oz_plane_off).  What each step bought: profiles/r02_int8_ablation.txt.
+// oz_gemm16p_kernel (256×256 tile per 8-wave workgroup, v_mfma_i32_16x16x64_i8 fed by an LDS-DMA ring, persistent, triangular
+// k-range, epilogue = symmetric mod + byte pack + LDS transpose; the register-staged 32×32×32 / 16×16×64 kernels and the
+// one-tile-per-workgroup kernel it grew out of are in the history up to round 5 and in profiles/r02_int8_ablation.txt,
+// r03_int8_ablation.txt), and oz_crt_kernel (reconstruction + squares + per-row-block column sums).  Residue planes are stored in
+// 16 KB blocks of 256 rows × 64 k-bytes (abo_oz_dev.h: oz_plane_off); U in 64 KB blocks of one 256 × 256 tile and modulus (oz_u_off).
 #include "abo_kernels.h"
 #include "abo_oz_dev.h"
 #include <cmath>
@@ -195,16 +195,8 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
 // U[l][i][j] = (Σ_{k < 256(ti+1)} WR[l][i][k]·KR[l][j][k]) mod p_l for the 256×256 tile (ti, tj) of modulus l.
 // MFMA roles: D[m = j][n = i] — the A operand is the candidate tile, the B operand the W tile, so that a lane's four
 // consecutive accumulator registers are four consecutive candidates of one row i (one packed dword of U).
-// Workgroup = 8 waves as 4 (j) × 2 (i); wave tile 64 (j) × 128 (i) = 2 × 4 MFMA tiles of 32×32 = 128 accumulator registers.
-// LDS: two stages of [256 rows][128 B of k] per operand, rows padded to 144 B (conflict-free ds_read_b128: the four 16-lane
-// groups of a read each hit 16 distinct 16-byte slots; ds_write_b128 writes whole rows).  One barrier per stage.
-// Lane l of a fragment read takes 16 k-bytes at offset 16·(l/32) of its 32-byte k-group, from row l%32 — the same k-assignment
-// on both operands, which is all the product needs.
+// Workgroup = 8 waves as 4 (j) × 2 (i); wave tile 64 (j) × 128 (i) (the kernel and its LDS ring: "16×16×64 GEMM fed by LDS-DMA" below).
 constexpr int OZ_T = 256;                  // tile edge
-constexpr int OZ_BK = 128;                 // k-bytes per stage
-constexpr int OZ_ROW = OZ_BK + 16;         // LDS row stride
-constexpr int OZ_STAGE = OZ_T * OZ_ROW;    // bytes per operand stage (36 864)
-constexpr int OZ_UROW = OZ_T + 8;          // row stride of the epilogue's transpose buffer (264: 2-way on ds_write_b32 = free)
 
 struct OzGemmArgs {
     const int8_t* KR;      // [n][Mc256][ldk]
@@ -218,59 +210,22 @@ struct OzGemmArgs {
     int p[OZ_MAXMOD];
 };
 
-// tile decode: groups of (4 row blocks × tjg column blocks) of ONE modulus, heaviest row blocks first; inside a group the
-// workgroups that land on one XCD (blockIdx % 8) form a 4 × (tjg/8) patch that shares its panels in L2.
-// Row-block offsets inside a group alternate direction from group to group: the CUs that ran a group's lightest tiles are free
-// first and take the next group's first workgroups — which are then its heaviest, so the four row blocks of a patch do not drift
-// apart in k (the candidate panels they share stay in L2 only while they walk k together; L2 hit rate 60 % → 78 %).
-__device__ __forceinline__ bool oz_decode_blk(const OzGemmArgs& a, int blk, int& ti, int& tj, int& l) {
-    const int per_group = 4 * a.tjg;
-    const int grp = blk / per_group, s = blk % per_group;
-    const int ngj = (a.Tj + a.tjg - 1) / a.tjg;
-    const int ngi = (a.Ti + 3) / 4;
-#ifdef OZ_EXP_ROWGROUP_OUTER
-    const int gh = grp % ngj, gl = (grp / ngj) % a.n, gg = grp / (ngj * a.n);
-#else
-    // row groups innermost: the residue planes of one modulus for 64 column blocks (128 MB at N = 8192) are swept by all row groups
-    // back to back and stay in the Infinity Cache meanwhile — with the row groups outermost every sweep streamed them from HBM again
-    const int gg = grp % ngi, gl = (grp / ngi) % a.n, gh = grp / (ngi * a.n);
-#endif
-    const int xcd = s & 7, c = s >> 3;
-    const int cols_x = a.tjg >> 3;                     // column blocks per XCD patch
-    const int ro = c / cols_x;
-    ti = 4 * (ngi - 1 - gg) + ((grp & 1) ? 3 - ro : ro);
-    tj = gh * a.tjg + xcd * cols_x + c % cols_x;
-    l = gl;
-    return ti < a.Ti && tj < a.Tj;
-}
-__device__ __forceinline__ bool oz_decode(const OzGemmArgs& a, int& ti, int& tj, int& l) { return oz_decode_blk(a, (int)blockIdx.x, ti, tj, l); }
+// Tile order (oz16p_decode_ticket): groups of (4 row blocks × tjg column blocks) of ONE modulus, heaviest row blocks first; inside a
+// group the tiles that land on one XCD form a 4 × (tjg/8) patch that shares its panels in L2.  Row-block offsets inside a group
+// alternate direction from group to group: the CUs that ran a group's lightest tiles are free first and take the next group's first
+// tiles — which are then its heaviest, so the four row blocks of a patch do not drift apart in k (the candidate panels they share stay
+// in L2 only while they walk k together; L2 hit rate 60 % → 78 %).  Row groups innermost: the residue planes of one modulus for 64
+// column blocks (128 MB at N = 8192) are swept by all row groups back to back and stay in the Infinity Cache meanwhile.
 
 // ---- epilogue pieces shared by the GEMM kernels -------------------------------------------------------------------------------------------
-// four accumulators (four consecutive candidates of one W row) → their symmetric residues mod p, one byte each.  The quotient is
-// exact: |x| < 2^31, so x/p in fp64 is far closer to the true quotient than 1/(2p), and r = x − q·p lands in [−p/2, p/2].
-__device__ __forceinline__ int oz_mod_pack4(int a0, int a1, int a2, int a3, double invp, double pd) {
-    const int v[4] = {a0, a1, a2, a3};
-    int w = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-#ifdef OZ_EXP_NOEPI
-        const int r = v[b];
-#else
-        const double x = (double)v[b];
-        const double q = __builtin_rint(x * invp);
-        const int r = (int)__builtin_fma(-q, pd, x);
-#endif
-        w |= (r & 0xff) << (8 * b);
-    }
-    return w;
-}
-
-// The same four residues in three VALU operations per accumulator instead of five (the persistent kernel's epilogue: its residue
+// four accumulators (four consecutive candidates of one W row) → their symmetric residues mod p, one byte each: q = rint(x/p) is exact
+// (|x| < 2^31, so x/p in fp64 is far closer to the true quotient than 1/(2p)) and r = x − q·p lands in [−p/2, p/2].
+// Three VALU operations per accumulator (the persistent kernel's epilogue: its residue
 // arithmetic is issue-bound, two waves per SIMD taking turns — 4.7 of a tile's 52 µs with the matrix pipe idle): the product x·(1/p)
 // is rounded to the nearest integer by adding 1.5·2^52 inside the fma (one rounding instead of two, the same integer: x/p is at
 // least 1/(2p) away from a half-integer for odd p), the quotient is then the low dword of the sum's mantissa as it stands — no
 // v_rndne, no conversion back —, and r = x − q·p is one v_mad_i32_i24 (|q| ≤ 2^30/199 < 2^23 for every row count the engine takes).
-// p = 256: ties round to even in both forms.  Same residues, bit for bit.
+// p = 256: ties round to even.
 __device__ __forceinline__ int oz_mod_pack4_mad(int a0, int a1, int a2, int a3, double invp, int p) {
     const int v[4] = {a0, a1, a2, a3};
     int r[4];
@@ -287,237 +242,10 @@ __device__ __forceinline__ int oz_mod_pack4_mad(int a0, int a1, int a2, int a3, 
     return (int)__builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
-// the tile's residues, transposed in LDS (Ut [256 rows i][OZ_UROW]), leave as 256-byte row segments of U[l][i][j]
-__device__ __forceinline__ void oz_store_tile(const OzGemmArgs& a, const char* Ut, int l, int ti, int tj) {
-    const int tid = threadIdx.x;
-    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
-    const int ur = tid >> 4, uc = (tid & 15) * 16;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int i = ur + 32 * q;
-        const char* src = Ut + i * OZ_UROW + uc;
-        const uint64_t lo = *reinterpret_cast<const uint64_t*>(src), hi = *reinterpret_cast<const uint64_t*>(src + 8);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(up + (int64_t)i * a.ldu + uc);
-        dst[0] = lo;
-        dst[1] = hi;
-    }
-}
-
-// epilogue of the 16×16×64 kernels: D layout lane → column (W row) lane % 16, register r → row (candidate) 4(lane/16) + r
-__device__ __forceinline__ void oz16_epilogue(const OzGemmArgs& a, char* Ut, const v4i_t (&acc)[4][8], int l, int ti, int tj, int wi, int wj,
-                                              int lane) {
-    const double invp = a.invp[l], pd = (double)a.p[l];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 8; ++nn) {
-            const int il = 128 * wi + 16 * nn + (lane & 15);
-            const int jl = 64 * wj + 16 * m + 4 * (lane >> 4);
-            *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) = oz_mod_pack4(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pd);
-        }
-    __syncthreads();
-    oz_store_tile(a, Ut, l, ti, tj);
-}
-
-// fragments of one 32-byte k-group: two candidate row-groups (A operand), four W row-groups (B operand)
-struct OzFrag { v4i_t a[2], b[4]; };
-
-__device__ __forceinline__ void oz_frag_read(const char* af, const char* bf, int ks, OzFrag& f) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) f.a[m] = *reinterpret_cast<const v4i_t*>(af + (32 * m) * OZ_ROW + 32 * ks);
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(bf + (32 * nn) * OZ_ROW + 32 * ks);
-}
-
-__device__ __forceinline__ void oz_frag_mma(const OzFrag& f, v16i_t (&acc)[2][4]) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) acc[m][nn] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[m], f.b[nn], acc[m][nn], 0, 0, 0);
-}
-
-struct OzStage { v4i_t a[4], b[4]; };      // one thread's share of a stage: 4 × 16 B of each operand
-
-// k = first k-byte of the stage (a multiple of 128): two 16 KB plane blocks further per stage
-__device__ __forceinline__ void oz_gload(const int8_t* __restrict__ ab, const int8_t* __restrict__ bb, const unsigned (&ao)[4],
-                                         const unsigned (&bo)[4], int k, OzStage& r) {
-    const int koff = (k >> 7) << 15;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        r.a[q] = *reinterpret_cast<const v4i_t*>(ab + koff + ao[q]);
-        r.b[q] = *reinterpret_cast<const v4i_t*>(bb + koff + bo[q]);
-    }
-}
-
-__device__ __forceinline__ void oz_lstore(char* As, char* Bs, int lr, int lc, const OzStage& r) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<v4i_t*>(As + (lr + 64 * q) * OZ_ROW + lc) = r.a[q];
-        *reinterpret_cast<v4i_t*>(Bs + (lr + 64 * q) * OZ_ROW + lc) = r.b[q];
-    }
-}
-
-// Software pipeline, iteration t (stage = 128 k-bytes = four 32-byte k-groups; LDS holds two stages):
-//     8 MFMA on F0 = fragments(t, group 0)   and behind them: 8 ds_write  S(stage t+1) → LDS[(t+1)&1], 6 ds_read group 1 → F1
-//     8 MFMA on F1                            and behind them: 8 global_load stage t+2 → S,             6 ds_read group 2 → F0
-//     8 MFMA on F0                            and behind them:                                           6 ds_read group 3 → F1
-//     barrier   (stage t+1 complete in LDS; nobody still reads stage t)
-//     8 MFMA on F1                            and behind them: 6 ds_read fragments(t+1, group 0) → F0
-// so the matrix pipe has a fragment set in registers on both sides of the barrier, and every memory instruction is issued
-// directly behind one of the wave's own MFMAs (the sched_group_barrier sequences pin that order).
-__global__ void __launch_bounds__(512) oz_gemm_kernel(OzGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char oz_lds[4 * OZ_STAGE];
-    int ti, tj, l;
-    if (!oz_decode(a, ti, tj, l)) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wj = wave & 3, wi = wave >> 2;
-    // LDS: stage buffer b = [A tile | B tile], each [256][144]
-    const int lr = tid >> 3, lc = (tid & 7) * 16;
-    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384;       // the tile's row block of plane blocks
-    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384;
-    unsigned ao[4], bo[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {     // this thread's 16 bytes: row lr + 64q, k-bytes lc … lc+15 of the stage's 128 (two 64-byte plane blocks)
-        ao[q] = (unsigned)((lc >> 6) * 16384 + (lr + 64 * q) * 64 + (lc & 63));
-        bo[q] = ao[q];
-    }
-    const int nst = 2 * (ti + 1);
-
-    v16i_t acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0;
-
-    const int foff = (lane & 31) * OZ_ROW + (lane >> 5) * 16;
-    const int afo = (64 * wj) * OZ_ROW + foff;                  // in the A tile
-    const int bfo = OZ_STAGE + (128 * wi) * OZ_ROW + foff;      // in the B tile
-
-    OzStage S;
-    OzFrag f0, f1;
-    oz_gload(ab, bb, ao, bo, 0, S);
-    oz_lstore(oz_lds, oz_lds + OZ_STAGE, lr, lc, S);
-    oz_gload(ab, bb, ao, bo, OZ_BK, S);                         // nst ≥ 2 always
-    __syncthreads();
-    oz_frag_read(oz_lds + afo, oz_lds + bfo, 0, f0);
-    int t = 0;
-    for (; t + 2 < nst; ++t) {
-        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE);
-        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE);
-        oz_lstore(nxt, nxt + OZ_STAGE, lr, lc, S);
-        oz_frag_read(cur + afo, cur + bfo, 1, f1);
-        oz_frag_mma(f0, acc);
-        oz_gload(ab, bb, ao, bo, (t + 2) * OZ_BK, S);
-        oz_frag_read(cur + afo, cur + bfo, 2, f0);
-        oz_frag_mma(f1, acc);
-        oz_frag_read(cur + afo, cur + bfo, 3, f1);
-        oz_frag_mma(f0, acc);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        oz_frag_read(nxt + afo, nxt + bfo, 0, f0);
-        oz_frag_mma(f1, acc);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (; t < nst; ++t) {                                      // the last two stages: nothing left to load
-        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE);
-        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE);
-        oz_frag_read(cur + afo, cur + bfo, 1, f1);
-        if (t + 1 < nst) oz_lstore(nxt, nxt + OZ_STAGE, lr, lc, S);
-        oz_frag_mma(f0, acc);
-        oz_frag_read(cur + afo, cur + bfo, 2, f0);
-        oz_frag_mma(f1, acc);
-        oz_frag_read(cur + afo, cur + bfo, 3, f1);
-        oz_frag_mma(f0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (t + 1 < nst) oz_frag_read(nxt + afo, nxt + bfo, 0, f0);
-        oz_frag_mma(f1, acc);
-    }
-    __syncthreads();
-
-    // ---- epilogue: symmetric mod p_l, four candidates per dword, transposed through LDS so that rows of U leave as 256-byte
-    //      segments.  D layout of v_mfma_i32_32x32x32_i8: lane → column n = lane % 32, register r → row m = 8(r/4) + 4(lane/32) + r%4
-    const double invp = a.invp[l], pd = (double)a.p[l];
-    char* Ut = oz_lds;                                  // [256 i][264]
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-            const int il = 128 * wi + 32 * nn + (lane & 31);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int jl = 64 * wj + 32 * m + 8 * g + 4 * (lane >> 5);
-                *reinterpret_cast<int*>(Ut + il * OZ_UROW + jl) =
-                    oz_mod_pack4(acc[m][nn][4 * g], acc[m][nn][4 * g + 1], acc[m][nn][4 * g + 2], acc[m][nn][4 * g + 3], invp, pd);
-            }
-        }
-    __syncthreads();
-    oz_store_tile(a, Ut, l, ti, tj);
-}
-
-
-// ---- the same GEMM on v_mfma_i32_16x16x64_i8 -------------------------------------------------------------------------------------------
-// On random operands the chip holds a higher clock with the 16×16×64 shape than with 32×32×32 (tools/mfma_i8_power_probe.hip:
-// 3.41 against 3.11 POP/s sustained).  Wave tile as above (64 candidates × 128 W rows) = 4 × 8 MFMA tiles of 16×16.
-// LDS rows are 128 B unpadded with the 16-byte chunks XOR-swizzled: chunk c of row r sits at position c ^ ((r >> 1) & 7) —
-// conflict-free for ds_read_b128 with lane → (row l%16, chunk l/16 + 4·group) and for the row-wise ds_write_b128.
-// D layout of v_mfma_i32_16x16x64_i8: lane → column n = lane % 16, register r → row m = 4(lane/16) + r.
-// Pipeline per iteration (stage = two 64-byte k-groups g0, g1; a unit = 4 A fragments × 4 B fragments = 16 MFMAs):
-//     unit (g0, B0-3) | 8 ds_write S(t+1), 4 ds_read B4-7(g0)
-//     unit (g0, B4-7) | 8 global_load stage t+2, 8 ds_read A(g1), B0-3(g1)
-//     unit (g1, B0-3) | 4 ds_read B4-7(g1)
-//     barrier
-//     unit (g1, B4-7) | 8 ds_read A(g0), B0-3(g0) of stage t+1
-constexpr int OZ_STAGE16 = OZ_T * OZ_BK;      // 32 768 bytes per operand stage
-
 struct OzFragA { v4i_t a[4]; };
 struct OzFragB { v4i_t b[4]; };
 
-__device__ __forceinline__ void oz16_read_a(const char* p, OzFragA& f) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) f.a[m] = *reinterpret_cast<const v4i_t*>(p + (16 * m) * OZ_BK);
-}
-__device__ __forceinline__ void oz16_read_b(const char* p, int half, OzFragB& f) {
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(p + (16 * (4 * half + nn)) * OZ_BK);
-}
+// a unit: 4 A fragments × 4 B fragments = 16 MFMAs on columns 4·half … 4·half+3 of the wave tile
 __device__ __forceinline__ void oz16_mma(const OzFragA& fa, const OzFragB& fb, int half, v4i_t (&acc)[4][8]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -525,118 +253,13 @@ __device__ __forceinline__ void oz16_mma(const OzFragA& fa, const OzFragB& fb, i
         for (int nn = 0; nn < 4; ++nn)
             acc[m][4 * half + nn] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa.a[m], fb.b[nn], acc[m][4 * half + nn], 0, 0, 0);
 }
-__device__ __forceinline__ void oz16_lstore(char* As, char* Bs, int lr, int pos, const OzStage& r) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<v4i_t*>(As + (lr + 64 * q) * OZ_BK + pos) = r.a[q];
-        *reinterpret_cast<v4i_t*>(Bs + (lr + 64 * q) * OZ_BK + pos) = r.b[q];
-    }
-}
-
-#define OZ_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
-__global__ void __launch_bounds__(512) oz_gemm16_kernel(OzGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char oz_lds[4 * OZ_STAGE16];
-    int ti, tj, l;
-    if (!oz_decode(a, ti, tj, l)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wj = wave & 3, wi = wave >> 2;
-    const int lr = tid >> 3, lc = (tid & 7) * 16;
-    const int wpos = ((tid & 7) ^ ((lr >> 1) & 7)) * 16;         // swizzled position of this thread's chunk in its rows
-    const int8_t* ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384;       // the tile's row block of plane blocks
-    const int8_t* bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384;
-    unsigned ao[4], bo[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {     // this thread's 16 bytes: row lr + 64q, k-bytes lc … lc+15 of the stage's 128 (two 64-byte plane blocks)
-        ao[q] = (unsigned)((lc >> 6) * 16384 + (lr + 64 * q) * 64 + (lc & 63));
-        bo[q] = ao[q];
-    }
-    const int nst = 2 * (ti + 1);
-
-    v4i_t acc[4][8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 8; ++nn) acc[m][nn] = v4i_t{0, 0, 0, 0};
-
-    // per-lane read offsets of the two k-groups of a stage: row lane%16, chunk (lane/16 + 4g) ^ swizzle
-    const int sw = (lane >> 1) & 7;
-    const int c0 = ((lane >> 4) ^ sw) * 16;
-    const int ro0 = (lane & 15) * OZ_BK + c0, ro1 = (lane & 15) * OZ_BK + (c0 ^ 64);
-    const int abase = (64 * wj) * OZ_BK;
-    const int bbase = OZ_STAGE16 + (128 * wi) * OZ_BK;
-
-    OzStage S;
-    OzFragA A0, A1;
-    OzFragB Bx, By;
-    oz_gload(ab, bb, ao, bo, 0, S);
-    oz16_lstore(oz_lds, oz_lds + OZ_STAGE16, lr, wpos, S);
-    oz_gload(ab, bb, ao, bo, OZ_BK, S);
-    __syncthreads();
-    oz16_read_a(oz_lds + abase + ro0, A0);
-    oz16_read_b(oz_lds + bbase + ro0, 0, Bx);
-    int t = 0;
-    for (; t + 2 < nst; ++t) {
-        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE16);
-        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE16);
-        oz16_lstore(nxt, nxt + OZ_STAGE16, lr, wpos, S);
-        oz16_read_b(cur + bbase + ro0, 1, By);
-        oz16_mma(A0, Bx, 0, acc);
-        oz_gload(ab, bb, ao, bo, (t + 2) * OZ_BK, S);
-        oz16_read_a(cur + abase + ro1, A1);
-        oz16_read_b(cur + bbase + ro1, 0, Bx);
-        oz16_mma(A0, By, 1, acc);
-        oz16_read_b(cur + bbase + ro1, 1, By);
-        oz16_mma(A1, Bx, 0, acc);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x200, 1); OZ_SGB(0x100, 1); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x200, 1); }
-        OZ_SGB(0x008, 8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x020, 1); OZ_SGB(0x100, 1); }
-        OZ_SGB(0x008, 8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { OZ_SGB(0x008, 1); OZ_SGB(0x100, 1); }
-        OZ_SGB(0x008, 12);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        oz16_read_a(nxt + abase + ro0, A0);
-        oz16_read_b(nxt + bbase + ro0, 0, Bx);
-        oz16_mma(A1, By, 1, acc);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 1); __builtin_amdgcn_sched_group_barrier(0x100, 1, 1); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (; t < nst; ++t) {                                      // the last two stages: nothing left to load
-        char* cur = oz_lds + (t & 1) * (2 * OZ_STAGE16);
-        char* nxt = oz_lds + ((t + 1) & 1) * (2 * OZ_STAGE16);
-        oz16_read_b(cur + bbase + ro0, 1, By);
-        if (t + 1 < nst) oz16_lstore(nxt, nxt + OZ_STAGE16, lr, wpos, S);
-        oz16_mma(A0, Bx, 0, acc);
-        oz16_read_a(cur + abase + ro1, A1);
-        oz16_read_b(cur + bbase + ro1, 0, Bx);
-        oz16_mma(A0, By, 1, acc);
-        oz16_read_b(cur + bbase + ro1, 1, By);
-        oz16_mma(A1, Bx, 0, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (t + 1 < nst) {
-            oz16_read_a(nxt + abase + ro0, A0);
-            oz16_read_b(nxt + bbase + ro0, 0, Bx);
-        }
-        oz16_mma(A1, By, 1, acc);
-    }
-    __syncthreads();
-
-    oz16_epilogue(a, oz_lds, acc, l, ti, tj, wi, wj, lane);
-}
-
 
 // ---- 16×16×64 GEMM fed by LDS-DMA --------------------------------------------------------------------------------------------------------
-// The register-staged kernels above can keep only half a stage of global loads in flight (246–253 VGPRs); an L2 miss (22 % of the
-// requests) is then waited for with the matrix pipe idle (SQ_WAIT_ANY 33 % of wave time).  Here the tiles go global → LDS directly
+// Wave tile 64 candidates × 128 W rows = 4 × 8 MFMA tiles of 16×16 (D layout of v_mfma_i32_16x16x64_i8: lane → column n = lane % 16,
+// register r → row m = 4(lane/16) + r).  On random operands the chip holds a higher clock with the 16×16×64 shape than with 32×32×32
+// (tools/mfma_i8_power_probe.hip: 3.41 against 3.11 POP/s sustained).  A register-staged kernel can keep only half a stage of global
+// loads in flight (246–253 VGPRs); an L2 miss (22 % of the requests) is then waited for with the matrix pipe idle (SQ_WAIT_ANY 33 % of
+// wave time).  Here the tiles go global → LDS directly
 // (global_load_lds_dwordx4: no staging registers, no ds_write), in HALF-stages of 64 k-bytes through a ring of four 32 KB slots,
 // three half-stages ahead of the one being multiplied.
 // LDS image of a slot: [A tile: 256 rows × 64 B][B tile: 256 rows × 64 B], the four 16-byte chunks of a row XOR-swizzled,
@@ -661,11 +284,7 @@ struct OzDmaCtx {
 
 template <int SLOT>
 __device__ __forceinline__ void oz_dma_issue(char* lds, const OzDmaCtx& c, int h) {
-#ifdef OZ_EXP_SAMEK
-    const int k = 0 * h;
-#else
     const int k = h * 16384;
-#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         char* da = lds + SLOT * OZ_SLOT + (c.wave + 8 * q) * 1024;
@@ -673,15 +292,6 @@ __device__ __forceinline__ void oz_dma_issue(char* lds, const OzDmaCtx& c, int h
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.ab + k + q * c.astep + c.ao), (oz_lds_ptr)da, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.bb + k + q * c.bstep + c.bo), (oz_lds_ptr)db, 16, 0, 0);
     }
-}
-
-__device__ __forceinline__ void oz16d_read_a(const char* p, OzFragA& f) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) f.a[m] = *reinterpret_cast<const v4i_t*>(p + (16 * m) * OZ_HS);
-}
-__device__ __forceinline__ void oz16d_read_b(const char* p, int half, OzFragB& f) {
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) f.b[nn] = *reinterpret_cast<const v4i_t*>(p + (16 * (4 * half + nn)) * OZ_HS);
 }
 
 // one DMA piece: q = 0/1 the wave's first / second 16-row group, op = 0 candidates (A), 1 W rows (B)
@@ -719,9 +329,6 @@ __device__ __forceinline__ void oz16d_step_k(char* lds, const OzDmaCtx& c, int k
     OzFragA& An = A[SLOT & 1];
     const OzFragA& Ao = A[(SLOT & 1) ^ 1];
     constexpr int NS = (SLOT + 3) & 3;
-#ifdef OZ_EXP_SAMEK
-    k = 0;                                             // timing-only build: every fetch hits the same (cached) plane block
-#endif
     // the previous half-stage's held-back unit (Ao × By, columns 4-7) with this half-stage's A and B0-3 fragments arriving
     An.a[0] = *reinterpret_cast<const v4i_t*>(pa);
     An.a[1] = *reinterpret_cast<const v4i_t*>(pa + 16 * OZ_HS);
@@ -731,31 +338,23 @@ __device__ __forceinline__ void oz16d_step_k(char* lds, const OzDmaCtx& c, int k
     An.a[3] = *reinterpret_cast<const v4i_t*>(pa + 48 * OZ_HS);
     if (!sk_prev) oz16_mma_row(Ao, By, 1, 1, acc);
     OZ_FENCE();
-#ifndef OZ_EXP_NODMA
     oz_dma_piece<NS>(lds, c, k, 0, 0);
-#endif
     Bx.b[0] = *reinterpret_cast<const v4i_t*>(pb);
     Bx.b[1] = *reinterpret_cast<const v4i_t*>(pb + 16 * OZ_HS);
     if (!sk_prev) oz16_mma_row(Ao, By, 1, 2, acc);
     OZ_FENCE();
-#ifndef OZ_EXP_NODMA
     oz_dma_piece<NS>(lds, c, k, 0, 1);
-#endif
     Bx.b[2] = *reinterpret_cast<const v4i_t*>(pb + 32 * OZ_HS);
     Bx.b[3] = *reinterpret_cast<const v4i_t*>(pb + 48 * OZ_HS);
     if (!sk_prev) oz16_mma_row(Ao, By, 1, 3, acc);
     OZ_FENCE();
     // this half-stage's first unit (An × Bx, columns 0-3) with the B4-7 fragments arriving
-#ifndef OZ_EXP_NODMA
     oz_dma_piece<NS>(lds, c, k, 1, 0);
-#endif
     By.b[0] = *reinterpret_cast<const v4i_t*>(pb + 64 * OZ_HS);
     By.b[1] = *reinterpret_cast<const v4i_t*>(pb + 80 * OZ_HS);
     if (!sk_u0) oz16_mma_row(An, Bx, 0, 0, acc);
     OZ_FENCE();
-#ifndef OZ_EXP_NODMA
     oz_dma_piece<NS>(lds, c, k, 1, 1);
-#endif
     By.b[2] = *reinterpret_cast<const v4i_t*>(pb + 96 * OZ_HS);
     By.b[3] = *reinterpret_cast<const v4i_t*>(pb + 112 * OZ_HS);
     if (!sk_u0) oz16_mma_row(An, Bx, 0, 1, acc);
@@ -763,101 +362,21 @@ __device__ __forceinline__ void oz16d_step_k(char* lds, const OzDmaCtx& c, int k
     if (!sk_u0) oz16_mma_row(An, Bx, 0, 2, acc);
     if (!sk_u0) oz16_mma_row(An, Bx, 0, 3, acc);
     OZ_FENCE();
-#if !defined(OZ_EXP_NOVMWAIT) && !defined(OZ_EXP_NODMA)
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef OZ_EXP_NOBARRIER
     __builtin_amdgcn_s_barrier();
-#endif
     OZ_FENCE();
 }
 
-// the step of the one-tile-per-workgroup kernel: fetches half-stage h + 3 of its own tile (clamped to the last one)
-template <int SLOT, bool DIAG>
-__device__ __forceinline__ void oz16d_step(char* lds, const OzDmaCtx& c, int h, int hmax, int ra, int rb, OzFragA (&A)[2], OzFragB& Bx,
-                                           OzFragB& By, v4i_t (&acc)[4][8], int hs = 0, int wi = 0) {
-#ifdef OZ_EXP_SAMEK
-    const int k = 0;
-#else
-    const int k = (h + 3 < hmax ? h + 3 : hmax) * 16384;      // byte offset of the half-stage's plane block
-#endif
-    oz16d_step_k<SLOT, DIAG>(lds, c, k, ra, rb, A, Bx, By, acc, hs, wi);
-}
-
-__global__ void __launch_bounds__(512) oz_gemm16d_kernel(OzGemmArgs a) {
-    __shared__ __attribute__((aligned(1024))) char oz_lds[4 * OZ_SLOT];
-    int ti, tj, l;
-    if (!oz_decode(a, ti, tj, l)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wj = wave & 3, wi = wave >> 2;
-    OzDmaCtx c;
-    c.ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384;
-    c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384;
-    c.wave = __builtin_amdgcn_readfirstlane(wave);
-    {
-        // piece P = wave + 8q covers rows 16P … 16P+15 of the half-stage's 16 KB plane block — 1 KiB of contiguous memory; lane L
-        // fills LDS row 16P + L/4, position L%4 with chunk (L%4) ^ ((row>>1)&3) of that row
-        const int chunk = (lane & 3) ^ ((lane >> 3) & 3);
-        c.ab += 1024 * c.wave;
-        c.bb += 1024 * c.wave;
-        c.astep = 8192;
-        c.bstep = 8192;
-        c.ao = (unsigned)((lane >> 2) * 64 + 16 * chunk);
-        c.bo = c.ao;
-    }
-    const int nh = 4 * (ti + 1);                     // half-stages of this tile
-
-    v4i_t acc[4][8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int nn = 0; nn < 8; ++nn) acc[m][nn] = v4i_t{0, 0, 0, 0};
-
-    // per-lane fragment read offset inside a tile: row lane%16, chunk position (lane/16) ^ ((lane>>1)&3)
-    const int ro = (lane & 15) * OZ_HS + (((lane >> 4) ^ ((lane >> 1) & 3)) * 16);
-    const int ra = (64 * wj) * OZ_HS + ro;
-    const int rb = OZ_T * OZ_HS + (128 * wi) * OZ_HS + ro;
-
-    OzFragA A[2];
-    OzFragB Bx, By;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { A[1].a[m] = v4i_t{0, 0, 0, 0}; By.b[m] = v4i_t{0, 0, 0, 0}; }   // the first step's held-back unit adds 0
-    oz_dma_issue<0>(oz_lds, c, 0);
-    oz_dma_issue<1>(oz_lds, c, 1);
-    oz_dma_issue<2>(oz_lds, c, 2);
-#ifndef OZ_EXP_NOPROLOGWAIT
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#endif
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    int hb = 0;
-    for (; hb < nh - 4; hb += 4) {
-        oz16d_step<0, false>(oz_lds, c, hb, nh - 1, ra, rb, A, Bx, By, acc);
-        oz16d_step<1, false>(oz_lds, c, hb + 1, nh - 1, ra, rb, A, Bx, By, acc);
-        oz16d_step<2, false>(oz_lds, c, hb + 2, nh - 1, ra, rb, A, Bx, By, acc);
-        oz16d_step<3, false>(oz_lds, c, hb + 3, nh - 1, ra, rb, A, Bx, By, acc);
-    }
-    oz16d_step<0, true>(oz_lds, c, hb, nh - 1, ra, rb, A, Bx, By, acc, 0, wi);        // the diagonal block
-    oz16d_step<1, true>(oz_lds, c, hb + 1, nh - 1, ra, rb, A, Bx, By, acc, 1, wi);
-    oz16d_step<2, true>(oz_lds, c, hb + 2, nh - 1, ra, rb, A, Bx, By, acc, 2, wi);
-    oz16d_step<3, true>(oz_lds, c, hb + 3, nh - 1, ra, rb, A, Bx, By, acc, 3, wi);
-    if (wi != 0) oz16_mma(A[1], By, 1, acc);          // the held-back unit of the last half-stage (slot 3 → A[1]); zeros for wave row 0
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's re-fetches have landed before the epilogue reuses the ring as Ut
-    __syncthreads();
-
-    oz16_epilogue(a, oz_lds, acc, l, ti, tj, wi, wj, lane);
-}
-
-// ---- the same GEMM as a PERSISTENT kernel -------------------------------------------------------------------------------------------------
+// ---- the GEMM: a PERSISTENT kernel ---------------------------------------------------------------------------------------------------------
 // One workgroup per CU stays resident and works through tiles of the launch's tile list (dealt out dynamically, below).  What a
-// tile cost beyond its MFMAs in the one-tile-per-workgroup kernel — the dispatch of a 128 KB-LDS
+// tile cost beyond its MFMAs in a one-tile-per-workgroup kernel (round 2) — the dispatch of a 128 KB-LDS
 // workgroup onto the CU that just drained, three half-stages of DMA latency before the first MFMA, the wait for the tail's
 // re-fetches before the epilogue may overlay the ring — was about 7 of 54 µs at N = 8192 and half of the tile at N = 1024, with
 // nothing else resident on the CU to hide it.  Here the last three steps of a tile fetch the first three half-stages of the NEXT
 // tile into ring slots 0-2 (a tile is a multiple of four half-stages: the ring phase carries over), and the epilogue keeps out of
 // their way: the residues leave through slot 3 alone, 64 W rows at a time in two 16 KB buffers (rows of 256 bytes, 16-byte chunks
-// rotated by the row index: conflict-free for the dword writes and the 16-byte reads).  Same products, same residues: same bits.
+// rotated by the row index: conflict-free for the dword writes and the 16-byte reads).
 __device__ __forceinline__ void oz16p_ctx(const OzGemmArgs& a, int ti, int tj, int l, int wave, OzDmaCtx& c) {
     c.ab = a.KR + (int64_t)l * a.sK + ((int64_t)tj * a.nhs) * 16384 + 1024 * wave;
     c.bb = a.WR + (int64_t)l * a.sW + ((int64_t)ti * a.nhs) * 16384 + 1024 * wave;
@@ -943,8 +462,8 @@ __device__ __forceinline__ void oz_divmod(int x, int d, float rd, int& q, int& r
     if (r >= d) { ++q; r -= d; }
 }
 
-// ticket q of list y → the tile (ti, tj, l) packed as ti | tj << 9 | l << 20, or −1 for a padding block: the same map as
-// oz_decode_blk for the block (q / cpx)·per_group + (q % cpx)·8 + y
+// ticket q of list y → the tile (ti, tj, l) packed as ti | tj << 9 | l << 20, or −1 for a padding block: block
+// (q / cpx)·per_group + (q % cpx)·8 + y of the order described at OzGemmArgs
 __device__ __forceinline__ int oz16p_decode_ticket(const OzGemmArgs& a, int q, int y) {
     const int cpx = a.tjg >> 1, cols_x = a.tjg >> 3;           // per_group / 8, column blocks per XCD patch
     const int ngi = (a.Ti + 3) / 4;
@@ -1153,12 +672,8 @@ __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
                             // signed byte → double without v_cvt_f64_i32 (quarter rate on this chip: with 14 of them per product
                             // the kernel was bound by the conversion, not by its 14 bytes per product): the byte biased by 128
                             // becomes the low mantissa bits of 2^52, and (2^52 + b + 128) − (2^52 + 128) is the byte's value, exactly
-#ifdef OZ_CRT_CVT
-                            const double ud = (double)((wl[l][g4] << (24 - 8 * b)) >> 24);
-#else
                             const unsigned ub = (wx >> (8 * b)) & 0xffu;
                             const double ud = __hiloint2double(0x43300000, (int)ub) - 4503599627370624.0;
-#endif
                             c1[b] = __builtin_fma(ud, s1, c1[b]);
                             c2[b] = __builtin_fma(ud, s2, c2[b]);
                         }
@@ -1351,21 +866,12 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256; g.sU = (int64_t)Np256 * Mc256;
     g.Ti = Np256 / OZ_T; g.Tj = Mc256 / OZ_T; g.n = pl.n;
     g.tjg = g.Tj >= 64 ? 64 : (int)pad_up(g.Tj, 8);
-    // A/B runs (profiles/r05_notes.md): column blocks per tile group — an XCD's patch is 4 row blocks × tjg/8 column blocks
-    static const int tjg_env = [] { const char* e = getenv("ABO_OZ_TJG"); const int v = e ? atoi(e) : 0; return (v >= 8 && v <= 2040 && v % 8 == 0) ? v : 0; }();
-    if (tjg_env && g.Tj >= tjg_env) g.tjg = tjg_env;
     for (int l = 0; l < pl.n; ++l) {
         g.invp[l] = pl.invp[l]; g.p[l] = pl.p[l];
     }
     const int ngj = (g.Tj + g.tjg - 1) / g.tjg, ngi = (g.Ti + 3) / 4;
     const unsigned blocks = (unsigned)(ngi * pl.n * ngj * 4 * g.tjg);
-    static const int shape32 = getenv("ABO_OZ_MFMA32") ? 1 : 0;       // A/B: the 32×32×32 kernel
-    static const int regstage = getenv("ABO_OZ_REGSTAGE") ? 1 : 0;    // A/B: the register-staged 16×16×64 kernel
-    static const int one_tile = getenv("ABO_OZ_ONE_TILE") ? 1 : 0;    // A/B: one tile per workgroup (the round-2 kernel)
-    if (shape32) hipLaunchKernelGGL(oz_gemm_kernel, dim3(blocks), dim3(512), 0, s, g);
-    else if (regstage) hipLaunchKernelGGL(oz_gemm16_kernel, dim3(blocks), dim3(512), 0, s, g);
-    else if (one_tile) hipLaunchKernelGGL(oz_gemm16d_kernel, dim3(blocks), dim3(512), 0, s, g);
-    else {
+    {
         // persistent: one workgroup per CU; the tile counters (one per XCD list) sit behind the chunk's bad_col flags
         static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
         int* ctr = v.bad_col + Mc256;
@@ -1387,8 +893,7 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
     c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
     c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
     c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
-    static const int crt_generic = getenv("ABO_OZ_CRT_GENERIC") ? 1 : 0;          // A/B: the run-time-n loop for every plan
-    if (pl.n == 14 && !crt_generic) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
+    if (pl.n == 14) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
     else hipLaunchKernelGGL(oz_crt_kernel<0>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
     return hipGetLastError();
 }

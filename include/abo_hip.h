@@ -534,8 +534,9 @@ int32_t abo_last_error(char* buf, size_t cap);
 int32_t abo_abi_version(void);
 
 /* --- building blocks exposed for tests and profiling (all buffers DEVICE memory) ------------------
- * C[i][j] = alpha·Σ_k A[i][k]·B[j][k] + beta·C[i][j]; M, N multiples of 128, K multiple of 16,
- * leading dimensions even.  Exercises the fp64 MFMA tile core every solver stage is built on. */
+ * NOT part of the shipped ABI: compiled only into the test build of the library (-DABO_TEST_HOOKS:
+ * abstractbayesopt.jl_amd/lib/libabo_hip_test.so, what the GPU suite loads); libabo_hip.so exports none of them. */
+#ifdef ABO_TEST_HOOKS
 /* The int8-residue engine's host constants for n moduli (no GPU needed): p[16] moduli, tables[4][16] = {1/p, 2^26 mod p
  * (symmetric), head and tail of (P/p)·((P/p)⁻¹ mod p)}, scal[3] = {head of P, tail of P, 1/P}, *eP with 2^eP ≤ P/4. */
 int32_t abo_test_oz_plan(int32_t n, int32_t* p, double* tables, double* scal, int32_t* eP);
@@ -552,9 +553,12 @@ int32_t abo_test_acq_grad_terms(abo_gp* gp, const abo_acq_term* terms, int32_t n
                                 double* f, double* grad);
 /* out[i] = kappa(family, d2[i]) evaluated with the device math of the kernel-matrix generator */
 int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double* out, int64_t n);
+/* C[i][j] = alpha·Σ_k A[i][k]·B[j][k] + beta·C[i][j]; M, N multiples of 128, K multiple of 16,
+ * leading dimensions even.  Exercises the fp64 MFMA tile core every solver stage is built on. */
 int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, double* C, int32_t M,
                          int32_t N, int32_t K, int64_t lda, int64_t ldb, int64_t ldc, double alpha,
                          double beta);
+#endif /* ABO_TEST_HOOKS */
 
 #ifdef __cplusplus
 }

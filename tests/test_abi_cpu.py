@@ -16,15 +16,40 @@ def _has_gpu():
     return torch.cuda.is_available()
 
 
-def test_library_exports_every_declared_symbol():
+def _declared():
+    """(shipped surface, test hooks) as include/abo_hip.h declares them: the hooks sit between #ifdef ABO_TEST_HOOKS and its #endif"""
     hdr = open(os.path.join(ROOT, "include", "abo_hip.h")).read()
-    declared = sorted(set(re.findall(r"^int32_t\s+(abo_\w+)\s*\(", hdr, flags=re.M)))
-    assert declared, "no declarations parsed"
-    assert sorted(abo._lib.EXPORTS) == declared
-    lib = abo._lib.lib()
-    for name in declared:
+    i0, i1 = hdr.index("#ifdef ABO_TEST_HOOKS"), hdr.index("#endif /* ABO_TEST_HOOKS */")
+    proto = r"^int32_t\s+(abo_\w+)\s*\("
+    hooks = sorted(set(re.findall(proto, hdr[i0:i1], flags=re.M)))
+    shipped = sorted(set(re.findall(proto, hdr[:i0] + hdr[i1:], flags=re.M)))
+    return hdr, shipped, hooks
+
+
+def test_library_exports_every_declared_symbol():
+    hdr, shipped, hooks = _declared()
+    assert shipped and hooks and all(h.startswith("abo_test_") for h in hooks) and not any(s.startswith("abo_test_") for s in shipped)
+    assert sorted(abo._lib.EXPORTS) == shipped and sorted(abo._lib.TEST_EXPORTS) == hooks
+    lib = abo._lib.lib()                 # the test suite runs on the test build (tests/conftest.py): surface + hooks
+    assert lib.has_test_hooks
+    for name in shipped + hooks:
         assert getattr(lib, name) is not None
     assert lib.abo_abi_version() == int(re.search(r"#define ABO_ABI_VERSION (\d+)", hdr).group(1))
+
+
+def test_shipped_library_exports_the_documented_surface_and_nothing_else():
+    """libabo_hip.so — what a Julia host links, what bench.py and smoke() load — defines every entry point of the header's documented
+    surface and NONE of the abo_test_* building blocks (six test hooks were exported from the shipped library)."""
+    import subprocess
+    _, shipped, hooks = _declared()
+    out = subprocess.run(["nm", "-D", "--defined-only", abo._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    abo_syms = sorted(s for s in syms if s.startswith("abo_"))
+    assert abo_syms == shipped, (sorted(set(abo_syms) - set(shipped)), sorted(set(shipped) - set(abo_syms)))
+    assert not any(h in syms for h in hooks)
+    out_t = subprocess.run(["nm", "-D", "--defined-only", abo._lib.LIB_TEST_PATH], capture_output=True, text=True, check=True).stdout
+    syms_t = {ln.split()[-1] for ln in out_t.splitlines() if ln.strip()}
+    assert sorted(s for s in syms_t if s.startswith("abo_")) == sorted(shipped + hooks)
 
 
 def test_struct_layout_matches_header():

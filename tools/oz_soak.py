@@ -1,6 +1,5 @@
 """Race / determinism screen of the int8-residue engine: the same posterior variance over and over at several sizes (every call must
-return the same bits), printed as one hash per size — run once per GEMM variant (default LDS-DMA kernel, ABO_OZ_REGSTAGE=1,
-ABO_OZ_MFMA32=1): exact integer products mean all three must print the same hashes."""
+return the same bits), printed as one hash per size."""
 import hashlib, sys
 import numpy as np
 sys.path.insert(0, ".")
