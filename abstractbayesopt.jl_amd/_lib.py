@@ -21,7 +21,7 @@ EXPORTS = ["abo_create", "abo_set_contraction", "abo_create_grad", "abo_predict_
            "abo_mgpu_cand_qei", "abo_refine", "abo_optimize_acquisition", "abo_mgpu_optimize_acquisition", "abo_fit_acq", "abo_mgpu_create_grad", "abo_mgpu_append_grad", "abo_mgpu_cand_get", "abo_acq_terms", "abo_acq_lhs", "abo_refine_terms",
            "abo_optimize_acquisition_terms", "abo_mgpu_optimize_acquisition_terms",
            "abo_set_qei_block", "abo_cand_qei", "abo_cand_qei_begin", "abo_cand_qei_top", "abo_cand_qei_block", "abo_cand_qei_pick",
-           "abo_cand_qei_end", "abo_cand_qei_has", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats", "abo_cand_qei_eligible"]
+           "abo_cand_qei_end", "abo_cand_qei_has", "abo_cand_qei_stats", "abo_mgpu_cand_qei_stats", "abo_cand_qei_eligible", "abo_fill_distance"]
 TEST_EXPORTS = ["abo_test_gemm_nt", "abo_test_kappa", "abo_test_oz_plan", "abo_test_oz_contract", "abo_test_acq_grad",
                 "abo_test_acq_grad_terms"]
 ABI_VERSION = 7
@@ -136,6 +136,7 @@ def lib():
     L.abo_nlml_grad.argtypes = [vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]
     L.abo_lhs.argtypes = [i32, i64, i32, vp, vp, C.c_uint64, i64, i64, vp]
     L.abo_score.argtypes = [i32, vp, vp, i64, i32, f64, f64, vp]
+    L.abo_fill_distance.argtypes = [i32, vp, i64, i32, i32, vp, i64, i32, C.POINTER(f64)]
     L.abo_get_factor.argtypes = [vp, vp, vp, vp]
     L.abo_get_n.argtypes = [vp, C.POINTER(i64), C.POINTER(i32)]
     L.abo_get_data.argtypes = [vp, vp, vp]

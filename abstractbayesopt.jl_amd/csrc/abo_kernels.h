@@ -338,6 +338,8 @@ struct QeiStepArgs {
 };
 hipError_t launch_qei_step(const QeiStepArgs& a, int nwg, hipStream_t st);
 
+// out[0] = max_s min_i ‖S_s − X_i‖ (out: one double in device memory)
+hipError_t launch_fill_distance(const double* X, int64_t N, int d, const double* S, int64_t ns, double* out, hipStream_t s);
 // Z[(j−j0)·d + c] for j in [j0, j0+count): Latin-hypercube points of an n-point design (device lower/upper)
 hipError_t launch_lhs(double* Z, int64_t n, int d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                       int64_t count, hipStream_t s);

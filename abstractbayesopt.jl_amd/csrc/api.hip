@@ -3218,6 +3218,31 @@ int32_t abo_pool_trim(int32_t device) {
     return ABO_OK;
 }
 
+int32_t abo_fill_distance(int32_t device, const double* X, int64_t N, int32_t d, int32_t x_space, const double* S, int64_t n_samples,
+                          int32_t s_space, double* out) {
+    if (!X || !S || !out) return fail(ABO_EINVAL, "abo_fill_distance: null argument");
+    if (N < 1 || n_samples < 1 || d < 1 || d > 65536) return fail(ABO_EINVAL, "abo_fill_distance: bad sizes");
+    if (device < 0 || device > 15) return fail(ABO_EINVAL, "abo_fill_distance: bad device %d", device);
+    HIPCHK(hipSetDevice(device));
+    ScratchBuf xb(device, nullptr), sb(device, nullptr), ob(device, nullptr);
+    const double *Xd = X, *Sd = S;
+    if (x_space != ABO_DEVICE) {
+        HIPCHK(xb.b.ensure(sizeof(double) * (size_t)N * d));
+        HIPCHK(hipMemcpyAsync(xb.b.p, X, sizeof(double) * (size_t)N * d, hipMemcpyHostToDevice, nullptr));
+        Xd = xb.b.as<double>();
+    }
+    if (s_space != ABO_DEVICE) {
+        HIPCHK(sb.b.ensure(sizeof(double) * (size_t)n_samples * d));
+        HIPCHK(hipMemcpyAsync(sb.b.p, S, sizeof(double) * (size_t)n_samples * d, hipMemcpyHostToDevice, nullptr));
+        Sd = sb.b.as<double>();
+    }
+    HIPCHK(ob.b.ensure(sizeof(double)));
+    HIPCHK(launch_fill_distance(Xd, N, d, Sd, n_samples, ob.b.as<double>(), nullptr));
+    HIPCHK(hipMemcpyAsync(out, ob.b.p, sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return ABO_OK;
+}
+
 int32_t abo_lhs(int32_t device, int64_t n, int32_t d, const double* lower, const double* upper, uint64_t seed, int64_t j0,
                 int64_t count, double* Z_dev) {
     if (!lower || !upper || !Z_dev) return fail(ABO_EINVAL, "abo_lhs: null argument");

@@ -44,157 +44,68 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// piv = sqrt(d), rp = 1/piv for d > 0 in one Goldschmidt chain (v_rsq_f64 seed, two coupled Newton steps, one
-// residual correction each: ≤ 1 ulp) — a third of the dependent instructions of an IEEE sqrt followed by an IEEE
-// divide, and this chain is the serial spine of the whole factorisation.  Valid for every positive NORMAL d (the
-// caller rejects anything else as "not positive definite"); no branches.
-__device__ __forceinline__ void sqrt_and_reciprocal(double d, double& piv, double& rp) {
-    const double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    piv = fma(fma(-g, g, d), h, g);
-    const double q = h + h;
-    rp = fma(fma(-piv, q, 1.0), q, q);
-}
-
 // The register step of a 16-column sub-step (phase 1, (1)+(2) below), shared by every build of the diagonal-block kernel: lanes 0-15
 // of the wave hold the 16 rows of the diagonal sub-block, lanes 16-63 rows below it, one row (16 doubles) per lane, in x[].
-// Right-looking, and scheduled that way: column j's pivot chain (v_rsq_f64 + 14 dependent fp64 operations, the steps of
-// sqrt_and_reciprocal) is the serial spine, its update of column j+1 is the only update the next pivot waits for, and the
-// 14 − j updates column j owes to the columns beyond are independent filler.  Left to itself the compiler either sinks
-// every update of a column to just before that column's pivot (left-looking: j more dependent operations on the spine) or
-// issues the chain back to back with nothing in its latency; here one owed update of column j−1 is issued behind every
-// step of column j's chain, and the scheduling fences pin that order.  Every element sees the same operations in the same
-// order as in the plain loop: same bits.
-// Returns the first column whose pivot is not a positive normal number (SB if none; wave-uniform); myrp = 1/pivot of the lane's own
-// column (lanes 0-15).
-__device__ __forceinline__ int register_potf2_step(double (&x)[16], int lane, double& myrp) {
-    constexpr int SBX = 16;
-    int failcol = SBX;
-    myrp = 0.0;
-    double d = readlane_f64(x[0], 0);
-#pragma unroll
-    for (int j = 0; j < SBX; ++j) {                    // straight-line: a failed pivot poisons what follows (never
-                                                       // stored) instead of branching out of the dependent chain
-        const int jp = j > 0 ? j - 1 : 0;              // the column whose owed updates fill this chain
-        int kq = j + 1;
-#define ABO_FILL() do { if (j > 0 && kq < SBX) { x[kq] = fma(-x[jp], readlane_f64(x[jp], kq), x[kq]); ++kq; } \
-                        __builtin_amdgcn_sched_barrier(0); } while (0)
-        failcol = (failcol == SBX && !(d >= 2.3e-308)) ? j : failcol;       // also catches NaN; wave-uniform
-        const double y = __builtin_amdgcn_rsq(d);
-        ABO_FILL();
-        double g = d * y, h = 0.5 * y;
-        ABO_FILL();
-        double r = fma(-h, g, 0.5);
-        ABO_FILL();
-        g = fma(g, r, g);
-        h = fma(h, r, h);
-        ABO_FILL();
-        r = fma(-h, g, 0.5);
-        ABO_FILL();
-        g = fma(g, r, g);
-        h = fma(h, r, h);
-        ABO_FILL();
-        const double e = fma(-g, g, d);
-        ABO_FILL();
-        const double piv = fma(e, h, g);
-        const double q = h + h;
-        ABO_FILL();
-        const double u = fma(-piv, q, 1.0);
-        ABO_FILL();
-        const double rp = fma(u, q, q);
-        ABO_FILL();
-        const double xs = x[j] * rp;
-        ABO_FILL();
-        x[j] = (lane == j) ? piv : xs;
-        myrp = (lane == j) ? rp : myrp;
-        ABO_FILL();
-#pragma unroll
-        for (int rest = 0; rest < SBX; ++rest) ABO_FILL();          // what column j−1 still owes (none once kq reaches SB)
-#undef ABO_FILL
-        if (j + 1 < SBX) {
-            x[j + 1] = fma(-x[j], readlane_f64(x[j], j + 1), x[j + 1]);
-            d = readlane_f64(x[j + 1], j + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // (column 15 owes nothing)
-    return failcol;
-}
-
-// The same register step with the owed updates fed from LDS (round 5; potf2_pipe_kernel): the step is bound by the ≈ 76 issue slots a
-// column takes, not by its dependent chain (tools/dp_latency_probe: a dependent v_fma_f64 issues every 5.2 cycles, the chain and its
-// v_readlane round trips come to ≈ 130 of a column's 390 cycles), and 26 of the slots are the v_readlane pairs that broadcast
-// L[k][j−1] for the 13 owed updates.  Here every lane writes its entry of column j to a 64-double buffer of its wave when the column is
-// final (lanes 0-15: L[lane][j]) and reads the entries it owes updates with back as broadcasts, two per ds_read_b128, at the top of
-// the next column's chain — the LDS queue of a wave is in order, no synchronisation.  The update of column j + 1 (the next pivot
-// waits for it) keeps its v_readlane.  The pivot test is one select per column (the pivot's argument kept in its own lane) and one
-// ballot at the end instead of six scalar instructions per column.  Same values, same operations in the same order: same bits.
+// Right-looking: column j's pivot chain is the serial spine, its update of column j+1 is the only update the next pivot waits for, and
+// the 14 − j updates column j owes to the columns beyond are filler issued behind the steps of the NEXT column's chain (the
+// scheduling fences pin that order: left to itself the compiler sinks every update of a column to just before that column's pivot).
+// The step is bound by the VALU slots a column takes, not by its dependent chain (tools/dp_latency_probe: a dependent v_fma_f64 issues
+// every 5.2 cycles), so round 6 — parity is the oracle's tolerance, no longer round 4's bits — cut slots:
+//   * the chain computes ONLY rp = 1/√d (v_rsq_f64 seed, two coupled Goldschmidt steps: 9 operations where √d and 1/√d to ≤ 1 ulp each
+//     took 14); the diagonal entry is L_jj = d·rp like every other entry of the column (≤ 1.5 ulp from √d; everything downstream divides
+//     by multiplying with rp, so factor and inverse stay consistent with each other);
+//   * no per-column selects: the pivot's reciprocal goes to LDS (dinv) from one lane, the pivot test is one compare on the wave-uniform
+//     argument, accumulated on the scalar unit;
+//   * the entries of column j−1 a column owes updates with come from a 64-double LDS buffer of the wave, written when the column is
+//     final and read back as broadcasts, two per ds_read_b128 (the LDS queue of a wave is in order, no synchronisation) — not by
+//     v_readlane pairs; only the update of column j + 1 (the next pivot waits for it) keeps its v_readlane.
+// Returns the mask of columns whose pivot argument was not a positive normal number (bit j; wave-uniform; NaN included).
 typedef __attribute__((address_space(3))) double lds_f64;
-__device__ __forceinline__ int register_potf2_step_lds(double (&x)[16], int lane, double& myrp, lds_f64* cb) {
+__device__ __forceinline__ unsigned register_potf2_step_lds(double (&x)[16], int lane, lds_f64* cb, lds_f64* dinv_out) {
     constexpr int SBX = 16;
-    myrp = 0.0;
-    double dsave = 1.0;
+    unsigned bad = 0;
     double d = readlane_f64(x[0], 0);
 #pragma unroll
     for (int j = 0; j < SBX; ++j) {
         const int jp = j > 0 ? j - 1 : 0;              // the column whose owed updates fill this chain
-        // the entries of column j−1 this column's chain owes updates with come from the wave's buffer; NRL > 0: the NRL nearest
-        // columns by v_readlane instead, their updates first (the LDS round trip, 72 cycles, is half a chain) — measured with NRL = 3:
-        // 2.44 µs a step against 2.40, the column is bound by its issue slots and a v_readlane pair costs two more than a read
-        constexpr int NRL = 0;
         double w[SBX];
         if (j > 0) {
 #pragma unroll
-            for (int k = j + 1 + NRL; k < SBX; ++k) w[k] = cb[k];       // L[k][j−1] (written at the end of column j−1)
+            for (int k = j + 1; k < SBX; ++k) w[k] = cb[k];           // L[k][j−1] (written at the end of column j−1)
         }
         __builtin_amdgcn_sched_barrier(0);
         int kq = j + 1;
-#define ABO_FILL() do { if (j > 0 && kq < SBX) { x[kq] = fma(-x[jp], kq <= j + NRL ? readlane_f64(x[jp], kq) : w[kq], x[kq]); ++kq; } \
+#define ABO_FILL() do { if (j > 0 && kq < SBX) { x[kq] = fma(-x[jp], w[kq], x[kq]); ++kq; } \
                         __builtin_amdgcn_sched_barrier(0); } while (0)
-#define ABO_FILL_RL() do { if (NRL > 0) ABO_FILL(); else __builtin_amdgcn_sched_barrier(0); } while (0)
-        dsave = (lane == j) ? d : dsave;
+        bad |= __ballot(d >= 2.3e-308) == 0ull ? (1u << j) : 0u;      // one v_cmp on the uniform argument; the rest is scalar
         const double y = __builtin_amdgcn_rsq(d);
-        ABO_FILL_RL();
+        __builtin_amdgcn_sched_barrier(0);
         double g = d * y, h = 0.5 * y;
-        ABO_FILL_RL();
+        __builtin_amdgcn_sched_barrier(0);
         double r = fma(-h, g, 0.5);
-        ABO_FILL_RL();                                 // (the reads are back about six instructions on)
+        ABO_FILL();                                    // (the LDS reads are back about six instructions on)
         g = fma(g, r, g);
         h = fma(h, r, h);
-        __builtin_amdgcn_sched_barrier(0);
+        ABO_FILL();
+        ABO_FILL();
         r = fma(-h, g, 0.5);
-        __builtin_amdgcn_sched_barrier(0);
-        g = fma(g, r, g);
+        ABO_FILL();
+        ABO_FILL();
         h = fma(h, r, h);
-        __builtin_amdgcn_sched_barrier(0);
-        const double e = fma(-g, g, d);
         ABO_FILL();
         ABO_FILL();
-        const double piv = fma(e, h, g);
-        const double q = h + h;
+        const double rp = h + h;
         ABO_FILL();
         ABO_FILL();
-        const double u = fma(-piv, q, 1.0);
+        x[j] = x[j] * rp;                              // the whole column, its diagonal entry included
+        if (dinv_out && lane == 0) dinv_out[j] = rp;
         ABO_FILL();
-        ABO_FILL();
-        const double rp = fma(u, q, q);
-        ABO_FILL();
-        ABO_FILL();
-        const double xs = x[j] * rp;
-        ABO_FILL();
-        x[j] = (lane == j) ? piv : xs;
-        myrp = (lane == j) ? rp : myrp;
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < SBX) {
-            if (j + 2 + NRL < SBX) cb[lane] = x[j];               // column j for the updates it owes through the buffer
+            if (j + 2 < SBX) cb[lane] = x[j];                         // column j for the updates it owes through the buffer
             const double lnext = readlane_f64(x[j], j + 1);
-            ABO_FILL();                                            // (two more in the latency of the v_readlane round trips)
+            ABO_FILL();                                            // (in the latency of the v_readlane round trip)
+            ABO_FILL();
             x[j + 1] = fma(-x[j], lnext, x[j + 1]);
             ABO_FILL();
             d = readlane_f64(x[j + 1], j + 1);
@@ -202,11 +113,9 @@ __device__ __forceinline__ int register_potf2_step_lds(double (&x)[16], int lane
 #pragma unroll
         for (int rest = 0; rest < SBX; ++rest) ABO_FILL();          // (none left: 14 slots above)
 #undef ABO_FILL
-#undef ABO_FILL_RL
         __builtin_amdgcn_sched_barrier(0);
     }
-    const unsigned long long bad = __ballot(!(dsave >= 2.3e-308)) & 0xffffull;      // lanes 0-15: column = lane; also catches NaN
-    return bad ? __builtin_ctzll(bad) : SBX;
+    return bad;
 }
 
 // One workgroup (16 waves), the 128×128 block resident in LDS (129 KB of the CU's 160 KB), worked on
@@ -251,6 +160,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
                                                         int64_t* info, FitSmallArgs fs) {
     __shared__ double a[NB * LDA];
     __shared__ double dinv[NB];
+    __shared__ __attribute__((aligned(16))) double colbuf[3][64];     // per register-step wave: the column just finished
     __shared__ int fail;
     __shared__ double xs[MODE == 3 ? NB * 16 : 1];          // mode 3: scaled inputs, δ and the intermediate of the two solves
     __shared__ double dl[MODE == 3 ? NB : 1];
@@ -329,16 +239,14 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
-            double myrp;
-            const int failcol = register_potf2_step(x, lane, myrp);
-            if (failcol < SB) {
-                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
+            const unsigned badc = register_potf2_step_lds(x, lane, (lds_f64*)colbuf[wave], wave == 0 ? (lds_f64*)&dinv[o] : (lds_f64*)nullptr);
+            if (badc) {
+                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + __builtin_ctz(badc) + 1; }
             } else if (valid) {
                 if (lane >= SB) {
 #pragma unroll
                     for (int c = 0; c < SB; ++c) AA(row, o + c) = x[c];
                 } else if (wave == 0) {
-                    dinv[o + lane] = myrp;
 #pragma unroll
                     for (int c = 0; c < SB; ++c)
                         if (c <= lane) AA(row, o + c) = x[c];      // strict upper part of the registers is scratch
@@ -651,16 +559,14 @@ __device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double 
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
-            double myrp;
-            const int failcol = register_potf2_step_lds(x, lane, myrp, (lds_f64*)colbuf[wave]);
-            if (failcol < SB) {
-                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + failcol + 1; }
+            const unsigned badc = register_potf2_step_lds(x, lane, (lds_f64*)colbuf[wave], wave == 0 ? (lds_f64*)&dinv[o] : (lds_f64*)nullptr);
+            if (badc) {
+                if (t == 0) { fail = 1; *info = (int64_t)r0 + o + __builtin_ctz(badc) + 1; }
             } else if (valid) {
                 if (lane >= SB) {
 #pragma unroll
                     for (int c = 0; c < SB; ++c) AA(row, o + c) = x[c];
                 } else if (wave == 0) {
-                    dinv[o + lane] = myrp;
 #pragma unroll
                     for (int c = 0; c < SB; ++c)
                         if (c <= lane) AA(row, o + c) = x[c];

@@ -585,6 +585,39 @@ hipError_t launch_topk(const double* scores, int64_t M, int k, int64_t idx_base,
     return hipGetLastError();
 }
 
+// ---- Monte-Carlo fill distance (src/BO_utils.jl:140-159): h = max over sample points of the distance to the nearest training point ----
+// One wave per sample: lanes stride the training points (squared distance summed over the coordinates in index order), min by the xor
+// tree, sqrt, then max over the samples through the order-preserving integer image of a non-negative double (an integer max: exact
+// and order-independent — deterministic).
+__global__ void __launch_bounds__(256) fill_distance_kernel(const double* __restrict__ X, int64_t N, int d, const double* __restrict__ S,
+                                                             int64_t ns, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t si = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (si >= ns) return;
+    const double* sp = S + si * d;
+    double best = HUGE_VAL;
+    for (int64_t i = lane; i < N; i += 64) {
+        const double* x = X + i * d;
+        double r = 0.0;
+        for (int c = 0; c < d; ++c) {
+            const double e = x[c] - sp[c];
+            r = fma(e, e, r);
+        }
+        best = fmin(best, r);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) best = fmin(best, __shfl_xor(best, o));
+    if (lane == 0) atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(best)));
+}
+
+hipError_t launch_fill_distance(const double* X, int64_t N, int d, const double* S, int64_t ns, double* out, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), s);            // +0.0: below every distance
+    if (e != hipSuccess || ns <= 0 || N <= 0) return e;
+    hipLaunchKernelGGL(fill_distance_kernel, dim3((unsigned)((ns + 3) / 4)), dim3(256), 0, s, X, N, d, S, ns,
+                       reinterpret_cast<unsigned long long*>(out));
+    return hipGetLastError();
+}
+
 __global__ void gather_points_kernel(const double* Z, const int64_t* idx, int64_t idx_base, int k, int d, double* out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= k * d) return;

@@ -198,11 +198,19 @@ __global__ void __launch_bounds__(256) oz_quant_kernel(OzQuantArgs a) {
 // Workgroup = 8 waves as 4 (j) × 2 (i); wave tile 64 (j) × 128 (i) (the kernel and its LDS ring: "16×16×64 GEMM fed by LDS-DMA" below).
 constexpr int OZ_T = 256;                  // tile edge
 
+// U, the residues of the products, lives in 64 KB blocks — one per (256 × 256 tile, modulus): [256 rows i][256 candidates j], the n
+// blocks of a tile back to back, tiles of one candidate block tj back to back over ti.  Round 6 (the plane-major [l][i][j] layout of
+// rounds 2 - 5 made the reconstruction read 1 KB pieces 65 KB apart — 5.2 TB/s; a block is written by ONE epilogue as a contiguous
+// 64 KB run and read by the reconstruction as contiguous 32 KB runs per modulus).
+__host__ __device__ __forceinline__ int64_t oz_u_block(int ti, int tj, int l, int Ti, int n) {
+    return (((int64_t)tj * Ti + ti) * n + l) * (int64_t)(OZ_T * OZ_T);
+}
+
 struct OzGemmArgs {
     const int8_t* KR;      // [n][Mc256][ldk]
     const int8_t* WR;      // [n][Np256][ldw]
-    int8_t* U;             // [n][Np256][ldu]
-    int64_t ldu, sK, sW, sU;
+    int8_t* U;             // [Tj][Ti][n] blocks of 64 KB: the residues of ONE 256 × 256 tile and modulus, [256 rows i][256 candidates j] (oz_u_block)
+    int64_t sK, sW;
     int nhs;               // 64-byte half-stages per row of a residue plane (Np256 / 64): plane block (R, H) at (R·nhs + H)·16 KB
     int Ti, Tj, n;
     int tjg;               // column blocks per group (multiple of 8; 64 unless Tj is smaller)
@@ -406,13 +414,13 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
         for (int nn = 0; nn < 8; ++nn) acc[m][nn][0] = oz_mod_pack4_mad(acc[m][nn][0], acc[m][nn][1], acc[m][nn][2], acc[m][nn][3], invp, pm);
     OZ_PROBE_T(pe1);
     OZ_PROBE_ADD(4, pe1);                              // (probe build: Σ of the clock behind the residue arithmetic)
-    int8_t* up = a.U + (int64_t)l * a.sU + ((int64_t)ti * OZ_T) * a.ldu + (int64_t)tj * OZ_T;
+    int8_t* up = a.U + oz_u_block(ti, tj, l, a.Ti, a.n);      // the tile's 64 KB block: rows of 256 bytes, contiguous
     const int r15 = lane & 15;
     // a thread's two 16-byte pieces of a pass: rows tid/16 and tid/16 + 32 (same rotation: the rows are 32 apart), chunk tid%16
     const int sr = tid >> 4, sc = tid & 15;
     const unsigned lds_off = (unsigned)(sr * 256 + ((16 * sc + 16 * (sr & 15)) & 255));
-    const unsigned g_off = (unsigned)(sr * (int)a.ldu + 16 * sc);         // < 2^24: 32-bit lane offset on a uniform row base
-    const unsigned g_step = (unsigned)(32 * (int)a.ldu);
+    const unsigned g_off = (unsigned)(sr * OZ_T + 16 * sc);               // 32-bit lane offset on a uniform row base
+    const unsigned g_step = (unsigned)(32 * OZ_T);
 #pragma unroll
     for (int P = 0; P < 5; ++P) {
         if (P < 4 && wi == (P >> 1)) {              // pass P: W rows 64P … 64P+63 of the tile = row groups nn = 4(P&1) … +3 of wave row P/2
@@ -426,9 +434,9 @@ __device__ __forceinline__ void oz16p_epilogue(const OzGemmArgs& a, char* slot3,
                     *reinterpret_cast<int*>(buf + r * 256 + ((jl + 16 * r15) & 255)) = acc[m][4 * (P & 1) + q][0];
                 }
         }
-        if (P > 0) {                                // rows of pass P−1 leave as 256-byte segments of U[l][i][·]
+        if (P > 0) {                                // rows of pass P−1 leave as ONE contiguous 16 KB run of the tile's block
             const char* buf = slot3 + ((P - 1) & 1) * 16384;
-            int8_t* rows = up + (int64_t)(64 * (P - 1)) * a.ldu;          // uniform
+            int8_t* rows = up + (64 * (P - 1)) * OZ_T;                    // uniform
             const v4i_t w0 = *reinterpret_cast<const v4i_t*>(buf + lds_off);
             const v4i_t w1 = *reinterpret_cast<const v4i_t*>(buf + lds_off + 32 * 256);
             *reinterpret_cast<v4i_t*>(rows + g_off) = w0;
@@ -612,8 +620,8 @@ __global__ void __launch_bounds__(512) oz_gemm16p_kernel(OzGemmArgs a, int total
 // ---- reconstruction + squares + column sums ------------------------------------------------------------------------------------------
 // partial[tb][j] = Σ_{i in row block tb (128 rows), i < nvalid} V[i][j]²,  V = CRT(U[·][i][j])·2^−(s_i + sK).
 struct OzCrtArgs {
-    const int8_t* U;
-    int64_t ldu, sU;
+    const int8_t* U;       // oz_u_block layout
+    int Ti;                // 256-row blocks of U (Np256 / 256)
     const int* sexp;       // s_i
     int sK;
     const int* bad_row;    // [Np256] W rows holding non-finite values (or nullptr)
@@ -627,106 +635,92 @@ struct OzCrtArgs {
     OzPlan pl;
 };
 
-// A workgroup = 4 waves × 64 lanes × 16 candidates over one 128-row block: each wave reconstructs 32 of the rows (one 16-byte load
-// per residue plane and row), the four partial column sums meet in LDS in a fixed order.
-// NM > 0: the moduli count is the compile-time NM (the default plan): the residues of a row's NM planes are fetched by NM loads
-// issued back to back — each wave keeps NM × 1 KiB in flight instead of one load per loop trip, which is what a kernel that reads
-// 7.5 GB once needs to approach the HBM rate — and read past the caches (non-temporal: nothing here is touched twice).
+// A workgroup = 4 waves over the 128 rows × 256 candidates that one tile of U holds for row block tb: lane (cg = lane % 16, rq = lane / 16)
+// takes the 16 candidates 16·cg … of the rows ≡ rq (mod 4) of its wave's 32 rows — a wave instruction reads 4 rows × 256 bytes = ONE
+// contiguous KB of a modulus' block, eight of them back to back per modulus.  The column sums over a wave's rows meet by two xor
+// shuffles (rq), the four waves' in LDS, in a fixed order.
+// NM > 0: the moduli count is the compile-time NM (the default plan): the residues of a row's NM planes are fetched by NM loads issued
+// back to back — each wave keeps NM × 1 KiB in flight instead of one load per loop trip, which is what a kernel that reads 7.5 GB once
+// needs to approach the HBM rate — and read past the caches (non-temporal: nothing here is touched twice).
 template <int NM>
 __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
-    __shared__ double red[3][64][17];
-    const int tb = blockIdx.y;
+    __shared__ double red[3][16][17];
+    const int tb = blockIdx.y, tj = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = (blockIdx.x * 64 + lane) * 16;
+    const int cg = lane & 15, rq = lane >> 4;
+    const int j = tj * OZ_T + 16 * cg;
     const bool live = j < a.Mc;                             // Mc is a multiple of 128: a thread's 16 candidates are all in or all out
     double sum[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) sum[b] = 0.0;
     bool bad = false;
-    const int n = a.pl.n;
-    const int i0 = tb * 128 + wave * 32;
-    int i1 = i0 + 32;
-    if (i1 > a.nvalid) i1 = a.nvalid;
+    const int n = NM > 0 ? NM : a.pl.n;
+    const int rt0 = (tb & 1) * 128 + wave * 32 + rq;        // this lane's first row inside the tile
+    const int8_t* ub = a.U + oz_u_block(tb >> 1, tj, 0, a.Ti, n) + (int64_t)rt0 * OZ_T + 16 * cg;
+    const int ig0 = (tb >> 1) * OZ_T + rt0;                 // … and in the matrix
     if (live) {
-        for (int i = i0; i < i1; ++i) {
-            const int8_t* u = a.U + (int64_t)i * a.ldu + j;
+        for (int step = 0; step < 8; ++step) {
+            const int i = ig0 + 4 * step;
+            if (i >= a.nvalid) break;                       // rows ≥ nvalid of the last block are padding for this view
+            const int8_t* u = ub + 4 * step * OZ_T;
+            v4i_t wl[NM > 0 ? NM : 1];
             if constexpr (NM > 0) {
-                v4i_t wl[NM];
 #pragma unroll
-                for (int l = 0; l < NM; ++l) wl[l] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(u + (int64_t)l * a.sU));
-                const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
-                if (a.bad_row && a.bad_row[i]) bad = true;
-                // four candidates (one dword of every plane) at a time: 8 partial sums live instead of 32 — 4 waves per SIMD
-                // instead of 3 (167 → ≤ 128 VGPRs); every product sees the same operations in the same order
+                for (int l = 0; l < NM; ++l) wl[l] = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(u + (int64_t)l * (OZ_T * OZ_T)));
+            }
+            const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
+            if (a.bad_row && a.bad_row[i]) bad = true;
+            // four candidates (one dword of every plane) at a time: 8 partial sums live instead of 32 — 4 waves per SIMD instead of 3
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    double c1[4], c2[4];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                double c1[4], c2[4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) { c1[b] = 0.0; c2[b] = 0.0; }
+                for (int b = 0; b < 4; ++b) { c1[b] = 0.0; c2[b] = 0.0; }
 #pragma unroll
-                    for (int l = 0; l < NM; ++l) {
-                        const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
-                        const unsigned wx = (unsigned)wl[l][g4] ^ 0x80808080u;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            // signed byte → double without v_cvt_f64_i32 (quarter rate on this chip: with 14 of them per product
-                            // the kernel was bound by the conversion, not by its 14 bytes per product): the byte biased by 128
-                            // becomes the low mantissa bits of 2^52, and (2^52 + b + 128) − (2^52 + 128) is the byte's value, exactly
-                            const unsigned ub = (wx >> (8 * b)) & 0xffu;
-                            const double ud = __hiloint2double(0x43300000, (int)ub) - 4503599627370624.0;
-                            c1[b] = __builtin_fma(ud, s1, c1[b]);
-                            c2[b] = __builtin_fma(ud, s2, c2[b]);
-                        }
-                    }
+                for (int l = 0; l < n; ++l) {
+                    const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
+                    unsigned wx;
+                    if constexpr (NM > 0) wx = (unsigned)wl[l][g4] ^ 0x80808080u;
+                    else wx = (unsigned)*reinterpret_cast<const int*>(u + (int64_t)l * (OZ_T * OZ_T) + 4 * g4) ^ 0x80808080u;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
-                        const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
-                        const double v = cp * sc;
-                        sum[4 * g4 + b] = __builtin_fma(v, v, sum[4 * g4 + b]);
-                    }
-                }
-                continue;
-            }
-            double c1[16], c2[16];
-#pragma unroll
-            for (int b = 0; b < 16; ++b) { c1[b] = 0.0; c2[b] = 0.0; }
-            {
-                for (int l = 0; l < n; ++l) {
-                    const v4i_t w = *reinterpret_cast<const v4i_t*>(u + (int64_t)l * a.sU);
-                    const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
-#pragma unroll
-                    for (int b = 0; b < 16; ++b) {
-                        const double ud = (double)((w[b >> 2] << (24 - 8 * (b & 3))) >> 24);
+                        // signed byte → double without v_cvt_f64_i32 (quarter rate on this chip: with 14 of them per product the kernel
+                        // was bound by the conversion, not by its 14 bytes per product): the byte biased by 128 becomes the low
+                        // mantissa bits of 2^52, and (2^52 + b + 128) − (2^52 + 128) is the byte's value, exactly
+                        const unsigned ub8 = (wx >> (8 * b)) & 0xffu;
+                        const double ud = __hiloint2double(0x43300000, (int)ub8) - 4503599627370624.0;
                         c1[b] = __builtin_fma(ud, s1, c1[b]);
                         c2[b] = __builtin_fma(ud, s2, c2[b]);
                     }
                 }
-            }
-            const double sc = __builtin_ldexp(1.0, -(a.sexp[i] + a.sK));
-            if (a.bad_row && a.bad_row[i]) bad = true;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
-                const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
-                const double v = cp * sc;
-                sum[b] = __builtin_fma(v, v, sum[b]);
+                for (int b = 0; b < 4; ++b) {
+                    const double Q = __builtin_rint((c1[b] + c2[b]) * a.pl.invP);
+                    const double cp = __builtin_fma(-Q, a.pl.P1, c1[b]) + __builtin_fma(-Q, a.pl.P2, c2[b]);
+                    const double v = cp * sc;
+                    sum[4 * g4 + b] = __builtin_fma(v, v, sum[4 * g4 + b]);
+                }
             }
         }
     }
     if (bad) sum[0] = __builtin_nan("");                    // a non-finite W row poisons the whole block of rows, as it does in fp64
-    if (wave > 0) {
 #pragma unroll
-        for (int b = 0; b < 16; ++b) red[wave - 1][lane][b] = sum[b];
+    for (int b = 0; b < 16; ++b) {                          // the four row classes of the wave: lanes cg, cg + 16, cg + 32, cg + 48
+        sum[b] += __shfl_xor(sum[b], 16);
+        sum[b] += __shfl_xor(sum[b], 32);
+    }
+    if (wave > 0 && rq == 0) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) red[wave - 1][cg][b] = sum[b];
     }
     __syncthreads();
-    if (wave == 0 && live) {
-        const bool anybad = sum[0] != sum[0] || red[0][lane][0] != red[0][lane][0] || red[1][lane][0] != red[1][lane][0] ||
-                            red[2][lane][0] != red[2][lane][0];
+    if (wave == 0 && rq == 0 && live) {
+        const bool anybad = sum[0] != sum[0] || red[0][cg][0] != red[0][cg][0] || red[1][cg][0] != red[1][cg][0] ||
+                            red[2][cg][0] != red[2][cg][0];
         const double nan = __builtin_nan("");
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            const double t = ((sum[b] + red[0][lane][b]) + red[1][lane][b]) + red[2][lane][b];
+            const double t = ((sum[b] + red[0][cg][b]) + red[1][cg][b]) + red[2][cg][b];
             const bool bb = anybad || (a.bad_col && a.bad_col[j + b]);
             const double cf = (a.rmode && oz_row_output(a.rmode, a.rper, a.r0, a.rpts, j + b) != 0) ? __builtin_ldexp(1.0, 2 * a.rtg) : 1.0;
             a.partial[(int64_t)tb * a.ldp + j + b] = bb ? nan : t * cf;
@@ -740,8 +734,8 @@ __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
 // candidates (one dword per residue plane and row) of 8 rows at a time, the wave's 8 × 256 block is transposed through LDS and leaves
 // as 64-byte runs of 8 consecutive rows per candidate.
 struct OzCrtVArgs {
-    const int8_t* U;
-    int64_t ldu, sU;
+    const int8_t* U;       // oz_u_block layout
+    int Ti;
     const int* sexp;
     int sK;
     const int* bad_row;
@@ -776,10 +770,10 @@ __global__ void __launch_bounds__(256) oz_crt_v_kernel(OzCrtVArgs a) {
             const int i = i0 + ii;
             double v[4] = {0.0, 0.0, 0.0, 0.0};
             if (live && i < a.nvalid) {
-                const int8_t* u = a.U + (int64_t)i * a.ldu + j;
+                const int8_t* u = a.U + oz_u_block(i >> 8, (int)blockIdx.x, 0, a.Ti, n) + (i & 255) * OZ_T + 4 * lane;
                 double c1[4] = {0.0, 0.0, 0.0, 0.0}, c2[4] = {0.0, 0.0, 0.0, 0.0};
                 for (int l = 0; l < n; ++l) {
-                    const int w = *reinterpret_cast<const int*>(u + (int64_t)l * a.sU);
+                    const int w = *reinterpret_cast<const int*>(u + (int64_t)l * (OZ_T * OZ_T));
                     const double s1 = a.pl.s1[l], s2 = a.pl.s2[l];
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
@@ -862,8 +856,8 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
 
     OzGemmArgs g{};
     g.KR = v.KR; g.WR = v.WR; g.U = v.U;
-    g.nhs = Np256 / 64; g.ldu = Mc256;
-    g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256; g.sU = (int64_t)Np256 * Mc256;
+    g.nhs = Np256 / 64;
+    g.sK = (int64_t)Mc256 * Np256; g.sW = (int64_t)Np256 * Np256;
     g.Ti = Np256 / OZ_T; g.Tj = Mc256 / OZ_T; g.n = pl.n;
     g.tjg = g.Tj >= 64 ? 64 : (int)pad_up(g.Tj, 8);
     for (int l = 0; l < pl.n; ++l) {
@@ -883,18 +877,18 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
 
     if (v.Vout) {
         OzCrtVArgs c{};
-        c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
+        c.U = v.U; c.Ti = g.Ti; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
         c.V = v.Vout; c.ldv = v.ldv; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
         c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
         hipLaunchKernelGGL(oz_crt_v_kernel, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
         return hipGetLastError();
     }
     OzCrtArgs c{};
-    c.U = v.U; c.ldu = Mc256; c.sU = g.sU; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
+    c.U = v.U; c.Ti = g.Ti; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
     c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
     c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
-    if (pl.n == 14) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
-    else hipLaunchKernelGGL(oz_crt_kernel<0>, dim3((v.Mc + 1023) / 1024, v.Np / 128), dim3(256), 0, s, c);
+    if (pl.n == 14) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
+    else hipLaunchKernelGGL(oz_crt_kernel<0>, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
     return hipGetLastError();
 }
 

@@ -66,11 +66,19 @@ def nlml_dual(model, params, xs, ys, value_and_grad=None):
     return Dual(v, part) if part is not None else v
 
 
-def monte_carlo_fill_distance(X_train, domain, n_samples: int = 10_000, rng=None) -> float:
-    """BO_utils.jl:140-159: sup over random x in the box of the distance to the nearest training point."""
+def monte_carlo_fill_distance(X_train, domain, n_samples: int = 10_000, rng=None, device=None) -> float:
+    """BO_utils.jl:140-159: sup over random x in the box of the distance to the nearest training point.  The samples are drawn on
+    the host (the reference draws them with its own RNG); device = a GPU ordinal: the N × n_samples scan runs there (abo_fill_distance —
+    on the host it is a second per call at N = 1024, most of a whole optimize_hyperparameters: profiles/r06_hyperparameter_latency.txt);
+    device = None: the NumPy scan below (host logic without a GPU, tests/test_host_logic_cpu.py)."""
     rng = np.random.default_rng() if rng is None else rng
-    X = np.asarray(X_train, dtype=np.float64)
-    xs = domain.lower + rng.random((n_samples, X.shape[1])) * (domain.upper - domain.lower)
+    X = np.ascontiguousarray(np.asarray(X_train, dtype=np.float64))
+    xs = np.ascontiguousarray(domain.lower + rng.random((n_samples, X.shape[1])) * (domain.upper - domain.lower))
+    if device is not None:
+        out = C.c_double()
+        _lib.check(_lib.lib().abo_fill_distance(int(device), X.ctypes.data, X.shape[0], X.shape[1], _lib.HOST, xs.ctypes.data,
+                                                n_samples, _lib.HOST, C.byref(out)))
+        return out.value
     h = 0.0
     for a in range(0, n_samples, 1024):
         blk = xs[a:a + 1024]
@@ -79,7 +87,7 @@ def monte_carlo_fill_distance(X_train, domain, n_samples: int = 10_000, rng=None
     return h
 
 
-def lengthscale_bounds(X_train, domain, min_frac: float = 0.1, max_frac: float = 1.0, n_samples: int = 10_000, rng=None):
+def lengthscale_bounds(X_train, domain, min_frac: float = 0.1, max_frac: float = 1.0, n_samples: int = 10_000, rng=None, device=None):
     """BO_utils.jl:87-125: ℓ_upper = max_frac·box width; ℓ_lower = min_frac·fill distance (≥ 1e-12)."""
     d = domain.lower.shape[0]
     ell_upper = max_frac * (domain.upper - domain.lower)
@@ -87,7 +95,7 @@ def lengthscale_bounds(X_train, domain, min_frac: float = 0.1, max_frac: float =
     if d > 1:
         if X.ndim != 2 or X.shape[1] != d:
             raise _lib.DimensionMismatch(f"All points in X_train must have dimension {d}")
-        h_fill = monte_carlo_fill_distance(X, domain, n_samples=n_samples, rng=rng)
+        h_fill = monte_carlo_fill_distance(X, domain, n_samples=n_samples, rng=rng, device=device)
     else:
         pts = np.sort(X.reshape(-1))
         h_fill = float(np.max(np.diff(np.concatenate([[domain.lower[0]], pts, [domain.upper[0]]]))))
@@ -104,7 +112,7 @@ def optimize_hyperparameters(model: HipStandardGP, x_train, y_train, old_params,
     rng = np.random.default_rng() if rng is None else rng
     ls_lo, ls_hi = 1e-3, 1e3
     if domain is not None:
-        lo_v, hi_v = lengthscale_bounds(x_train, domain, rng=rng)
+        lo_v, hi_v = lengthscale_bounds(x_train, domain, rng=rng, device=getattr(model, "device", None))
         ls_lo, ls_hi = max(float(np.min(lo_v)), 1e-6), float(np.max(hi_v))
         assert ls_lo < ls_hi
     sc_lo, sc_hi = 1e-3 / scale_std ** 2, 1e6 / scale_std ** 2

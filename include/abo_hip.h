@@ -39,7 +39,9 @@ extern "C" {
                                   abo_cand_downdate finds the down-date column of a pick appended for real in the batch's chain
                                7: abo_cand_qei_top takes the capacity of the caller's record buffer; abo_cand_qei_eligible (what ranks
                                   that shard a set themselves agree on before they take the block form); abo_cand_qei keeps its
-                                  pick loop on the device (one launch per pick, one read-back per batch) */
+                                  pick loop on the device (one launch per pick, one read-back per batch); abo_fill_distance;
+                                  abo_timings grew (abo_nlml_grad phases, the bordered append's mat-vecs); the abo_test_* building
+                                  blocks left the shipped library (test build only: ABO_TEST_HOOKS) */
 
 /* status codes */
 enum {
@@ -402,6 +404,12 @@ int32_t abo_lhs(int32_t device, int64_t n, int32_t d, const double* lower, const
                 int64_t j0, int64_t count, double* Z_dev);
 int32_t abo_score(int32_t device, const double* mu, const double* var, int64_t M, int32_t kind, double p0,
                   double best_y, double* scores);
+/* monte_carlo_fill_distance (src/BO_utils.jl:140-159; the lower length-scale bound of optimize_hyperparameters,
+ * src/BO_utils.jl:87-125): *out = max over the n_samples points S of the distance to the nearest of the N training points X
+ * (both point-major, d coordinates; HOST or DEVICE memory each; out: one host double).  The caller draws the sample points — the
+ * reference draws them with its own RNG in the box — so the result is the reference's for the same samples (ABI 7). */
+int32_t abo_fill_distance(int32_t device, const double* X, int64_t N, int32_t d, int32_t x_space, const double* S, int64_t n_samples,
+                          int32_t s_space, double* out);
 
 /* --- scalars ----------------------------------------------------------------------------------
  * nlml (src/surrogates/StandardGP.jl:99-114) of the fitted state:

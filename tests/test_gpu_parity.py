@@ -679,6 +679,22 @@ def test_optimize_hyperparameters_improves_nlml():
     assert abo.get_scale(only) == [1.0] and abo.get_lengthscale(only)[0] != 0.05
 
 
+@pytest.mark.parametrize("N,d,ns", [(7, 2, 1000), (1024, 8, 10000), (300, 40, 2001)])
+def test_fill_distance_on_the_device_equals_the_host_scan(N, d, ns):
+    """monte_carlo_fill_distance (src/BO_utils.jl:140-159) — the lower length-scale bound of optimize_hyperparameters — with the
+    N × n_samples scan on the device (abo_fill_distance): the same sample points (drawn on the host from the same RNG state) give the
+    host NumPy scan's value to rounding, whichever coordinate count."""
+    X = synth.points(1, N, d) * 3.0 - 1.0
+    dom = abo.ContinuousDomain(np.full(d, -1.5), np.full(d, 2.5))
+    h_dev = abo.monte_carlo_fill_distance(X, dom, n_samples=ns, rng=np.random.default_rng(5), device=0)
+    h_host = abo.monte_carlo_fill_distance(X, dom, n_samples=ns, rng=np.random.default_rng(5))
+    assert h_host > 0 and abs(h_dev - h_host) <= 1e-13 * h_host, (h_dev, h_host)
+    lo_d, hi_d = abo.lengthscale_bounds(X, dom, rng=np.random.default_rng(2), device=0)
+    lo_h, hi_h = abo.lengthscale_bounds(X, dom, rng=np.random.default_rng(2))
+    np.testing.assert_allclose(lo_d, lo_h, rtol=1e-13)
+    np.testing.assert_array_equal(hi_d, hi_h)
+
+
 def test_ensemble_acquisition_is_weighted_sum_on_one_posterior():
     # test/test_acquisition.jl:223-253: ensemble value == Σ wᵢ·acqᵢ
     import torch
