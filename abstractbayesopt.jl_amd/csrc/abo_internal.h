@@ -36,7 +36,7 @@ void pick_best_point(const double* starts_x, const double* starts_val, const dou
 // the batch driver over the n shards of one set (n = 1: abo_cand_qei; n > 1: abo_mgpu_cand_qei, whose shards run on their worker
 // threads and exchange records through the group's all-gather)
 int32_t qei_eligible(abo_gp* g, abo_cand* c, int q);       // ABO_OK when the block form can run on this shard (else the reason)
-int32_t qei_begin(abo_gp* g, abo_cand* c, int q, int T);
+int32_t qei_begin(abo_gp* g, abo_cand* c, int q, int T, bool snapshot = true);
 int32_t qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64_t idx_base, int k, double* rec_d);
 int32_t qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t* gidx, int T);
 int32_t qei_has(const abo_cand* c, int64_t gidx);

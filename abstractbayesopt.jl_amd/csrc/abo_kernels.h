@@ -307,6 +307,8 @@ hipError_t launch_qei_record(const double* tv, const int64_t* ti, int k, int64_t
 //       s = σ²(x) + σ²_n and γ_i = c_i(x)/s_i and applies c = C₀[slot] − Σ γ_i c_i, σ² −= c²/s to its candidates (the arithmetic of
 //       qei_pick_kernel), then
 //   (C) scores its candidates (EI) and leaves its partial arg-max {key, index, μ, σ²} for launch k + 1.
+// Launch 0 also snapshots (μ, σ²) — it reads them anyway —, the tail launch (k = q) writes the last record and rolls them back: the
+// batch needs no copy of its own before or behind it.
 // No workgroup waits for another inside a launch (stream order is the only synchronisation): no atomics, no fences — bit-reproducible.
 // A pick outside every block, or s ≤ 0, raises st->stop: the remaining launches return at once, the host builds the block (or reports
 // the failed pivot) and resumes from launch k.
@@ -319,6 +321,7 @@ struct QeiStepState {                    // device memory, one per candidate set
 struct QeiStepPartial { uint64_t key; int64_t idx; double mu, var; };
 struct QeiStepArgs {
     double* mu; double* var;             // [M] stored posterior of the set (σ² is conditioned in place; the batch rolls it back)
+    double* snap_mu; double* snap_var;   // [M] launch 0 copies (μ, σ²) here, the tail launch (k = q) copies them back
     const double* Z;                     // [M][d]
     const double* blk;                   // [slots][Mp] block columns
     double* chain;                       // [rows][Mp]

@@ -2207,7 +2207,7 @@ int32_t abo::qei_eligible(abo_gp* g, abo_cand* c, int q) {
     return ABO_OK;
 }
 
-int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T) {
+int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T, bool snapshot) {
     int32_t rc = abo::qei_eligible(g, c, q);
     if (rc) return rc;
     if (T <= 0) T = qei_default_block();
@@ -2255,8 +2255,10 @@ int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T) {
     const size_t bytes = sizeof(double) * (c->M > 0 ? c->M : 1);
     HIPCHK(c->qmu.ensure(bytes));
     HIPCHK(c->qvar.ensure(bytes));
-    HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
+    if (snapshot) {                                        // (the device pick loop takes the snapshot in its first launch)
+        HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, s));
+    }
     // the fantasies of the last batch go; blocks and real entries stay
     Q.nchain = Q.nreal;
     Q.chain_x.resize((size_t)Q.nreal * c->d);
@@ -2468,11 +2470,12 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
     if (T > QEI_MAXT) T = QEI_MAXT;
     const int d = c->d;
     const int Tk = (int64_t)T < c->M ? T : (int)c->M;
-    int32_t rc = abo::qei_begin(g, c, q, T);
+    int32_t rc = abo::qei_begin(g, c, q, T, /*snapshot=*/false);
     if (rc) return rc;
     abo_cand::Qei& Q = c->qei;
     hipStream_t s = g->stream;
     std::string keep;
+    bool launched = false, restored = false;               // launch 0 snapshots (μ, σ²), the tail launch rolls them back
     const int wmax = 4 + d + QEI_MAXQ;
     const size_t off_part = (sizeof(QeiStepState) + 255) / 256 * 256;
     const size_t off_rec = off_part + sizeof(QeiStepPartial) * 2 * QEI_STEP_MAXWG;
@@ -2487,6 +2490,7 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
         char* base = static_cast<char*>(c->qdev.p);
         QeiStepArgs a{};
         a.mu = c->mu.as<double>(); a.var = c->var.as<double>(); a.Z = c->Z.as<double>();
+        a.snap_mu = c->qmu.as<double>(); a.snap_var = c->qvar.as<double>();
         a.blk = c->qblk.as<double>(); a.chain = c->qchain.as<double>();
         a.st = reinterpret_cast<QeiStepState*>(base);
         a.part = reinterpret_cast<QeiStepPartial*>(base + off_part);
@@ -2500,7 +2504,7 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
         while (true) {
             for (int b = 0; b < 4; ++b) a.blk_base[b] = b < Q.nblk_cap ? Q.blk_base[b] : 0;
             for (int e2 = 0; e2 < 4 * QEI_MAXT; ++e2) a.slot_gidx[e2] = e2 < a.nslots ? Q.slot_gidx[e2] : -1;
-            for (int k = k_from; k <= q && e == hipSuccess; ++k) { a.k = k; e = launch_qei_step(a, nwg, s); }
+            for (int k = k_from; k <= q && e == hipSuccess; ++k) { a.k = k; e = launch_qei_step(a, nwg, s); launched = true; }
             PinStage pin(g->ctx);
             if (e == hipSuccess) e = pin.d2h(&hst, a.st, sizeof(QeiStepState), s);
             if (e == hipSuccess) e = pin.d2h(rec.data(), a.rec, rec_bytes, s);
@@ -2517,7 +2521,7 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
                 Q.chain_x.insert(Q.chain_x.end(), r + 4, r + 4 + d);
             }
             done = cond;
-            if (!hst.stop) break;
+            if (!hst.stop) { restored = true; break; }    // the tail launch ran: the stored posterior is the batch's starting point again
             const double* r = &rec[(size_t)hst.stop_at * wmax];
             if (hst.stop == 2) {                               // s = σ²(x) + σ²_n ≤ 0: the failed pivot of the plain loop's bordered append
                 const long long at = (long long)(g->N + (Q.nchain - Q.nreal) + 1);
@@ -2551,7 +2555,9 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
         }
     } while (false);
     if (rc) keep = g_err;
-    const int32_t r2 = abo::qei_end(g, c);
+    int32_t r2 = ABO_OK;
+    if (restored || !launched) c->qei.open = false;        // nothing to roll back (or nothing was touched)
+    else r2 = abo::qei_end(g, c);                          // an error after launch 0: σ², μ back from the snapshot it took
     if (rc) return fail(rc, "%s", keep.c_str());
     return r2;
 }

@@ -46,72 +46,109 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // The register step of a 16-column sub-step (phase 1, (1)+(2) below), shared by every build of the diagonal-block kernel: lanes 0-15
 // of the wave hold the 16 rows of the diagonal sub-block, lanes 16-63 rows below it, one row (16 doubles) per lane, in x[].
-// Right-looking: column j's pivot chain is the serial spine, its update of column j+1 is the only update the next pivot waits for, and
-// the 14 − j updates column j owes to the columns beyond are filler issued behind the steps of the NEXT column's chain (the
-// scheduling fences pin that order: left to itself the compiler sinks every update of a column to just before that column's pivot).
-// The step is bound by the VALU slots a column takes, not by its dependent chain (tools/dp_latency_probe: a dependent v_fma_f64 issues
-// every 5.2 cycles), so round 6 — parity is the oracle's tolerance, no longer round 4's bits — cut slots:
-//   * the chain computes ONLY rp = 1/√d (v_rsq_f64 seed, two coupled Goldschmidt steps: 9 operations where √d and 1/√d to ≤ 1 ulp each
-//     took 14); the diagonal entry is L_jj = d·rp like every other entry of the column (≤ 1.5 ulp from √d; everything downstream divides
-//     by multiplying with rp, so factor and inverse stay consistent with each other);
-//   * no per-column selects: the pivot's reciprocal goes to LDS (dinv) from one lane, the pivot test is one compare on the wave-uniform
-//     argument, accumulated on the scalar unit;
-//   * the entries of column j−1 a column owes updates with come from a 64-double LDS buffer of the wave, written when the column is
-//     final and read back as broadcasts, two per ds_read_b128 (the LDS queue of a wave is in order, no synchronisation) — not by
-//     v_readlane pairs; only the update of column j + 1 (the next pivot waits for it) keeps its v_readlane.
-// Returns the mask of columns whose pivot argument was not a positive normal number (bit j; wave-uniform; NaN included).
+// The step is a LATENCY chain, not an issue-slot problem (round 6 measured it: a third fewer VALU instructions per column — pivot
+// reciprocal only, no selects — left the step at its 2.1 µs; tools/chol_diag_probe): per column the dependent path is
+// v_readlane → v_rsq_f64 → seven dependent fp64 operations → scale → v_readlane → fma → v_readlane, ≈ 275 cycles.  So — parity is the
+// oracle's tolerance since round 6, no longer round 4's bits — the columns are taken TWO at a time, in closed form:
+//     d0 = A_jj,  b = A_{j+1,j},  a = A_{j+1,j+1}:     det = a·d0 − b²      (the second pivot is d1 = det/d0)
+//     r0 = 1/√d0 and rD = 1/√det from v_rsq_f64 seeds, two coupled Goldschmidt steps each, INTERLEAVED (one chain's latency)
+//     1/L_jj = r0,   L_{j+1,j} = b·r0,   1/L_{j+1,j+1} = √d0/√det = (d0·r0)·rD
+//     column j ← column j · r0;   column j+1 ← (column j+1 − column j · L_{j+1,j}) · (d0·r0)·rD
+// — one dependent chain per PAIR of columns (≈ 14 operations, one v_rsq latency, three v_readlane round trips) where two columns took
+// two (≈ 22, two, four).  det = a·d0 − b² cancels exactly as a − (b/√d0)² does (relative error ε·a·d0/det against ε·a/d1: the
+// same).  The diagonal entries are L_jj = d0·r0 and L_{j+1,j+1} = d1·r1 like every other entry of their columns (≤ 2 ulp from the
+// square roots; everything downstream divides by multiplying with the stored reciprocals, so factor and inverse stay consistent).
+// What a finished pair owes the columns beyond the next pair is issued as filler behind the steps of the NEXT pair's chain (the
+// scheduling fences pin that order), with the pair's entries L[k][j], L[k][j+1] read back as broadcasts from a 2 × 64-double LDS
+// buffer of the wave (the LDS queue of a wave is in order: no synchronisation); only the updates of the next pair's two columns —
+// the next chain waits for them — take their multipliers by v_readlane.  No per-column selects: the reciprocals go to LDS from one
+// lane, the pivot tests are compares on wave-uniform arguments accumulated on the scalar unit.
+// cb: 2 × 64 doubles of LDS per wave; dinv_out: 16 doubles of LDS that receive 1/L_jj (the wave that owns the block's dinv passes it,
+// the others a scratch row).  Returns the mask of columns whose pivot was not a positive normal number (bit j; wave-uniform; NaN
+// included; LAPACK's info is its lowest set bit).
 typedef __attribute__((address_space(3))) double lds_f64;
 __device__ __forceinline__ unsigned register_potf2_step_lds(double (&x)[16], int lane, lds_f64* cb, lds_f64* dinv_out) {
     constexpr int SBX = 16;
     unsigned bad = 0;
-    double d = readlane_f64(x[0], 0);
+#ifdef ABO_STEP_EMPTY                                   /* tools/chol_diag_probe: what a sub-step costs WITHOUT its register step */
+    return 0u;
+#endif
+    const unsigned dinv_addr = (unsigned)(size_t)dinv_out;         // LDS byte address (wave-uniform)
+    double d0 = readlane_f64(x[0], 0), b = readlane_f64(x[0], 1), a = readlane_f64(x[1], 1);
+    double w0[SBX], w1[SBX];                           // L[k][j−2], L[k][j−1]: read from the buffer at the END of the pair before (below)
 #pragma unroll
-    for (int j = 0; j < SBX; ++j) {
-        const int jp = j > 0 ? j - 1 : 0;              // the column whose owed updates fill this chain
-        double w[SBX];
-        if (j > 0) {
-#pragma unroll
-            for (int k = j + 1; k < SBX; ++k) w[k] = cb[k];           // L[k][j−1] (written at the end of column j−1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        int kq = j + 1;
-#define ABO_FILL() do { if (j > 0 && kq < SBX) { x[kq] = fma(-x[jp], w[kq], x[kq]); ++kq; } \
+    for (int j = 0; j < SBX; j += 2) {
+        const int j2 = j >= 2 ? j - 2 : 0, j1 = j >= 2 ? j - 1 : 0;         // the finished pair whose owed updates fill this chain
+        int ka = j + 2, kb = j + 2;
+#define ABO_FILL() do { if (j > 0 && ka < SBX) { x[ka] = fma(-x[j2], w0[ka], x[ka]); ++ka; } \
+                        if (j > 0 && kb < SBX) { x[kb] = fma(-x[j1], w1[kb], x[kb]); ++kb; } \
                         __builtin_amdgcn_sched_barrier(0); } while (0)
-        bad |= __ballot(d >= 2.3e-308) == 0ull ? (1u << j) : 0u;      // one v_cmp on the uniform argument; the rest is scalar
-        const double y = __builtin_amdgcn_rsq(d);
+        const double t = b * b;
+        bad |= __ballot(d0 >= 2.3e-308) == 0ull ? (1u << j) : 0u;         // one v_cmp on the uniform argument; the rest is scalar
+        const double y0 = __builtin_amdgcn_rsq(d0);
         __builtin_amdgcn_sched_barrier(0);
-        double g = d * y, h = 0.5 * y;
-        __builtin_amdgcn_sched_barrier(0);
-        double r = fma(-h, g, 0.5);
-        ABO_FILL();                                    // (the LDS reads are back about six instructions on)
-        g = fma(g, r, g);
-        h = fma(h, r, h);
+        const double det = fma(a, d0, -t);
+        double g0 = d0 * y0, h0 = 0.5 * y0;
         ABO_FILL();
+        bad |= __ballot(det >= 2.3e-308) == 0ull ? (2u << j) : 0u;
+        const double yD = __builtin_amdgcn_rsq(det);
+        double r0 = fma(-h0, g0, 0.5);
+        ABO_FILL();                                    // (the LDS reads are back about here)
+        double gD = det * yD, hD = 0.5 * yD;
+        g0 = fma(g0, r0, g0);
+        h0 = fma(h0, r0, h0);
         ABO_FILL();
-        r = fma(-h, g, 0.5);
+        double rD = fma(-hD, gD, 0.5);
+        r0 = fma(-h0, g0, 0.5);
         ABO_FILL();
+        gD = fma(gD, rD, gD);
+        hD = fma(hD, rD, hD);
+        h0 = fma(h0, r0, h0);
         ABO_FILL();
-        h = fma(h, r, h);
+        rD = fma(-hD, gD, 0.5);
+        const double rp0 = h0 + h0;
         ABO_FILL();
+        hD = fma(hD, rD, hD);
+        const double m = d0 * rp0, l10 = b * rp0;
+        x[j] = x[j] * rp0;                             // column j, its diagonal entry included
         ABO_FILL();
-        const double rp = h + h;
+        const double rdet = hD + hD;
+        double tmp = fma(-x[j], l10, x[j + 1]);
         ABO_FILL();
+        const double rp1 = m * rdet;
         ABO_FILL();
-        x[j] = x[j] * rp;                              // the whole column, its diagonal entry included
-        if (dinv_out && lane == 0) dinv_out[j] = rp;
+        x[j + 1] = tmp * rp1;                          // column j + 1
+        // the two reciprocals to LDS from lane 0 alone, without a branch (a conditional store puts a control-flow region into every
+        // chain and the scheduler's order with it: measured 2.4 → 5.4 µs a step): the wave runs this function with all lanes enabled
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\ts_mov_b64 exec, -1"
+                     :: "v"(dinv_addr + 8u * j), "v"(rp0), "v"(rp1) : "memory");
         ABO_FILL();
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < SBX) {
-            if (j + 2 < SBX) cb[lane] = x[j];                         // column j for the updates it owes through the buffer
-            const double lnext = readlane_f64(x[j], j + 1);
-            ABO_FILL();                                            // (in the latency of the v_readlane round trip)
-            ABO_FILL();
-            x[j + 1] = fma(-x[j], lnext, x[j + 1]);
-            ABO_FILL();
-            d = readlane_f64(x[j + 1], j + 1);
-        }
 #pragma unroll
-        for (int rest = 0; rest < SBX; ++rest) ABO_FILL();          // (none left: 14 slots above)
+        for (int rest = 0; rest < SBX; ++rest) ABO_FILL();             // whatever the previous pair still owes
+        if (j + 2 < SBX) {
+            if (j + 4 < SBX) {
+                // the pair goes to the wave's buffer, and the broadcasts the NEXT chain's fillers multiply with are read back at once:
+                // they have a whole chain prologue to arrive in (read at the top of the chain that uses them, the first filler's
+                // s_waitcnt stalled the wave — and the pivot chain with it — for the LDS round trip, once per pair)
+                cb[lane] = x[j];
+                cb[64 + lane] = x[j + 1];
+#pragma unroll
+                for (int k = j + 4; k < SBX; ++k) { w0[k] = cb[k]; w1[k] = cb[64 + k]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const double l20 = readlane_f64(x[j], j + 2), l30 = readlane_f64(x[j], j + 3);
+            const double l21 = readlane_f64(x[j + 1], j + 2), l31 = readlane_f64(x[j + 1], j + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            x[j + 2] = fma(-x[j], l20, x[j + 2]);
+            x[j + 3] = fma(-x[j], l30, x[j + 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            x[j + 2] = fma(-x[j + 1], l21, x[j + 2]);
+            x[j + 3] = fma(-x[j + 1], l31, x[j + 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            d0 = readlane_f64(x[j + 2], j + 2);
+            b = readlane_f64(x[j + 2], j + 3);
+            a = readlane_f64(x[j + 3], j + 3);
+        }
 #undef ABO_FILL
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -160,7 +197,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
                                                         int64_t* info, FitSmallArgs fs) {
     __shared__ double a[NB * LDA];
     __shared__ double dinv[NB];
-    __shared__ __attribute__((aligned(16))) double colbuf[3][64];     // per register-step wave: the column just finished
+    __shared__ __attribute__((aligned(16))) double colbuf[3][128];    // per register-step wave: the pair of columns just finished
     __shared__ int fail;
     __shared__ double xs[MODE == 3 ? NB * 16 : 1];          // mode 3: scaled inputs, δ and the intermediate of the two solves
     __shared__ double dl[MODE == 3 ? NB : 1];
@@ -239,7 +276,7 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
-            const unsigned badc = register_potf2_step_lds(x, lane, (lds_f64*)colbuf[wave], wave == 0 ? (lds_f64*)&dinv[o] : (lds_f64*)nullptr);
+            const unsigned badc = register_potf2_step_lds(x, lane, (lds_f64*)colbuf[wave], wave == 0 ? (lds_f64*)&dinv[o] : (lds_f64*)&colbuf[wave][32]);
             if (badc) {
                 if (t == 0) { fail = 1; *info = (int64_t)r0 + o + __builtin_ctz(badc) + 1; }
             } else if (valid) {
@@ -412,10 +449,10 @@ __host__ __device__ constexpr int trsm_stage_base(int k) { return 32 * k - 2 * k
 #define POTF2_PIPE_LDS() \
     __shared__ __attribute__((aligned(16))) double a[NB * LDA]; \
     __shared__ double dinv[NB]; \
-    __shared__ __attribute__((aligned(16))) double colbuf[3][64];          /* per spine wave: the column just finished (register_potf2_step_lds) */ \
+    __shared__ __attribute__((aligned(16))) double colbuf[3][128];         /* per spine wave: the pair of columns just finished (register_potf2_step_lds) */ \
     __shared__ int fail
 
-__device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double (*colbuf)[64], int& fail,
+__device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double (*colbuf)[128], int& fail,
                                                 double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, double* P) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     const int t = threadIdx.x;
@@ -559,7 +596,7 @@ __device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double 
             double x[SB];
 #pragma unroll
             for (int c = 0; c < SB; ++c) x[c] = valid ? AA(row, o + c) : 0.0;
-            const unsigned badc = register_potf2_step_lds(x, lane, (lds_f64*)colbuf[wave], wave == 0 ? (lds_f64*)&dinv[o] : (lds_f64*)nullptr);
+            const unsigned badc = register_potf2_step_lds(x, lane, (lds_f64*)colbuf[wave], wave == 0 ? (lds_f64*)&dinv[o] : (lds_f64*)&colbuf[wave][32]);
             if (badc) {
                 if (t == 0) { fail = 1; *info = (int64_t)r0 + o + __builtin_ctz(badc) + 1; }
             } else if (valid) {
@@ -577,12 +614,17 @@ __device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double 
             // (beside a wave that issues MFMA updates an inverse takes 3.4 µs instead of 2.1 — longer than the register step)
             const int qi = 2 * (p - 4) + (wave == 15 ? 0 : 1);
             if ((wave == 15 || wave == 14) && qi < NSB - 1) inverse(qi);
-        } else if (p > 0 && (wave & 3) >= nspine) {
-            // D(p−1) and the write-back of column block p−1, over the waves of ALL SIMDs without a spine wave (at p < 4: 2 and 3, then
-            // SIMD 1): an update is four dependent MFMAs, 256 cycles of ONE SIMD's matrix pipe — 21 of them on one SIMD outlast the step
-            const int lo = nspine, hi = p >= 4 ? 2 : 4;                     // SIMDs lo … hi−1
+        } else if (p > 0 && (p < 4 || (wave & 3) >= nspine)) {
+            // D(p−1) and the write-back of column block p−1.  Steps 1 – 3 (21, 15, 10 sub-block updates: four dependent MFMAs each, 256
+            // cycles of ONE SIMD's matrix pipe): over ALL the waves that are not spine waves — round 5 kept them off the spine waves'
+            // SIMDs, and round 6 measured these sub-steps with the register step EMPTY at the same 3.4 / 2.9 / 2.2 µs: the side work
+            // on two SIMDs was the critical path there, not the spine (tools/chol_diag_probe -DABO_STEP_EMPTY); spread over all
+            // SIMDs it and the spine waves slow each other down to 2.8 / 2.4 / 2.3 µs.  Steps 4 – 7 (≤ 6 updates): SIMD 1 only, as
+            // before — SIMDs 2 and 3 belong to the inverses.
+            const int lo = p < 4 ? 0 : nspine, hi = p < 4 ? 4 : 2;          // SIMDs lo … hi−1 (p < 4: all, minus the spine waves themselves)
             const int per = hi - lo;
-            const int hid = (wave >> 2) * per + ((wave & 3) - lo), Hd = 4 * per;
+            const int hid = p < 4 ? wave - nspine : (wave >> 2) * per + ((wave & 3) - lo);
+            const int Hd = p < 4 ? DT / 64 - nspine : 4 * per;
             const int q = p - 1;
             const int nb = NSB - 1 - q;                                    // sub-block rows / columns behind panel q; column 0 is done (F)
             const int total = (nb - 1) * nb / 2;

@@ -321,45 +321,6 @@ __global__ void __launch_bounds__(256) gemm_nt_small_kernel(GemmArgs p) {
     }
 }
 
-// In-place variant (C aliases A: the TRSM panel solve L[r,p] = A[r,p]·W_ppᵀ with N = K = 128): a workgroup owns
-// 16 complete rows — every wave has read them in full before the barrier that precedes the first store.
-// 4 waves, 16×32 outputs each; same k order as tile_loop.
-__global__ void __launch_bounds__(256) gemm_nt_rowpanel_kernel(GemmArgs p) {
-    if (p.info != nullptr && *p.info != 0) return;
-    const int si = blockIdx.x, bz = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
-    const double* Ap = p.A + (int64_t)bz * p.sA + (int64_t)(si * 16 + r16) * p.lda + 2 * g;
-    const double* Bp = p.B + (int64_t)bz * p.sB + (int64_t)(wave * 32 + r16) * p.ldb + 2 * g;
-    d4_t acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    d2_t a[16], b0[16], b1[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        a[q] = *reinterpret_cast<const d2_t*>(Ap + 8 * q);
-        b0[q] = *reinterpret_cast<const d2_t*>(Bp + 8 * q);
-        b1[q] = *reinterpret_cast<const d2_t*>(Bp + 16 * p.ldb + 8 * q);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b0[q][0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][0], b1[q][0], acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b0[q][1], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][1], b1[q][1], acc[1], 0, 0, 0);
-    }
-    __syncthreads();
-    double* Cg = p.C + (int64_t)bz * p.sC;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = (int64_t)si * 16 + g + 4 * r;
-            const int64_t col = wave * 32 + ni * 16 + r16;
-            double v = p.alpha * acc[ni][r];
-            if (p.beta != 0.0) v += p.beta * Cg[row * p.ldc + col];
-            Cg[row * p.ldc + col] = v;
-        }
-}
-
 // Split-k chunk of a product with FEW rows of A (16·RG ≤ 64) against a 128-row block of B: no LDS, no barriers.  Wave w owns B rows
 // 32w … 32w+31 of the block (two 16-row MFMA groups) and streams them exactly once; the RG row groups of A are re-read by every wave
 // (they are small and sit in L2).  Lane ↔ k map and k order of gemm_nt_small_kernel.  P[z][r][i] = Σ_{k in chunk z} A[r][k]·B[i][k].
@@ -567,9 +528,7 @@ hipError_t launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    if (small && in_place && a.C == a.A && a.N == BN && a.K == 128 && a.kmode == K_FULL && !a.lower_only && !a.Ct) {
-        hipLaunchKernelGGL(gemm_nt_rowpanel_kernel, dim3(a.M / 16, a.batch), dim3(256), 0, s, a);
-    } else if (small && !in_place && a.K % 128 == 0) {
+    if (small && !in_place && a.K % 128 == 0) {
         dim3 grid(a.N / 32, a.M / 32, a.batch);
         hipLaunchKernelGGL(gemm_nt_small_kernel, grid, dim3(256), 0, s, a);
     } else if (a.lower_only && a.kmode == K_FULL && a.M == a.N && a.batch == 1 && Tm >= 16 && !getenv("ABO_GEMM_NO_SWIZZLE")) {

@@ -158,7 +158,13 @@ __global__ void __launch_bounds__(256) qei_step_kernel(const QeiStepArgs a) {
             for (int c = t; c < a.d; c += 256) r[4 + c] = a.Z[li * a.d + c];
             for (int i = t; i < n; i += 256) r[4 + a.d + i] = a.chain[(int64_t)i * a.Mp + li];
         }
-        if (k == a.q) return;                                 // the tail launch: the last pick conditions nothing
+        if (k == a.q) {                                       // the tail launch: the last pick conditions nothing; the batch is rolled back
+            for (int64_t z = (int64_t)blockIdx.x * 256 + t; z < a.M; z += (int64_t)gridDim.x * 256) {
+                a.var[z] = a.snap_var[z];
+                if (a.distinct) a.mu[z] = a.snap_mu[z];
+            }
+            return;
+        }
         // the pick's block row: the FIRST slot holding its index (qei_find_slot's order)
         if (t == 0) s_slot = 0x7fffffff;
         __syncthreads();
@@ -187,6 +193,7 @@ __global__ void __launch_bounds__(256) qei_step_kernel(const QeiStepArgs a) {
     double bm = 0.0, bv = 0.0;
     for (int64_t z = (int64_t)blockIdx.x * 256 + t; z < a.M; z += (int64_t)gridDim.x * 256) {
         double m = a.mu[z], v = a.var[z];
+        if (k == 0) { a.snap_mu[z] = m; a.snap_var[z] = v; }  // (a resumed batch never re-runs launch 0)
         if (apply) {
             double c = blk[z];
             for (int i = first; i < n; ++i) c = fma(-gam[i], a.chain[(int64_t)i * a.Mp + z], c);     // fixed order: entry first, first + 1, …
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(256) qei_step_kernel(const QeiStepArgs a) {
 
 hipError_t launch_qei_step(const QeiStepArgs& a, int nwg, hipStream_t st) {
     if (nwg < 1 || nwg > QEI_STEP_MAXWG || a.M < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(qei_step_kernel, dim3((unsigned)(a.k == a.q ? 1 : nwg)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(qei_step_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

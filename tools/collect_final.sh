@@ -1,5 +1,5 @@
 # copy what tools/run_final.sh left under gpurun_out/ into profiles/ (run here, after the gpurun call): bash tools/collect_final.sh r04
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd gpurun_out
 cp final_bench_default.json ../profiles/${TAG}_bench_default.json
 cp final_bench_c2.json ../profiles/${TAG}_c2_bench.json
@@ -9,6 +9,10 @@ cp final_bench_c3_2shards_one_device.json ../profiles/${TAG}_bench_c3_2shards_on
 cp final_bench_c5_2shards_one_device.json ../profiles/${TAG}_bench_c5_2shards_one_device.json
 cp final_bench_c4_8shards_one_device.json ../profiles/${TAG}_bench_c4_8shards_one_device_rehearsal.json
 cp final_bench_c5_4shards_one_device.json ../profiles/${TAG}_bench_c5_4shards_one_device_rehearsal.json
+cp final_bench_c4_1gpu.json ../profiles/${TAG}_bench_c4_1gpu.json
+cp final_hyperparameter_latency.txt ../profiles/${TAG}_hyperparameter_latency.txt
+cp final_refine_diag_c3.txt ../profiles/${TAG}_refine_diag_c3.txt
+[ -f final_c5_refresh_drift.txt ] && cp final_c5_refresh_drift.txt ../profiles/${TAG}_c5_refresh_drift.txt
 cp final_grad_engine_latency.txt ../profiles/${TAG}_grad_engine_latency.txt
 cp final_oz_soak.txt ../profiles/${TAG}_oz_soak.txt
 for c in c2 c3 c5; do cp final_bench_under_rocprof_$c.json ../profiles/${TAG}_${c}_bench_under_rocprof.json; cp final_kernel_stats_$c.csv ../profiles/${TAG}_${c}_kernel_stats.csv; done

@@ -3,13 +3,14 @@
 #   pmc      PMC passes of the dominant kernels (first: the bench lines of the next stage read their traffic figures)
 #   bench    default line (C3 headline + C2 / C5 / C1-shape secondaries), fp64 engine, C2, C5, shards on one device (2 x C3, 2 x C5,
 #            8 x C4 at its own size, 4 x C5 at its own size: rehearsals of the fan-out, not scaling figures)
-#   latency  small-N / optimize_acquisition / plain-C host / fit / gradient-engine latencies, soaks
+#   latency  small-N / optimize_acquisition / plain-C host / fit / gradient-engine / hyper-parameter latencies, soaks
+#   drift    config 5 without its refresh: 64 appends against an oracle refit every 16 (tools/c5_refresh_drift.py)
 #   traces   rocprofv3 --kernel-trace --stats per configuration
 # everything lands in gpurun_out/final_*; tools/collect_final.sh copies it into profiles/ afterwards (run here, not on the box)
 set -e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 STAGE=${2:-all}
 want() { [ "$STAGE" = all ] || [ "$STAGE" = "$1" ]; }
 if want tests; then
@@ -43,6 +44,8 @@ timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 -
 # BASELINE config 4 at its own size through the 8-shard path, all shards on this one GPU (a rehearsal of the fan-out, NOT a scaling figure)
 timeout -k 10 600 python bench.py --gpus 8 --share-device --config c4 --steps 2 --warmup 1 > gpurun_out/final_bench_c4_8shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 600 python bench.py --gpus 4 --share-device --config c5 --steps 3 --warmup 1 > gpurun_out/final_bench_c5_4shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+# BASELINE config 4's candidate count on ONE GPU (one rank, M = 2^23: the denominator of the >= 6x scaling target — a real single-GPU line)
+timeout -k 10 300 python bench.py --config c4 --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c4_1gpu.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 echo "bench done"
 fi
 if want latency; then
@@ -50,10 +53,16 @@ if want latency; then
 (timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep -v amdgpu.ids; echo; echo "--- the one-launch kernel at every size (ABO_REFINE_LOCKSTEP_NP=0)"; ABO_REFINE_LOCKSTEP_NP=0 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N="; echo "--- lockstep rounds at every size (ABO_REFINE_LOCKSTEP_NP=128)"; ABO_REFINE_LOCKSTEP_NP=128 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2>/dev/null | grep "^N="; echo "--- lockstep rounds without the split-k / skinny products (ABO_REFINE_KSPLIT=0: round 3)"; ABO_REFINE_KSPLIT=0 timeout -k 10 600 python tools/optimize_acquisition_latency.py 2048 8192 2>/dev/null | grep "^N=") > gpurun_out/final_optimize_acquisition_latency.txt
 (echo "tools/c_host_latency.sh: per-step latency from the plain-C host (tests/c_abi_harness.c latency; system HIP runtime, no interpreter, host arrays in, top-100 out)"; bash tools/c_host_latency.sh 2>&1 | grep "^latency") > gpurun_out/final_c_host_latency.txt
 timeout -k 10 300 bash tools/fit_times.sh > gpurun_out/final_fit_times.txt 2>&1 || true
-(timeout -k 10 300 python tools/grad_engine_latency.py 2>&1 | grep -v amdgpu; timeout -k 10 300 python tools/grad_engine_latency.py 400 16 2048 2>&1 | grep -v amdgpu; echo "--- ABO_OZ_UNFUSED=1 (fp64 chunk + separate quantiser pass: round 3)"; ABO_OZ_UNFUSED=1 timeout -k 10 300 python tools/grad_engine_latency.py 2>&1 | grep "^int8") > gpurun_out/final_grad_engine_latency.txt
+(timeout -k 10 300 python tools/grad_engine_latency.py 2>&1 | grep -v amdgpu; timeout -k 10 300 python tools/grad_engine_latency.py 400 16 2048 2>&1 | grep -v amdgpu) > gpurun_out/final_grad_engine_latency.txt
 timeout -k 10 600 python tools/oz_soak.py 40 2>&1 | grep "^N=" > gpurun_out/final_oz_soak.txt || true
 timeout -k 10 600 python tools/soak.py > gpurun_out/final_soak.txt 2>&1 || { tail -5 gpurun_out/final_soak.txt; exit 1; }
+(timeout -k 10 300 python tools/hyperparameter_latency.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_hyperparameter_latency.txt
+(timeout -k 10 300 python tools/refine_diag.py c3 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_refine_diag_c3.txt
 echo "latency tools done"
+fi
+if want drift; then
+(timeout -k 10 900 python tools/c5_refresh_drift.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_c5_refresh_drift.txt
+tail -3 gpurun_out/final_c5_refresh_drift.txt
 fi
 if want traces; then
 rm -rf gpurun_out/prof_${TAG}_c3fp64
