@@ -7,7 +7,7 @@
 namespace abo {
 
 constexpr int TB = 128;  // block (tile) edge used by every blocked stage; all padded sizes are multiples of it
-constexpr int MAX_P = 33; // outputs per point of a gradient-enhanced GP (f + d ≤ 32 partial derivatives)
+constexpr int MAX_P = 129; // outputs per point of a gradient-enhanced GP (f + d ≤ 128 partial derivatives; d ≤ 32: register-resident generator)
 
 inline int64_t pad_up(int64_t n, int64_t m) { return (n + m - 1) / m * m; }
 

@@ -180,6 +180,125 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
 }
 
 
+// d > 32 (dp = d rounded up to a multiple of 32; GradientGP.jl:617-639 has no dimension limit): the same blocks with the coordinates
+// taken in slabs of 32, as kgen_wide_kernel does for the StandardGP — per (row, training row) pair the squared distance and the two
+// coordinate differences a derivative block needs (e_c of the row's output, e_c' of the training row's) are carried across the slabs;
+// same c = 0 … d−1 summation order as kgen_grad_kernel.  fp64 output only (the int8 engine then quantises the chunk in a pass of
+// its own: oz_quant_kernel).
+template <int FAM, bool DLOGELL>
+__global__ void __launch_bounds__(256) kgen_grad_wide_kernel(KgenArgs p) {
+    constexpr int GSLAB = 32;                            // coordinates per slab (dp is a multiple of it)
+    constexpr int JH = 8;                                // rows taken together: their carried state (6 doubles per row and training row
+                                                         // pair) and one slab of the lane's two training points fill the register file
+    __shared__ double zs[JT][GSLAB];
+    __shared__ int zq[JT];
+    __shared__ double red[4][JT];
+    const int t = threadIdx.x;
+    const int jb = blockIdx.x * JT;
+    const int64_t rows_total = p.M * p.pc;
+    if (t < JT) {
+        const int64_t g = p.j0 + jb + t;
+        zq[t] = (g < rows_total) ? (int)(p.point_major ? g % p.pc : g / p.M) : -1;
+    }
+    const double il = p.s;
+    double mu[JT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) mu[jj] = 0.0;
+    const int R = p.rvalid > 0 ? p.rvalid : p.N * p.pt;
+    for (int k0 = 0; k0 < p.Np; k0 += KSTEP) {
+        const int k = k0 + 2 * t;
+        const bool live = k < p.Np;                      // the barriers below are taken by every thread
+        const int i0 = live ? k / p.pt : 0, i1 = live ? (k + 1) / p.pt : 0;
+        const int qp0 = k % p.pt - 1, qp1 = (k + 1) % p.pt - 1;
+        const bool ok0 = live && k < R, ok1 = live && (k + 1) < R;
+        double a0 = 0.0, a1 = 0.0;
+        if (live && p.alpha) { a0 = p.alpha[k]; a1 = p.alpha[k + 1]; }
+#pragma unroll
+        for (int h = 0; h < JT / JH; ++h) {
+            double u0[JH], u1[JH], ec0[JH], ec1[JH], ep0[JH], ep1[JH];
+#pragma unroll
+            for (int jj = 0; jj < JH; ++jj) { u0[jj] = u1[jj] = ec0[jj] = ec1[jj] = ep0[jj] = ep1[jj] = 0.0; }
+            for (int c0 = 0; c0 < p.dp; c0 += GSLAB) {
+                __syncthreads();
+                for (int idx = t; idx < JH * GSLAB; idx += 256) {
+                    const int jj = idx / GSLAB, c = c0 + idx % GSLAB;
+                    const int64_t g = p.j0 + jb + JH * h + jj;
+                    const int64_t j = p.point_major ? g / p.pc : g % p.M;
+                    zs[jj][idx % GSLAB] = (c < p.d && g < rows_total) ? p.Z[j * p.d + c] * p.s : 0.0;
+                }
+                __syncthreads();
+                if (live) {
+                    double x0[GSLAB], x1[GSLAB];
+#pragma unroll
+                    for (int c = 0; c < GSLAB; ++c) {
+                        x0[c] = ok0 ? p.Xs[(int64_t)i0 * p.dp + c0 + c] : 0.0;
+                        x1[c] = ok1 ? p.Xs[(int64_t)i1 * p.dp + c0 + c] : 0.0;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < JH; ++jj) {
+                        asm volatile("" ::: "memory");
+                        const int qc = zq[JH * h + jj] - 1 - c0;      // the row's derivative coordinate, relative to this slab
+                        const int q0 = qp0 - c0, q1 = qp1 - c0;
+                        double a = u0[jj], b = u1[jj];
+#pragma unroll
+                        for (int c = 0; c < GSLAB; ++c) {
+                            const double z = zs[jj][c];
+                            const double e0 = x0[c] - z, e1 = x1[c] - z;
+                            a = fma(e0, e0, a);
+                            b = fma(e1, e1, b);
+                            if (c == qc) { ec0[jj] = e0; ec1[jj] = e1; }
+                            if (c == q0) ep0[jj] = e0;
+                            if (c == q1) ep1[jj] = e1;
+                        }
+                        u0[jj] = a; u1[jj] = b;
+                    }
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) {
+                    const int q = zq[JH * h + jj];
+                    const int qc = q - 1;
+                    double f0, g0, h0, f1, g1, h1;
+                    if constexpr (DLOGELL) {
+                        phi_derivs_dlogell<FAM>(u0[jj], f0, g0, h0);
+                        phi_derivs_dlogell<FAM>(u1[jj], f1, g1, h1);
+                    } else {
+                        phi_derivs<FAM>(u0[jj], f0, g0, h0);
+                        phi_derivs<FAM>(u1[jj], f1, g1, h1);
+                    }
+                    double v0, v1;
+                    if (qc < 0) {
+                        v0 = qp0 < 0 ? f0 : 2.0 * il * g0 * ep0[jj];
+                        v1 = qp1 < 0 ? f1 : 2.0 * il * g1 * ep1[jj];
+                    } else {
+                        v0 = qp0 < 0 ? -2.0 * il * g0 * ec0[jj] : -il * il * fma(4.0 * h0, ec0[jj] * ep0[jj], qp0 == qc ? 2.0 * g0 : 0.0);
+                        v1 = qp1 < 0 ? -2.0 * il * g1 * ec1[jj] : -il * il * fma(4.0 * h1, ec1[jj] * ep1[jj], qp1 == qc ? 2.0 * g1 : 0.0);
+                    }
+                    v0 = (ok0 && q >= 0) ? p.sigma_f2 * v0 : 0.0;
+                    v1 = (ok1 && q >= 0) ? p.sigma_f2 * v1 : 0.0;
+                    if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + JH * h + jj) * p.ldk + k) = d2_t{v0, v1};
+                    mu[JH * h + jj] = fma(v1, a1, fma(v0, a0, mu[JH * h + jj]));
+                }
+            }
+        }
+    }
+    if (p.mu == nullptr) return;
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        double v = mu[jj];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][jj] = v;
+    }
+    __syncthreads();
+    if (t < JT) {
+        const int q = zq[t];
+        p.mu[jb + t] = (q >= 0 ? p.mean_vec[q] : 0.0) + (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]);
+    }
+}
+
 // launch kgen_grad_kernel<FAM, dp, DLOGELL, RES> for the run-time dp
 template <int FAM, bool DLOGELL, int RES>
 static hipError_t launch_grad_kgen_dp(const KgenArgs& a, hipStream_t s) {
@@ -191,7 +310,10 @@ static hipError_t launch_grad_kgen_dp(const KgenArgs& a, hipStream_t s) {
         case 8: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 8, DLOGELL, RES>), grid, block, 0, s, a); break;
         case 16: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 16, DLOGELL, RES>), grid, block, 0, s, a); break;
         case 32: hipLaunchKernelGGL((kgen_grad_kernel<FAM, 32, DLOGELL, RES>), grid, block, 0, s, a); break;
-        default: return hipErrorInvalidValue;
+        default:
+            if (RES != 0 || a.dp <= 32 || a.dp % 32) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((kgen_grad_wide_kernel<FAM, DLOGELL>), grid, block, 0, s, a);
+            break;
     }
     return hipGetLastError();
 }

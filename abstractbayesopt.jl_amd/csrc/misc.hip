@@ -173,8 +173,9 @@ hipError_t launch_pick_record(const double* tv, const int64_t* ti, int64_t idx_b
 // (src/acquisition_functions/gradNormUCB.jl:43-51).  V rows are point-major: row j·p + q holds L⁻¹k for output q
 // of point j.  One workgroup per point; wave w reduces the (q,q') pairs w, w+4, … (lanes stride the R entries).
 __global__ void __launch_bounds__(256) grad_cov_kernel(GradCovArgs a) {
-    __shared__ double C[MAX_P * MAX_P];
-    __shared__ double m[MAX_P];
+    extern __shared__ double gc_lds[];                         // C[p][p], m[p]: 9 KB at p = 33, 134 KB at p = 129
+    double* C = gc_lds;
+    double* m = gc_lds + a.p * a.p;
     const int j = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int p = a.p;
@@ -209,7 +210,14 @@ __global__ void __launch_bounds__(256) grad_cov_kernel(GradCovArgs a) {
 
 hipError_t launch_grad_cov(const GradCovArgs& a, int npoints, hipStream_t s) {
     if (npoints <= 0) return hipSuccess;
-    hipLaunchKernelGGL(grad_cov_kernel, dim3(npoints), dim3(256), 0, s, a);
+    const size_t lds = sizeof(double) * ((size_t)a.p * a.p + a.p);
+    if (lds > 160 * 1024 - 512) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {                                      // beyond the default cap of dynamic LDS: raised once per process
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grad_cov_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (attr != hipSuccess) return attr;
+    }
+    hipLaunchKernelGGL(grad_cov_kernel, dim3(npoints), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

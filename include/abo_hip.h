@@ -153,7 +153,8 @@ int32_t abo_create(const abo_params* params, abo_gp** out);
 /* GradientGP(kernel, p, noise_var; mean=gradConstMean(c)) (src/surrogates/GradientGP.jl:617-639): gradient-
  * enhanced GP with p = d+1 outputs per point (f and ∂f/∂x_c), multi-output kernel gradKernel (:573-606) with
  * analytic derivatives, rows ordered by outputs (MOInputIsotopicByOutputs).  mean_c: p prior means (NULL = 0).
- * 2 ≤ p ≤ 33 (d ≤ 32 inputs: the derivative blocks are generated from register-resident coordinates).
+ * 2 ≤ p ≤ 129 (d ≤ 128 inputs; d ≤ 32: the derivative blocks are generated from register-resident coordinates, beyond that from
+ * slabs of 32 coordinates, fp64 output only — ABI 7; rounds 2 - 5 stopped at d = 32).
  * abo_fit then takes y of length p·N ordered by outputs (prep_output, :893-895); abo_predict / abo_acq address
  * the function output.  Inside the library the (d+1)N-row system is kept POINT-MAJOR (row i·p + q: all outputs of point i
  * adjacent), so that a new observation appends p rows at the end of the factor (abo_append_grad); every vector that crosses

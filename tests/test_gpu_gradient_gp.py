@@ -69,7 +69,12 @@ def test_reference_closed_form_case_shapes_and_copy():
 
 
 @pytest.mark.parametrize("family,d,N,M,ell,noise", [(O.SE, 2, 60, 500, 0.6, 1e-3), (O.MATERN52, 3, 100, 700, 0.8, 1e-3),
-                                                    (O.MATERN72, 4, 90, 300, 1.1, 1e-2), (O.MATERN52, 8, 150, 400, 1.5, 1e-2)])
+                                                    (O.MATERN72, 4, 90, 300, 1.1, 1e-2), (O.MATERN52, 8, 150, 400, 1.5, 1e-2),
+                                                    # round 6: beyond 32 inputs (GradientGP.jl:617-639 has no limit) — the slab
+                                                    # generator kgen_grad_wide_kernel; 41·40 = 1640 factor rows: the AUTO engine is the
+                                                    # int8 one, fed by the quantiser pass (the slab generator writes fp64 only)
+                                                    (O.SE, 40, 20, 60, 2.5, 1e-2), (O.MATERN52, 70, 12, 40, 4.0, 1e-2),
+                                                    (O.MATERN52, 40, 40, 64, 3.0, 1e-2), (O.MATERN72, 128, 5, 20, 6.0, 1e-2)])
 def test_gradient_gp_against_oracle(family, d, N, M, ell, noise):
     p = d + 1
     X = synth.points(1, N, d)
@@ -154,6 +159,16 @@ def test_gradient_gp_nlml_and_hyperparameter_mle():
         fd = (G.nlml(G.fit(O.MATERN52, float(np.exp(pp[0])), float(np.exp(pp[1])), 1e-3, np.zeros(d + 1), X, Ys))
               - G.nlml(G.fit(O.MATERN52, float(np.exp(pm[0])), float(np.exp(pm[1])), 1e-3, np.zeros(d + 1), X, Ys))) / (2 * h)
         assert abs(g0[c] - fd) <= 1e-5 * max(1.0, abs(fd))
+    # the same beyond 32 inputs (the slab generator's ∂/∂log ℓ build)
+    dw, Nw = 40, 12
+    Xw = synth.points(3, Nw, dw)
+    Yw = np.column_stack([np.sin(2 * np.pi * Xw).sum(axis=1) / np.sqrt(dw), 2 * np.pi * np.cos(2 * np.pi * Xw) / np.sqrt(dw)])
+    gw = make_grad(O.MATERN52, 2.5, 1.1, 1e-2, dw + 1)
+    pw = [np.log(2.5), np.log(1.1)]
+    stw = G.fit(O.MATERN52, 2.5, 1.1, 1e-2, np.zeros(dw + 1), Xw, Yw)
+    assert abs(abo.nlml(gw, pw, Xw, Yw) - G.nlml(stw)) <= 1e-9 * max(1.0, abs(G.nlml(stw)))
+    ga, gf = abo.gradient_gp.nlml_and_grad(gw, pw, Xw, Yw)[1], abo.gradient_gp.nlml_and_grad_fd(gw, pw, Xw, Yw)[1]
+    assert np.max(np.abs(ga - gf)) <= 1e-7 * max(1.0, np.max(np.abs(gf))), (ga, gf)
     dom = abo.ContinuousDomain(np.zeros(d), np.ones(d))
     new = abo.optimize_hyperparameters(gp, X, Ys, [np.log(0.9), 0.0], domain=dom, rng=np.random.default_rng(0))
     assert isinstance(new, abo.GradientGP) and new.gpx is None and new.p == d + 1
@@ -165,6 +180,7 @@ def test_gradient_gp_nlml_and_hyperparameter_mle():
     (O.SE, 2, 20, 6, 0.6, 1e-3, 64),
     (O.MATERN52, 3, 40, 9, 0.8, 1e-3, 64),          # 160 rows → 196: crosses the 128-row padding boundary twice
     (O.MATERN72, 4, 30, 5, 1.1, 1e-2, 0),           # no spare capacity: the first append refits with room to grow
+    (O.MATERN52, 36, 8, 3, 2.5, 1e-2, 16),          # beyond 32 inputs: the appended kernel rows come from the slab generator
 ])
 def test_gradient_gp_append_matches_full_refit(family, d, N0, n_app, ell, noise, n_max):
     """abo_append_grad: p bordered row-appends per observation on the point-major factor.  The reference refits per step

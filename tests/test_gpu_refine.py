@@ -444,6 +444,35 @@ def test_gradient_enhanced_objective_gradients_against_the_oracle(family, d, N):
         check(f"refine/gradgp_fam{family}_d{d}_N{N}", f"{type(acq).__name__}_rel_vs_oracle_central_differences", err, 2e-5)
 
 
+def test_gradient_enhanced_optimize_acquisition_beyond_32_inputs(monkeypatch):
+    """optimize_acquisition on a GradientGP with d = 36 inputs (round 6: the slab generator serves d = 33 … 128; GradientGP.jl:617-639
+    has no limit): one C-ABI call — grid, scores, starts, refinement in lockstep rounds on the all-output posterior (GradientNormUCB
+    through its 2d-point stencils) — never below the best start, inside the box, the reported value is the ORACLE's acquisition at
+    the reported point; the host loop is not reached."""
+    from oracle import grad_oracle as G
+    from tests.test_gpu_gradient_gp import make_grad
+    _no_host_loop(monkeypatch)
+    d, N = 36, 8
+    X, Y = _grad_problem(N, d)
+    ell, sf2, noise = 2.5, 1.0, 0.02
+    m = abo.update(make_grad(O.MATERN52, ell, sf2, noise, d + 1), X, Y)
+    st = G.fit(O.MATERN52, ell, sf2, noise, np.zeros(d + 1), X, Y)
+    best = float(np.median(Y[:, 0]))
+    lower, upper = np.zeros(d), np.ones(d)
+    dom = abo.ContinuousDomain(lower, upper)
+
+    def o_ei(z):
+        mu, var = G.predict(st, z)
+        return O.expected_improvement(mu, var, best, 0.01)
+
+    for acq, oracle in ((abo.ExpectedImprovement(0.01, best), o_ei), (abo.GradientNormUCB(2.0), lambda z: G.grad_norm_ucb(st, z, 2.0))):
+        b, v, sx, sv, rx, rv = abo.optimize_acquisition_device(acq, m, dom, n_grid=400, n_local=4, seed=5, return_all=True)
+        assert v >= sv[0] - 1e-12 and np.all(b >= lower) and np.all(b <= upper) and np.all(rv >= sv - 1e-9)
+        np.testing.assert_allclose(oracle(sx), sv, rtol=1e-8, atol=1e-10)          # the grid stage's scores are the oracle's
+        np.testing.assert_allclose(oracle(b[None, :])[0], v, rtol=1e-7, atol=1e-9)
+        assert m.timings()["refine_evals"] >= 4
+
+
 @pytest.mark.parametrize("family,d,N", [(O.MATERN52, 2, 40), (O.SE, 3, 50)])
 def test_gradient_enhanced_refinement_and_optimize_acquisition_on_the_device(family, d, N, monkeypatch):
     """optimize_acquisition(acqf, ::GradientGP, domain) — what the reference's tutorials run (gradNormUCB.jl:39-51 on a
