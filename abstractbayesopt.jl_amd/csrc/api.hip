@@ -242,7 +242,8 @@ std::atomic<uint64_t> g_storage_gen{1};
 // contraction engine of the posterior variance: process default (ABO_CONTRACTION = auto | fp64 | int8 | int8:<moduli>),
 // overridable per handle (abo_set_contraction)
 constexpr int OZ_DEFAULT_NMOD = 14;   // P ≈ 2^110: the fixed-point images keep 50+ bits of W per row and 52–53 bits of K_XZ
-constexpr int OZ_AUTO_MIN_NP = 1536;  // below this the fp64 kernels win (tools/engine_crossover.py: 0.81 at 1024, 1.05 at 1536, 1.23 at 2048)
+constexpr int OZ_AUTO_MIN_NP = 1280;  // below this the fp64 kernels win (tools/engine_crossover.py, profiles/r06_engine_crossover.txt: fp64/int8 = 0.97 at
+                                      // 1024, 1.09 at 1280, 1.21 at 1536, 1.90 at 4096; round 2's engine crossed at 1536)
 std::atomic<int> g_oz_engine{-1}, g_oz_nmod{OZ_DEFAULT_NMOD};
 void oz_defaults(int* engine, int* nmod) {
     int e = g_oz_engine.load();
@@ -551,7 +552,9 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // kernel leaves (trsm_stream_kernel; the stream lives in T, which the factorisation does not use — the blocked inverse behind it
     // does) → in-strip update.  The 128×128 inverses of the diagonal blocks (the seeds of the blocked L⁻¹ below) are not on that chain:
     // all of them are formed by ONE batched launch behind the factorisation.  Measured and not adopted (profiles/r05_notes.md D, removed
-    // from the library in round 6): a two-stream look-ahead, one launch per panel with in-launch hand-overs, 256 × 128 trailing tiles.
+    // from the library in round 6): a two-stream look-ahead, one launch per panel with in-launch hand-overs, 256 × 128 trailing tiles;
+    // round 6: the same look-ahead on CU-MASKED streams (hipExtStreamCreateWithCUMask: chain and trailing update on disjoint compute
+    // units, so the chain never waits for a slot) — 7.4 – 9.1 ms against 7.0 at N = 8192 (profiles/r06_chol_lookahead_cumask_ab.txt).
     const bool split = Np > TB;                            // a single block has no chain: factor + inverse in one launch
     if (split) HIPCHK(g->T.ensure(TRSM_STREAM_BYTES));
     double* trsm_ops = g->T.as<double>();

@@ -93,7 +93,7 @@ enum { ABO_HOST = 0, ABO_DEVICE = 1 };
  *                      Its scratch is 2·nmod bytes per (candidate, factor row) of a chunk plus nmod·rows² bytes of planes; when the
  *                      device cannot give that (or more than ABO_OZ_SCRATCH_LIMIT_MB allows) the chunk is halved down to 4096
  *                      candidates, and below that the call runs on the fp64 kernels — never an error.
- *   ABO_CONTRACT_AUTO  INT8 from 1536 (padded) factor rows on, FP64 below */
+ *   ABO_CONTRACT_AUTO  INT8 from 1280 (padded) factor rows on, FP64 below (the measured crossover: profiles/r06_engine_crossover.txt) */
 enum { ABO_CONTRACT_AUTO = 0, ABO_CONTRACT_FP64 = 1, ABO_CONTRACT_INT8 = 2 };
 
 typedef struct abo_gp abo_gp;     /* opaque, reference-counted: one (immutable) conditioned model */

@@ -8,7 +8,7 @@ from abstractbayesopt.jl_amd import synth
 
 M, d = 262144, 8
 Zd = torch.from_numpy(synth.points(2, M, d)).cuda()
-for N in (1024, 1536, 2048, 2560, 3072, 4096, 6144):
+for N in (512, 768, 1024, 1280, 1536, 2048, 3072, 4096):
     X, y = synth.standardized_problem(N, d, 0.03)
     row = []
     for eng in ("fp64", "int8"):
