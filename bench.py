@@ -42,7 +42,7 @@ def sustained_int8_tops(with_source=False):
     """what v_mfma_i32_16x16x64_i8 sustains on random operands from registers (tools/mfma_i8_power_probe.hip), read from the
     NEWEST committed probe output; None when no file is there.  with_source: (value, the file it came from)"""
     import re
-    for tag in ("r05", "r04", "r03", "r02"):
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         rel = os.path.join("profiles", f"{tag}_mfma_i8_power_probe.txt")
         try:
             with open(os.path.join(ROOT, rel)) as f:
@@ -287,7 +287,7 @@ def pmc_traffic(config, mc_per_launch):
     traffic of that pass scaled to this run's candidates per launch.  The pass records the hash of the kernel's
     source file; when the file has changed since, the figure is STALE and `traffic` is reported as null."""
     key = config.replace("c4", "c3")                         # C4 = C3 per launch
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_{key}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -303,6 +303,15 @@ def pmc_traffic(config, mc_per_launch):
     return (per * mc_per_launch if per is not None else d.get("traffic_bytes_per_launch")), d
 
 
+def trmv_traffic(c5_pmc):
+    """HBM-side bytes per launch of trmv_kernel from the committed C5 FETCH_SIZE pass (tools/run_pmc_c5.sh), null when chol.hip has
+    changed since"""
+    t = (c5_pmc or {}).get("trmv")
+    if not t or t.get("kernel_source_sha") != source_sha(["chol.hip"]):
+        return None
+    return t.get("traffic_bytes_per_launch")
+
+
 def contraction_label(abo, med):
     """what `config.contraction` says about the engine that ran: the int8-residue engine's only approximation is the fixed-point
     image of its operands, and the guarantee is stated per ROW of L^-1 (ozaki.hip: oz_rowscale_kernel), not per entry"""
@@ -311,7 +320,7 @@ def contraction_label(abo, med):
     return (f"int8-residue, {int(med['oz_nmod'])} moduli: exact integer products and sums of fixed-point images of the fp64 operands "
             "(K_XZ kept to 2^-52 of sigma_f2; each row of L^-1 kept to >= 50 bits below that row's L1 norm, i.e. an entry far below its "
             "row's L1 norm keeps fewer of its own bits - at most log2(N) fewer than 53 for a dense equal-magnitude row); results fp64, "
-            "parity vs the oracle recorded in profiles/parity_r05.json")
+            "parity vs the oracle recorded in profiles/parity_r06.json")
 
 
 def dominant_kernel_roofline(abo, med, config, N, M_per):
@@ -617,7 +626,8 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
             gbs = med["append_trmv_bytes"] / (med["append_trmv_ms"] * 1e-3) / 1e9
             roof = {"kernel": "trmv_kernel x2 (bordered append: l = L^-1 k over the lower triangle of L^-1, v = L^-T l over the upper "
                               "triangle of L^-T)", "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
-                    "frac": gbs / 8000.0, "traffic": None,
+                    "frac": gbs / 8000.0, "traffic": trmv_traffic(tr_src),
+                    "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2, profiles/)",
                     "algorithmic_bytes_per_launch": med["append_trmv_bytes"] / 2.0, "avg_launch_ms": med["append_trmv_ms"] / 2.0,
                     "launches_per_step": 2,
                     "share_of_step": med["append_trmv_ms"] / ms if ms > 0 else None,

@@ -2,7 +2,7 @@
 # (qei_pass_kernel, gemm.hip) — and of the bordered append's triangular mat-vecs: FETCH_SIZE pass (own run, --kernel-trace only)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 rm -rf gpurun_out/pmc_c5_fetch
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_c5_fetch -- python3 bench.py --config c5 --steps 3 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_c5_fetch.log 2>&1 || { tail -5 gpurun_out/pmc_c5_fetch.log; exit 1; }
 python3 - <<'PY'
@@ -39,5 +39,11 @@ if key:
                "kernel_source_sha": hashlib.sha256(b"".join(open("abstractbayesopt.jl_amd/csrc/" + n, "rb").read() for n in srcs)).hexdigest()[:16],
                "FETCH_SIZE_KB_mean": kb, "correction": "gfx950: x2 (64 B counted per 128-B request of a 16-B/lane stream)",
                "traffic_bytes_per_launch": kb * 2048, "algorithmic_bytes_per_launch": 8.0 * 16384 * 131072,
-               "avg_launch_ms_under_pmc": dm / 1e3}, open("gpurun_out/c5_pmc_traffic.json", "w"), indent=1)
+               "avg_launch_ms_under_pmc": dm / 1e3,
+               # the timed step's dominant kernel (bench.py: roofline of the C5 line): the bordered append's two triangular mat-vecs
+               "trmv": ({"kernel": "trmv_kernel", "kernel_sources": ["chol.hip"],
+                         "kernel_source_sha": hashlib.sha256(open("abstractbayesopt.jl_amd/csrc/chol.hip", "rb").read()).hexdigest()[:16],
+                         "traffic_bytes_per_launch": out["trmv_kernel"][0] * 2048, "avg_launch_ms_under_pmc": out["trmv_kernel"][1] / 1e3}
+                        if "trmv_kernel" in out else None)},
+              open("gpurun_out/c5_pmc_traffic.json", "w"), indent=1)
 PY
