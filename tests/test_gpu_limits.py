@@ -90,9 +90,10 @@ def test_gradient_gp_beyond_sixteen_inputs():
     assert np.max(np.abs(abo.posterior_grad_var(m, Z) - var_o)) < 1e-8
     s = abo.GradientNormUCB(2.0)(m, Z[:16])
     np.testing.assert_allclose(s, G.grad_norm_ucb(st, Z[:16], 2.0), rtol=1e-7, atol=1e-8)
+    # round 6: 33 … 128 inputs run the slab generator (tests/test_gpu_gradient_gp.py); beyond that the library refuses by name
     with pytest.raises(ValueError) as e:
-        abo.update(abo.GradientGP(abo.SqExponentialKernel(), 40, 0.1), synth.points(1, 4, 39), np.zeros((4, 40)))
-    assert "33" in str(e.value)                 # the message names the limit
+        abo.update(abo.GradientGP(abo.SqExponentialKernel(), 140, 0.1), synth.points(1, 4, 139), np.zeros((4, 140)))
+    assert "129" in str(e.value)                # the message names the limit
 
 
 def test_candidate_set_refuses_a_model_from_another_factor_of_the_same_size():
