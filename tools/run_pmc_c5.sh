@@ -31,6 +31,7 @@ for k in sorted(acc):
 open("gpurun_out/pmc_c5_fetch_summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 key = [k for k in out if "qei_passd_kernel" in k]
+tk = [k for k in out if "trmv_kernel" in k]
 if key:
     kb, dm = out[key[0]]
     srcs = ("gemm.hip", "abo_kernels.h")            # = bench.py PMC_SOURCES["c5"]
@@ -43,7 +44,7 @@ if key:
                # the timed step's dominant kernel (bench.py: roofline of the C5 line): the bordered append's two triangular mat-vecs
                "trmv": ({"kernel": "trmv_kernel", "kernel_sources": ["chol.hip"],
                          "kernel_source_sha": hashlib.sha256(open("abstractbayesopt.jl_amd/csrc/chol.hip", "rb").read()).hexdigest()[:16],
-                         "traffic_bytes_per_launch": out["trmv_kernel"][0] * 2048, "avg_launch_ms_under_pmc": out["trmv_kernel"][1] / 1e3}
-                        if "trmv_kernel" in out else None)},
+                         "traffic_bytes_per_launch": out[tk[0]][0] * 2048, "avg_launch_ms_under_pmc": out[tk[0]][1] / 1e3}
+                        if tk else None)},
               open("gpurun_out/c5_pmc_traffic.json", "w"), indent=1)
 PY
