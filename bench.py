@@ -186,7 +186,8 @@ def _cpu_baseline(cfg, sample_m):
     # ratio a measure of NumPy temporaries.  Here the chunk's candidates are dealt to `workers` threads, each assembling its rows with
     # the oracle's own function (NumPy ufuncs release the GIL; rows of K_ZX are independent) — same values, bit for bit.  K_XZ is
     # still built TWICE per chunk, as the reference does (posterior_mean and posterior_var each evaluate the kernel matrix,
-    # ExpectedImprovement.jl:41-42).  The fit's N x N assembly gets the same treatment through fit_threaded below.
+    # ExpectedImprovement.jl:41-42).  The refit is the oracle's own fit (its N x N assembly single-threaded: < 3 % of the extrapolated
+    # step).
     from concurrent.futures import ThreadPoolExecutor
     workers = max(1, usable_cores())
     pool = ThreadPoolExecutor(max_workers=workers)
