@@ -399,6 +399,35 @@ def quick_config(abo, synth, torch, dev, local_rank, name, k_top, steps=20, warm
             "value": ms, "unit": "ms", "steps": steps, "warmup": warmup}
 
 
+def quick_nlml_grad(abo, synth, torch, dev, local_rank, N=8192, d=8, reps=7):
+    """One objective evaluation of the hyper-parameter search (nlml, StandardGP.jl:99-114, under
+    optimize_hyperparameters, bayesian_opt.jl:196-328) at the headline's N: refit + abo_nlml_grad (value and analytic gradient
+    w.r.t. log ell, log sigma_f2).  Its dominant kernel beyond the refit is K^-1 = L^-T L^-1 on the fp64 MFMA tile core (N^3/3
+    flop on the lower tiles); tools/hyperparameter_latency.py prints the same at three sizes and a whole optimize_hyperparameters."""
+    import ctypes as C
+    X, y = synth.standardized_problem(N, d, 0.03)
+    Xd, yd = torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev)
+    walls, tms = [], []
+    for r in range(reps + 2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        m = abo.update(abo.HipStandardGP(abo.with_lengthscale(abo.Matern52Kernel(), 1.0), 1e-3, device=local_rank), Xd, yd)
+        v, d1, d2 = C.c_double(), C.c_double(), C.c_double()
+        abo._lib.check(abo._lib.lib().abo_nlml_grad(m._require(), C.byref(v), C.byref(d1), C.byref(d2)))
+        if r >= 2:
+            walls.append((time.perf_counter() - t0) * 1e3)
+            tms.append(m.timings())
+    med = {k: float(np.median([t[k] for t in tms])) for k in tms[0]}
+    tf = N ** 3 / 3.0 / (med["nlml_kinv_ms"] * 1e-3) / 1e12 if med["nlml_kinv_ms"] > 0 else None
+    return {"workload": f"hyper-parameter objective: N={N}, d={d}, Matern52Kernel: refit + nlml value and analytic gradient (abo_nlml_grad)",
+            "value": float(np.median(walls)), "unit": "ms", "steps": reps, "warmup": 2,
+            "phases_ms": {"refit": med["fit_total_ms"], "kinv_gemm": med["nlml_kinv_ms"], "trace_sweep": med["nlml_trace_ms"]},
+            "roofline": {"kernel": "gemm_nt_kernel (K^-1 = L^-T L^-1, lower tiles)", "bound": "mfma", "achieved": tf, "peak": 78.6,
+                         "unit": "TFLOP/s", "frac": (tf / 78.6 if tf else None), "traffic": None,
+                         "note": "algorithmic flop N^3/3 / HIP events around the product (abo_timings.nlml_kinv_ms)"},
+            "nlml": v.value, "grad": [d1.value, d2.value]}
+
+
 def quick_c1_shape(abo, synth, torch, dev, local_rank, k_top=100, steps=200, warmup=20):
     """The reference's own loop size (BASELINE config 1's shape: tens of points, acq_utils.jl:37's 10 000 grid points): a step =
     refit + EI over the grid + top-100, through the two C-ABI calls and through the fused one (abo_fit_acq); and one whole
@@ -1120,6 +1149,7 @@ def main():
             leg("C2", lambda: quick_config(abo, synth, torch, dev, local_rank, "c2", K_TOP))
             leg("C5", c5_leg)
             leg("C1 shape", lambda: quick_c1_shape(abo, synth, torch, dev, local_rank, K_TOP))
+            leg("hyper-parameter objective", lambda: quick_nlml_grad(abo, synth, torch, dev, local_rank))
             out["secondary"] = secondary
         print(json.dumps(out))
     if use_dist:
