@@ -155,11 +155,15 @@ hipError_t launch_nlml_grad_matrix(const NlmlGradArgs& a, const double* D, int64
 // test hook: out[i] = kappa(family, d2[i]) with the device math the generator uses
 hipError_t launch_kappa_test(int family, const double* d2, double* out, int64_t n, hipStream_t s);
 // K[i][i] += noise for i < N; K[i][i] = 1 for N ≤ i < Np (identity padding keeps the factor PD)
-hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s);
+hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s, int64_t* info_reset = nullptr);
 // A[i][i] = v for lo ≤ i < hi
 hipError_t launch_set_diag(double* A, int64_t ld, int lo, int hi, double v, hipStream_t s);
 // Xs[i][c] = X[i][c]·s (zero padded to [Np][dp])
 hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st);
+// everything in front of a fit's kernel matrix in one launch: the model's copies of the caller's X / y (when Xsrc / ysrc are not
+// those copies already), scaled zero-padded points, centred targets, alpha = 0
+hipError_t launch_fit_prep(const double* Xsrc, const double* ysrc, double* Xraw, double* ybuf, double* Xs, double* delta, double* alpha,
+                           int N, int Np, int d, int dp, double s, double mean_c, hipStream_t st);
 
 // ---- factorisation pieces (chol.hip) --------------------------------------------------------
 // factor the 128×128 diagonal block at (r0,r0) of K in place (lower), write its inverse into the
@@ -169,8 +173,10 @@ hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0
 // The whole fit of an N ≤ 128, d ≤ 16 model in ONE launch of the diagonal-block kernel (mode 3): writes Xs [128][dp], delta,
 // L (→ K), L⁻¹ (→ W, WT), alpha, scal = {log det, δᵀα}; K / W / WT have leading dimension 128.  *info as launch_chol_diag.
 struct FitSmallArgs {
-    const double* Xraw;   // [N][d] raw inputs (device)
+    const double* Xraw;   // [N][d] raw inputs (device): the model's copy, or the caller's array when Xkeep is set
     const double* y;      // [N]
+    double* Xkeep;        // non-null: the kernel also writes the model's own copies of the inputs it read (the caller's device
+    double* ykeep;        //           arrays go straight into the one launch: no staging copies in front of it)
     double* Xs;           // [128][dp]
     double* delta;        // [128]
     double* alpha;        // [128]
@@ -182,7 +188,7 @@ hipError_t launch_fit_small(double* K, double* W, double* WT, int64_t* info, con
 // the same split for the panel chain: potf2 (factor + the eight 16×16 diagonal sub-block inverses, which go to their final
 // places in W / WT), the panel solve below the block as a blocked triangular solve on L (rows r0+128 … r0+128+nrows), and —
 // once, after the factorisation — the 128×128 inverses of ALL diagonal blocks in one batched launch
-hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P);
+hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P, bool zero_rows = false);
 constexpr size_t TRSM_STREAM_BYTES = 144 * 64 * sizeof(double);      // the packed operands potf2_pipe_kernel leaves for trsm_stream_kernel
 hipError_t launch_trsm_stream(double* K, const double* P, int64_t ld, int r0, int nrows, const int64_t* info, hipStream_t s);
 hipError_t launch_trtri_diag_batched(double* K, double* W, double* WT, int64_t ld, int nblocks, int64_t* info, hipStream_t s);

@@ -337,6 +337,8 @@ struct abo_gp {
     double* h_sc() { return ctx && ctx->pin ? reinterpret_cast<double*>(ctx->pin) : h_sc_; }
     int64_t& h_info() { return ctx && ctx->pin ? *reinterpret_cast<int64_t*>(ctx->pin + 16) : h_info_; }
     bool fit_small_path = false;
+    const double* in_x = nullptr;      // the caller's device arrays while a one-launch fit reads them itself (abo_fit: no staging copies);
+    const double* in_y = nullptr;      // null: the model's own copies
     // posterior workspace
     DevBuf Zdev, Kxz, partial, mu_c, mu_all, var_all, score_all, tk_keys0, tk_keys1, tk_idx0, tk_idx1, top_val, top_idx;
     // int8-residue contraction (ozaki.hip): engine choice, the residue planes of this view's W (valid for oz_gen / oz_N /
@@ -518,18 +520,25 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     int64_t* info = g->info.as<int64_t>();              // the LAPACK-style status
 
     HIPCHK(hipEventRecord(g->evs()[0], s));
-    HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
-    // whole capacity region: zeros, identity on the padded diagonal (rows ≥ N), K on the active part
+    // whole capacity region: zeros, identity on the padded diagonal (rows ≥ N), K on the active part.  With a panel chain (more than
+    // one block) rows < Np of W / WT are zeroed by the chain's own launches — the idle workgroups of each diagonal-block launch take
+    // that panel's rows (chol.hip: potf2_pipe_kernel) — instead of two whole-matrix memsets in front of the fit (148 µs at N = 8192).
+    const bool split = Np > TB;                            // a single block has no chain: factor + inverse in one launch
     if (ld > Np) HIPCHK(hipMemsetAsync(K, 0, sizeof(double) * ld * ld, s));
-    HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
-    HIPCHK(hipMemsetAsync(WT, 0, sizeof(double) * ld * ld, s));
+    if (!split) {
+        HIPCHK(hipMemsetAsync(W, 0, sizeof(double) * ld * ld, s));
+        HIPCHK(hipMemsetAsync(WT, 0, sizeof(double) * ld * ld, s));
+    } else if (ld > Np) {
+        HIPCHK(hipMemsetAsync(W + (int64_t)Np * ld, 0, sizeof(double) * (ld - Np) * ld, s));
+        HIPCHK(hipMemsetAsync(WT + (int64_t)Np * ld, 0, sizeof(double) * (ld - Np) * ld, s));
+    }
     KgenArgs ka{};
     ka.Xs = st->Xs.as<double>(); ka.Z = st->Xraw.as<double>(); ka.alpha = nullptr; ka.Kout = K; ka.mu = nullptr;
     ka.ldk = ld; ka.M = g->npts; ka.j0 = 0; ka.Mc = Np; ka.N = (int)g->npts; ka.Np = Np; ka.d = g->d; ka.dp = g->dp;
     ka.family = g->prm.family; ka.s = 1.0 / g->prm.ell; ka.sigma_f2 = g->prm.sigma_f2; ka.mean_c = 0.0;
     ka.pt = g->p_out; ka.pc = g->p_out; ka.point_major = 1;      // K_XX: rows and columns point-major → symmetric
     HIPCHK(launch_kgen(ka, s));
-    HIPCHK(launch_diag_fix(K, ld, N, (int)ld, noise, s));
+    HIPCHK(launch_diag_fix(K, ld, N, (int)ld, noise, s, info));      // also resets the status word
     if (ld > Np) {
         HIPCHK(launch_set_diag(W, ld, Np, (int)ld, 1.0, s));
         HIPCHK(launch_set_diag(WT, ld, Np, (int)ld, 1.0, s));
@@ -555,7 +564,6 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     // from the library in round 6): a two-stream look-ahead, one launch per panel with in-launch hand-overs, 256 × 128 trailing tiles;
     // round 6: the same look-ahead on CU-MASKED streams (hipExtStreamCreateWithCUMask: chain and trailing update on disjoint compute
     // units, so the chain never waits for a slot) — 7.4 – 9.1 ms against 7.0 at N = 8192 (profiles/r06_chol_lookahead_cumask_ab.txt).
-    const bool split = Np > TB;                            // a single block has no chain: factor + inverse in one launch
     if (split) HIPCHK(g->T.ensure(TRSM_STREAM_BYTES));
     double* trsm_ops = g->T.as<double>();
     for (int S0 = 0, SS = SW; S0 < Np; S0 += SS) {
@@ -566,7 +574,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
             for (int r0 = s0; r0 < s0 + sw; r0 += TB) {
                 const int rem = Np - r0 - TB;
                 if (!split) { HIPCHK(launch_chol_diag(K, W, WT, ld, r0, info, s)); break; }
-                HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s, trsm_ops));
+                HIPCHK(launch_potf2_diag(K, W, WT, ld, r0, info, s, trsm_ops, true));
                 if (rem <= 0) break;
                 HIPCHK(launch_trsm_stream(K, trsm_ops, ld, r0, rem, info, s));
                 // in-strip update  A[r,c] −= L[r,p]·L[c,p]ᵀ  for the strip's remaining columns c, lower tiles only
@@ -667,10 +675,10 @@ int32_t fit_small(abo_gp* g, double noise, int64_t* info_host) {
     Storage* st = g->st;
     int64_t* info = g->info.as<int64_t>();
     HIPCHK(hipEventRecord(g->evs()[0], s));
-    HIPCHK(hipMemsetAsync(info, 0, sizeof(int64_t), s));
-    PHASE_EVENT(g->evs()[1], s);
+    PHASE_EVENT(g->evs()[1], s);                            // (the launch resets the status word itself)
     FitSmallArgs fs{};
     fs.Xraw = st->Xraw.as<double>(); fs.y = st->ybuf.as<double>(); fs.Xs = st->Xs.as<double>(); fs.delta = st->delta.as<double>();
+    if (g->in_x) { fs.Xraw = g->in_x; fs.y = g->in_y; fs.Xkeep = st->Xraw.as<double>(); fs.ykeep = st->ybuf.as<double>(); }
     fs.alpha = g->alpha.as<double>(); fs.scal = g->scal.as<double>();
     fs.N = (int)g->N; fs.d = g->d; fs.dp = g->dp; fs.family = g->prm.family;
     fs.s = 1.0 / g->prm.ell; fs.sigma_f2 = g->prm.sigma_f2; fs.noise = noise; fs.mean_c = g->prm.mean_c;
@@ -1049,32 +1057,47 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
         storage_unref(st);
         return fail(e == hipErrorOutOfMemory ? ABO_ENOMEM : ABO_EHIP, "abo_fit: device allocation failed: %s", hipGetErrorString(e));
     }
-    // stage the inputs BEFORE dropping the previous storage: X / y may alias it (refit after append)
-    int32_t rc = copy_in(st->Xraw.p, X, sizeof(double) * N * d, space, s);
-    // (gradient-enhanced: staged in K — overwritten by the kernel matrix later — and reordered into ybuf below)
-    if (!rc) rc = copy_in(P == 1 ? st->ybuf.p : st->K.p, y, sizeof(double) * R, space, s);
-    if (rc) { storage_unref(st); return rc; }
+    const int64_t Np = pad_up(R, TB);
+    {
+        hipError_t eh = g->alpha.ensure(sizeof(double) * cap);      // the handle's own buffers, BEFORE the previous storage goes back to
+        if (eh == hipSuccess) eh = g->tvec.ensure(sizeof(double) * cap);      // the pool: nothing handed out below may be memory the
+        if (eh == hipSuccess) eh = g->T.ensure(sizeof(double) * Np * Np);     // caller's X / y still live in (refit after append)
+        if (eh == hipSuccess) eh = g->info.ensure(sizeof(int64_t));
+        if (eh == hipSuccess) eh = g->scal.ensure(sizeof(double) * 8);
+        if (eh != hipSuccess) {
+            storage_unref(st);
+            return fail(eh == hipErrorOutOfMemory ? ABO_ENOMEM : ABO_EHIP, "abo_fit: device allocation failed: %s", hipGetErrorString(eh));
+        }
+    }
+    // N ≤ 128, d ≤ 16, no spare capacity: the whole fit is one launch (chol.hip, mode 3 of the diagonal-block kernel)
+    const bool fused_small = P == 1 && cap == TB && st->dp <= 16;
+    // Inputs.  Device arrays of a StandardGP are read by the fit's first launch itself, which also writes the model's own copies — the
+    // prep launch (larger models; issued right here), or the one-launch fit of a fresh handle — instead of two staging copies and three
+    // tiny launches in front of the kernel matrix.  Everything else is staged as before.  All of it BEFORE the previous storage is
+    // dropped: X / y may alias it (refit after append).
+    g->in_x = g->in_y = nullptr;
+    const bool direct = P == 1 && space == ABO_DEVICE && N > 0;
+    int32_t rc = ABO_OK;
+    if (direct && fused_small && g->st == nullptr) {        // (a handle that holds a storage stages: its launch runs behind the drop)
+        g->in_x = X; g->in_y = y;
+    } else if (!direct || fused_small) {
+        rc = copy_in(st->Xraw.p, X, sizeof(double) * N * d, space, s);
+        // (gradient-enhanced: staged in K — overwritten by the kernel matrix later — and reordered into ybuf below)
+        if (!rc) rc = copy_in(P == 1 ? st->ybuf.p : st->K.p, y, sizeof(double) * R, space, s);
+        if (rc) { storage_unref(st); return rc; }
+    }
+    if (P == 1 && !fused_small)
+        HIPCHK(launch_fit_prep(direct ? X : st->Xraw.as<double>(), direct ? y : st->ybuf.as<double>(), st->Xraw.as<double>(),
+                               st->ybuf.as<double>(), st->Xs.as<double>(), st->delta.as<double>(), g->alpha.as<double>(), (int)N, (int)cap,
+                               d, st->dp, 1.0 / g->prm.ell, g->prm.mean_c, s));
     if (g->st) HIPCHK(hipStreamSynchronize(s));         // a fresh handle (what update() makes) has nothing the inputs could alias
     if (g->st && g->fitted) g->st->drop_view(g->N);
     g->fitted = false;
     storage_unref(g->st);
     g->st = st;
-    g->npts = N; g->N = R; g->d = d; g->dp = st->dp; g->Np = pad_up(R, TB);
-    const int64_t Np = g->Np;
+    g->npts = N; g->N = R; g->d = d; g->dp = st->dp; g->Np = Np;
     tl_phase_np = Np;
-    HIPCHK(g->alpha.ensure(sizeof(double) * cap));
-    HIPCHK(g->tvec.ensure(sizeof(double) * cap));
-    HIPCHK(g->T.ensure(sizeof(double) * Np * Np));
-    HIPCHK(g->info.ensure(sizeof(int64_t)));
-    HIPCHK(g->scal.ensure(sizeof(double) * 8));
-    // N ≤ 128, d ≤ 16, no spare capacity: the whole fit is one launch (chol.hip, mode 3 of the diagonal-block kernel)
-    const bool fused_small = P == 1 && cap == TB && st->dp <= 16;
     if (defer) {
-        if (!fused_small) {
-            HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
-            HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
-            HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
-        }
         rc = fused_small ? fit_small(g, g->prm.noise_var, nullptr) : factorise(g, g->prm.noise_var, nullptr);
         if (rc) return rc;
         st->noise_used = g->prm.noise_var;
@@ -1101,16 +1124,14 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
         g->fitted = true;
         return ABO_OK;
     }
-    HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
-    if (P == 1) {
-        HIPCHK(launch_center(st->ybuf.as<double>(), st->delta.as<double>(), (int)N, (int)cap, g->prm.mean_c, s));
-    } else {                                             // point-major rows i·p + q, output q centred by mean_vec[q]
+    if (P > 1) {                                         // point-major rows i·p + q, output q centred by mean_vec[q]
+        HIPCHK(launch_scale_points(st->Xraw.as<double>(), st->Xs.as<double>(), (int)N, (int)cap, d, st->dp, 1.0 / g->prm.ell, s));
         MeanVec mv{};
         for (int q = 0; q < P; ++q) mv.c[q] = g->mean_vec[q];
         HIPCHK(launch_center_grad(st->K.as<double>(), st->ybuf.as<double>(), st->delta.as<double>(), (int)N, P, (int)cap, mv,
                                   y_point_major, s));
+        HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
     }
-    HIPCHK(hipMemsetAsync(g->alpha.p, 0, sizeof(double) * cap, s));
 
     int64_t inf = 0;
     double noise = g->prm.noise_var;

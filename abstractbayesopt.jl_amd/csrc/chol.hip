@@ -205,7 +205,11 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    if (*info != 0) return;
+    if constexpr (MODE == 3) {
+        if (t == 0) *info = 0;       // the one launch of the fit: nothing ran before it that could have failed (a failing pivot writes behind a barrier)
+    } else {
+        if (*info != 0) return;
+    }
     if (t == 0) fail = 0;
     if constexpr (MODE == 2) r0 = blockIdx.x * NB;
     // mode 3 (the whole fit of an N ≤ 128 model): the block beyond the last sub-block that holds a training point is the identity —
@@ -220,12 +224,17 @@ __global__ void __launch_bounds__(DT) chol_diag_kernel(double* K, double* W, dou
         // scaled, zero-padded inputs (also the model's Xs) and centred targets
         for (int idx = t; idx < NB * fs.dp; idx += DT) {
             const int i = idx / fs.dp, c = idx % fs.dp;
-            const double v = (i < fs.N && c < fs.d) ? fs.Xraw[(int64_t)i * fs.d + c] * fs.s : 0.0;
+            const bool real = i < fs.N && c < fs.d;
+            const double raw = real ? fs.Xraw[(int64_t)i * fs.d + c] : 0.0;
+            if (real && fs.Xkeep) fs.Xkeep[(int64_t)i * fs.d + c] = raw;      // the model's own copy of the caller's inputs
+            const double v = raw * fs.s;
             xs[i * 16 + c] = v;
             fs.Xs[idx] = v;
         }
         if (t < NB) {
-            const double v = t < fs.N ? fs.y[t] - fs.mean_c : 0.0;
+            const double yv = t < fs.N ? fs.y[t] : 0.0;
+            if (t < fs.N && fs.ykeep) fs.ykeep[t] = yv;
+            const double v = t < fs.N ? yv - fs.mean_c : 0.0;
             dl[t] = v;
             fs.delta[t] = v;
         }
@@ -665,7 +674,26 @@ __device__ __forceinline__ void potf2_pipe_body(double* a, double* dinv, double 
     PROBE(5);
 }
 
+// Workgroup 0 is the diagonal-block kernel.  The chain leaves 255 compute units idle while it runs, so the launch's other workgroups
+// (nz of them, when the caller asks) do what two whole-matrix memsets in front of the fit used to: they zero rows r0 … r0+127 of W and
+// WT over all ld columns EXCEPT the 128 × 128 diagonal block (workgroup 0 puts the 16 × 16 inverses there, the batched trtri behind the
+// factorisation rewrites the whole block) — 16 MB per launch at N = 8192, done long before the block is factored.
 __global__ void __launch_bounds__(DT) potf2_pipe_kernel(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, double* P) {
+    if (blockIdx.x > 0) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const int64_t per_row = ld / 2;                                  // 16-byte stores: ld is a multiple of 128
+        const int64_t total = 2 * (int64_t)NB * per_row;                 // both matrices
+        const d2_t z = {0.0, 0.0};
+        for (int64_t idx = (int64_t)(blockIdx.x - 1) * DT + threadIdx.x; idx < total; idx += (int64_t)(gridDim.x - 1) * DT) {
+            const int64_t e = idx >= (int64_t)NB * per_row ? idx - (int64_t)NB * per_row : idx;
+            const int row = (int)(e / per_row);
+            const int64_t col = 2 * (e % per_row);
+            if (col >= r0 && col < r0 + NB) continue;
+            double* base = idx >= (int64_t)NB * per_row ? WT : W;
+            *reinterpret_cast<d2_t*>(base + (int64_t)(r0 + row) * ld + col) = z;
+        }
+        return;
+    }
     POTF2_PIPE_LDS();
     potf2_pipe_body(a, dinv, colbuf, fail, K, W, WT, ld, r0, info, P);
 }
@@ -679,8 +707,11 @@ hipError_t launch_chol_diag(double* K, double* W, double* WT, int64_t ld, int r0
 }
 
 // the diagonal block of a panel; P: where the packed operands of the panel solve go (TRSM_OPS × 64 doubles)
-hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P) {
-    hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1), dim3(DT), 0, s, K, W, WT, ld, r0, info, P);
+// zero_rows: the launch also zeroes rows r0 … r0+127 of W / WT outside the diagonal block (see the kernel)
+hipError_t launch_potf2_diag(double* K, double* W, double* WT, int64_t ld, int r0, int64_t* info, hipStream_t s, double* P, bool zero_rows) {
+    int nz = 0;
+    if (zero_rows) { nz = (int)(ld / 32); nz = nz < 1 ? 1 : (nz > 255 ? 255 : nz); }     // ≥ 4 stores a thread
+    hipLaunchKernelGGL(potf2_pipe_kernel, dim3(1 + nz), dim3(DT), 0, s, K, W, WT, ld, r0, info, P);
     return hipGetLastError();
 }
 

@@ -455,15 +455,16 @@ hipError_t launch_cand_newcol_grad(const double* Xs, const double* Z, double* Kz
     return hipGetLastError();
 }
 
-__global__ void diag_fix_kernel(double* K, int64_t ld, int N, int Np, double noise) {
+__global__ void diag_fix_kernel(double* K, int64_t ld, int N, int Np, double noise, int64_t* info_reset) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && info_reset) *info_reset = 0;          // the factorisation's status word: the chain behind this launch reads it
     if (i >= Np) return;
     if (i < N) K[(int64_t)i * ld + i] += noise;
     else K[(int64_t)i * ld + i] = 1.0;
 }
 
-hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s) {
-    hipLaunchKernelGGL(diag_fix_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, K, ld, N, Np, noise);
+hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, hipStream_t s, int64_t* info_reset) {
+    hipLaunchKernelGGL(diag_fix_kernel, dim3((Np + 255) / 256), dim3(256), 0, s, K, ld, N, Np, noise, info_reset);
     return hipGetLastError();
 }
 
@@ -483,6 +484,38 @@ __global__ void scale_points_kernel(const double* X, double* Xs, int N, int Np, 
     if (idx >= (int64_t)Np * dp) return;
     const int i = (int)(idx / dp), c = (int)(idx % dp);
     Xs[idx] = (i < N && c < d) ? X[(int64_t)i * d + c] * s : 0.0;
+}
+
+__global__ void fit_prep_kernel(const double* Xsrc, const double* ysrc, double* Xraw, double* ybuf, double* Xs, double* delta, double* alpha,
+                                int N, int Np, int d, int dp, double s, double mean_c) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (int64_t)Np * dp) {
+        const int i = (int)(idx / dp), c = (int)(idx % dp);
+        double v = 0.0;
+        if (i < N && c < d) {
+            v = Xsrc[(int64_t)i * d + c];
+            if (Xsrc != Xraw) Xraw[(int64_t)i * d + c] = v;
+        }
+        Xs[idx] = v * s;
+    }
+    if (idx < Np) {
+        double v = 0.0;
+        if (idx < N) {
+            v = ysrc[idx];
+            if (ysrc != ybuf) ybuf[idx] = v;
+            v -= mean_c;
+        }
+        delta[idx] = v;
+        alpha[idx] = 0.0;
+    }
+}
+
+hipError_t launch_fit_prep(const double* Xsrc, const double* ysrc, double* Xraw, double* ybuf, double* Xs, double* delta, double* alpha,
+                           int N, int Np, int d, int dp, double s, double mean_c, hipStream_t st) {
+    const int64_t n = (int64_t)Np * dp;
+    hipLaunchKernelGGL(fit_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Xsrc, ysrc, Xraw, ybuf, Xs, delta, alpha, N, Np,
+                       d, dp, s, mean_c);
+    return hipGetLastError();
 }
 
 hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st) {

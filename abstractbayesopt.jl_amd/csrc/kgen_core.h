@@ -48,17 +48,10 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
             // plane offset = (uniform) row part + (per-lane, row-independent) k part: the stores take a scalar base and a 32-bit lane offset
             const unsigned koff = (unsigned)(((k >> 6) << 14) + (k & 63));
             const int64_t rowoff = ((int64_t)((jb + jj) >> 8) * (p.res_ld >> 6)) * 16384 + ((jb + jj) & 255) * 64;
-            {
-                const OzLimbs x0 = oz_limbs(v0, rsc), x1 = oz_limbs(v1, rsc);
-#pragma unroll
-                for (int l = 0; l < RES; ++l) {
-                    const float pf = (float)oz_mod_p(l), invp = 1.0f / (float)oz_mod_p(l);
-                    const int r0 = sym_residue_f32(x0, oz_mod_c14(l, 1), oz_mod_c14(l, 2), oz_mod_c14(l, 3), invp, pf);
-                    const int r1 = sym_residue_f32(x1, oz_mod_c14(l, 1), oz_mod_c14(l, 2), oz_mod_c14(l, 3), invp, pf);
-                    int8_t* plane = p.res + (int64_t)l * p.res_plane + rowoff;        // uniform
-                    *reinterpret_cast<short*>(plane + koff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
-                }
-            }
+            oz_residue_pair<RES>(__builtin_rint(v0 * rsc), __builtin_rint(v1 * rsc), [&](int l, unsigned two) {
+                int8_t* plane = p.res + (int64_t)l * p.res_plane + rowoff;        // uniform
+                *reinterpret_cast<unsigned short*>(plane + koff) = (unsigned short)two;
+            });
         }
         mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
     }

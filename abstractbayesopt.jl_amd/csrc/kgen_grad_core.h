@@ -148,16 +148,11 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
                     const unsigned koff = (unsigned)(((k >> 6) << 14) + (k & 63));
                     const int64_t rowoff = ((int64_t)((jb + jj) >> 8) * (p.res_ld >> 6)) * 16384 + ((jb + jj) & 255) * 64;
                     const int nd0 = (qc >= 0 ? 1 : 0) + (qp0 >= 0 ? 1 : 0), nd1 = (qc >= 0 ? 1 : 0) + (qp1 >= 0 ? 1 : 0);
-                    const OzLimbs y0 = oz_limbs(v0, nd0 == 0 ? rsc0 : (nd0 == 1 ? rsc1 : rsc2));
-                    const OzLimbs y1 = oz_limbs(v1, nd1 == 0 ? rsc0 : (nd1 == 1 ? rsc1 : rsc2));
-#pragma unroll
-                    for (int l = 0; l < RES; ++l) {
-                        const float pf = (float)oz_mod_p(l), invp = 1.0f / (float)oz_mod_p(l);
-                        const int r0 = sym_residue_f32(y0, oz_mod_c14(l, 1), oz_mod_c14(l, 2), oz_mod_c14(l, 3), invp, pf);
-                        const int r1 = sym_residue_f32(y1, oz_mod_c14(l, 1), oz_mod_c14(l, 2), oz_mod_c14(l, 3), invp, pf);
+                    oz_residue_pair<RES>(__builtin_rint(v0 * (nd0 == 0 ? rsc0 : (nd0 == 1 ? rsc1 : rsc2))),
+                                         __builtin_rint(v1 * (nd1 == 0 ? rsc0 : (nd1 == 1 ? rsc1 : rsc2))), [&](int l, unsigned two) {
                         int8_t* plane = p.res + (int64_t)l * p.res_plane + rowoff;        // uniform
-                        *reinterpret_cast<short*>(plane + koff) = (short)((r0 & 0xff) | ((r1 & 0xff) << 8));
-                    }
+                        *reinterpret_cast<unsigned short*>(plane + koff) = (unsigned short)two;
+                    });
                 }
                 mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
             }
