@@ -28,6 +28,7 @@
 //    SIMD partner — while dealt out one per MFMA they cost nothing; a strict ping-pong of MFMA and
 //    memory roles between the two waves of a SIMD is slower still (the memory phase becomes as long
 //    as the MFMA phase).  Static s_setprio between the co-resident workgroups changes nothing.
+#include <type_traits>
 #include "abo_kernels.h"
 #include <cstdlib>
 
@@ -666,94 +667,96 @@ __global__ void __launch_bounds__(512, 2) var_gemm256s_kernel(VarGemmArgs p) {
             *reinterpret_cast<d2_t*>((buf) + (BM2 + srow + 64 * q) * LDT + skk) = sb[q];                        \
     } while (0)
 
-#define FRAG_READ(buf, half, f)                                                                                  \
+#define FRAG_READ(buf, half, f, a0)                                                                              \
     do {                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
+        _Pragma("unroll") for (int i = (a0); i < 4; ++i)                                                        \
             (f).a[i] = *reinterpret_cast<const d2_t*>((buf) + aoff + i * 64 * LDT + (half) * 8);                \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                           \
-            (f).b[i] = *reinterpret_cast<const d2_t*>((buf) + boff + i * 16 * LDT + (half) * 8);                \
+        if ((a0) < 4) {                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+                (f).b[i] = *reinterpret_cast<const d2_t*>((buf) + boff + i * 16 * LDT + (half) * 8);            \
+        }                                                                                                       \
     } while (0)
 #define MMA_FROM(KK, f, a0)                                                                                     \
     do {                                                                                                        \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                        \
-            if (mi >= (a0)) {                                                                                   \
-                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64((f).a[mi][KK], (f).b[ni][KK], acc[mi][ni], 0, 0, 0); \
-            }                                                                                                   \
+        _Pragma("unroll") for (int mi = (a0); mi < 4; ++mi) {                                                   \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                    \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64((f).a[mi][KK], (f).b[ni][KK], acc[mi][ni], 0, 0, 0); \
+        }                                                                                                       \
     } while (0)
+
+    // One stage = 16 k: 32 MFMAs on F0 (fragments of the stage's first half) with the next stage's LDS stores, the second half's fragment
+    // reads and the loads of the stage after next dealt out between them, a barrier, 32 MFMAs on F1 with the next stage's first fragment
+    // reads.  A0 = the first live A fragment of this wave (below): the stage runs the same schedule over fragments A0 … 3.
+    // Loads past the tile's k range (the last two stages) re-read its last 16 columns: stored to LDS, never used.
+    const int klast = (nk - 1) * BK;
+    auto stage = [&](int st, auto a0c) {
+        constexpr int A0 = decltype(a0c)::value;
+        double* cur = smem + (st & 1) * STAGE2;
+        double* nxt = smem + ((st + 1) & 1) * STAGE2;
+        L_STORE(nxt);
+        FRAG_READ(cur, 1, f1, A0);
+        const int kn = (st + 2) * BK;
+        G_LOAD(kn < klast ? kn : klast);
+        MMA_FROM(0, f0, A0);
+        MMA_FROM(1, f0, A0);
+        // 16·(4 − A0) MFMAs; behind one MFMA each: 6 LDS stores, 8 − A0 fragment reads, 6 loads (what does not fit behind an MFMA follows)
+        constexpr int NM = 8 * (4 - A0);                              // MFMAs of this half stage
+        if constexpr (NM > 0) {
+            constexpr int NR = 8 - A0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            }
+#pragma unroll
+            for (int i = 0; i < (NM - 6 < NR ? NM - 6 : NR); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            }
+            constexpr int left = NM - 6 - (NM - 6 < NR ? NM - 6 : NR);
+#pragma unroll
+            for (int i = 0; i < (left < 6 ? left : 6); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+            if constexpr (left > 6) __builtin_amdgcn_sched_group_barrier(0x008, left - 6, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        FRAG_READ(nxt, 0, f0, A0);
+        MMA_FROM(0, f1, A0);
+        MMA_FROM(1, f1, A0);
+        if constexpr (NM > 0) {
+            constexpr int NR = 8 - A0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     G_LOAD(0);
     L_STORE(smem);
     G_LOAD(BK);                                             // nk ≥ 16
     __syncthreads();
-    FRAG_READ(smem, 0, f0);
+    FRAG_READ(smem, 0, f0, 0);
+    // The last 16 stages run through the two diagonal 128-blocks of W (upper block: stages nk−16 … nk−9, lower block: the last 8).  In
+    // stage s of a diagonal block the 16-row sub-tile m of that block is non-zero only for m ≥ s, and the upper block is zero throughout
+    // the last 8 stages.  This wave's fragments are sub-tiles wm, wm + 4 of the upper block, then wm, wm + 4 of the lower block (the
+    // interleaved row ↔ wave map keeps the skipped work spread over the four SIMDs), so with s16 = stage − (nk − 16):
+    //     fragment 0 is zero from s16 = wm + 1 on, fragment 1 from wm + 5, fragment 2 from wm + 9, fragment 3 from wm + 13:
+    // the live set is always {A0 … 3}, and the stages of one A0 are consecutive — five copies of ONE dealt-out schedule, run one after the
+    // other.  (Round 5 skipped behind run-time branches on A0: four scheduling regions a stage with nothing dealt out between them.)
     int st = 0;
-    for (; st < nk - 16; ++st) {                            // left of both diagonal blocks: every sub-tile is dense
-        double* cur = smem + (st & 1) * STAGE2;
-        double* nxt = smem + ((st + 1) & 1) * STAGE2;
-        L_STORE(nxt);
-        FRAG_READ(cur, 1, f1);
-        G_LOAD((st + 2) * BK);
-        frag_mma<0>(f0, acc);
-        frag_mma<1>(f0, acc);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        FRAG_READ(nxt, 0, f0);
-        frag_mma<0>(f1, acc);
-        frag_mma<1>(f1, acc);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 24, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // The last 16 stages run through the two diagonal 128-blocks of W (upper block: stages nk−16..nk−9, lower block:
-    // the last 8).  In stage s of a diagonal block the 16-row sub-tile m of that block is non-zero only for m ≥ s,
-    // and the upper block is zero throughout the last 8 stages: fragment i of this wave (sub-tiles wm, wm+4 of the
-    // upper block, then wm, wm+4 of the lower block) is skipped when it is structurally zero.  The live set is
-    // always {a0..3}; the interleaved row ↔ wave map keeps the skipped work spread over the four SIMDs.
-    // (Giving these stages the dealt-out schedule of the main loop, one copy per live set, spills 700 VGPRs.)
-    for (; st < nk; ++st) {
-        const int s16 = st - (nk - 16);
-        int a0;
-        if (s16 < 8) a0 = s16 > wm + 4 ? 2 : (s16 > wm ? 1 : 0);
-        else a0 = (s16 - 8) > wm + 4 ? 4 : ((s16 - 8) > wm ? 3 : 2);
-        double* cur = smem + (st & 1) * STAGE2;
-        double* nxt = smem + ((st + 1) & 1) * STAGE2;
-        MMA_FROM(0, f0, a0);
-        __builtin_amdgcn_sched_barrier(0);
-        FRAG_READ(cur, 1, f1);
-        if (st + 1 < nk) {
-            L_STORE(nxt);
-            if (st + 2 < nk) G_LOAD((st + 2) * BK);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        MMA_FROM(1, f0, a0);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (st + 1 < nk) FRAG_READ(nxt, 0, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        MMA_FROM(0, f1, a0);
-        MMA_FROM(1, f1, a0);
-    }
+    const int d0 = nk - 16 + wm;
+    for (; st <= d0; ++st) stage(st, std::integral_constant<int, 0>{});
+    for (; st <= d0 + 4; ++st) stage(st, std::integral_constant<int, 1>{});
+    for (; st <= d0 + 8; ++st) stage(st, std::integral_constant<int, 2>{});
+    for (; st <= d0 + 12 && st < nk; ++st) stage(st, std::integral_constant<int, 3>{});
+    for (; st < nk; ++st) stage(st, std::integral_constant<int, 4>{});
     __syncthreads();
 #undef G_LOAD
 #undef L_STORE
