@@ -160,6 +160,10 @@ hipError_t launch_diag_fix(double* K, int64_t ld, int N, int Np, double noise, h
 hipError_t launch_set_diag(double* A, int64_t ld, int lo, int hi, double v, hipStream_t s);
 // Xs[i][c] = X[i][c]·s (zero padded to [Np][dp])
 hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st);
+// a bordered append's new observation (x on the HOST, d ≤ APPEND_POINT_MAXD) → rows of Xraw / Xs, y, δ = y − m, *info = 0: one launch
+constexpr int APPEND_POINT_MAXD = 64;
+hipError_t launch_append_point(const double* x_host, int d, int dp, double s, double y, double mean_c, double* Xraw_row, double* Xs_row,
+                               double* y_at, double* delta_at, int64_t* info, hipStream_t st);
 // everything in front of a fit's kernel matrix in one launch: the model's copies of the caller's X / y (when Xsrc / ysrc are not
 // those copies already), scaled zero-padded points, centred targets, alpha = 0
 hipError_t launch_fit_prep(const double* Xsrc, const double* ysrc, double* Xraw, double* ybuf, double* Xs, double* delta, double* alpha,

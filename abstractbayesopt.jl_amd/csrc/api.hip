@@ -327,6 +327,7 @@ struct abo_gp {
     // bordered-append bookkeeping (valid when this view was produced by abo_append)
     bool from_append = false;
     double ap_s2 = 0.0, ap_beta = 0.0; // Schur complement l_nn² and (y* − μ(x*))/l_nn²
+    std::vector<double> ap_x;          // the point a one-row append added, as the host handed it over (abo_cand_downdate matches it against the q-EI chain)
     double ap_s2v[MAX_P] = {0}, ap_betav[MAX_P] = {0};   // gradient-enhanced append: the same per appended row (p_out of them)
     DevBuf alpha, vext, tvec, T, info, scal;
     // host landing zone of the fit's scalars ({log det, δᵀα} and the LAPACK-style info): read back by one asynchronous copy at
@@ -1036,6 +1037,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
                  int y_point_major = 0, bool defer = false) {
     hipStream_t s = g->stream;
     g->from_append = false;
+    g->ap_x.clear();
     Storage* st = new (std::nothrow) Storage();
     if (!st) return fail(ABO_ENOMEM, "abo_fit: host allocation failed");
     st->set_device(g->prm.device);
@@ -1190,11 +1192,16 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     HIPCHK(n->scal.ensure(sizeof(double) * 8));
     double* Xraw = st->Xraw.as<double>();
     // new point: raw coordinates, scaled coordinates, centred target (rows N — beyond every older view)
-    HIPCHK(hipMemcpyAsync(Xraw + N * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(st->ybuf.as<double>() + N, &y, sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(launch_scale_points(Xraw + N * d, st->Xs.as<double>() + N * st->dp, 1, 1, d, st->dp, 1.0 / g->prm.ell, s));
-    HIPCHK(launch_center(st->ybuf.as<double>() + N, st->delta.as<double>() + N, 1, 1, g->prm.mean_c, s));
-    HIPCHK(hipMemsetAsync(n->info.p, 0, sizeof(int64_t), s));
+    if (d <= APPEND_POINT_MAXD && st->dp <= APPEND_POINT_MAXD) {
+        HIPCHK(launch_append_point(x, d, st->dp, 1.0 / g->prm.ell, y, g->prm.mean_c, Xraw + N * d, st->Xs.as<double>() + N * st->dp,
+                                   st->ybuf.as<double>() + N, st->delta.as<double>() + N, n->info.as<int64_t>(), s));
+    } else {
+        HIPCHK(hipMemcpyAsync(Xraw + N * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(st->ybuf.as<double>() + N, &y, sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(launch_scale_points(Xraw + N * d, st->Xs.as<double>() + N * st->dp, 1, 1, d, st->dp, 1.0 / g->prm.ell, s));
+        HIPCHK(launch_center(st->ybuf.as<double>() + N, st->delta.as<double>() + N, 1, 1, g->prm.mean_c, s));
+        HIPCHK(hipMemsetAsync(n->info.p, 0, sizeof(int64_t), s));
+    }
     // k = k(X, x*): one kernel evaluation per training point (the training points play the candidates of the
     // column kernel; same scaled differences and the same kappa as kgen, so the values are bit-identical to a refit's)
     HIPCHK(launch_cand_newcol(st->Xs.as<double>() + N * st->dp, Xraw, n->Kxz.as<double>(), 1, N, 0, d, st->dp, g->prm.family,
@@ -1237,6 +1244,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     n->tm.append_trmv_ms = timed ? ev_ms(n->evs()[EV_BASE], n->evs()[EV_BASE + 1]) : 0.0;
     n->tm.append_trmv_bytes = 8.0 * (double)N * (double)N;
     n->ap_s2 = sc[0]; n->ap_beta = sc[1];
+    n->ap_x.assign(x, x + d);
     n->logdet = g->logdet + 2.0 * std::log(sc[2]);
     n->quad = g->quad + sc[1] * sc[1] * sc[0];
     n->fitted = true;
@@ -2053,8 +2061,12 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
         if (qok) {
             const int i = Q.nreal;
             std::vector<double> row(g->d);
-            HIPCHK(hipMemcpyAsync(row.data(), g->st->Xraw.as<double>() + (Q.N + i) * g->d, sizeof(double) * g->d, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            if ((int)g->ap_x.size() == g->d && Q.N + i == g->N - 1) {
+                row = g->ap_x;                                     // the appended point as the host handed it over: no read-back, no wait
+            } else {
+                HIPCHK(hipMemcpyAsync(row.data(), g->st->Xraw.as<double>() + (Q.N + i) * g->d, sizeof(double) * g->d, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
             if (i < Q.nchain && !memcmp(row.data(), &Q.chain_x[(size_t)i * g->d], sizeof(double) * g->d)) chain_i = i;
             else if (i < Q.chain_rows) { chain_put = i; newx = row; }
             else Q = abo_cand::Qei();                                                                                  // no room: start over

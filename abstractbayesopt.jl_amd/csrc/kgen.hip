@@ -518,6 +518,26 @@ hipError_t launch_fit_prep(const double* Xsrc, const double* ysrc, double* Xraw,
     return hipGetLastError();
 }
 
+// the observation a bordered append adds, handed over in the kernel arguments: raw and scaled coordinates, target, centred target and
+// the reset status word in ONE launch (instead of two pageable host-to-device copies, two one-thread kernels and a memset)
+struct AppendPoint { double x[APPEND_POINT_MAXD]; };
+__global__ void append_point_kernel(AppendPoint pt, int d, int dp, double s, double y, double mean_c, double* Xraw_row, double* Xs_row,
+                                    double* y_at, double* delta_at, int64_t* info) {
+    const int c = threadIdx.x;
+    if (c < d) Xraw_row[c] = pt.x[c];
+    if (c < dp) Xs_row[c] = c < d ? pt.x[c] * s : 0.0;
+    if (c == 0) { *y_at = y; *delta_at = y - mean_c; *info = 0; }
+}
+
+hipError_t launch_append_point(const double* x_host, int d, int dp, double s, double y, double mean_c, double* Xraw_row, double* Xs_row,
+                               double* y_at, double* delta_at, int64_t* info, hipStream_t st) {
+    if (d > APPEND_POINT_MAXD || dp > APPEND_POINT_MAXD) return hipErrorInvalidValue;
+    AppendPoint pt{};
+    for (int c = 0; c < d; ++c) pt.x[c] = x_host[c];
+    hipLaunchKernelGGL(append_point_kernel, dim3(1), dim3(APPEND_POINT_MAXD), 0, st, pt, d, dp, s, y, mean_c, Xraw_row, Xs_row, y_at, delta_at, info);
+    return hipGetLastError();
+}
+
 hipError_t launch_scale_points(const double* X, double* Xs, int N, int Np, int d, int dp, double s, hipStream_t st) {
     const int64_t n = (int64_t)Np * dp;
     hipLaunchKernelGGL(scale_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, Xs, N, Np, d, dp, s);
