@@ -54,6 +54,30 @@ int32_t fail(int32_t code, const char* fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                    \
     } while (0)
 
+// The end of a call waits for its stream.  hipStreamSynchronize blocks the host thread on an interrupt as soon as the work is not done at
+// once: 20 – 40 µs from the last kernel's end to the return, three times a BO step on the incremental path (0.7 ms) and once per 0.15 ms
+// step at the reference's own sizes.  Short waits are therefore polled (hipStreamQuery reads the queue's completion signal, ≈ 1 µs a
+// call); a wait that outlasts ABO_SPIN_WAIT_US (default 400, 0 = always block) falls back to the blocking call — a 450 ms
+// posterior does not spin a core.
+hipError_t wait_stream(hipStream_t s) {
+    static const long spin_us = [] { const char* e = getenv("ABO_SPIN_WAIT_US"); return e ? atol(e) : 400L; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool pending = false;
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) {
+                if (pending && e == hipSuccess) (void)hipGetLastError();      // hipErrorNotReady must not stay in the runtime's last-error slot:
+                return e;                                                     // the launch wrappers return hipGetLastError()
+            }
+            pending = true;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+        (void)hipGetLastError();
+    }
+    return hipStreamSynchronize(s);
+}
+
 // ---- process teardown guard (abo_internal.h) -------------------------------------------------------------------------------
 std::atomic<bool> g_exiting{false};
 std::atomic<bool> g_exit_armed{false};
@@ -234,7 +258,7 @@ struct ScratchBuf {
     DevBuf b;
     hipStream_t s;
     ScratchBuf(int dev, hipStream_t st) : s(st) { b.dev = dev; }
-    ~ScratchBuf() { if (b.p) { (void)hipStreamSynchronize(s); b.release(); } }
+    ~ScratchBuf() { if (b.p) { (void)wait_stream(s); b.release(); } }
 };
 
 std::atomic<uint64_t> g_storage_gen{1};
@@ -664,7 +688,7 @@ int32_t factorise(abo_gp* g, double noise, int64_t* info_host) {
     HIPCHK(hipMemcpyAsync(g->h_sc(), g->scal.as<double>(), 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&g->h_info(), info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (!info_host) return ABO_OK;        // deferred: fit_collect() after the caller's synchronisation
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     *info_host = g->h_info();
     if (g->h_info() == 0) fit_collect(g);   // else the caller decides (retry with jitter or ENOTPD)
     return ABO_OK;
@@ -690,7 +714,7 @@ int32_t fit_small(abo_gp* g, double noise, int64_t* info_host) {
     HIPCHK(hipMemcpyAsync(g->h_sc(), g->scal.as<double>(), 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&g->h_info(), info, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (!info_host) return ABO_OK;        // deferred: fit_collect() after the caller's synchronisation
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     *info_host = g->h_info();
     if (g->h_info() == 0) fit_collect(g);
     return ABO_OK;
@@ -1092,7 +1116,7 @@ int32_t fit_impl(abo_gp* g, const double* X, int64_t N, int d, const double* y, 
         HIPCHK(launch_fit_prep(direct ? X : st->Xraw.as<double>(), direct ? y : st->ybuf.as<double>(), st->Xraw.as<double>(),
                                st->ybuf.as<double>(), st->Xs.as<double>(), st->delta.as<double>(), g->alpha.as<double>(), (int)N, (int)cap,
                                d, st->dp, 1.0 / g->prm.ell, g->prm.mean_c, s));
-    if (g->st) HIPCHK(hipStreamSynchronize(s));         // a fresh handle (what update() makes) has nothing the inputs could alias
+    if (g->st) HIPCHK(wait_stream(s));         // a fresh handle (what update() makes) has nothing the inputs could alias
     if (g->st && g->fitted) g->st->drop_view(g->N);
     g->fitted = false;
     storage_unref(g->st);
@@ -1175,7 +1199,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
         HIPCHK(hipMemcpyAsync(yb.p, st->ybuf.p, sizeof(double) * N, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(xb.as<double>() + N * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(yb.as<double>() + N, &y, sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(wait_stream(s));
         if (n->prm.n_max < 2 * (N + 1)) n->prm.n_max = 2 * (N + 1);
         return fit_impl(n, xb.as<double>(), N + 1, d, yb.as<double>(), ABO_DEVICE, info);
     }
@@ -1227,7 +1251,7 @@ int32_t append_impl(abo_gp* g, abo_gp* n, const double* x, double y, int64_t* in
     PinStage pin(n->ctx);                            // the NEW handle's staging block: `g` may be in use by another thread (a copy of it)
     HIPCHK(pin.d2h(sc, n->scal.p, sizeof sc, s));
     HIPCHK(pin.d2h(&inf, n->info.p, sizeof inf, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     pin.flush();
     if (inf != 0) {
         if (info) *info = inf;
@@ -1270,7 +1294,7 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
         HIPCHK(hipMemcpyAsync(yb.p, st->ybuf.p, sizeof(double) * R, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(xb.as<double>() + npts * d, x, sizeof(double) * d, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(yb.as<double>() + R, yv, sizeof(double) * P, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(wait_stream(s));
         if (n->prm.n_max < 2 * (npts + 1)) n->prm.n_max = 2 * (npts + 1);
         return fit_impl(n, xb.as<double>(), npts + 1, d, yb.as<double>(), ABO_DEVICE, info, /*y_point_major=*/1);
     }
@@ -1319,7 +1343,7 @@ int32_t append_grad_impl(abo_gp* g, abo_gp* n, const double* x, const double* yv
     PinStage pin(n->ctx);
     HIPCHK(pin.d2h(sc, n->scal.p, sizeof(double) * 4 * P, s));
     HIPCHK(pin.d2h(&inf, n->info.p, sizeof inf, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     pin.flush();
     if (inf != 0) {
         if (info) *info = inf;
@@ -1444,7 +1468,7 @@ int32_t abo_destroy(abo_gp* gp) {
     if (g_exiting.load()) return ABO_OK;
     if (gp->refs.fetch_sub(1) == 1) {
         hipError_t e = hipSetDevice(gp->prm.device);
-        if (e == hipSuccess && gp->stream) e = hipStreamSynchronize(gp->stream);
+        if (e == hipSuccess && gp->stream) e = wait_stream(gp->stream);
         if (abo::gone(e)) { g_exiting.store(true); return ABO_OK; }      // the runtime says it has been torn down: the process is exiting
         // any other error of these two calls concerns this handle only: its buffers still go back to the pool, nothing is latched
         (void)hipGetLastError();
@@ -1530,7 +1554,7 @@ int32_t abo_predict(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t z_
     HIPCHK(hipEventRecord(g->evs()[6], s));
     if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
     if (var && out_space == ABO_HOST) { rc = copy_out(var, var_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     collect_posterior_timings(g, M, var != nullptr);
     g->tm.acq_topk_ms = 0.0;
     g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[6]);
@@ -1558,7 +1582,7 @@ int32_t abo_predict_grad(abo_gp* g, const double* Z, int64_t M, int32_t d, int32
     if (rc) return rc;
     if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
     if (var && out_space == ABO_HOST) { rc = copy_out(var, var_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     return ABO_OK;
 }
 
@@ -1584,7 +1608,7 @@ int32_t abo_predict_grad_cov(abo_gp* g, const double* Z, int64_t M, int32_t d, i
     if (mu && out_space == ABO_HOST) { rc = copy_out(mu, mu_d, sizeof(double) * M * P, ABO_HOST, s); if (rc) return rc; }
     if (cov && out_space == ABO_HOST) { rc = copy_out(cov, cov_d, sizeof(double) * M * P * P, ABO_HOST, s); if (rc) return rc; }
     if (score && out_space == ABO_HOST) { rc = copy_out(score, sc_d, sizeof(double) * M, ABO_HOST, s); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     return ABO_OK;
 }
 
@@ -1713,7 +1737,7 @@ int32_t acq_terms_impl(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_t
         int32_t rc = copy_out(scores, sc_d, sizeof(double) * M, ABO_HOST, s);
         if (rc) return rc;
     }
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     pin.flush();
     if (M > 0 && fused_timings) collect_posterior_timings(g, M, with_var);
     g->tm.acq_topk_ms = phase_events() ? ev_ms(g->evs()[6], g->evs()[7]) : 0.0;
@@ -1788,7 +1812,7 @@ int32_t abo_fit_acq(abo_gp* g, const double* X, int64_t N, int32_t d, const doub
     // the acquisition's launches go straight behind the fit's: after a failed pivot they work on finite leftovers or exit on
     // `info`, and their results are discarded below
     rc = abo::acq_ex(g, Z, M, d, z_space, kind, p0, best_y, idx_base, scores, out_space, k, top_val, top_idx, out_space);
-    if (rc) { (void)hipStreamSynchronize(g->stream); (void)fit_finish(g, info); return rc; }
+    if (rc) { (void)wait_stream(g->stream); (void)fit_finish(g, info); return rc; }
     return fit_finish(g, info);           // acq_ex returned behind its stream synchronisation: the fit's scalars have landed
 }
 
@@ -1842,7 +1866,7 @@ int32_t abo_nlml_grad(abo_gp* g, double* nlml, double* d_log_ell, double* d_log_
     HIPCHK(hipEventRecord(ev[2], s));
     double o[4];
     HIPCHK(hipMemcpyAsync(o, g->scal.as<double>() + 4, sizeof o, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     g->tm.nlml_kinv_ms = ev_ms(ev[0], ev[1]);
     g->tm.nlml_trace_ms = ev_ms(ev[1], ev[2]);
     // ∂NLML/∂θ = ½ tr((K⁻¹ − ααᵀ) ∂K/∂θ);  ∂K/∂log σ_f² = K − noise·I  and  K α = δ
@@ -1888,7 +1912,7 @@ int32_t abo_get_factor(abo_gp* g, double* L, double* alpha, double* Linv) {
                                 hipMemcpyDeviceToHost, s));
     }
     if (alpha) HIPCHK(hipMemcpyAsync(alpha, g->alpha.p, sizeof(double) * N, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     if (alpha && g->p_out > 1) to_by_outputs(alpha, g->npts, g->p_out);
     if (L)   // off-diagonal upper blocks of the in-place factor still hold K: present a clean L
         for (int64_t i = 0; i < N; ++i)
@@ -1903,7 +1927,7 @@ int32_t abo_get_data(abo_gp* g, double* X, double* y) {
     hipStream_t s = g->stream;
     if (X) HIPCHK(hipMemcpyAsync(X, g->st->Xraw.p, sizeof(double) * g->npts * g->d, hipMemcpyDeviceToHost, s));
     if (y) HIPCHK(hipMemcpyAsync(y, g->st->ybuf.p, sizeof(double) * g->N, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     if (y && g->p_out > 1) to_by_outputs(y, g->npts, g->p_out);
     return ABO_OK;
 }
@@ -1923,7 +1947,7 @@ static int32_t qei_resync(abo_gp* g, abo_cand* c, int64_t rows_now, bool* ok) {
     if (i > 0) {
         std::vector<double> rows((size_t)i * g->d);
         HIPCHK(hipMemcpyAsync(rows.data(), g->st->Xraw.as<double>() + Q.N * g->d, sizeof(double) * rows.size(), hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipStreamSynchronize(g->stream));
+        HIPCHK(wait_stream(g->stream));
         if (memcmp(rows.data(), Q.chain_x.data(), sizeof(double) * rows.size())) { Q = abo_cand::Qei(); return ABO_OK; }
     }
     if (i < Q.nreal) {
@@ -1992,7 +2016,7 @@ int32_t abo_cand_refresh(abo_gp* g, abo_cand* c) {
                        c->kzx_ld ? c->Kzx.as<double>() : nullptr, c->kzx_ld);
         if (rc) return rc;
         HIPCHK(hipEventRecord(g->evs()[6], g->stream));
-        HIPCHK(hipStreamSynchronize(g->stream));
+        HIPCHK(wait_stream(g->stream));
         collect_posterior_timings(g, c->M, true);
         g->tm.acq_topk_ms = 0.0;
         g->tm.acq_total_ms = ev_ms(g->evs()[5], g->evs()[6]);
@@ -2019,7 +2043,7 @@ int32_t abo_cand_create(abo_gp* g, const double* Z, int64_t M, int32_t d, int32_
     if (e != hipSuccess) { c->free_all(); delete c; return fail(ABO_ENOMEM, "abo_cand_create: %s", hipGetErrorString(e)); }
     rc = copy_in(c->Z.p, Z, sizeof(double) * M * d, z_space, g->stream);
     if (!rc) rc = abo_cand_refresh(g, c);
-    if (rc) { (void)hipStreamSynchronize(g->stream); c->free_all(); delete c; return rc; }
+    if (rc) { (void)wait_stream(g->stream); c->free_all(); delete c; return rc; }
     *out = c;
     return ABO_OK;
 }
@@ -2065,7 +2089,7 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
                 row = g->ap_x;                                     // the appended point as the host handed it over: no read-back, no wait
             } else {
                 HIPCHK(hipMemcpyAsync(row.data(), g->st->Xraw.as<double>() + (Q.N + i) * g->d, sizeof(double) * g->d, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
+                HIPCHK(wait_stream(s));
             }
             if (i < Q.nchain && !memcmp(row.data(), &Q.chain_x[(size_t)i * g->d], sizeof(double) * g->d)) chain_i = i;
             else if (i < Q.chain_rows) { chain_put = i; newx = row; }
@@ -2123,7 +2147,7 @@ int32_t abo_cand_downdate(abo_gp* g, abo_cand* c) {
                 Q.nreal = Q.nchain = chain_put + 1;
             }
         }
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(wait_stream(s));
         pass_ms = ev_ms(g->evs()[5], g->evs()[6]);
         g->tm.downdate_ms = pass_ms;
         g->tm.downdate_bytes = (resident && chain_i < 0) ? 8.0 * (double)g->N * (double)c->M * P : 0.0;
@@ -2156,7 +2180,7 @@ int32_t abo::cand_acq_ex(abo_gp* g, abo_cand* c, int32_t kind, double p0, double
         int32_t rc = copy_out(scores, sc_d, sizeof(double) * c->M, ABO_HOST, s);
         if (rc) return rc;
     }
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     return ABO_OK;
 }
 
@@ -2276,7 +2300,7 @@ int32_t abo::qei_begin(abo_gp* g, abo_cand* c, int q, int T, bool snapshot) {
             ScratchBuf keep(g->prm.device, s);
             HIPCHK(keep.b.ensure(sizeof(double) * (size_t)Q.nreal * Mp));
             HIPCHK(hipMemcpyAsync(keep.b.p, c->qchain.p, sizeof(double) * (size_t)Q.nreal * Mp, hipMemcpyDeviceToDevice, s));
-            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(wait_stream(s));
             HIPCHK(c->qchain.ensure(sizeof(double) * (size_t)want * Mp));
             HIPCHK(hipMemcpyAsync(c->qchain.p, keep.b.p, sizeof(double) * (size_t)Q.nreal * Mp, hipMemcpyDeviceToDevice, s));
         } else {
@@ -2381,7 +2405,7 @@ int32_t abo::qei_block(abo_gp* g, abo_cand* c, const double* pts, const int64_t*
     HIPCHK(hipEventRecord(ev[2], s));
     HIPCHK(launch_qei_cov(w.Ps, dp, c->Z.as<double>(), c->M, Mp, d, T, g->prm.family, 1.0 / g->prm.ell, g->prm.sigma_f2, C, s));
     HIPCHK(hipEventRecord(ev[3], s));
-    HIPCHK(hipStreamSynchronize(s));                          // (pts is the caller's; the events are read)
+    HIPCHK(wait_stream(s));                          // (pts is the caller's; the events are read)
     Q.block_ms += ev_ms(ev[0], ev[3]);
     Q.pass_ms = ev_ms(ev[1], ev[2]);
     Q.pass_bytes = 8.0 * (double)g->N * (double)c->M;
@@ -2435,7 +2459,7 @@ int32_t abo::qei_pick(abo_gp* g, abo_cand* c, int64_t gidx, double var_x, const 
         const double ex[2] = {HUGE_VAL, 0.0};                // abo_cand_exclude: μ = +Inf, σ² = 0
         HIPCHK(hipMemcpyAsync(c->mu.as<double>() + excl, &ex[0], sizeof(double), hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->var.as<double>() + excl, &ex[1], sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));                      // (ex lives on this frame)
+        HIPCHK(wait_stream(s));                      // (ex lives on this frame)
     }
     ++Q.nchain;
     Q.chain_s.push_back(sj);
@@ -2449,7 +2473,7 @@ int32_t abo::qei_end(abo_gp* g, abo_cand* c) {
     HIPCHK(hipSetDevice(g->prm.device));
     HIPCHK(hipMemcpyAsync(c->mu.p, c->qmu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(c->var.p, c->qvar.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(wait_stream(g->stream));
     c->qei.open = false;
     return ABO_OK;
 }
@@ -2544,7 +2568,7 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
             PinStage pin(g->ctx);
             if (e == hipSuccess) e = pin.d2h(&hst, a.st, sizeof(QeiStepState), s);
             if (e == hipSuccess) e = pin.d2h(rec.data(), a.rec, rec_bytes, s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e == hipSuccess) e = wait_stream(s);
             if (e != hipSuccess) { rc = fail(ABO_EHIP, "abo_cand_qei: %s", hipGetErrorString(e)); break; }
             pin.flush();
             // the picks conditioned on since the last read-back join the host's image of the chain (abo_cand_downdate compares a real
@@ -2575,7 +2599,7 @@ static int32_t qei_drive_device(abo_gp* g, abo_cand* c, int q, double xi, double
             S.rec = [c](int) { return c->qrec.as<double>(); };
             S.gather = [g, c](size_t words, double* out) -> int32_t {
                 HIPCHK(hipMemcpyAsync(out, c->qrec.p, sizeof(double) * words, hipMemcpyDeviceToHost, g->stream));
-                HIPCHK(hipStreamSynchronize(g->stream));
+                HIPCHK(wait_stream(g->stream));
                 return ABO_OK;
             };
             if ((rc = qei_build_block(S, xi, best_y, Tk, 4 + d + Q.nchain, (int64_t)r[1]))) break;
@@ -2793,7 +2817,7 @@ static int32_t refine_terms_impl(abo_gp* g, const AcqTerms& terms, const double*
     HIPCHK(pin.d2h(x_out, xd, sizeof(double) * ns, s));
     HIPCHK(pin.d2h(f_out, fd, sizeof(double) * S, s));
     HIPCHK(pin.d2h(it.data(), id, sizeof(int) * 2 * S, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     pin.flush();
     g->tm.refine_ms = ev_ms(g->evs()[5], g->evs()[6]);
     g->tm.refine_starts = S;
@@ -2847,7 +2871,7 @@ int32_t abo_test_acq_grad_terms(abo_gp* g, const abo_acq_term* terms, int32_t nt
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(grad, xd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(f, fd, sizeof(double) * M, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     return ABO_OK;
 }
 
@@ -2912,7 +2936,7 @@ static int32_t optimize_terms_impl(abo_gp* g, const AcqTerms& t, const double* l
     HIPCHK(pin.d2h(hx.data(), xd, sizeof(double) * ns, s));
     HIPCHK(pin.d2h(hf.data(), fd, sizeof(double) * k, s));
     HIPCHK(pin.d2h(it.data(), id, sizeof(int) * 2 * k, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     pin.flush();
     g->tm.acq_total_ms = grid_ms;
     g->tm.refine_ms = ev_ms(g->evs()[8], g->evs()[9]);
@@ -3005,7 +3029,7 @@ int32_t abo_acq_lhs(abo_gp* g, int64_t n, int32_t d, const double* lower, const 
     HIPCHK(hipMemcpyAsync(top_val, tv, sizeof(double) * k, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(top_idx, ti, sizeof(int64_t) * k, hipMemcpyDeviceToHost, s));
     if (top_x) HIPCHK(hipMemcpyAsync(top_x, sd, sizeof(double) * ns, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     if (top_x) {
         const double nan = std::numeric_limits<double>::quiet_NaN();
         for (int e = 0; e < k; ++e)
@@ -3048,7 +3072,7 @@ int32_t abo_cand_save(abo_gp* g, abo_cand* c) {
     HIPCHK(c->var_bak.ensure(bytes));
     HIPCHK(hipMemcpyAsync(c->mu_bak.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(c->var_bak.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(wait_stream(g->stream));
     c->bak_gen = c->synced_gen; c->bak_N = c->synced_N;
     return ABO_OK;
 }
@@ -3059,7 +3083,7 @@ int32_t abo_cand_restore(abo_gp* g, abo_cand* c) {
     HIPCHK(hipSetDevice(g->prm.device));
     HIPCHK(hipMemcpyAsync(c->mu.p, c->mu_bak.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(c->var.p, c->var_bak.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(wait_stream(g->stream));
     c->synced_gen = c->bak_gen; c->synced_N = c->bak_N;
     return ABO_OK;
 }
@@ -3069,7 +3093,7 @@ int32_t abo_cand_get(abo_gp* g, abo_cand* c, double* mu, double* var, int32_t ou
     HIPCHK(hipSetDevice(g->prm.device));
     if (mu) { int32_t rc = copy_out(mu, c->mu.p, sizeof(double) * c->M, out_space, g->stream); if (rc) return rc; }
     if (var) { int32_t rc = copy_out(var, c->var.p, sizeof(double) * c->M, out_space, g->stream); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(wait_stream(g->stream));
     return ABO_OK;
 }
 
@@ -3082,7 +3106,7 @@ int32_t abo_cand_point(abo_gp* g, abo_cand* c, int64_t idx, double* x, double* m
     if (x) HIPCHK(pin.d2h(x, c->Z.as<double>() + idx * c->d, sizeof(double) * c->d, s));
     if (mu) HIPCHK(pin.d2h(mu, c->mu.as<double>() + idx, sizeof(double), s));
     if (var) HIPCHK(pin.d2h(var, c->var.as<double>() + idx, sizeof(double), s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     pin.flush();
     return ABO_OK;
 }
@@ -3095,7 +3119,7 @@ int32_t abo_cand_exclude(abo_gp* g, abo_cand* c, int64_t idx) {
     const double excl[2] = {HUGE_VAL, 0.0};                 // μ = +Inf, σ² = 0: EI = PI = 0, UCB = −Inf
     HIPCHK(hipMemcpyAsync(c->mu.as<double>() + idx, &excl[0], sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->var.as<double>() + idx, &excl[1], sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(wait_stream(s));
     return ABO_OK;
 }
 
@@ -3129,7 +3153,7 @@ int32_t abo_cand_qei_top(abo_gp* g, abo_cand* c, double xi, double best_y, int64
     int32_t rc = abo::qei_top(g, c, xi, best_y, idx_base, k, c->qrec.as<double>());
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(rec, c->qrec.p, sizeof(double) * words, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(wait_stream(g->stream));
     return ABO_OK;
 }
 
@@ -3171,7 +3195,7 @@ static int32_t qei_plain(abo_gp* g, abo_cand* c, int q, double xi, double best_y
     HIPCHK(c->qvar.ensure(bytes));
     HIPCHK(hipMemcpyAsync(c->qmu.p, c->mu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(hipMemcpyAsync(c->qvar.p, c->var.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
+    HIPCHK(wait_stream(g->stream));
     const uint64_t gen0 = c->synced_gen;
     const int64_t N0 = c->synced_N;
     c->qei = abo_cand::Qei();
@@ -3206,7 +3230,7 @@ static int32_t qei_plain(abo_gp* g, abo_cand* c, int q, double xi, double best_y
     if (cur != g) abo_destroy(cur);
     hipError_t e = hipMemcpyAsync(c->mu.p, c->qmu.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->var.p, c->qvar.p, sizeof(double) * c->M, hipMemcpyDeviceToDevice, g->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    if (e == hipSuccess) e = wait_stream(g->stream);
     c->synced_gen = gen0; c->synced_N = N0;
     if (rc) return fail(rc, "%s", keep.c_str());
     HIPCHK(e);
@@ -3233,7 +3257,7 @@ int32_t abo_cand_qei(abo_gp* g, abo_cand* c, int32_t q, double xi, double best_y
         S.rec = [c](int) { return c->qrec.as<double>(); };
         S.gather = [g, c](size_t words, double* out) -> int32_t {
             HIPCHK(hipMemcpyAsync(out, c->qrec.p, sizeof(double) * words, hipMemcpyDeviceToHost, g->stream));
-            HIPCHK(hipStreamSynchronize(g->stream));
+            HIPCHK(wait_stream(g->stream));
             return ABO_OK;
         };
         // one handle, at least one candidate: the pick loop stays on the device; an empty set goes through the shard driver (its
@@ -3281,7 +3305,7 @@ int32_t abo_fill_distance(int32_t device, const double* X, int64_t N, int32_t d,
     HIPCHK(ob.b.ensure(sizeof(double)));
     HIPCHK(launch_fill_distance(Xd, N, d, Sd, n_samples, ob.b.as<double>(), nullptr));
     HIPCHK(hipMemcpyAsync(out, ob.b.p, sizeof(double), hipMemcpyDeviceToHost, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(wait_stream(nullptr));
     return ABO_OK;
 }
 
@@ -3296,7 +3320,7 @@ int32_t abo_lhs(int32_t device, int64_t n, int32_t d, const double* lower, const
     HIPCHK(hipMemcpyAsync(b.p, lower, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemcpyAsync(b.as<double>() + d, upper, sizeof(double) * d, hipMemcpyHostToDevice, nullptr));
     HIPCHK(launch_lhs(Z_dev, n, d, b.as<double>(), b.as<double>() + d, seed, j0, count, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(wait_stream(nullptr));
     return ABO_OK;
 }
 
@@ -3306,7 +3330,7 @@ int32_t abo_score(int32_t device, const double* mu, const double* var, int64_t M
     if (kind < ABO_ACQ_EI || kind > ABO_ACQ_MEAN) return fail(ABO_EINVAL, "abo_score: unknown acquisition kind %d", kind);
     HIPCHK(hipSetDevice(device));
     HIPCHK(launch_score(mu, var, scores, M, kind, p0, best_y, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(wait_stream(nullptr));
     return ABO_OK;
 }
 
@@ -3348,7 +3372,7 @@ int32_t abo_test_oz_contract(int32_t device, const double* W, int64_t ldw, int32
     oa.KR = kr.b.as<int8_t>(); oa.U = u.b.as<int8_t>(); oa.bad_col = sexp + 2 * q; oa.partial = partial; oa.ldp = ldp;
     oa.Np = Np; oa.Mc = Mc; oa.nvalid = nvalid; oa.sK = oz_k_scale(kmax);
     HIPCHK(launch_var_ozaki(oa, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(wait_stream(nullptr));
     return ABO_OK;
 }
 
@@ -3357,7 +3381,7 @@ int32_t abo_test_kappa(int32_t device, int32_t family, const double* d2, double*
     if (family < ABO_KERNEL_SE || family > ABO_KERNEL_MATERN32) return fail(ABO_EINVAL, "abo_test_kappa: unknown family");
     HIPCHK(hipSetDevice(device));
     HIPCHK(launch_kappa_test(family, d2, out, n, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(wait_stream(nullptr));
     return ABO_OK;
 }
 
@@ -3371,7 +3395,7 @@ int32_t abo_test_gemm_nt(int32_t device, const double* A, const double* B, doubl
     a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
     a.kmode = K_FULL; a.batch = 1; a.alpha = alpha; a.beta = beta;
     HIPCHK(launch_gemm_nt(a, nullptr));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(wait_stream(nullptr));
     return ABO_OK;
 }
 #endif  // ABO_TEST_HOOKS
