@@ -102,6 +102,10 @@ struct OzVarArgs {
     double* Vout = nullptr;     // when given: V = W.K_XZ itself, [Mc][ldv] fp64 (candidate-major), instead of the column sums of squares
     int64_t ldv = 0;
     hipEvent_t ev_quant = nullptr, ev_gemm = nullptr;   // optional: recorded after the quantisation / after the GEMM
+    // optional, HOST: where the owner remembers which tile-counter block is known to hold zeros.  The reconstruction kernel that ends a
+    // call zeroes the counters again, so the next call on the same scratch needs no memset in front of its GEMM; the slot is cleared
+    // while a call is between its GEMM and its reconstruction (an error in there leaves the counters dirty: the next call memsets).
+    int** ctr_clean = nullptr;
 };
 hipError_t launch_var_ozaki(const OzVarArgs& a, hipStream_t s);
 

@@ -369,6 +369,7 @@ struct abo_gp {
     // int8-residue contraction (ozaki.hip): engine choice, the residue planes of this view's W (valid for oz_gen / oz_N /
     // oz_plan.n) and the per-chunk scratch
     int oz_engine = ABO_CONTRACT_AUTO, oz_nmod = 0;
+    int* oz_ctr_clean = nullptr;       // the tile-counter block of oz_badc known to hold zeros (OzVarArgs::ctr_clean)
     OzPlan oz_plan{};
     bool oz_prepare_pending = false;  // events 8/9 of the current call bracket a rebuild of the residue planes of W (read with its timings)
     uint64_t oz_gen = 0;
@@ -393,6 +394,7 @@ struct abo_gp {
                          &oz_WR, &oz_sexp, &oz_badr, &oz_KR, &oz_U, &oz_badc};
         for (DevBuf* b : all) b->release();
         oz_N = -1;
+        oz_ctr_clean = nullptr;
         if (st && fitted) st->drop_view(N);
         storage_unref(st);
         st = nullptr;
@@ -897,7 +899,7 @@ int32_t posterior(abo_gp* g, const double* Zd, int64_t Mpts, int kind, double p0
             OzVarArgs oa{};
             oa.plan = &g->oz_plan; oa.Kxz = kchunk; oa.ldk = ldk; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
             oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
-            oa.bad_col = g->oz_badc.as<int>(); oa.partial = g->partial.as<double>(); oa.ldp = Mc; oa.Np = (int)Np; oa.Mc = mcp;
+            oa.bad_col = g->oz_badc.as<int>(); oa.ctr_clean = &g->oz_ctr_clean; oa.partial = g->partial.as<double>(); oa.ldp = Mc; oa.Np = (int)Np; oa.Mc = mcp;
             // a gradient-enhanced model's scaled chunk is bounded by σ_f²·√2 (oz_prepare_w), a StandardGP's by σ_f²
             // (derivative candidates against derivative training rows, both scaled: 2σ_f²)
             oa.nvalid = (int)g->N; oa.sK = oz_k_scale(g->p_out > 1 ? (pc > 1 ? 2.0 : 1.5) * g->prm.sigma_f2 : g->prm.sigma_f2);
@@ -989,7 +991,7 @@ int32_t grad_eval_device(abo_gp* g, const double* Zd, int64_t M, double beta, do
             OzVarArgs oa{};
             oa.plan = &g->oz_plan; oa.Kxz = g->Kxz.as<double>(); oa.ldk = Np; oa.WR = g->oz_WR.as<int8_t>(); oa.sexp = g->oz_sexp.as<int>();
             oa.bad_row = g->oz_badr.as<int>(); oa.KR = g->oz_KR.as<int8_t>(); oa.U = g->oz_U.as<int8_t>();
-            oa.bad_col = g->oz_badc.as<int>(); oa.partial = nullptr; oa.ldp = 0; oa.Np = (int)Np; oa.Mc = rows;
+            oa.bad_col = g->oz_badc.as<int>(); oa.ctr_clean = &g->oz_ctr_clean; oa.partial = nullptr; oa.ldp = 0; oa.Np = (int)Np; oa.Mc = rows;
             oa.nvalid = (int)g->N; oa.sK = oz_k_scale(2.0 * g->prm.sigma_f2);
             oa.kper = P; oa.ktg = oz_grad_exp(g); oa.planes_ready = fused ? 1 : 0;
             oa.rmode = 1; oa.rper = P; oa.r0 = p0 * P; oa.rpts = M;

@@ -24,9 +24,7 @@ template <int FAM>
 static hipError_t launch_grad_kgen_fam(const KgenArgs& a, hipStream_t s) {
     if (a.res) {                                       // residue planes in the same pass (posterior chunks only)
         if (a.res_n != 14 || a.dlogell) return hipErrorInvalidValue;
-        hipError_t e = hipMemsetAsync(a.res_bad, 0, sizeof(int) * a.Mc, s);
-        if (e != hipSuccess) return e;
-        return launch_kgen_grad_res14(a, s);
+        return launch_kgen_grad_res14(a, s);          // (writes every res_bad entry of the chunk itself)
     }
     return a.dlogell ? launch_grad_kgen_dp<FAM, true, 0>(a, s) : launch_grad_kgen_dp<FAM, false, 0>(a, s);
 }
@@ -363,9 +361,7 @@ static hipError_t launch_fam(const KgenArgs& a, hipStream_t s) {
     }
     if (a.res) {
         if (a.res_n != 14) return hipErrorInvalidValue;          // kgen_writes_residues() told the caller not to ask
-        hipError_t e = hipMemsetAsync(a.res_bad, 0, sizeof(int) * a.Mc, s);
-        if (e != hipSuccess) return e;
-        return launch_kgen_res14(a, s);
+        return launch_kgen_res14(a, s);               // (writes every res_bad entry of the chunk itself)
     }
     return launch_kgen_dp<FAM, 0>(a, s);
 }

@@ -18,7 +18,7 @@ constexpr int KSTEP = 512;    // k per sweep step (256 threads × 2)
 // (instantiated for the default plan, n = 14; other moduli counts go through the separate quantiser of ozaki.hip)
 template <int FAM, int DP, bool FULL, int RES>
 __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[DP], const double (&x0)[DP], const double (&x1)[DP],
-                                          double s0, double s1, double a0, double a1, int jb, int k, double (&mu)[JT]) {
+                                          double s0, double s1, double a0, double a1, int jb, int k, double (&mu)[JT], int* lds_bad) {
     const double rsc = RES != 0 ? __builtin_ldexp(1.0, p.res_sK) : 0.0;
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
@@ -44,7 +44,7 @@ __device__ __forceinline__ void kgen_rows(const KgenArgs& p, const double (*zs)[
         if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
         if constexpr (RES != 0) {
             // the int8-residue engine's image of the pair: two bytes per modulus (a wave writes one 128-byte line per row and plane)
-            if (!(__builtin_fabs(v0) < 1.0e300) || !(__builtin_fabs(v1) < 1.0e300)) p.res_bad[jb + jj] = 1;
+            if (!(__builtin_fabs(v0) < 1.0e300) || !(__builtin_fabs(v1) < 1.0e300)) lds_bad[jj] = 1;
             // plane offset = (uniform) row part + (per-lane, row-independent) k part: the stores take a scalar base and a 32-bit lane offset
             const unsigned koff = (unsigned)(((k >> 6) << 14) + (k & 63));
             const int64_t rowoff = ((int64_t)((jb + jj) >> 8) * (p.res_ld >> 6)) * 16384 + ((jb + jj) & 255) * 64;
@@ -61,8 +61,11 @@ template <int FAM, int DP, int RES>
 __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
     __shared__ double zs[JT][DP];
     __shared__ double red[4][JT];
+    __shared__ int bad[JT];          // RES: a candidate row with a non-finite kernel value (any lane sets it; written out once per row below —
+                                     // every res_bad entry of the chunk is written by its workgroup: no memset in front of the launch)
     const int t = threadIdx.x;
     const int jb = blockIdx.x * JT;
+    if (t < JT) bad[t] = 0;
     for (int idx = t; idx < JT * DP; idx += 256) {
         const int jj = idx / DP, c = idx % DP;
         const int64_t gj = p.j0 + jb + jj;
@@ -97,9 +100,13 @@ __global__ void __launch_bounds__(256) kgen_kernel(KgenArgs p) {
             if (p.alpha) { a0 = p.alpha[k]; a1 = p.alpha[k + 1]; }
             // a workgroup whose 16 rows are all real candidates runs the branch-free body; an edge workgroup (the one-row
             // launch of a bordered append above all) skips the kernel evaluations of its padding rows
-            if (p.j0 + jb + JT <= p.M) kgen_rows<FAM, DP, true, RES>(p, zs, x0, x1, s0, s1, a0, a1, jb, k, mu);
-            else kgen_rows<FAM, DP, false, RES>(p, zs, x0, x1, s0, s1, a0, a1, jb, k, mu);
+            if (p.j0 + jb + JT <= p.M) kgen_rows<FAM, DP, true, RES>(p, zs, x0, x1, s0, s1, a0, a1, jb, k, mu, bad);
+            else kgen_rows<FAM, DP, false, RES>(p, zs, x0, x1, s0, s1, a0, a1, jb, k, mu, bad);
         }
+    }
+    if constexpr (RES != 0) {
+        __syncthreads();
+        if (t < JT) p.res_bad[jb + t] = bad[t];
     }
     if (p.mu == nullptr) return;
     // fixed-order reduction: lanes (xor tree) → 4 waves (serial)

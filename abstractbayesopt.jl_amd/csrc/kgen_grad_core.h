@@ -71,8 +71,10 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
     __shared__ double zs[JT][DP];
     __shared__ int zq[JT];
     __shared__ double red[4][JT];
+    __shared__ int bad[JT];          // RES: rows with a non-finite value (kgen_core.h)
     const int t = threadIdx.x;
     const int jb = blockIdx.x * JT;
+    if (t < JT) bad[t] = 0;
     const int64_t rows_total = p.M * p.pc;              // candidate rows overall
     for (int idx = t; idx < JT * DP; idx += 256) {
         const int jj = idx / DP, c = idx % DP;
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
                 v1 = (ok1 && q >= 0) ? p.sigma_f2 * v1 : 0.0;
                 if (p.Kout) *reinterpret_cast<d2_t*>(p.Kout + (int64_t)(jb + jj) * p.ldk + k) = d2_t{v0, v1};
                 if constexpr (RES != 0) {
-                    if (!(__builtin_fabs(v0) < 1.0e300) || !(__builtin_fabs(v1) < 1.0e300)) p.res_bad[jb + jj] = 1;
+                    if (!(__builtin_fabs(v0) < 1.0e300) || !(__builtin_fabs(v1) < 1.0e300)) bad[jj] = 1;
                     const unsigned koff = (unsigned)(((k >> 6) << 14) + (k & 63));
                     const int64_t rowoff = ((int64_t)((jb + jj) >> 8) * (p.res_ld >> 6)) * 16384 + ((jb + jj) & 255) * 64;
                     const int nd0 = (qc >= 0 ? 1 : 0) + (qp0 >= 0 ? 1 : 0), nd1 = (qc >= 0 ? 1 : 0) + (qp1 >= 0 ? 1 : 0);
@@ -157,6 +159,10 @@ __global__ void __launch_bounds__(256) kgen_grad_kernel(KgenArgs p) {
                 mu[jj] = fma(v1, a1, fma(v0, a0, mu[jj]));
             }
         }
+    }
+    if constexpr (RES != 0) {
+        __syncthreads();
+        if (t < JT) p.res_bad[jb + t] = bad[t];
     }
     if (p.mu == nullptr) return;
     const int lane = t & 63, wave = t >> 6;

@@ -632,6 +632,7 @@ struct OzCrtArgs {
     int nvalid;
     int rmode, rper, rtg;  // candidate j is a derivative output (oz_row_output != 0): its image was taken at 2^-rtg, sums get 2^(2 rtg)
     int64_t r0, rpts;
+    int* ctr_reset;        // the residue GEMM's tile counters (OZ_CTR_INTS): zeroed here, behind the GEMM that used them (or nullptr)
     OzPlan pl;
 };
 
@@ -646,6 +647,7 @@ template <int NM>
 __global__ void __launch_bounds__(256) oz_crt_kernel(OzCrtArgs a) {
     __shared__ double red[3][16][17];
     const int tb = blockIdx.y, tj = blockIdx.x;
+    if (a.ctr_reset && tb == 0 && tj == 0 && threadIdx.x < 8) a.ctr_reset[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cg = lane & 15, rq = lane >> 4;
     const int j = tj * OZ_T + 16 * cg;
@@ -745,11 +747,13 @@ struct OzCrtVArgs {
     int Mc, nvalid;
     int rmode, rper, rtg;
     int64_t r0, rpts;
+    int* ctr_reset;        // the residue GEMM's tile counters (OZ_CTR_INTS): zeroed here, behind the GEMM that used them (or nullptr)
     OzPlan pl;
 };
 
 __global__ void __launch_bounds__(256) oz_crt_v_kernel(OzCrtVArgs a) {
     __shared__ double tile[4][256][9];
+    if (a.ctr_reset && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) a.ctr_reset[threadIdx.x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 256 + 4 * lane;
     const bool live = j < a.Mc;                              // Mc is a multiple of 128, blocks cover 256: whole quads are in or out
@@ -869,7 +873,8 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
         // persistent: one workgroup per CU; the tile counters (one per XCD list) sit behind the chunk's bad_col flags
         static const int cus = [] { int d = 0; hipDeviceProp_t pr; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
         int* ctr = v.bad_col + Mc256;
-        if ((e = hipMemsetAsync(ctr, 0, sizeof(int) * 8, s)) != hipSuccess) return e;
+        if (!(v.ctr_clean && *v.ctr_clean == ctr) && (e = hipMemsetAsync(ctr, 0, sizeof(int) * 8, s)) != hipSuccess) return e;
+        if (v.ctr_clean) *v.ctr_clean = nullptr;
         const int G = (unsigned)cus < blocks ? cus : (int)blocks;
         hipLaunchKernelGGL(oz_gemm16p_kernel, dim3(G), dim3(512), 0, s, g, (int)blocks, ctr);
     }
@@ -880,16 +885,22 @@ hipError_t launch_var_ozaki(const OzVarArgs& v, hipStream_t s) {
         c.U = v.U; c.Ti = g.Ti; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
         c.V = v.Vout; c.ldv = v.ldv; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
         c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
+        c.ctr_reset = v.ctr_clean ? v.bad_col + Mc256 : nullptr;
         hipLaunchKernelGGL(oz_crt_v_kernel, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
-        return hipGetLastError();
+        e = hipGetLastError();
+        if (e == hipSuccess && v.ctr_clean) *v.ctr_clean = v.bad_col + Mc256;
+        return e;
     }
     OzCrtArgs c{};
     c.U = v.U; c.Ti = g.Ti; c.sexp = v.sexp; c.sK = v.sK; c.bad_row = v.bad_row; c.bad_col = v.bad_col;
     c.partial = v.partial; c.ldp = v.ldp; c.Mc = v.Mc; c.nvalid = v.nvalid; c.pl = pl;
     c.rmode = v.rmode; c.rper = v.rper; c.rtg = v.ktg; c.r0 = v.r0; c.rpts = v.rpts;
+    c.ctr_reset = v.ctr_clean ? v.bad_col + Mc256 : nullptr;
     if (pl.n == 14) hipLaunchKernelGGL(oz_crt_kernel<14>, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
     else hipLaunchKernelGGL(oz_crt_kernel<0>, dim3((v.Mc + 255) / 256, v.Np / 128), dim3(256), 0, s, c);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e == hipSuccess && v.ctr_clean) *v.ctr_clean = v.bad_col + Mc256;
+    return e;
 }
 
 }  // namespace abo
