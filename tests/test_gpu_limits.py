@@ -211,12 +211,14 @@ def test_small_batch_topk_single_launch_radix_select():
     rng = np.random.default_rng(0)
     m = abo.update(abo.HipStandardGP(abo.SqExponentialKernel(), 0.1), np.array([[0.0], [1.0]]), np.array([0.0, 1.0]))
     acq = abo.UpperConfidenceBound(2.0)
-    for M in (1, 2, 63, 65, 1000, 1025, 4097, 10000, 16383, 16384, 16385, 20000):
+    # above 16384: slices of 16384 selected by one workgroup each, then one merge — two launches while the slices' picks fit one
+    # workgroup (16385: a last slice of ONE entry; 32769; 300000 with k = 1024 is back on the block-sort passes)
+    for M in (1, 2, 63, 65, 1000, 1025, 4097, 10000, 16383, 16384, 16385, 20000, 32768, 32769, 65536, 70001, 300000):
         Z = np.concatenate([rng.uniform(0, 1, M // 2), np.full(M - M // 2, 50.0) + np.arange(M - M // 2)])
         rng.shuffle(Z)
         if M > 10:
             Z[3] = np.nan
-        for k in (1, 7, 100, 128, 129, 1024):
+        for k in (1, 2, 7, 100, 128, 129, 1024):
             s, tv, ti = abo.evaluate(acq, m, Z, k=k)
             ov, oi = O.top_k(s, k)
             kk = min(k, M)
