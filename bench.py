@@ -530,8 +530,11 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
     # |dmu| 7.0e-12, |dvar| 6.9e-14 after 64 appends against 5.2e-14, 5.2e-12, 6.9e-14 after 16 (profiles/r06_c5_refresh_drift.txt):
     # there is no drift to bound, appends alone never force a refresh.  What does is the factor's capacity (n_max rows) and a change of
     # hyper-parameters (the reference re-optimises them every 10 iterations when asked to, bayesian_opt.jl:388 — a refit either way).
-    # The cadence is therefore the capacity the caller gives the model: --refresh-every (default 64), n_max = N + cadence.
-    cadence = max(1, int(getattr(args, "refresh_every", 64) or 64))
+    # The cadence is therefore the capacity the caller gives the model: --refresh-every, n_max = N + cadence.  Default 512: the same
+    # measurement run for 512 appends (|dmu| 1.5e-11, |dvar| 9.5e-14, |dL| 6.9e-14, alpha 1.2e-11, top-100 of EI unchanged).  Over such a
+    # cycle the q-EI state is rebuilt (one pass over K_ZX) whenever its chain of 64 conditioning columns is used up — about every 56
+    # steps: value_amortized carries that term too.
+    cadence = max(1, int(getattr(args, "refresh_every", 512) or 512))
     if n_warm + n_steps + 3 > cadence:
         raise SystemExit(f"bench.py --config c5: {n_warm} + {n_steps} (+ 3 untimed) appends exceed the model's capacity N + {cadence} "
                          "(--refresh-every): a refresh inside the timed region is not what this line times")
@@ -701,11 +704,15 @@ def run_c5(args, cfg, world, rank, local_rank, dev, use_dist=False, steps=None, 
                     "note": "value = the BO loop as it runs: blocks and chain follow the model from step to step, a step streams "
                             "K_ZX (one pass per block) only when a pick falls outside every block; step_with_a_fresh_block_ms = "
                             "the same step with nothing carried over (every batch builds its block)"},
-            "refresh_ms": refresh_ms, "refresh_ms_all": refresh_all, "value_amortized": ms + refresh_ms / cadence,
-            "refresh": {"every_steps": cadence, "value_amortized_at_16": ms + refresh_ms / 16.0,
-                        "why": "capacity of the factor (n_max = N + every_steps) or a hyper-parameter change; NOT numerical drift: "
-                               "64 appends without a refresh stay at 7e-12 (mu) / 7e-14 (var) of an independent oracle refit, the "
-                               "same as after 16 (profiles/r06_c5_refresh_drift.txt)"},
+            "refresh_ms": refresh_ms, "refresh_ms_all": refresh_all,
+            "value_amortized": ms + refresh_ms / cadence + (((float(np.median(fresh_ms)) - ms) / 56.0) if fresh_ms and cadence > 56 else 0.0),
+            "refresh": {"every_steps": cadence, "value_amortized_at_64": ms + refresh_ms / 64.0, "value_amortized_at_16": ms + refresh_ms / 16.0,
+                        "block_rebuild_every_steps": 56 if cadence > 56 else None,
+                        "why": "value_amortized = value + refresh_ms / every_steps + (step_with_a_fresh_block_ms - value) / 56: a refresh when the "
+                               "factor's capacity (n_max = N + every_steps) is used up or the hyper-parameters change, a rebuilt q-EI block when "
+                               "the chain of 64 conditioning columns is used up.  NOT numerical drift: 512 appends without a refresh stay at "
+                               "1.5e-11 (mu) / 9.5e-14 (var) / 6.9e-14 (L) of an independent oracle refit, 64 appends at 8e-12 / 9.5e-14 / 6.2e-14 "
+                               "(profiles/r06_c5_refresh_drift.txt, r06_c5_refresh_drift_512.txt)"},
             "refresh_phases_ms": {k: v for k, v in fit_t.items() if k.endswith("_ms")},
             "roofline": roof,
             "block_build_roofline": block_roof,
@@ -919,9 +926,10 @@ def main():
     ap.add_argument("--qei-block", type=int, default=None,
                     help="config 5: points per block of the block-form greedy q-EI (default: the library's, 16; 0 = the plain loop "
                          "with one pass over K_ZX per pick, for A/B runs)")
-    ap.add_argument("--refresh-every", type=int, default=64,
+    ap.add_argument("--refresh-every", type=int, default=512,
                     help="config 5: BO steps between full refreshes = spare rows of the factor (n_max = N + this); value_amortized = "
-                         "value + refresh_ms / this.  64: what profiles/r06_c5_refresh_drift.txt supports (no drift after 64 appends)")
+                         "value + refresh_ms / this (+ the q-EI block rebuilds of such a cycle).  512: what profiles/r06_c5_refresh_drift_512.txt supports "
+                         "(no drift after 512 appends)")
     ap.add_argument("--contraction", default=None,
                     help="engine of the N^2*M variance contraction: auto (library default), fp64, int8 or int8:<moduli>")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

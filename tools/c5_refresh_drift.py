@@ -86,4 +86,8 @@ for k in range(1, appends + 1):
           f" {np.max(np.abs(mu_c - mu_r)):.3e}    {np.max(np.abs(var_c - var_r)):.3e}    {same_top!s:5}                   |"
           f" {np.median(t_steps):6.2f}   {t_fit * 1e3:8.0f}", flush=True)
     del st, L
-print(f"median step (q-EI batch + real append + down-date, host wall clock, Python driver): {np.median(t_steps):.3f} ms")
+ts = np.asarray(t_steps)
+slow = ts > 3.0 * np.median(ts)
+print(f"median step (q-EI batch + real append + down-date, host wall clock, Python driver): {np.median(ts):.3f} ms;  MEAN over the {appends} "
+      f"steps {ts.mean():.3f} ms — {int(slow.sum())} steps rebuilt the q-EI block (the chain of {64} conditioning columns was used up, or a pick "
+      f"fell outside every block: one pass over K_ZX, {np.median(ts[slow]) if slow.any() else float('nan'):.2f} ms each)")

@@ -63,6 +63,8 @@ fi
 if want drift; then
 (timeout -k 10 900 python tools/c5_refresh_drift.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_c5_refresh_drift.txt
 tail -3 gpurun_out/final_c5_refresh_drift.txt
+(timeout -k 10 900 python tools/c5_refresh_drift.py 512 128 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_c5_refresh_drift_512.txt
+tail -3 gpurun_out/final_c5_refresh_drift_512.txt
 fi
 if want traces; then
 rm -rf gpurun_out/prof_${TAG}_c3fp64
