@@ -2202,7 +2202,10 @@ int qei_default_block() {
     int v = g_qei_block.load();
     if (v < 0) {
         const char* e = getenv("ABO_QEI_BLOCK");
-        v = e ? atoi(e) : 16;                  // 16 columns ride entirely under the K_ZX stream (6.3 TB/s); 32 cost 10 % more per pass
+        // 16 columns ride entirely under the K_ZX stream (6.3 TB/s), 32 cost 10 % more per pass — and halve how often a batch has to
+        // build a block: over a 512-step cycle of config 5 with noisy observations one step in 8 rebuilt at T = 16, one in 16 at 32,
+        // one in 27 at 64 (whose pass is MFMA-bound); mean step 1.13 / 0.98 / 0.99 ms (tools/c5_cycle.py, profiles/r06_c5_cycle.txt)
+        v = e ? atoi(e) : 32;
         if (v < 0) v = 0;
         if (v > QEI_MAXT) v = QEI_MAXT;
         g_qei_block.store(v);

@@ -348,7 +348,7 @@ int32_t abo_cand_exclude(abo_gp* gp, abo_cand* c, int64_t idx);
  * another lineage of the model or 64 chain entries start the state afresh.
  *   abo_cand_qei: the whole batch on one handle.  x_out q × d, idx_out / ei_out q (idx = idx_base + local index);
  *     distinct != 0 excludes every picked candidate for the rest of the call; block = T (16 … 64, rounded up to a multiple of
- *     16; 0 = the process default, abo_set_qei_block / ABO_QEI_BLOCK, initially 16; < 0 = the plain loop).  The plain loop
+ *     16; 0 = the process default, abo_set_qei_block / ABO_QEI_BLOCK, initially 32; < 0 = the plain loop).  The plain loop
  *     is also what runs for a gradient-enhanced model, for a set whose K_ZX is not resident, and for q > 64.  stats may be NULL.
  *   For a host that shards the set itself (one process per GPU: abstractbayesopt.jl_amd/incremental.py over torch.distributed)
  *   the same batch in steps; every shard makes the same calls with the same exchanged numbers, so a sharded set repeats the

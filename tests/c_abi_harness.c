@@ -492,7 +492,7 @@ int main(int argc, char** argv) {
         abo_qei_stats qs;
         CHECK(d <= 64, "q-EI section: d = %d", d);
         ok_or_die(abo_cand_qei(g, cs, Q, a[1], a[2], 0, 0, 0, xb, ib, eb, &qs), "abo_cand_qei (block form)");
-        CHECK(qs.block == 16 && qs.block_builds >= 1 && qs.block_builds + qs.block_hits == Q - 1 && qs.picks == Q,
+        CHECK(qs.block == 32 && qs.block_builds >= 1 && qs.block_builds + qs.block_hits == Q - 1 && qs.picks == Q,
               "q-EI stats: block %d builds %d hits %d picks %d", qs.block, qs.block_builds, qs.block_hits, qs.picks);
         ok_or_die(abo_cand_qei(g, cs, Q, a[1], a[2], 0, 0, -1, xp, ip, ep, &qs), "abo_cand_qei (plain loop)");
         CHECK(qs.block == 0, "q-EI: block = -1 must run the plain loop (stats say block %d)", qs.block);

@@ -262,7 +262,7 @@ def test_full_size_block_qei_c5_against_the_from_scratch_path_and_the_oracle():
     cands = abo.ResidentCandidates(m, Z)
     ei0, tv16, ti16 = cands.evaluate(acq, k=16, return_scores=True)
     mu0, var0 = cands.mean_and_var()
-    pts, idx, val, st = cands.qei(q, xi, best)
+    pts, idx, val, st = cands.qei(q, xi, best, block=16)
     assert st["block"] == 16 and st["block_builds"] >= 1 and st["block_builds"] + st["block_hits"] == q - 1, st
     assert st["pass_bytes"] == 8.0 * N * M                    # the block came from one pass over the resident K_ZX
     np.testing.assert_array_equal(pts, Z[idx])
@@ -397,7 +397,7 @@ def test_block_qei_equals_the_plain_loop_and_the_from_scratch_batch(fam, d, N0, 
     cands = abo.ResidentCandidates(m, Z)
     mu0, var0 = cands.mean_and_var()
     pts_c, idx_c, val_c, st = cands.qei(q, xi, best, block=block)
-    assert st["block"] == (16 if block == 0 else block) and st["picks"] == q
+    assert st["block"] == (32 if block == 0 else block) and st["picks"] == q      # 0: the library's default
     assert st["block_builds"] >= 1 and st["block_builds"] + st["block_hits"] == q - 1
     if fam == O.SE:
         assert st["block_builds"] > 1, st                      # this case exists for the rebuild path

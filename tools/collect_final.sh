@@ -16,6 +16,7 @@ cp final_refine_diag_c3.txt ../profiles/${TAG}_refine_diag_c3.txt
 [ -f final_c5_refresh_drift_512.txt ] && cp final_c5_refresh_drift_512.txt ../profiles/${TAG}_c5_refresh_drift_512.txt
 cp final_grad_engine_latency.txt ../profiles/${TAG}_grad_engine_latency.txt
 cp final_oz_soak.txt ../profiles/${TAG}_oz_soak.txt
+[ -f final_c5_cycle.txt ] && cp final_c5_cycle.txt ../profiles/${TAG}_c5_cycle.txt
 for c in c2 c3 c5; do cp final_bench_under_rocprof_$c.json ../profiles/${TAG}_${c}_bench_under_rocprof.json; cp final_kernel_stats_$c.csv ../profiles/${TAG}_${c}_kernel_stats.csv; done
 cp final_kernel_stats_c3_fp64_engine.csv ../profiles/${TAG}_c3_kernel_stats_fp64_engine.csv
 cp final_pmc_int8_summary.txt ../profiles/${TAG}_c3_int8_pmc_summary.txt

@@ -38,12 +38,12 @@ if want bench; then
 timeout -k 10 900 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --contraction fp64 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c3_fp64_engine.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 300 python bench.py --config c2 --steps 30 --warmup 5 --cpu-sample-m 65536 --cpu-reps 3 > gpurun_out/final_bench_c2.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
-timeout -k 10 300 python bench.py --config c5 --steps 20 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --config c5 --steps 128 --warmup 2 > gpurun_out/final_bench_c5.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 timeout -k 10 600 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 > gpurun_out/final_bench_c3_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
-timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 3 --warmup 1 --config c5 > gpurun_out/final_bench_c5_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 300 python bench.py --gpus 2 --share-device --steps 16 --warmup 1 --config c5 > gpurun_out/final_bench_c5_2shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 # BASELINE config 4 at its own size through the 8-shard path, all shards on this one GPU (a rehearsal of the fan-out, NOT a scaling figure)
 timeout -k 10 600 python bench.py --gpus 8 --share-device --config c4 --steps 2 --warmup 1 > gpurun_out/final_bench_c4_8shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
-timeout -k 10 600 python bench.py --gpus 4 --share-device --config c5 --steps 3 --warmup 1 > gpurun_out/final_bench_c5_4shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
+timeout -k 10 600 python bench.py --gpus 4 --share-device --config c5 --steps 16 --warmup 1 > gpurun_out/final_bench_c5_4shards_one_device.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 # BASELINE config 4's candidate count on ONE GPU (one rank, M = 2^23: the denominator of the >= 6x scaling target — a real single-GPU line)
 timeout -k 10 300 python bench.py --config c4 --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/final_bench_c4_1gpu.json 2> gpurun_out/bench.err || { tail -5 gpurun_out/bench.err; exit 1; }
 echo "bench done"
@@ -55,6 +55,7 @@ if want latency; then
 timeout -k 10 300 bash tools/fit_times.sh > gpurun_out/final_fit_times.txt 2>&1 || true
 (timeout -k 10 300 python tools/grad_engine_latency.py 2>&1 | grep -v amdgpu; timeout -k 10 300 python tools/grad_engine_latency.py 400 16 2048 2>&1 | grep -v amdgpu) > gpurun_out/final_grad_engine_latency.txt
 timeout -k 10 600 python tools/oz_soak.py 40 2>&1 | grep "^N=" > gpurun_out/final_oz_soak.txt || true
+(timeout -k 10 300 python tools/c5_cycle.py 512 16 32 64 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_c5_cycle.txt
 timeout -k 10 600 python tools/soak.py > gpurun_out/final_soak.txt 2>&1 || { tail -5 gpurun_out/final_soak.txt; exit 1; }
 (timeout -k 10 300 python tools/hyperparameter_latency.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_hyperparameter_latency.txt
 (timeout -k 10 300 python tools/refine_diag.py c3 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_refine_diag_c3.txt
