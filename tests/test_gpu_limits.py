@@ -248,8 +248,9 @@ def test_small_read_backs_through_pinned_memory_equal_the_direct_copies():
         "print(h.hexdigest())\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for extra in ({}, {"ABO_NO_PINNED": "1"}):
+    # … and the way a call waits for its stream (polled for short waits, blocking beyond ABO_SPIN_WAIT_US; 0 = always block) changes nothing
+    for extra in ({}, {"ABO_NO_PINNED": "1"}, {"ABO_SPIN_WAIT_US": "0"}, {"ABO_SPIN_WAIT_US": "1"}):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **extra))
         assert r.returncode == 0, r.stderr[-2000:]
         out.append([ln for ln in r.stdout.split() if len(ln) == 64][-1])
-    assert out[0] == out[1]
+    assert out[0] == out[1] == out[2] == out[3]
