@@ -11,6 +11,7 @@ cp final_bench_c4_8shards_one_device.json ../profiles/${TAG}_bench_c4_8shards_on
 cp final_bench_c5_4shards_one_device.json ../profiles/${TAG}_bench_c5_4shards_one_device_rehearsal.json
 cp final_bench_c4_1gpu.json ../profiles/${TAG}_bench_c4_1gpu.json
 cp final_hyperparameter_latency.txt ../profiles/${TAG}_hyperparameter_latency.txt
+[ -f final_ensemble_latency.txt ] && cp final_ensemble_latency.txt ../profiles/${TAG}_ensemble_latency.txt
 cp final_refine_diag_c3.txt ../profiles/${TAG}_refine_diag_c3.txt
 [ -f final_c5_refresh_drift.txt ] && cp final_c5_refresh_drift.txt ../profiles/${TAG}_c5_refresh_drift.txt
 [ -f final_c5_refresh_drift_512.txt ] && cp final_c5_refresh_drift_512.txt ../profiles/${TAG}_c5_refresh_drift_512.txt

@@ -57,6 +57,7 @@ timeout -k 10 300 bash tools/fit_times.sh > gpurun_out/final_fit_times.txt 2>&1 
 timeout -k 10 600 python tools/oz_soak.py 40 2>&1 | grep "^N=" > gpurun_out/final_oz_soak.txt || true
 (timeout -k 10 300 python tools/c5_cycle.py 512 16 32 64 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_c5_cycle.txt
 timeout -k 10 600 python tools/soak.py > gpurun_out/final_soak.txt 2>&1 || { tail -5 gpurun_out/final_soak.txt; exit 1; }
+(timeout -k 10 200 python tools/ensemble_latency.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_ensemble_latency.txt
 (timeout -k 10 300 python tools/hyperparameter_latency.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_hyperparameter_latency.txt
 (timeout -k 10 300 python tools/refine_diag.py c3 2>&1 | grep -v amdgpu.ids) > gpurun_out/final_refine_diag_c3.txt
 echo "latency tools done"
